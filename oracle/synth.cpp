@@ -1,0 +1,166 @@
+/*
+ * synth.cpp -- deterministic synthetic RGB-D frame pairs.
+ *
+ * TEST INFRASTRUCTURE (see dvo_oracle.h).  There is no TUM dataset on disk and no network, so the
+ * parity tests, the bench workload and the CPU baseline all consume these frames.  The generator
+ * renders the SAME analytic scene from two camera poses (exact re-render by ray/surface root
+ * finding, not image warping), then quantises exactly like the reference's ingest does:
+ * grey -> u8 (stored as float 0..255 by the caller), depth -> u16 at 5000 counts per metre, 0 = hole
+ * (dvo_benchmark/src/benchmark_slam.cpp:46-93, dvo_core/src/core/surface_pyramid.cpp:65-105).
+ */
+#include "dvo_oracle.h"
+#include "se3_oracle.h"
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace {
+
+struct Pcg32 {
+  uint64_t state, inc;
+  explicit Pcg32(uint64_t seed, uint64_t seq = 54u) {
+    state = 0u;
+    inc = (seq << 1u) | 1u;
+    next();
+    state += seed;
+    next();
+  }
+  uint32_t next() {
+    uint64_t old = state;
+    state = old * 6364136223846793005ULL + inc;
+    uint32_t xorshifted = uint32_t(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = uint32_t(old >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((-rot) & 31));
+  }
+  double uniform() { return (next() >> 8) * (1.0 / 16777216.0); }   // [0,1)
+  double uniform(double a, double b) { return a + (b - a) * uniform(); }
+};
+
+struct Scene {
+  int W, H;
+  double fx, fy, ox, oy;
+  double dir[6][3], k[6], phase[6], amp[6];
+  double tex_lo, tex_hi;
+
+  double depth_at(double u, double v) const {   // analytic reference-view depth, defined for any real (u,v)
+    return 1.5 + 0.5 * std::sin(2.0 * M_PI * u / W * 1.5) * std::cos(2.0 * M_PI * v / H) + 0.3 * (v / H);
+  }
+  double texture_raw(const double p[3]) const {
+    double s = 0;
+    for (int i = 0; i < 6; ++i) s += amp[i] * std::sin(k[i] * (dir[i][0] * p[0] + dir[i][1] * p[1] + dir[i][2] * p[2]) + phase[i]);
+    return s;
+  }
+  double texture(const double p[3]) const {   // mapped to 20..235 grey levels
+    double t = (texture_raw(p) - tex_lo) / (tex_hi - tex_lo);
+    return 20.0 + 215.0 * t;
+  }
+};
+
+void make_scene(Scene& sc, Pcg32& rng) {
+  static const double wavelengths[6] = {0.05, 0.09, 0.15, 0.25, 0.4, 0.6};
+  double asum = 0;
+  for (int i = 0; i < 6; ++i) {
+    double d[3] = {rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.3, 0.3)};
+    double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 1e-9;
+    for (int j = 0; j < 3; ++j) sc.dir[i][j] = d[j] / n;
+    sc.k[i] = 2.0 * M_PI / wavelengths[i];
+    sc.phase[i] = rng.uniform(0, 2.0 * M_PI);
+    sc.amp[i] = 0.5 + 0.5 * double(i) / 5.0;   // longer wavelengths carry more contrast
+    asum += sc.amp[i];
+  }
+  sc.tex_lo = -0.75 * asum;   // the sum rarely reaches +-asum; clip the tails instead of wasting range
+  sc.tex_hi = 0.75 * asum;
+}
+
+inline uint8_t quantise_grey(double g) {
+  if (g < 0) g = 0;
+  if (g > 255) g = 255;
+  return uint8_t(std::lround(g));
+}
+
+inline uint16_t quantise_depth(double z) {
+  double q = std::round(z * 5000.0);
+  if (!(q >= 1.0)) return 0;
+  if (q > 65535.0) return 0;
+  return uint16_t(q);
+}
+
+void punch_holes(uint16_t* depth, int W, int H, Pcg32& rng) {
+  for (int by = 0; by < H; by += 8)
+    for (int bx = 0; bx < W; bx += 8)
+      if (rng.uniform() < 0.12)
+        for (int y = by; y < by + 8 && y < H; ++y)
+          for (int x = bx; x < bx + 8 && x < W; ++x) depth[size_t(y) * W + x] = 0;
+  const int band = (10 * W) / 640 > 0 ? (10 * W) / 640 : 1;   // Kinect-style shadow band on the right
+  for (int y = 0; y < H; ++y)
+    for (int x = W - band; x < W; ++x) depth[size_t(y) * W + x] = 0;
+}
+
+}  // namespace
+
+extern "C" void oracle_synth_pair(uint64_t seed, int W, int H, const float K[4], uint8_t* grey_ref, uint16_t* depth_ref,
+                                  uint8_t* grey_cur, uint16_t* depth_cur, double xi_true[6]) {
+  Pcg32 rng(seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL, seed + 7);
+  Scene sc;
+  sc.W = W; sc.H = H;
+  sc.fx = K[0]; sc.fy = K[1]; sc.ox = K[2]; sc.oy = K[3];
+  make_scene(sc, rng);
+
+  // motion: |v| <= 0.03 m, |omega| <= 0.03 rad (typical 30 Hz fr1 inter-frame motion)
+  double xi[6];
+  for (int part = 0; part < 2; ++part) {
+    double d[3] = {rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-1, 1)};
+    double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 1e-9;
+    double mag = 0.03 * rng.uniform(0.3, 1.0);
+    for (int j = 0; j < 3; ++j) xi[part * 3 + j] = d[j] / n * mag;
+  }
+  for (int i = 0; i < 6; ++i) xi_true[i] = xi[i];
+  const oracle::SE3 T_rc = oracle::se3_exp(xi);   // current -> reference: what match() returns
+  double Mrc[16];
+  oracle::se3_to_matrix(T_rc, Mrc);
+
+  Pcg32 noise_ref(seed * 31 + 1, 11), noise_cur(seed * 31 + 2, 13);
+  Pcg32 holes_ref(seed * 131 + 5, 17), holes_cur(seed * 131 + 6, 19);
+
+  // reference view
+  for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) {
+      const double z = sc.depth_at(u, v);
+      const double p[3] = {(u - sc.ox) / sc.fx * z, (v - sc.oy) / sc.fy * z, z};
+      grey_ref[size_t(v) * W + u] = quantise_grey(sc.texture(p) + noise_ref.uniform(-1.5, 1.5));
+      depth_ref[size_t(v) * W + u] = quantise_depth(z);
+    }
+  punch_holes(depth_ref, W, H, holes_ref);
+
+  // current view: intersect each pixel ray with the surface  p.z = depth_at(project(p)),  p = R s d + t
+  for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) {
+      const double d[3] = {(u - sc.ox) / sc.fx, (v - sc.oy) / sc.fy, 1.0};
+      double rd[3], t[3] = {Mrc[3], Mrc[7], Mrc[11]};
+      for (int i = 0; i < 3; ++i) rd[i] = Mrc[i * 4 + 0] * d[0] + Mrc[i * 4 + 1] * d[1] + Mrc[i * 4 + 2] * d[2];
+      auto g = [&](double s, double p[3]) {
+        for (int i = 0; i < 3; ++i) p[i] = rd[i] * s + t[i];
+        const double pu = sc.fx * p[0] / p[2] + sc.ox, pv = sc.fy * p[1] / p[2] + sc.oy;
+        return p[2] - sc.depth_at(pu, pv);
+      };
+      double s = sc.depth_at(u, v), p[3];
+      for (int it = 0; it < 20; ++it) {
+        const double g0 = g(s, p);
+        if (std::fabs(g0) < 1e-9) break;
+        double ph[3];
+        const double h = 1e-4;
+        const double g1 = g(s + h, ph);
+        double dg = (g1 - g0) / h;
+        if (std::fabs(dg) < 0.05) dg = dg < 0 ? -0.05 : 0.05;
+        double step = g0 / dg;
+        if (step > 0.2) step = 0.2;
+        if (step < -0.2) step = -0.2;
+        s -= step;
+      }
+      g(s, p);
+      grey_cur[size_t(v) * W + u] = quantise_grey(sc.texture(p) + noise_cur.uniform(-1.5, 1.5));
+      depth_cur[size_t(v) * W + u] = quantise_depth(s);
+    }
+  punch_holes(depth_cur, W, H, holes_cur);
+}
