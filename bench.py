@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py -- frame-pair alignments/s of the MI355X dense RGB-D alignment path (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+  re-ingest the raw planes of the batch's frames (u8 grey + u16 depth -> device pyramids, selection)  [SURVEY a11-a14]
+  + dvo_hip_match_batch: the coarse-to-fine Gauss-Newton alignment of every pair                      [SURVEY a1-a10]
+  (+ for N > 1: one all-gather of the 256-byte result records over RCCL)
+Workload at any N: `--pairs-per-gpu` (default 128) independent 640x480 pairs per GPU, 4-level pyramid, FirstLevel 3,
+LastLevel 0 (finest level 640x480), MaxIterationsPerLevel 100, Precision 5e-7, Mu 0 -- the per-GPU shard of
+BASELINE config 4 (1024 pairs over 8 GPUs), i.e. weak scaling; BASELINE config 2 (a single pair) is the same call
+with a batch of one and is reported as `single_pair_ms` (latency), because one 15 MB pair lives in the 256 MB
+Infinity Cache and cannot exercise HBM.
+
+Launch: `python bench.py --gpus 1 --steps K --warmup W`, or for N > 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H = 640, 480
+ALGO_BYTES_PER_PIXEL = 40.0          # ref {Z,I,Idx,Idy} 16 B + cur {I,Z,Idx,Idy,Zdx,Zdy} 24 B
+HBM_PEAK_GBPS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(pairs_np, cfg_kwargs, sample_pairs, reps):
+    """The oracle's quirk-faithful REF_SSE mode (kind 'port': the reference itself cannot be built here), one match per
+    host thread like the reference's tbb::parallel_reduce over proposals.  Checker code timed as a baseline only."""
+    from oracle import pyoracle as po
+    cores = len(os.sched_getaffinity(0))
+    n = min(sample_pairs, pairs_np["grey_ref"].shape[0])
+    refs, curs = [], []
+    for i in range(n):
+        pair = {k: pairs_np[k][i] for k in ("grey_ref", "depth_ref", "grey_cur", "depth_cur")}
+        pair["K"] = pairs_np["K"]
+        r, c = po.pyramids_from_pair(pair, 4)
+        refs.append(r)
+        curs.append(c)
+    cfg = po.make_config(mode=po.REF_SSE, **cfg_kwargs)
+    po.match_batch(refs[:min(n, cores)], curs[:min(n, cores)], cfg, nthreads=cores)      # warm-up (also builds caches)
+    t_multi = 0.0
+    for _ in range(reps):
+        _, secs = po.match_batch(refs, curs, cfg, nthreads=cores)
+        t_multi += secs
+    n1 = min(n, 8)
+    _, t_single = po.match_batch(refs[:n1], curs[:n1], cfg, nthreads=1)
+    return dict(value=n * reps / t_multi, unit="alignments/s", cores=cores, kind="port",
+                sample="%d synthetic 640x480 pairs x %d repetitions (oracle REF_SSE mode, -O3 -march=native), %d threads, one match per thread; "
+                       "single thread: %.1f alignments/s" % (n, reps, cores, n1 / t_single),
+                single_thread_value=n1 / t_single)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs-per-gpu", type=int, default=128)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=64)
+    ap.add_argument("--cpu-reps", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rows-per-wave", type=int, default=0)
+    ap.add_argument("--iters-per-sync", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import dvo_slam_amd as d
+    from dvo_slam_amd import datagen, parallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and libdvo_hip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    B = args.pairs_per_gpu
+    n_total = B * world
+    my_pairs = parallel.shard_indices(n_total, rank, world)      # pair i -> rank i mod N
+    # synthetic input, identical bytes on the CPU and GPU sides (seed = global pair index)
+    if world > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max(1, min(8, (os.cpu_count() or 8) // world))) as ex:   # ctypes releases the GIL
+            batches = list(ex.map(lambda i: datagen.synth_batch(i, 1, W, H, nthreads=1), my_pairs))
+    else:
+        batches = [datagen.synth_batch(0, B, W, H)]
+    pairs_np = {k: np.concatenate([b[k] for b in batches]) for k in ("grey_ref", "depth_ref", "grey_cur", "depth_cur", "xi_true")}
+    pairs_np["K"] = batches[0]["K"]
+
+    dev = torch.device("cuda", local_rank)
+    grey = torch.from_numpy(np.concatenate([pairs_np["grey_ref"], pairs_np["grey_cur"]])).to(dev)                     # [2B,H,W] u8
+    depth = torch.from_numpy(np.concatenate([pairs_np["depth_ref"], pairs_np["depth_cur"]]).view(np.int16)).to(dev)   # [2B,H,W] u16 bits
+    torch.cuda.synchronize()
+    grey_ptrs = [grey[i].data_ptr() for i in range(2 * B)]
+    depth_ptrs = [depth[i].data_ptr() for i in range(2 * B)]
+
+    ctx = d.Context(local_rank)
+    if args.rows_per_wave:
+        ctx.set_option("rows_per_wave", args.rows_per_wave)
+    if args.iters_per_sync:
+        ctx.set_option("iters_per_sync", args.iters_per_sync)
+    cam = d.RgbdCameraPyramid(W, H, pairs_np["K"], ctx)
+    cam.build(4)
+    frames = [cam.create_raw_device(grey_ptrs[i], depth_ptrs[i]) for i in range(2 * B)]
+    refs, curs = frames[:B], frames[B:]
+    cfg_kwargs = dict(first_level=3, last_level=0, max_iterations=100, precision=5e-7, mu=0.0)
+    cfg = d.Config(FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0.0)
+    tracker = d.DenseTracker(cfg, ctx)
+    results = [d.Result() for _ in range(B)]
+
+    def step():
+        d.update_raw_device_batch(frames, grey_ptrs, depth_ptrs)       # ingest + pyramids + selection, from HBM-resident raw planes
+        tracker.match_batch(refs, curs, results)                        # synchronous: returns when the twists are on the host
+        if world > 1:
+            tw = [_twist(r.Transformation) for r in results]
+            rec = parallel.pack_records(tw, [r.Information for r in results], [r.LogLikelihood for r in results])
+            return parallel.gather_records(rec, n_total, rank, world, device=dev)
+        return None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- everything below is outside the timed region -------------------------------------------------------
+    twist_err = max(float(np.abs(_twist(r.Transformation) - pairs_np["xi_true"][i]).max()) for i, r in enumerate(results))
+    nan_results = sum(int(r.isNaN()) for r in results)
+    t_match0 = time.perf_counter()
+    tracker.match_batch(refs, curs, results)
+    match_only_ms = (time.perf_counter() - t_match0) * 1e3
+
+    # roofline of the dominant kernel: finest-level fused warp/residual/Jacobian/reduce sweep, HIP events on the context stream
+    k_ms = {lvl: tracker.time_residual_kernel(refs, curs, lvl, reps=20) for lvl in (0, 1, 2, 3)}
+    algo_bytes = ALGO_BYTES_PER_PIXEL * W * H * B
+    achieved = algo_bytes / (k_ms[0] * 1e-3) / 1e9
+    roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
+                    traffic=None, kernel="dvo_hip::k_residual_reduce<RPW, true> (level 0, %d pairs per launch)" % B,
+                    kernel_ms=round(k_ms[0], 4), algorithmic_bytes_per_launch=algo_bytes,
+                    per_level_kernel_ms={str(k): round(v, 4) for k, v in k_ms.items()})
+
+    # latency of BASELINE config 2: one 640x480 pair, 4 levels
+    one = d.Result()
+    lat = []
+    for _ in range(12):
+        t1 = time.perf_counter()
+        tracker.match(refs[0], curs[0], one, with_stats=False)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    single_pair_ms = float(np.median(lat[2:]))
+
+    out = None
+    if rank == 0:
+        value = n_total * args.steps / elapsed
+        out = {
+            "metric": "frame-pair alignments/s (640x480, 4-level pyramid) + finest-level HBM GB/s vs roofline",
+            "value": round(value, 2), "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "batch of %d independent 640x480 RGB-D frame pairs per GPU (per-GPU shard of BASELINE config 4), "
+                                   "4-level pyramid, FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0; "
+                                   "step = re-ingest raw planes from HBM + pyramids + selection + coarse-to-fine match_batch" % B,
+                       "pairs_per_gpu": B, "global_pairs_per_step": n_total, "width": W, "height": H,
+                       "parallelism": "independent pairs sharded round-robin over %d GPU(s), one all-gather of 256-B records per step" % world},
+            "roofline": roofline,
+            "match_only_ms_per_batch": round(match_only_ms, 3),
+            "single_pair_ms": round(single_pair_ms, 3),
+            "max_twist_error_vs_truth": twist_err, "nan_results": nan_results,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pairs_np, cfg_kwargs, args.cpu_sample_pairs, args.cpu_reps)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def _twist(T):
+    """log of a 4x4 rigid transform as (v, omega) -- small-angle safe closed form, used only for reporting."""
+    R, t = T[:3, :3], T[:3, 3]
+    c = max(-1.0, min(1.0, (np.trace(R) - 1.0) / 2.0))
+    th = np.arccos(c)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2.0
+    w = v * (1.0 + th * th / 6.0 if th < 1e-6 else th / np.sin(th))
+    O = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    th2 = float(w @ w)
+    cc = 1.0 / 12.0 if th2 < 1e-10 else (1.0 - np.sqrt(th2) * np.cos(np.sqrt(th2) / 2) / (2 * np.sin(np.sqrt(th2) / 2))) / th2
+    Vinv = np.eye(3) - 0.5 * O + cc * (O @ O)
+    return np.concatenate([Vinv @ t, w])
+
+
+if __name__ == "__main__":
+    main()

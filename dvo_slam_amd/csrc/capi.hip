@@ -1,0 +1,733 @@
+// capi.hip -- host side of libdvo_hip.so: contexts, device-resident frame pyramids and the batched
+// coarse-to-fine Gauss-Newton driver behind the C-ABI of include/dvo_hip.h.
+//
+// The host never touches pixels or poses: it uploads two raw planes per frame, enqueues kernels on the
+// context's HIP stream and polls one integer ("pairs still iterating") every few iterations.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dvo_hip.h"
+#include "device_types.h"
+#include "launch.h"
+
+using namespace dvo_hip;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct CameraGeom {             // RgbdCameraPyramid: per-level size, intrinsics and the point-cloud template
+  int w0 = 0, h0 = 0, levels = 0;
+  float K0[4] = {0, 0, 0, 0};
+  int w[kMaxLevels], h[kMaxLevels];
+  float K[kMaxLevels][4];
+  float* tx[kMaxLevels];
+  float* ty[kMaxLevels];
+  DevBuf tables;
+};
+
+struct FrameLevel {
+  int w = 0, h = 0;
+  float* I = nullptr;
+  float* Z = nullptr;
+  float4* A = nullptr;
+  float2* B = nullptr;
+  float4* R = nullptr;
+  bool selected = false;       // R / count valid for (ithr, dthr)
+  float ithr = 0, dthr = 0;
+};
+
+}  // namespace
+
+struct dvo_hip_frame {
+  int levels = 0;
+  const CameraGeom* cam = nullptr;
+  FrameLevel lv[kMaxLevels];
+  DevBuf pool;
+  int* sel_count = nullptr;    // device, one int per level
+};
+
+struct dvo_hip_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int opt_rows_per_wave = 0;
+  int opt_iters_per_sync = 0;
+  std::vector<CameraGeom*> cameras;
+  // batch workspace
+  DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters, misc, build_tbl;
+  int* host_counter = nullptr;   // pinned
+};
+
+namespace {
+
+#define DVO_HIP_TRY(ctx, expr)                                                                   \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess) {                                                                      \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                            \
+      return DVO_HIP_ERR_HIP;                                                                     \
+    }                                                                                             \
+  } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int fail(dvo_hip_context* ctx, int code, const char* msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+const int kLlBlocksPerPair = 8;
+
+// RgbdCameraPyramid::build (rgbd_image.cpp:283-296) + RgbdCamera ctor template (:186-204)
+int get_camera(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, const CameraGeom** out) {
+  for (CameraGeom* c : ctx->cameras)
+    if (c->w0 == w && c->h0 == h && c->levels >= levels && std::memcmp(c->K0, K, 16) == 0) {
+      *out = c;
+      return DVO_HIP_OK;
+    }
+  CameraGeom* c = new CameraGeom();
+  c->w0 = w; c->h0 = h; c->levels = levels;
+  std::memcpy(c->K0, K, 16);
+  size_t total = 0;
+  for (int l = 0; l < levels; ++l) {
+    c->w[l] = l == 0 ? w : c->w[l - 1] / 2;
+    c->h[l] = l == 0 ? h : c->h[l - 1] / 2;
+    for (int k = 0; k < 4; ++k) c->K[l][k] = l == 0 ? K[k] : c->K[l - 1][k] * 0.5f;   // IntrinsicMatrix::scale(0.5f), Q17
+    total += align_up(size_t(c->w[l]) * 4, 256) + align_up(size_t(c->h[l]) * 4, 256);
+  }
+  hipError_t e = c->tables.reserve(total);
+  if (e != hipSuccess) {
+    delete c;
+    ctx->err = std::string("hipMalloc(camera tables): ") + hipGetErrorString(e);
+    return DVO_HIP_ERR_HIP;
+  }
+  std::vector<float> host;
+  char* base = c->tables.as<char>();
+  size_t off = 0;
+  for (int l = 0; l < levels; ++l) {
+    const float fx = c->K[l][0], fy = c->K[l][1], ox = c->K[l][2], oy = c->K[l][3];
+    host.resize(size_t(c->w[l]) + c->h[l]);
+    for (int x = 0; x < c->w[l]; ++x) host[x] = (float(x) - ox) / fx;            // rgbd_image.cpp:198
+    for (int y = 0; y < c->h[l]; ++y) host[c->w[l] + y] = (float(y) - oy) / fy;  // rgbd_image.cpp:199
+    c->tx[l] = reinterpret_cast<float*>(base + off);
+    off += align_up(size_t(c->w[l]) * 4, 256);
+    c->ty[l] = reinterpret_cast<float*>(base + off);
+    off += align_up(size_t(c->h[l]) * 4, 256);
+    e = hipMemcpy(c->tx[l], host.data(), size_t(c->w[l]) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->ty[l], host.data() + c->w[l], size_t(c->h[l]) * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      c->tables.release();
+      delete c;
+      ctx->err = std::string("hipMemcpy(camera tables): ") + hipGetErrorString(e);
+      return DVO_HIP_ERR_HIP;
+    }
+  }
+  ctx->cameras.push_back(c);
+  *out = c;
+  return DVO_HIP_OK;
+}
+
+LevelGeom make_geom(const CameraGeom* cam, int level, int rows_per_wave) {
+  LevelGeom g;
+  g.w = cam->w[level]; g.h = cam->h[level];
+  g.fx = cam->K[level][0]; g.fy = cam->K[level][1]; g.ox = cam->K[level][2]; g.oy = cam->K[level][3];
+  g.wi_x = 0.5f * g.fx / 255.0f; g.wi_y = 0.5f * g.fy / 255.0f;
+  g.tx = cam->tx[level]; g.ty = cam->ty[level];
+  g.tiles_x = (g.w + kTileW - 1) / kTileW;
+  const int th = kWavesPerBlock * rows_per_wave;
+  g.tiles_y = (g.h + th - 1) / th;
+  return g;
+}
+
+// rows of 64 pixels each wavefront sweeps: large tiles amortise the 85-value wave reduction, small tiles
+// keep all 256 CUs busy when the batch is small
+int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_pairs) {
+  if (ctx->opt_rows_per_wave > 0) return ctx->opt_rows_per_wave;
+  const int candidates[4] = {8, 4, 2, 1};
+  for (int r : candidates) {
+    const int tiles = ((cam->w[level] + kTileW - 1) / kTileW) * ((cam->h[level] + kWavesPerBlock * r - 1) / (kWavesPerBlock * r));
+    if (size_t(tiles) * n_pairs >= 1024) return r;
+  }
+  return 1;
+}
+
+// device layout of a frame: [raw staging][per level: I Z A B R][sel counts]
+int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, dvo_hip_frame** out, size_t* raw_off) {
+  if (!ctx) return DVO_HIP_ERR_INVALID;
+  if (w < 4 || h < 4 || levels < 1 || levels > kMaxLevels || (w >> (levels - 1)) < 2 || (h >> (levels - 1)) < 2)
+    return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create: bad width/height/levels");
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const CameraGeom* cam = nullptr;
+  int rc = get_camera(ctx, w, h, K, levels, &cam);
+  if (rc != DVO_HIP_OK) return rc;
+  dvo_hip_frame* f = new dvo_hip_frame();
+  f->levels = levels;
+  f->cam = cam;
+  size_t total = align_up(size_t(w) * h * 3, 256);   // u8 grey + u16 depth staging
+  *raw_off = 0;
+  size_t offs[kMaxLevels][5];
+  for (int l = 0; l < levels; ++l) {
+    const size_t n = size_t(cam->w[l]) * cam->h[l];
+    const size_t sz[5] = {n * 4, n * 4, n * 16, n * 8, n * 16};
+    for (int k = 0; k < 5; ++k) {
+      offs[l][k] = total;
+      total += align_up(sz[k], 256);
+    }
+  }
+  const size_t cnt_off = total;
+  total += 256;
+  hipError_t e = f->pool.reserve(total);
+  if (e != hipSuccess) {
+    delete f;
+    ctx->err = std::string("hipMalloc(frame): ") + hipGetErrorString(e);
+    return DVO_HIP_ERR_HIP;
+  }
+  char* base = f->pool.as<char>();
+  for (int l = 0; l < levels; ++l) {
+    FrameLevel& L = f->lv[l];
+    L.w = cam->w[l]; L.h = cam->h[l];
+    L.I = reinterpret_cast<float*>(base + offs[l][0]);
+    L.Z = reinterpret_cast<float*>(base + offs[l][1]);
+    L.A = reinterpret_cast<float4*>(base + offs[l][2]);
+    L.B = reinterpret_cast<float2*>(base + offs[l][3]);
+    L.R = reinterpret_cast<float4*>(base + offs[l][4]);
+  }
+  f->sel_count = reinterpret_cast<int*>(base + cnt_off);
+  *out = f;
+  return DVO_HIP_OK;
+}
+
+// RgbdImagePyramid::build + buildAccelerationStructure + PointSelection (default thresholds 0/0) for every
+// level of n frames of one camera: one launch per level for the whole batch.  grey/raw may be null arrays for
+// frames whose level-0 float planes were uploaded directly.
+int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, const void* const* grey, const void* const* raw,
+                 float depth_scale) {
+  const CameraGeom* cam = frames[0]->cam;
+  const int levels = frames[0]->levels;
+  std::vector<FrameBuildPtrs> host(n);
+  for (int i = 0; i < n; ++i) {
+    dvo_hip_frame* f = frames[i];
+    if (f->cam != cam || f->levels != levels) return fail(ctx, DVO_HIP_ERR_INVALID, "frames of one build batch must share camera and levels");
+    FrameBuildPtrs& p = host[i];
+    p.grey = grey ? static_cast<const uint8_t*>(grey[i]) : nullptr;
+    p.raw = raw ? static_cast<const uint16_t*>(raw[i]) : nullptr;
+    for (int l = 0; l < levels; ++l) {
+      p.I[l] = f->lv[l].I; p.Z[l] = f->lv[l].Z; p.A[l] = f->lv[l].A; p.B[l] = f->lv[l].B; p.R[l] = f->lv[l].R;
+      f->lv[l].selected = true;   // built below with the default predicate thresholds
+      f->lv[l].ithr = 0.0f;
+      f->lv[l].dthr = 0.0f;
+    }
+    p.sel_count = f->sel_count;
+  }
+  DVO_HIP_TRY(ctx, ctx->build_tbl.reserve(size_t(n) * sizeof(FrameBuildPtrs)));
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->build_tbl.p, host.data(), size_t(n) * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, ctx->stream));
+  const FrameBuildPtrs* tbl = ctx->build_tbl.as<FrameBuildPtrs>();
+  if (grey) launch_ingest_raw(ctx->stream, tbl, n, depth_scale, cam->w[0] * cam->h[0], levels);
+  for (int l = 0; l < levels; ++l) {
+    if (l > 0) launch_pyr_down(ctx->stream, tbl, n, l, cam->w[l - 1], cam->h[l - 1]);
+    launch_derive_pack(ctx->stream, tbl, n, l, cam->w[l], cam->h[l], 0.0f, 0.0f);
+  }
+  DVO_HIP_TRY(ctx, hipGetLastError());
+  return DVO_HIP_OK;
+}
+
+int ensure_selection(dvo_hip_context* ctx, dvo_hip_frame* f, int level, float ithr, float dthr, uint8_t* mask_dev) {
+  FrameLevel& L = f->lv[level];
+  if (L.selected && L.ithr == ithr && L.dthr == dthr && !mask_dev) return DVO_HIP_OK;
+  DVO_HIP_TRY(ctx, hipMemsetAsync(f->sel_count + level, 0, sizeof(int), ctx->stream));
+  launch_select_pack(ctx->stream, L.A, L.B, L.w * L.h, ithr, dthr, L.R, f->sel_count + level, mask_dev);
+  L.selected = true;
+  L.ithr = ithr;
+  L.dthr = dthr;
+  return DVO_HIP_OK;
+}
+
+struct BatchPlan {
+  int n = 0, nlev = 0, cap_levels = 0, cap_iters = 0;
+  SolverParams prm;
+  const CameraGeom* cam = nullptr;
+  std::vector<int> rpw;          // per absolute level
+  std::vector<LevelGeom> geom;   // per absolute level
+  PairPtrs* pair_ptrs = nullptr; // device [levels][n]
+};
+
+int prepare_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
+                  BatchPlan& bp) {
+  if (!ctx || n < 1 || !refs || !curs || !cfg) return fail(ctx, DVO_HIP_ERR_INVALID, "match: null argument");
+  if (cfg->first_level < cfg->last_level || cfg->last_level < 0 || cfg->first_level >= kMaxLevels)   // Config::IsSane, DT.cpp:74
+    return fail(ctx, DVO_HIP_ERR_INVALID, "match: need 0 <= last_level <= first_level < DVO_HIP_MAX_LEVELS");
+  if (cfg->max_iterations_per_level < 1) return fail(ctx, DVO_HIP_ERR_INVALID, "match: max_iterations_per_level < 1");
+  const int need_levels = cfg->first_level + 1;   // Config::getNumLevels
+  const CameraGeom* cam = refs[0] ? refs[0]->cam : nullptr;
+  for (int i = 0; i < n; ++i) {
+    if (!refs[i] || !curs[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "match: null frame");
+    if (refs[i]->levels < need_levels || curs[i]->levels < need_levels)
+      return fail(ctx, DVO_HIP_ERR_INVALID, "match: frame pyramid has fewer levels than first_level + 1");
+    if (refs[i]->cam != cam || curs[i]->cam != cam)
+      return fail(ctx, DVO_HIP_ERR_INVALID, "match: all frames of a batch must share size, intrinsics and level count");
+  }
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  bp.n = n;
+  bp.cam = cam;
+  bp.nlev = cfg->first_level - cfg->last_level + 1;
+  bp.cap_levels = bp.nlev;
+  bp.cap_iters = bp.nlev * cfg->max_iterations_per_level;
+  bp.prm.max_iterations = cfg->max_iterations_per_level;
+  bp.prm.first_level = cfg->first_level;
+  bp.prm.last_level = cfg->last_level;
+  bp.prm.use_initial_estimate = cfg->use_initial_estimate;
+  bp.prm.precision = cfg->precision;
+  bp.prm.mu = cfg->mu;
+  bp.prm.cap_iters = bp.cap_iters;
+  bp.prm.cap_levels = bp.cap_levels;
+  bp.prm.max_points_level0 = cam->w0 * cam->h0;
+  bp.rpw.assign(need_levels, 1);
+  bp.geom.resize(need_levels);
+  size_t max_tiles = 1;
+  for (int l = cfg->last_level; l <= cfg->first_level; ++l) {
+    bp.rpw[l] = pick_rows_per_wave(ctx, cam, l, n);
+    bp.geom[l] = make_geom(cam, l, bp.rpw[l]);
+    max_tiles = std::max(max_tiles, size_t(bp.geom[l].tiles_x) * bp.geom[l].tiles_y);
+  }
+  const size_t npx = size_t(cam->w[cfg->last_level]) * cam->h[cfg->last_level];
+  DVO_HIP_TRY(ctx, ctx->states.reserve(size_t(n) * sizeof(PairState)));
+  DVO_HIP_TRY(ctx, ctx->pair_ptrs.reserve(size_t(n) * need_levels * sizeof(PairPtrs)));
+  DVO_HIP_TRY(ctx, ctx->partials.reserve(size_t(n) * max_tiles * kAccStride * sizeof(float)));
+  DVO_HIP_TRY(ctx, ctx->scratch.reserve(size_t(n) * npx * sizeof(float2)));
+  DVO_HIP_TRY(ctx, ctx->ll_partials.reserve(size_t(n) * kLlBlocksPerPair * sizeof(double)));
+  DVO_HIP_TRY(ctx, ctx->lvl_stats.reserve(size_t(n) * bp.cap_levels * sizeof(dvo_hip_level_stats)));
+  DVO_HIP_TRY(ctx, ctx->it_stats.reserve(size_t(n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats)));
+  DVO_HIP_TRY(ctx, ctx->results.reserve(size_t(n) * sizeof(dvo_hip_result)));
+  DVO_HIP_TRY(ctx, ctx->t_init.reserve(size_t(n) * 16 * sizeof(double)));
+  DVO_HIP_TRY(ctx, ctx->counters.reserve(size_t(bp.cap_iters + 8) * sizeof(int)));
+
+  // PointSelection::select for every reference level (cached per frame), then the pointer tables
+  std::vector<PairPtrs> host(size_t(n) * need_levels);
+  for (int l = cfg->last_level; l <= cfg->first_level; ++l)
+    for (int i = 0; i < n; ++i) {
+      int rc = ensure_selection(ctx, refs[i], l, cfg->intensity_derivative_threshold, cfg->depth_derivative_threshold, nullptr);
+      if (rc != DVO_HIP_OK) return rc;
+      PairPtrs& p = host[size_t(l) * n + i];
+      p.refR = refs[i]->lv[l].R;
+      p.curA = curs[i]->lv[l].A;
+      p.curB = curs[i]->lv[l].B;
+      p.n_selected = refs[i]->sel_count + l;
+    }
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs), hipMemcpyHostToDevice, ctx->stream));
+  DVO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `host` goes out of scope
+  bp.pair_ptrs = ctx->pair_ptrs.as<PairPtrs>();
+  return DVO_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dvo_hip_version(void) { return "dvo_hip 0.1 (gfx950)"; }
+
+int dvo_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int dvo_hip_context_create(int device, dvo_hip_context** out) {
+  if (!out) return DVO_HIP_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = "no HIP device available (libdvo_hip has no CPU fallback)";
+    return DVO_HIP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    g_create_error = "device index out of range";
+    return DVO_HIP_ERR_INVALID;
+  }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    return DVO_HIP_ERR_HIP;
+  }
+  dvo_hip_context* ctx = new dvo_hip_context();
+  ctx->device = device;
+  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counter), 64, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    g_create_error = std::string("context setup: ") + hipGetErrorString(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DVO_HIP_ERR_HIP;
+  }
+  *out = ctx;
+  return DVO_HIP_OK;
+}
+
+void dvo_hip_context_destroy(dvo_hip_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (DevBuf* b : {&ctx->states, &ctx->pair_ptrs, &ctx->partials, &ctx->scratch, &ctx->ll_partials, &ctx->lvl_stats,
+                    &ctx->it_stats, &ctx->results, &ctx->t_init, &ctx->counters, &ctx->misc, &ctx->build_tbl})
+    b->release();
+  for (CameraGeom* c : ctx->cameras) {
+    c->tables.release();
+    delete c;
+  }
+  if (ctx->host_counter) (void)hipHostFree(ctx->host_counter);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* dvo_hip_last_error(const dvo_hip_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void* dvo_hip_context_stream(dvo_hip_context* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
+  if (!ctx || !key) return DVO_HIP_ERR_INVALID;
+  if (std::strcmp(key, "rows_per_wave") == 0) {
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
+      return fail(ctx, DVO_HIP_ERR_INVALID, "rows_per_wave must be 0,1,2,4,8,16");
+    ctx->opt_rows_per_wave = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "iters_per_sync") == 0) {
+    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "iters_per_sync must be >= 0");
+    ctx->opt_iters_per_sync = value;
+    return DVO_HIP_OK;
+  }
+  return fail(ctx, DVO_HIP_ERR_INVALID, "unknown option");
+}
+
+int dvo_hip_frame_create_f32(dvo_hip_context* ctx, int width, int height, const float K[4], const float* intensity,
+                             const float* depth, int levels, dvo_hip_frame** out) {
+  if (!ctx || !out || !intensity || !depth || !K) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create_f32: null argument");
+  size_t raw_off;
+  dvo_hip_frame* f = nullptr;
+  int rc = frame_alloc(ctx, width, height, K, levels, &f, &raw_off);
+  if (rc != DVO_HIP_OK) return rc;
+  const size_t n = size_t(width) * height;
+  hipError_t e = hipMemcpyAsync(f->lv[0].I, intensity, n * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(f->lv[0].Z, depth, n * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(f->sel_count, 0, sizeof(int) * kMaxLevels, ctx->stream);
+  if (e == hipSuccess) {
+    rc = frames_build(ctx, 1, &f, nullptr, nullptr, 0.0f);
+    if (rc == DVO_HIP_OK) e = hipStreamSynchronize(ctx->stream);   // the caller's host buffers may go away
+  }
+  if (e != hipSuccess) ctx->err = std::string("frame_create_f32: ") + hipGetErrorString(e);
+  if (e != hipSuccess || rc != DVO_HIP_OK) {
+    dvo_hip_frame_destroy(ctx, f);
+    return rc != DVO_HIP_OK ? rc : DVO_HIP_ERR_HIP;
+  }
+  *out = f;
+  return DVO_HIP_OK;
+}
+
+int dvo_hip_frame_create_raw(dvo_hip_context* ctx, int width, int height, const float K[4], const uint8_t* grey,
+                             const uint16_t* raw_depth, float depth_scale, int levels, dvo_hip_frame** out) {
+  if (!ctx || !out || !grey || !raw_depth || !K) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create_raw: null argument");
+  size_t raw_off;
+  dvo_hip_frame* f = nullptr;
+  int rc = frame_alloc(ctx, width, height, K, levels, &f, &raw_off);
+  if (rc != DVO_HIP_OK) return rc;
+  const size_t n = size_t(width) * height;
+  char* stage = f->pool.as<char>() + raw_off;
+  uint16_t* d_raw = reinterpret_cast<uint16_t*>(stage);
+  uint8_t* d_grey = reinterpret_cast<uint8_t*>(stage + n * 2);
+  hipError_t e = hipMemcpyAsync(d_raw, raw_depth, n * 2, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_grey, grey, n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    const void* g[1] = {d_grey};
+    const void* r[1] = {d_raw};
+    rc = frames_build(ctx, 1, &f, g, r, depth_scale);
+    if (rc == DVO_HIP_OK) e = hipStreamSynchronize(ctx->stream);
+  }
+  if (e != hipSuccess) ctx->err = std::string("frame_create_raw: ") + hipGetErrorString(e);
+  if (e != hipSuccess || rc != DVO_HIP_OK) {
+    dvo_hip_frame_destroy(ctx, f);
+    return rc != DVO_HIP_OK ? rc : DVO_HIP_ERR_HIP;
+  }
+  *out = f;
+  return DVO_HIP_OK;
+}
+
+int dvo_hip_frame_create_raw_device(dvo_hip_context* ctx, int width, int height, const float K[4], const void* grey_dev,
+                                    const void* raw_depth_dev, float depth_scale, int levels, dvo_hip_frame** out) {
+  if (!ctx || !out || !grey_dev || !raw_depth_dev || !K) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create_raw_device: null argument");
+  size_t raw_off;
+  dvo_hip_frame* f = nullptr;
+  int rc = frame_alloc(ctx, width, height, K, levels, &f, &raw_off);
+  if (rc != DVO_HIP_OK) return rc;
+  const void* g[1] = {grey_dev};
+  const void* r[1] = {raw_depth_dev};
+  rc = frames_build(ctx, 1, &f, g, r, depth_scale);
+  if (rc != DVO_HIP_OK) {
+    dvo_hip_frame_destroy(ctx, f);
+    return rc;
+  }
+  *out = f;   // asynchronous: later work on this context's stream is ordered after the build
+  return DVO_HIP_OK;
+}
+
+int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
+                                     const void* const* raw_depth_dev, float depth_scale) {
+  if (!ctx || n_frames < 1 || !frames || !grey_dev || !raw_depth_dev) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device: null argument");
+  for (int i = 0; i < n_frames; ++i)
+    if (!frames[i] || !grey_dev[i] || !raw_depth_dev[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device: null entry");
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return frames_build(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale);
+}
+
+int dvo_hip_frame_update_raw_device(dvo_hip_context* ctx, dvo_hip_frame* frame, const void* grey_dev, const void* raw_depth_dev,
+                                    float depth_scale) {
+  dvo_hip_frame* f[1] = {frame};
+  const void* g[1] = {grey_dev};
+  const void* r[1] = {raw_depth_dev};
+  return dvo_hip_frames_update_raw_device(ctx, 1, f, g, r, depth_scale);
+}
+
+void dvo_hip_frame_destroy(dvo_hip_context* ctx, dvo_hip_frame* frame) {
+  if (!frame) return;
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  frame->pool.release();
+  delete frame;
+}
+
+int dvo_hip_frame_info(const dvo_hip_frame* frame, int level, int* width, int* height, float K[4]) {
+  if (!frame || level < 0 || level >= frame->levels) return DVO_HIP_ERR_INVALID;
+  if (width) *width = frame->lv[level].w;
+  if (height) *height = frame->lv[level].h;
+  if (K) std::memcpy(K, frame->cam->K[level], 16);
+  return DVO_HIP_OK;
+}
+
+int dvo_hip_frame_download_plane(dvo_hip_context* ctx, dvo_hip_frame* frame, int level, int plane, float* out) {
+  if (!ctx || !frame || !out || level < 0 || level >= frame->levels || plane < 0 || plane > 5)
+    return fail(ctx, DVO_HIP_ERR_INVALID, "frame_download_plane: bad argument");
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const FrameLevel& L = frame->lv[level];
+  const size_t n = size_t(L.w) * L.h;
+  DVO_HIP_TRY(ctx, ctx->misc.reserve(n * 4));
+  launch_unpack_plane(ctx->stream, L.A, L.B, int(n), plane, ctx->misc.as<float>());
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->misc.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DVO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DVO_HIP_OK;
+}
+
+int dvo_hip_frame_select(dvo_hip_context* ctx, dvo_hip_frame* frame, int level, float ithr, float dthr, int* n_selected,
+                         uint8_t* mask_or_null) {
+  if (!ctx || !frame || level < 0 || level >= frame->levels) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_select: bad argument");
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n = size_t(frame->lv[level].w) * frame->lv[level].h;
+  uint8_t* mask_dev = nullptr;
+  if (mask_or_null) {
+    DVO_HIP_TRY(ctx, ctx->misc.reserve(n));
+    mask_dev = ctx->misc.as<uint8_t>();
+  }
+  int rc = ensure_selection(ctx, frame, level, ithr, dthr, mask_dev);
+  if (rc != DVO_HIP_OK) return rc;
+  int count = 0;
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(&count, frame->sel_count + level, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  if (mask_or_null) DVO_HIP_TRY(ctx, hipMemcpyAsync(mask_or_null, mask_dev, n, hipMemcpyDeviceToHost, ctx->stream));
+  DVO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_selected) *n_selected = count;
+  return DVO_HIP_OK;
+}
+
+int dvo_hip_match_batch(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
+                        const dvo_hip_config* cfg, dvo_hip_result* results, dvo_hip_level_stats* levels, int cap_levels,
+                        dvo_hip_iteration_stats* iters, int cap_iters) {
+  if (!results) return fail(ctx, DVO_HIP_ERR_INVALID, "match: results is null");
+  BatchPlan bp;
+  int rc = prepare_batch(ctx, n_pairs, references, currents, cfg, bp);
+  if (rc != DVO_HIP_OK) return rc;
+  hipStream_t s = ctx->stream;
+  const int n = bp.n;
+
+  // initial guesses (Result.Transformation is in/out, dense_tracking.cpp:137-147)
+  std::vector<double> tinit(size_t(n) * 16);
+  for (int i = 0; i < n; ++i) std::memcpy(&tinit[size_t(i) * 16], results[i].transformation, 16 * sizeof(double));
+  if (cfg->use_initial_estimate)
+    for (double v : tinit)
+      if (!std::isfinite(v)) return fail(ctx, DVO_HIP_ERR_INVALID, "match: provided initialization is NaN (dense_tracking.cpp:139)");
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->t_init.p, tinit.data(), tinit.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  DVO_HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, size_t(bp.cap_iters + 8) * sizeof(int), s));
+
+  PairState* states = ctx->states.as<PairState>();
+  dvo_hip_level_stats* d_levels = ctx->lvl_stats.as<dvo_hip_level_stats>();
+  dvo_hip_iteration_stats* d_iters = ctx->it_stats.as<dvo_hip_iteration_stats>();
+  int* counters = ctx->counters.as<int>();
+  launch_init_pairs(s, states, n, bp.prm, ctx->t_init.as<double>());
+
+  const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 4;
+  int step = 0;
+  for (int level = cfg->first_level; level >= cfg->last_level; --level) {
+    const LevelGeom& g = bp.geom[level];
+    const PairPtrs* pp = bp.pair_ptrs + size_t(level) * n;
+    launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels);
+    int it = 0;
+    while (it < cfg->max_iterations_per_level) {
+      const int chunk = std::min(per_sync, cfg->max_iterations_per_level - it);
+      for (int c = 0; c < chunk; ++c, ++step) {
+        launch_residual_reduce(s, bp.rpw[level], level == 0, g, pp, states, n, ctx->partials.as<float>(), ctx->scratch.as<float2>());
+        launch_loglik(s, g, states, n, ctx->partials.as<float>(), ctx->scratch.as<float2>(), ctx->ll_partials.as<double>(), kLlBlocksPerPair);
+        launch_solver_step(s, states, n, bp.prm, g, ctx->partials.as<float>(), ctx->ll_partials.as<double>(), kLlBlocksPerPair,
+                           d_levels, d_iters, counters + step);
+      }
+      it += chunk;
+      DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->host_counter, counters + (step - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+      DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
+      if (*ctx->host_counter == 0) break;   // every pair left this level
+    }
+  }
+  launch_finish(s, states, n, bp.prm, d_levels, d_iters, ctx->results.as<dvo_hip_result>());
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(results, ctx->results.p, size_t(n) * sizeof(dvo_hip_result), hipMemcpyDeviceToHost, s));
+  std::vector<dvo_hip_level_stats> hl;
+  std::vector<dvo_hip_iteration_stats> hi;
+  if (levels && cap_levels > 0) {
+    hl.resize(size_t(n) * bp.cap_levels);
+    DVO_HIP_TRY(ctx, hipMemcpyAsync(hl.data(), d_levels, hl.size() * sizeof(dvo_hip_level_stats), hipMemcpyDeviceToHost, s));
+  }
+  if (iters && cap_iters > 0) {
+    hi.resize(size_t(n) * bp.cap_iters);
+    DVO_HIP_TRY(ctx, hipMemcpyAsync(hi.data(), d_iters, hi.size() * sizeof(dvo_hip_iteration_stats), hipMemcpyDeviceToHost, s));
+  }
+  DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
+  DVO_HIP_TRY(ctx, hipGetLastError());
+  bool truncated = false;
+  for (int i = 0; i < n; ++i) {
+    if (!hl.empty()) {
+      const int nl = std::min(results[i].n_levels, std::min(cap_levels, bp.cap_levels));
+      std::memcpy(levels + size_t(i) * cap_levels, &hl[size_t(i) * bp.cap_levels], size_t(nl) * sizeof(dvo_hip_level_stats));
+      truncated |= results[i].n_levels > cap_levels;
+    }
+    if (!hi.empty()) {
+      const int ni = std::min(results[i].n_iterations_total, std::min(cap_iters, bp.cap_iters));
+      std::memcpy(iters + size_t(i) * cap_iters, &hi[size_t(i) * bp.cap_iters], size_t(ni) * sizeof(dvo_hip_iteration_stats));
+      truncated |= results[i].n_iterations_total > cap_iters;
+    }
+  }
+  if (truncated) return fail(ctx, DVO_HIP_ERR_CAPACITY, "match: statistics arrays too small (results are valid)");
+  return DVO_HIP_OK;
+}
+
+int dvo_hip_match(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame* current, const dvo_hip_config* cfg,
+                  dvo_hip_result* result, dvo_hip_level_stats* levels, int cap_levels, dvo_hip_iteration_stats* iters, int cap_iters) {
+  dvo_hip_frame* r[1] = {reference};
+  dvo_hip_frame* c[1] = {current};
+  return dvo_hip_match_batch(ctx, 1, r, c, cfg, result, levels, cap_levels, iters, cap_iters);
+}
+
+int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame* current, int level, float ithr,
+                            float dthr, const float T34[12], const float P_prev[4], int first_iteration_on_level,
+                            dvo_hip_iteration_out* out, float* residuals_or_null) {
+  if (!ctx || !reference || !current || !T34 || !P_prev || !out) return fail(ctx, DVO_HIP_ERR_INVALID, "level_iteration: null argument");
+  dvo_hip_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.first_level = level;
+  cfg.last_level = level;
+  cfg.max_iterations_per_level = 1;
+  cfg.intensity_derivative_threshold = ithr;
+  cfg.depth_derivative_threshold = dthr;
+  if (level < 0 || level >= reference->levels || level >= current->levels) return fail(ctx, DVO_HIP_ERR_INVALID, "level_iteration: bad level");
+  dvo_hip_frame* r[1] = {reference};
+  dvo_hip_frame* c[1] = {current};
+  BatchPlan bp;
+  int rc = prepare_batch(ctx, 1, r, c, &cfg, bp);
+  if (rc != DVO_HIP_OK) return rc;
+  hipStream_t s = ctx->stream;
+  const LevelGeom& g = bp.geom[level];
+  const size_t npx = size_t(g.w) * g.h;
+  DVO_HIP_TRY(ctx, ctx->misc.reserve(256 + sizeof(dvo_hip_iteration_out)));
+  float* d_T = ctx->misc.as<float>();
+  float* d_P = d_T + 12;
+  dvo_hip_iteration_out* d_out = reinterpret_cast<dvo_hip_iteration_out*>(ctx->misc.as<char>() + 256);
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(d_T, T34, 48, hipMemcpyHostToDevice, s));
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(d_P, P_prev, 16, hipMemcpyHostToDevice, s));
+  PairState* states = ctx->states.as<PairState>();
+  DVO_HIP_TRY(ctx, hipMemsetAsync(states, 0, sizeof(PairState), s));
+  launch_set_fixed_state(s, states, g, d_T, d_P, first_iteration_on_level ? 1 : 0);
+  const PairPtrs* pp = bp.pair_ptrs + size_t(level);
+  launch_residual_reduce(s, bp.rpw[level], level == 0, g, pp, states, 1, ctx->partials.as<float>(), ctx->scratch.as<float2>());
+  launch_loglik(s, g, states, 1, ctx->partials.as<float>(), ctx->scratch.as<float2>(), ctx->ll_partials.as<double>(), kLlBlocksPerPair);
+  int n_sel = 0;
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(&n_sel, reference->sel_count + level, sizeof(int), hipMemcpyDeviceToHost, s));
+  DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
+  launch_single_shot_out(s, g, ctx->partials.as<float>(), ctx->ll_partials.as<double>(), kLlBlocksPerPair, n_sel, d_out);
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(out, d_out, sizeof(dvo_hip_iteration_out), hipMemcpyDeviceToHost, s));
+  if (residuals_or_null) DVO_HIP_TRY(ctx, hipMemcpyAsync(residuals_or_null, ctx->scratch.p, npx * sizeof(float2), hipMemcpyDeviceToHost, s));
+  DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
+  DVO_HIP_TRY(ctx, hipGetLastError());
+  return DVO_HIP_OK;
+}
+
+int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
+                                 int level, int reps, float* avg_ms) {
+  if (!avg_ms || reps < 1) return fail(ctx, DVO_HIP_ERR_INVALID, "time_residual_kernel: bad argument");
+  dvo_hip_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.first_level = level;
+  cfg.last_level = level;
+  cfg.max_iterations_per_level = 1;
+  BatchPlan bp;
+  int rc = prepare_batch(ctx, n_pairs, references, currents, &cfg, bp);
+  if (rc != DVO_HIP_OK) return rc;
+  hipStream_t s = ctx->stream;
+  const LevelGeom& g = bp.geom[level];
+  const PairPtrs* pp = bp.pair_ptrs + size_t(level) * bp.n;
+  std::vector<double> tinit(size_t(bp.n) * 16, 0.0);
+  for (int i = 0; i < bp.n; ++i)
+    for (int k = 0; k < 4; ++k) tinit[size_t(i) * 16 + k * 5] = 1.0;
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->t_init.p, tinit.data(), tinit.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  PairState* states = ctx->states.as<PairState>();
+  launch_init_pairs(s, states, bp.n, bp.prm, ctx->t_init.as<double>());
+  launch_level_begin(s, states, bp.n, bp.prm, g, level, pp, ctx->lvl_stats.as<dvo_hip_level_stats>());
+  hipEvent_t e0, e1;
+  DVO_HIP_TRY(ctx, hipEventCreate(&e0));
+  DVO_HIP_TRY(ctx, hipEventCreate(&e1));
+  launch_residual_reduce(s, bp.rpw[level], level == 0, g, pp, states, bp.n, ctx->partials.as<float>(), ctx->scratch.as<float2>());   // warm
+  DVO_HIP_TRY(ctx, hipEventRecord(e0, s));
+  for (int r = 0; r < reps; ++r)
+    launch_residual_reduce(s, bp.rpw[level], level == 0, g, pp, states, bp.n, ctx->partials.as<float>(), ctx->scratch.as<float2>());
+  DVO_HIP_TRY(ctx, hipEventRecord(e1, s));
+  DVO_HIP_TRY(ctx, hipEventSynchronize(e1));
+  float ms = 0;
+  DVO_HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  DVO_HIP_TRY(ctx, hipGetLastError());
+  *avg_ms = ms / float(reps);
+  return DVO_HIP_OK;
+}
+
+}  // extern "C"

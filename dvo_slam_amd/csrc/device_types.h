@@ -1,0 +1,92 @@
+// device_types.h -- PODs shared by the host side (capi.hip) and the gfx950 kernels.
+#pragma once
+
+#include <stdint.h>
+
+#include "hd_compat.h"
+
+#include "../../include/dvo_hip.h"
+
+namespace dvo_hip {
+
+constexpr int kMaxLevels = DVO_HIP_MAX_LEVELS;
+constexpr int kBlock = 256;          // 4 wavefronts of 64
+constexpr int kWavesPerBlock = 4;
+constexpr int kTileW = 64;           // one wavefront spans 64 consecutive pixels of a row
+
+// Accumulator layout of the fused residual/Jacobian/reduce kernel (all float):
+//   0            n  (count of valid constraints)
+//   1..3         S00 S01 S11          = sum w r r^T                    (scale, DT.cpp:295)
+//   4..24        sum w J0_i J0_j  (i<=j, row-major upper triangle)
+//   25..45       sum w J1_i J1_j
+//   46..66       sum w (J0_i J1_j + J0_j J1_i)
+//   67..72       sum w J0_k r0
+//   73..78       sum w (J0_k r1 + J1_k r0)
+//   79..84       sum w J1_k r1
+// The 2x2 precision P is only known after the pass (it is the inverse of S/(n-3)), so the pass
+// accumulates the P-independent Gram sums and the tiny per-pair solver kernel contracts them with P.
+constexpr int kAccN = 0, kAccS = 1, kAccJ00 = 4, kAccJ11 = 25, kAccJ01 = 46, kAccB00 = 67, kAccB01 = 73, kAccB11 = 79;
+constexpr int kNumAcc = 85;
+constexpr int kAccStride = 88;       // padded row of the per-block partial table
+
+struct LevelGeom {                    // identical for every pair of a batch (one camera)
+  int w, h;
+  float fx, fy, ox, oy;
+  float wi_x, wi_y;                   // 0.5f * fx / 255.0f, 0.5f * fy / 255.0f (intensity-gradient weights)
+  const float* tx;                    // (u - ox)/fx per column, the reference's pointcloud_template_
+  const float* ty;                    // (v - oy)/fy per row
+  int tiles_x, tiles_y;
+};
+
+struct PairPtrs {                     // device planes of one pair at one level
+  const float4* refR;                 // {Z (NaN = not selected), I, Idx, Idy}   16 B / pixel, streamed
+  const float4* curA;                 // {I, Z, Idx, Idy}                        16 B / pixel, gathered
+  const float2* curB;                 // {Zdx, Zdy}                               8 B / pixel, gathered
+  const int* n_selected;              // device counter: selected reference pixels at this level
+};
+
+struct FrameBuildPtrs {                // one frame of a batched pyramid build
+  const uint8_t* grey;                 // raw planes (device), may be null for the float ingest path
+  const uint16_t* raw;
+  float* I[kMaxLevels];
+  float* Z[kMaxLevels];
+  float4* A[kMaxLevels];
+  float2* B[kMaxLevels];
+  float4* R[kMaxLevels];
+  int* sel_count;                      // one counter per level
+};
+
+struct SE3d {
+  double R[9];
+  double t[3];
+};
+
+struct PairState {
+  SE3d inc, initial, initial_old, estimate, estimate_old;
+  double x[6];
+  double error, last_error;
+  double A_last[36];
+  float KT[12];                       // float(K * estimate) for the residual kernel
+  float P_prev[4];                    // precision used for the weights of this pass
+  int level;                          // level this pair is working on
+  int iteration;                      // iterations completed on this level
+  int active;                         // 1 while the pair still iterates on `level`
+  int first;                          // first pass on the level: weights = 1
+  int n_iters_total;                  // iteration records written so far
+  int n_levels;                       // level records written so far
+  int level_first_iter;               // index of the first iteration record of the current level
+  int pad;
+};
+
+struct SolverParams {
+  int max_iterations;
+  int first_level, last_level;
+  int use_initial_estimate;
+  double precision;
+  double mu;
+  int cap_iters;                      // per-pair capacity of the iteration record array
+  int cap_levels;
+  int max_points_level0;
+};
+
+}  // namespace dvo_hip

@@ -1,0 +1,37 @@
+// launch.h -- host-callable launchers of the gfx950 kernels (one per .hip translation unit).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+namespace dvo_hip {
+
+// pyramid_kernels.hip
+void launch_ingest_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int n, int levels);
+void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h);
+void launch_derive_pack(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr);
+void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float4* R, int* count, uint8_t* mask);
+void launch_unpack_plane(hipStream_t s, const float4* A, const float2* B, int n, int plane, float* out);
+
+// align_kernels.hip
+void launch_residual_reduce(hipStream_t s, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
+                            const PairState* states, int n_pairs, float* partials, float2* scratch);
+void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,
+                   const float2* scratch, double* ll_partials, int blocks_per_pair);
+
+// solver_kernels.hip
+void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, const double* T_init);
+void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
+                        const PairPtrs* pairs, dvo_hip_level_stats* levels);
+void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
+                        const float* partials, const double* ll_partials, int ll_blocks_per_pair,
+                        dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, int* active_counter);
+void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverParams prm,
+                   const dvo_hip_level_stats* levels, const dvo_hip_iteration_stats* iters, dvo_hip_result* results);
+// single-shot linearisation for parity tests: fixed T34 / P_prev, no state machine
+void launch_set_fixed_state(hipStream_t s, PairState* states, LevelGeom g, const float* T34_dev, const float* Pprev_dev, int first);
+void launch_single_shot_out(hipStream_t s, LevelGeom g, const float* partials, const double* ll_partials, int ll_blocks_per_pair,
+                            int n_selected, dvo_hip_iteration_out* out_dev);
+
+}  // namespace dvo_hip

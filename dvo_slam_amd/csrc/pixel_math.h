@@ -1,0 +1,149 @@
+// pixel_math.h -- the per-pixel arithmetic of the alignment kernels (host/device inline functions).
+//
+// Used by align_kernels.hip on the GPU.  tests/ also compiles this header with the host compiler to
+// emulate the device code path pixel by pixel when no GPU is present (test-only).
+//
+// Semantics = the oracle's MATH mode: the reference algorithm (dvo_core/src/dense_tracking_impl.cpp:133-393,
+// dvo_core/src/dense_tracking.cpp:217-220, 448-476) with exact division instead of _mm_rcp_ps and
+// round-to-nearest instead of MXCSR round-toward-zero.  Everything that decides
+// validity or feeds the residual is written with floating-point contraction OFF and in the oracle's
+// operation order, so that the valid-pixel count and the residuals agree bit-for-bit with it.
+#pragma once
+
+#include "device_types.h"
+
+namespace dvo_hip {
+
+// reciprocal for the Jacobian (not parity-critical): v_rcp_f32 (1 ulp) on the device
+DVO_HD float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+
+struct PixelTerms {
+  float r0, r1;       // intensity / depth residual
+  float gix, giy;     // intensity gradient row  (0.5 fx (Icx + Irx)/255 , 0.5 fy (Icy + Iry)/255)
+  float gzx, gzy;     // depth gradient row      (fx Zcx, fy Zcy)
+  float X, Y, Z;      // untransformed reference point
+};
+
+// r^T P r with Eigen's (r^T P) r grouping; P row-major (dense_tracking_impl.cpp:415, :643)
+DVO_HD float mahalanobis(float r0, float r1, const float* P) {
+#pragma clang fp contract(off)
+  return (r0 * P[0] + r1 * P[2]) * r0 + (r0 * P[1] + r1 * P[3]) * r1;
+}
+
+// t-distribution weight, nu = 5: (2+5)/(5 + r^T P r)  (dense_tracking_impl.cpp:640-644)
+DVO_HD float tdist_weight(float r0, float r1, const float* P) {
+#pragma clang fp contract(off)
+  return 7.0f / (5.0f + mahalanobis(r0, r1, P));
+}
+
+// C = S/(n-3) rounded to float, P = C^-1 in Eigen's 2x2 inverse order (dense_tracking.cpp:295)
+DVO_HD void scale_to_precision(double c00, double c01, double c11, float* C, float* P) {
+#pragma clang fp contract(off)
+  C[0] = float(c00); C[1] = float(c01); C[2] = float(c11);
+  const float det = C[0] * C[2] - C[1] * C[1];
+  const float inv = 1.0f / det;
+  P[0] = C[2] * inv;
+  P[1] = -C[1] * inv;
+  P[2] = -C[1] * inv;
+  P[3] = C[0] * inv;
+}
+
+// float(K * T) in Eigen's coefficient order (dense_tracking_impl.cpp:142-148); T row-major 3x4 float
+DVO_HD void make_KT(float fx, float fy, float ox, float oy, const float* T, float* KT) {
+#pragma clang fp contract(off)
+  for (int j = 0; j < 4; ++j) {
+    KT[0 * 4 + j] = fx * T[0 * 4 + j] + 0.0f * T[1 * 4 + j] + ox * T[2 * 4 + j];
+    KT[1 * 4 + j] = 0.0f * T[0 * 4 + j] + fy * T[1 * 4 + j] + oy * T[2 * 4 + j];
+    KT[2 * 4 + j] = 0.0f * T[0 * 4 + j] + 0.0f * T[1 * 4 + j] + 1.0f * T[2 * 4 + j];
+  }
+}
+
+// Warp one reference pixel, sample the current frame, form the residual and the gradient rows.
+// Returns false if the pixel contributes no constraint.
+template <typename PtrA, typename PtrB>
+DVO_HD bool pixel_residual(const LevelGeom& g, const float* KT, PtrA curA, PtrB curB, const float4 ref, int u_r, int v_r,
+                           PixelTerms& o) {
+#pragma clang fp contract(off)
+  const float Z = ref.x;
+  if (!(Z == Z)) return false;                      // not selected / no depth (Q19)
+  const float X = g.tx[u_r] * Z;                    // rgbd_image.cpp:198-201, 258
+  const float Y = g.ty[v_r] * Z;
+  const float qx = (KT[0] * X + KT[1] * Y) + (KT[2] * Z + KT[3]);
+  const float qy = (KT[4] * X + KT[5] * Y) + (KT[6] * Z + KT[7]);
+  const float qz = (KT[8] * X + KT[9] * Y) + (KT[10] * Z + KT[11]);
+  const float u = qx / qz, v = qy / qz;             // correctly rounded division (MATH semantics, Q1)
+  if (!(u >= 0.0f && u <= float(g.w - 2) && v >= 0.0f && v <= float(g.h - 2))) return false;   // Q4
+  const float uf = floorf(u), vf = floorf(v);
+  const int u0 = int(uf), v0 = int(vf);
+  const float a1 = u - uf, a0 = 1.0f - a1, b1 = v - vf, b0 = 1.0f - b1;
+  const int base = v0 * g.w + u0;
+  const float4 A00 = curA[base], A10 = curA[base + 1], A01 = curA[base + g.w], A11 = curA[base + g.w + 1];
+  const float2 B00 = curB[base], B10 = curB[base + 1], B01 = curB[base + g.w], B11 = curB[base + g.w + 1];
+#define DVO_BILERP(f) (b0 * (a0 * A00.f + a1 * A10.f) + b1 * (a0 * A01.f + a1 * A11.f))
+  const float cI = DVO_BILERP(x), cZ = DVO_BILERP(y), cIx = DVO_BILERP(z), cIy = DVO_BILERP(w);
+#undef DVO_BILERP
+  const float cZx = b0 * (a0 * B00.x + a1 * B10.x) + b1 * (a0 * B01.x + a1 * B11.x);
+  const float cZy = b0 * (a0 * B00.y + a1 * B10.y) + b1 * (a0 * B01.y + a1 * B11.y);
+  if (!(cI == cI && cZ == cZ && cIx == cIx && cIy == cIy && cZx == cZx && cZy == cZy)) return false;   // Q9
+  // residual = wcur * interpolated + wref * reference with the weights of dense_tracking.cpp:217-220
+  const float inv255 = 1.0f / 255.0f;
+  o.r0 = inv255 * cI + (-inv255) * ref.y;
+  o.r1 = 1.0f * cZ + (-1.0f) * qz;                   // reference depth := transformed z (:269)
+  float sigma = Z - 0.4f;                            // dense_tracking_impl.cpp:122-128
+  sigma = 0.0012f + 0.0019f * sigma * sigma;
+  if (!(o.r1 > -20.0f * sigma)) return false;        // occlusion test (Q5)
+  const float wi_x = g.wi_x, wi_y = g.wi_y;          // 0.5 fx / 255, 0.5 fy / 255 (dense_tracking.cpp:219-220)
+  o.gix = wi_x * cIx + wi_x * ref.z;                 // ESM-style average of both gradients (Q10)
+  o.giy = wi_y * cIy + wi_y * ref.w;
+  o.gzx = (1.0f * g.fx) * cZx;                       // wref_zd = 0: current-frame depth gradient only
+  o.gzy = (1.0f * g.fy) * cZy;
+  o.X = X; o.Y = Y; o.Z = Z;
+  return true;
+}
+
+// 2x6 Jacobian at the UNtransformed reference point (Q10; dense_tracking.cpp:448-476, :333-340) and the
+// rank update of the P-independent Gram sums (layout in device_types.h).
+DVO_HD void accumulate_pixel(float* acc, const PixelTerms& t, float w) {
+  const float iz = fast_rcp(t.Z), iz2 = iz * iz;
+  float ja[6], jb[6];
+  ja[0] = iz; ja[1] = 0.0f; ja[2] = -t.X * iz2; ja[3] = ja[2] * t.Y; ja[4] = 1.0f - ja[2] * t.X; ja[5] = -t.Y * iz;
+  jb[0] = 0.0f; jb[1] = iz; jb[2] = -t.Y * iz2; jb[3] = -1.0f + jb[2] * t.Y; jb[4] = -ja[3]; jb[5] = t.X * iz;
+  const float jz[6] = {0.0f, 0.0f, 1.0f, t.Y, -t.X, 0.0f};
+  float J0[6], J1[6], wJ0[6], wJ1[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    J0[i] = t.gix * ja[i] + t.giy * jb[i];
+    J1[i] = (t.gzx * ja[i] + t.gzy * jb[i]) - jz[i];
+    wJ0[i] = w * J0[i];
+    wJ1[i] = w * J1[i];
+  }
+  acc[kAccN] += 1.0f;
+  acc[kAccS + 0] += w * t.r0 * t.r0;
+  acc[kAccS + 1] += w * t.r0 * t.r1;
+  acc[kAccS + 2] += w * t.r1 * t.r1;
+  int o = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = i; j < 6; ++j) {
+      acc[kAccJ00 + o] += wJ0[i] * J0[j];
+      acc[kAccJ11 + o] += wJ1[i] * J1[j];
+      acc[kAccJ01 + o] += wJ0[i] * J1[j] + wJ0[j] * J1[i];
+      ++o;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    acc[kAccB00 + i] += wJ0[i] * t.r0;
+    acc[kAccB01 + i] += wJ0[i] * t.r1 + wJ1[i] * t.r0;
+    acc[kAccB11 + i] += wJ1[i] * t.r1;
+  }
+}
+
+}  // namespace dvo_hip

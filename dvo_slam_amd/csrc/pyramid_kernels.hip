@@ -1,0 +1,128 @@
+// pyramid_kernels.hip -- device-resident image data model, batched over frames.
+//
+// What the reference does on the host per frame and per level
+//   ingest        dvo_benchmark/src/benchmark_slam.cpp:46-93, dvo_core/src/core/surface_pyramid.cpp:65-105
+//   pyr-down      dvo_core/src/core/rgbd_image.cpp:38-55 (2x2 mean), :127-139 (depth subsample), :156-172
+//   derivatives   dvo_core/src/core/rgbd_image.cpp:419-489, rgbd_image_sse.cpp:241-284
+//   accel struct  dvo_core/src/core/rgbd_image.cpp:534-543   (8 interleaved float channels, 32 B/pixel)
+//   selection     dvo_core/src/core/point_selection.cpp:89-152, point_selection.h:49-67
+// is done here on the GPU, one launch per pyramid level for a whole batch of frames (blockIdx.z = frame),
+// so a frame upload is two raw planes and every derived plane stays in HBM.  Layout (all float32):
+//   I, Z          planar, 4 B/pixel each (pyr-down source)
+//   A             float4 {I, Z, Idx, Idy}  current-side sampling plane, one 16-B tap per bilinear corner
+//   B             float2 {Zdx, Zdy}        current-side sampling plane,  8-B tap
+//   R             float4 {Zsel, I, Idx, Idy} reference-side stream; Zsel = NaN where the selection
+//                 predicate rejects the pixel, so the reduce kernel needs no separate mask or list
+// These are bandwidth-trivial elementwise kernels; they are written for coalescing only.
+#include "launch.h"
+
+namespace dvo_hip {
+
+__global__ void k_ingest_raw(const FrameBuildPtrs* __restrict__ tbl, float scale, int n, int levels) {
+  const FrameBuildPtrs& f = tbl[blockIdx.z];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < levels) f.sel_count[i] = 0;                  // the selection counters are rebuilt by k_derive_pack
+  if (i >= n) return;
+  f.I[0][i] = float(f.grey[i]);
+  const uint16_t d = f.raw[i];
+  f.Z[0][i] = d == 0 ? __builtin_nanf("") : float(d) * scale;
+}
+
+__global__ void k_pyr_down(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h) {
+#pragma clang fp contract(off)
+  const FrameBuildPtrs& f = tbl[blockIdx.z];
+  const float* __restrict__ I = f.I[level - 1];
+  const float* __restrict__ Z = f.Z[level - 1];
+  const int ow = w >> 1, oh = h >> 1;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= ow || y >= oh) return;
+  const float* r0 = I + size_t(2 * y) * w + 2 * x;
+  const float* r1 = r0 + w;
+  f.I[level][size_t(y) * ow + x] = (r0[0] + r0[1] + r1[0] + r1[1]) / 4.0f;   // same summation order as the reference
+  f.Z[level][size_t(y) * ow + x] = Z[size_t(2 * y) * w + 2 * x];             // top-left sample, NaN holes kept (Q18)
+}
+
+// central differences with clamped borders, the two sampling planes, and the reference-side stream with the
+// selection predicate folded into Z; counts the selected pixels
+__global__ void k_derive_pack(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h, float ithr, float dthr) {
+#pragma clang fp contract(off)
+  const FrameBuildPtrs& f = tbl[blockIdx.z];
+  const float* __restrict__ I = f.I[level];
+  const float* __restrict__ Z = f.Z[level];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  bool ok = false;
+  if (x < w && y < h) {
+    const int xp = max(x - 1, 0), xn = min(x + 1, w - 1);
+    const int yp = max(y - 1, 0), yn = min(y + 1, h - 1);
+    const size_t row = size_t(y) * w;
+    const float i0 = I[row + x], z0 = Z[row + x];
+    const float idx = (I[row + xn] - I[row + xp]) * 0.5f;
+    const float idy = (I[size_t(yn) * w + x] - I[size_t(yp) * w + x]) * 0.5f;
+    const float zdx = (Z[row + xn] - Z[row + xp]) * 0.5f;
+    const float zdy = (Z[size_t(yn) * w + x] - Z[size_t(yp) * w + x]) * 0.5f;
+    f.A[level][row + x] = make_float4(i0, z0, idx, idy);
+    f.B[level][row + x] = make_float2(zdx, zdy);
+    ok = z0 == z0 && zdx == zdx && zdy == zdy &&
+         (fabsf(idx) > ithr || fabsf(idy) > ithr || fabsf(zdx) > dthr || fabsf(zdy) > dthr);
+    f.R[level][row + x] = make_float4(ok ? z0 : __builtin_nanf(""), i0, idx, idy);
+  }
+  const unsigned long long ballot = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(f.sel_count + level, __popcll(ballot));
+}
+
+// re-selection with other thresholds (PointSelection with a different predicate), one frame
+__global__ void k_select_pack(const float4* __restrict__ A, const float2* __restrict__ B, int n, float ithr, float dthr,
+                              float4* __restrict__ R, int* __restrict__ count, uint8_t* __restrict__ mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (i < n) {
+    const float4 a = A[i];
+    const float2 b = B[i];
+    ok = a.y == a.y && b.x == b.x && b.y == b.y &&
+         (fabsf(a.z) > ithr || fabsf(a.w) > ithr || fabsf(b.x) > dthr || fabsf(b.y) > dthr);
+    R[i] = make_float4(ok ? a.y : __builtin_nanf(""), a.x, a.z, a.w);
+    if (mask) mask[i] = ok ? 1 : 0;
+  }
+  const unsigned long long ballot = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(count, __popcll(ballot));
+}
+
+__global__ void k_unpack_plane(const float4* __restrict__ A, const float2* __restrict__ B, int n, int plane, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v;
+  switch (plane) {
+    case 0: v = A[i].x; break;
+    case 1: v = A[i].y; break;
+    case 2: v = A[i].z; break;
+    case 3: v = A[i].w; break;
+    case 4: v = B[i].x; break;
+    default: v = B[i].y; break;
+  }
+  out[i] = v;
+}
+
+void launch_ingest_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int n, int levels) {
+  k_ingest_raw<<<dim3((n + 255) / 256, 1, n_frames), dim3(256), 0, s>>>(tbl, scale, n, levels);
+}
+
+void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h) {
+  const int ow = w / 2, oh = h / 2;
+  k_pyr_down<<<dim3((ow + 63) / 64, oh, n_frames), dim3(64), 0, s>>>(tbl, level, w, h);
+}
+
+void launch_derive_pack(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr) {
+  k_derive_pack<<<dim3((w + 63) / 64, h, n_frames), dim3(64), 0, s>>>(tbl, level, w, h, ithr, dthr);
+}
+
+void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float4* R, int* count, uint8_t* mask) {
+  k_select_pack<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(A, B, n, ithr, dthr, R, count, mask);
+}
+
+void launch_unpack_plane(hipStream_t s, const float4* A, const float2* B, int n, int plane, float* out) {
+  k_unpack_plane<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(A, B, n, plane, out);
+}
+
+}  // namespace dvo_hip

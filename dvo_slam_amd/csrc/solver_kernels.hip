@@ -1,0 +1,152 @@
+// solver_kernels.hip -- per-pair Gauss-Newton bookkeeping on the device (one workgroup per frame pair).
+//
+// k_solver_step finishes the deterministic reduction (stage 3: the per-tile float partials are summed
+// in tile order in float64), then lane 0 runs the reference's loop body after the residual sweep:
+// precision, log-likelihood, accept/revert, normal-equation contraction, 6x6 solve, SE(3) update,
+// termination (dvo_core/src/dense_tracking.cpp:273-363; logic in solver_logic.h).  Keeping this on the
+// device removes the per-iteration D2H/H2D round trip a host-driven loop would need; the host only
+// polls one integer (pairs still active) every few iterations.
+#include "launch.h"
+#include "reduce_scale.h"
+#include "solver_logic.h"
+
+namespace dvo_hip {
+
+__global__ void k_init_pairs(PairState* states, int n_pairs, SolverParams prm, const double* __restrict__ T_init) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  gn_init_pair(states[p], prm, T_init + size_t(p) * 16);
+}
+
+__global__ void k_level_begin(PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
+                              const PairPtrs* __restrict__ pairs, dvo_hip_level_stats* levels) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  gn_level_begin(states[p], prm, g, level, *pairs[p].n_selected, levels + size_t(p) * prm.cap_levels);
+}
+
+__global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
+                                                        const float* __restrict__ partials,
+                                                        const double* __restrict__ ll_partials, int ll_blocks_per_pair,
+                                                        dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters,
+                                                        int* active_counter) {
+  const int pair = blockIdx.x;
+  PairState& st = states[pair];
+  if (!st.active) return;   // uniform
+  __shared__ double sh[4 * kBlock];
+  __shared__ double sums[kAccStride];
+  __shared__ double ll_sum;
+  const int tiles = g.tiles_x * g.tiles_y;
+  float C[3], P[4];
+  double s4[4];
+  reduce_scale(partials, pair, tiles, sh, s4, C, P);
+  const int tid = threadIdx.x;
+  if (tid < kNumAcc) {
+    double s = 0.0;
+    const float* p = partials + size_t(pair) * tiles * kAccStride + tid;
+    for (int b = 0; b < tiles; ++b) s += double(p[size_t(b) * kAccStride]);
+    sums[tid] = s;
+  }
+  if (tid == kBlock - 1) {
+    double s = 0.0;
+    const double* p = ll_partials + size_t(pair) * ll_blocks_per_pair;
+    for (int b = 0; b < ll_blocks_per_pair; ++b) s += p[b];
+    ll_sum = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // n and S must be the very values the log-likelihood kernel derived P from
+    sums[kAccN] = s4[0]; sums[kAccS] = s4[1]; sums[kAccS + 1] = s4[2]; sums[kAccS + 2] = s4[3];
+    gn_step(st, prm, g, sums, ll_sum, levels + size_t(pair) * prm.cap_levels, iters + size_t(pair) * prm.cap_iters);
+    if (st.active) atomicAdd(active_counter, 1);
+  }
+}
+
+__global__ void k_finish(const PairState* states, int n_pairs, SolverParams prm, const dvo_hip_level_stats* levels,
+                         const dvo_hip_iteration_stats* iters, dvo_hip_result* results) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  gn_finish(states[p], prm, levels + size_t(p) * prm.cap_levels, iters + size_t(p) * prm.cap_iters, results + p);
+}
+
+// ---- single-shot linearisation (parity entry point dvo_hip_level_iteration) ---------------------------
+__global__ void k_set_fixed_state(PairState* states, LevelGeom g, const float* __restrict__ T34, const float* __restrict__ Pprev, int first) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  PairState& st = states[0];
+  float T[12];
+  for (int i = 0; i < 12; ++i) T[i] = T34[i];
+  make_KT(g.fx, g.fy, g.ox, g.oy, T, st.KT);
+  for (int i = 0; i < 4; ++i) st.P_prev[i] = Pprev[i];
+  st.first = first;
+  st.active = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_single_shot_out(LevelGeom g, const float* __restrict__ partials,
+                                                            const double* __restrict__ ll_partials, int ll_blocks_per_pair,
+                                                            int n_selected, dvo_hip_iteration_out* out) {
+  __shared__ double sh[4 * kBlock];
+  __shared__ double sums[kAccStride];
+  const int tiles = g.tiles_x * g.tiles_y;
+  float C[3], P[4];
+  double s4[4];
+  const int n = reduce_scale(partials, 0, tiles, sh, s4, C, P);
+  const int tid = threadIdx.x;
+  if (tid < kNumAcc) {
+    double s = 0.0;
+    for (int b = 0; b < tiles; ++b) s += double(partials[size_t(b) * kAccStride + tid]);
+    sums[tid] = s;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  out->n = n;
+  out->n_selected = n_selected;
+  out->sum_w = 0.0;
+  for (int i = 0; i < 3; ++i) out->scale_cov[i] = C[i];
+  for (int i = 0; i < 4; ++i) out->precision[i] = P[i];
+  double ll_sum = 0.0;
+  for (int b = 0; b < ll_blocks_per_pair; ++b) ll_sum += ll_partials[b];
+  const double det = double(P[0]) * double(P[3]) - double(P[1]) * double(P[2]);
+  out->neg_loglik = -(0.5 * double(n) * log(det) - 3.5 * ll_sum);
+  const double p00 = double(P[0]), p01 = double(P[1]), p11 = double(P[3]);
+  int o = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) {
+      const double a = p00 * sums[kAccJ00 + o] + p01 * sums[kAccJ01 + o] + p11 * sums[kAccJ11 + o];
+      out->A[i * 6 + j] = a;
+      out->A[j * 6 + i] = a;
+      ++o;
+    }
+  for (int i = 0; i < 6; ++i) out->b[i] = -(p00 * sums[kAccB00 + i] + p01 * sums[kAccB01 + i] + p11 * sums[kAccB11 + i]);
+}
+
+void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, const double* T_init) {
+  k_init_pairs<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, T_init);
+}
+
+void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
+                        const PairPtrs* pairs, dvo_hip_level_stats* levels) {
+  k_level_begin<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, g, level, pairs, levels);
+}
+
+void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
+                        const float* partials, const double* ll_partials, int ll_blocks_per_pair,
+                        dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, int* active_counter) {
+  k_solver_step<<<dim3(n_pairs), dim3(kBlock), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
+                                                       levels, iters, active_counter);
+}
+
+void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverParams prm,
+                   const dvo_hip_level_stats* levels, const dvo_hip_iteration_stats* iters, dvo_hip_result* results) {
+  k_finish<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, levels, iters, results);
+}
+
+void launch_set_fixed_state(hipStream_t s, PairState* states, LevelGeom g, const float* T34_dev, const float* Pprev_dev, int first) {
+  k_set_fixed_state<<<dim3(1), dim3(64), 0, s>>>(states, g, T34_dev, Pprev_dev, first);
+}
+
+void launch_single_shot_out(hipStream_t s, LevelGeom g, const float* partials, const double* ll_partials, int ll_blocks_per_pair,
+                            int n_selected, dvo_hip_iteration_out* out_dev) {
+  k_single_shot_out<<<dim3(1), dim3(kBlock), 0, s>>>(g, partials, ll_partials, ll_blocks_per_pair, n_selected, out_dev);
+}
+
+}  // namespace dvo_hip

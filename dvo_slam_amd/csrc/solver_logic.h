@@ -1,0 +1,226 @@
+// solver_logic.h -- the Gauss-Newton state machine of DenseTracker::match, one instance per frame pair.
+//
+// Restates the control flow of dvo_core/src/dense_tracking.cpp:131-376 (accept / revert / termination,
+// level hand-over of the increment, statistics) as host/device inline functions.  On the GPU they
+// are executed by lane 0 of the per-pair solver workgroup (solver_kernels.hip), so a whole
+// coarse-to-fine alignment -- or a batch of them -- runs without the pose ever visiting the host.
+// tests/ compiles the same header with the host compiler to check the logic against the oracle
+// without a GPU (test-only).
+#pragma once
+
+#include <float.h>
+
+#include "device_types.h"
+#include "pixel_math.h"
+#include "se3_device.h"
+
+namespace dvo_hip {
+
+DVO_HD double dvo_nan() { return __builtin_nan(""); }
+
+DVO_HD double inf_norm6(const double* v) {
+  double m = 0;
+  for (int i = 0; i < 6; ++i) {
+    if (v[i] != v[i]) return dvo_nan();
+    const double a = fabs(v[i]);
+    if (a > m) m = a;
+  }
+  return m;
+}
+
+// inc = exp(x); initial = inc^-1 * initial; estimate = inc * estimate; KT = float(K * estimate)
+// (dense_tracking.cpp:259-263)
+DVO_HD void gn_begin_iteration(PairState& st, const LevelGeom& g) {
+  se3_exp(st.x, st.inc);
+  SE3d inv;
+  se3_inverse(st.inc, inv);
+  st.initial_old = st.initial;
+  se3_mul(inv, st.initial, st.initial);
+  st.estimate_old = st.estimate;
+  se3_mul(st.inc, st.estimate, st.estimate);
+  float T[12];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T[i * 4 + j] = float(st.estimate.R[i * 3 + j]);
+    T[i * 4 + 3] = float(st.estimate.t[i]);
+  }
+  make_KT(g.fx, g.fy, g.ox, g.oy, T, st.KT);
+}
+
+// dense_tracking.cpp:137-150
+DVO_HD void gn_init_pair(PairState& st, const SolverParams& prm, const double* T_init_row_major_4x4) {
+  if (prm.use_initial_estimate) {
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) st.inc.R[i * 3 + j] = T_init_row_major_4x4[i * 4 + j];
+      st.inc.t[i] = T_init_row_major_4x4[i * 4 + 3];
+    }
+  } else {
+    se3_identity(st.inc);
+  }
+  st.initial = st.inc;
+  st.initial_old = st.inc;
+  se3_identity(st.estimate);
+  se3_identity(st.estimate_old);
+  for (int i = 0; i < 6; ++i) st.x[i] = 0;
+  for (int i = 0; i < 36; ++i) st.A_last[i] = dvo_nan();
+  st.error = DBL_MAX;
+  st.last_error = DBL_MAX;
+  st.level = prm.first_level;
+  st.iteration = 0;
+  st.active = 0;
+  st.first = 1;
+  st.n_iters_total = 0;
+  st.n_levels = 0;
+  st.level_first_iter = 0;
+  for (int i = 0; i < 4; ++i) st.P_prev[i] = 0.0f;
+  for (int i = 0; i < 12; ++i) st.KT[i] = 0.0f;
+}
+
+// dense_tracking.cpp:200-238 : per-level reset and "x = inc.log()" (Q12, Q21)
+DVO_HD void gn_level_begin(PairState& st, const SolverParams& prm, const LevelGeom& g, int level, int n_selected,
+                           dvo_hip_level_stats* levels) {
+  st.level = level;
+  st.iteration = 0;
+  st.error = DBL_MAX;
+  st.last_error = DBL_MAX;
+  st.first = 1;
+  st.active = 1;
+  for (int i = 0; i < 4; ++i) st.P_prev[i] = 0.0f;
+  st.level_first_iter = st.n_iters_total;
+  if (st.n_levels < prm.cap_levels) {
+    dvo_hip_level_stats& ls = levels[st.n_levels];
+    ls.id = level;
+    double maxp = double(prm.max_points_level0);
+    for (int l = 0; l < level; ++l) maxp *= 0.25;          // point_selection.cpp:68-71
+    ls.max_valid_pixels = int(maxp);
+    ls.valid_pixels = n_selected;
+    ls.termination = DVO_HIP_TERMINATION_UNSET;
+    ls.n_iterations = 0;
+    ls.first_iteration_index = st.n_iters_total;
+  }
+  st.n_levels += 1;
+  se3_log(st.inc, st.x);
+  gn_begin_iteration(st, g);
+}
+
+// dense_tracking.cpp:359-363 run after the do/while however it was left
+DVO_HD void gn_level_end(PairState& st, const SolverParams& prm, dvo_hip_level_stats* levels) {
+  if (st.n_levels - 1 < prm.cap_levels) {
+    dvo_hip_level_stats& ls = levels[st.n_levels - 1];
+    if (inf_norm6(st.x) <= prm.precision) ls.termination = DVO_HIP_INCREMENT_TOO_SMALL;
+    if (st.iteration >= prm.max_iterations) ls.termination = DVO_HIP_ITERATIONS_EXCEEDED;
+  }
+  st.active = 0;
+}
+
+// One pass of the loop body after the residual sweep: dense_tracking.cpp:273-357.
+// sums = the kNumAcc accumulators reduced over all tiles; ll_sum = sum log(1 + 0.2 r^T P r).
+DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, const double* sums, double ll_sum,
+                    dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters) {
+  if (!st.active) return;
+  dvo_hip_iteration_stats dummy;
+  dvo_hip_iteration_stats& rec = (st.n_iters_total < prm.cap_iters) ? iters[st.n_iters_total] : dummy;
+  st.n_iters_total += 1;
+  if (st.n_levels - 1 < prm.cap_levels) levels[st.n_levels - 1].n_iterations += 1;
+
+  const int n = int(sums[kAccN] + 0.5);
+  rec.id = st.iteration;
+  rec.valid_constraints = n;
+  rec.tdist_loglik = dvo_nan();
+  rec.prior_loglik = dvo_nan();
+  rec.tdist_mean[0] = rec.tdist_mean[1] = 0.0;              // Q8
+  for (int i = 0; i < 4; ++i) rec.tdist_precision[i] = dvo_nan();
+  for (int i = 0; i < 6; ++i) rec.increment[i] = dvo_nan();
+  for (int i = 0; i < 36; ++i) rec.information[i] = dvo_nan();
+
+  if (n < 6) {                                               // :276-284
+    st.initial = st.initial_old;
+    st.estimate = st.estimate_old;
+    if (st.n_levels - 1 < prm.cap_levels) levels[st.n_levels - 1].termination = DVO_HIP_TOO_FEW_CONSTRAINTS;
+    gn_level_end(st, prm, levels);
+    return;
+  }
+
+  float C[3], P[4];
+  const double d = double(n) - 3.0;
+  scale_to_precision(sums[kAccS] / d, sums[kAccS + 1] / d, sums[kAccS + 2] / d, C, P);   // :295
+  const double det = double(P[0]) * double(P[3]) - double(P[1]) * double(P[2]);
+  const double ll = 0.5 * double(n) * log(det) - 3.5 * ll_sum;                           // :297, impl:424
+  rec.tdist_loglik = -ll;
+  for (int i = 0; i < 4; ++i) rec.tdist_precision[i] = double(P[i]);
+  double li[6];
+  se3_log(st.initial, li);
+  double sq = 0;
+  for (int i = 0; i < 6; ++i) sq += li[i] * li[i];
+  rec.prior_loglik = prm.mu * sq;                            // :302
+
+  st.last_error = st.error;
+  st.error = -ll;
+  const bool accept = st.error < st.last_error;              // :312
+  if (!accept) {
+    st.initial = st.initial_old;
+    st.estimate = st.estimate_old;
+    if (st.n_levels - 1 < prm.cap_levels) levels[st.n_levels - 1].termination = DVO_HIP_LOGLIKELIHOOD_DECREASED;
+    gn_level_end(st, prm, levels);
+    return;
+  }
+
+  // contract the Gram sums with W = w P : A = J^T W J, b = -J^T W r (least_squares.cpp:58-64)
+  const double p00 = double(P[0]), p01 = double(P[1]), p11 = double(P[3]);
+  double A[36], b[6];
+  int o = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) {
+      const double a = p00 * sums[kAccJ00 + o] + p01 * sums[kAccJ01 + o] + p11 * sums[kAccJ11 + o];
+      A[i * 6 + j] = a;
+      A[j * 6 + i] = a;
+      ++o;
+    }
+  for (int i = 0; i < 6; ++i) b[i] = -(p00 * sums[kAccB00 + i] + p01 * sums[kAccB01 + i] + p11 * sums[kAccB11 + i]);
+  for (int i = 0; i < 6; ++i) {                              // :345-346
+    A[i * 6 + i] += prm.mu;
+    b[i] += prm.mu * li[i];
+  }
+  solve6(A, b, st.x);                                        // :347
+  for (int i = 0; i < 6; ++i) rec.increment[i] = st.x[i];
+  for (int i = 0; i < 36; ++i) { rec.information[i] = A[i]; st.A_last[i] = A[i]; }
+  st.iteration += 1;
+
+  const double xn = inf_norm6(st.x);
+  if (xn > prm.precision && st.iteration < prm.max_iterations) {   // :357
+    for (int i = 0; i < 4; ++i) st.P_prev[i] = P[i];         // next pass weights use this P (Q11)
+    st.first = 0;
+    gn_begin_iteration(st, g);
+  } else {
+    gn_level_end(st, prm, levels);
+  }
+}
+
+// dense_tracking.cpp:368-373
+DVO_HD void gn_finish(const PairState& st, const SolverParams& prm, const dvo_hip_level_stats* levels,
+                      const dvo_hip_iteration_stats* iters, dvo_hip_result* out) {
+  SE3d inv;
+  se3_inverse(st.estimate, inv);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) out->transformation[i * 4 + j] = inv.R[i * 3 + j];
+    out->transformation[i * 4 + 3] = inv.t[i];
+  }
+  out->transformation[12] = out->transformation[13] = out->transformation[14] = 0.0;
+  out->transformation[15] = 1.0;
+  for (int i = 0; i < 36; ++i) out->information[i] = dvo_nan();
+  out->loglik = dvo_nan();
+  out->n_levels = st.n_levels;
+  out->n_iterations_total = st.n_iters_total;
+  if (st.n_levels >= 1 && st.n_levels - 1 < prm.cap_levels) {
+    const dvo_hip_level_stats& ls = levels[st.n_levels - 1];
+    int idx = ls.n_iterations - 1;
+    if (ls.termination == DVO_HIP_LOGLIKELIHOOD_DECREASED) idx -= 1;   // :369
+    const int abs_idx = ls.first_iteration_index + idx;
+    if (idx >= 0 && abs_idx < prm.cap_iters) {
+      const dvo_hip_iteration_stats& it = iters[abs_idx];
+      for (int i = 0; i < 36; ++i) out->information[i] = it.information[i] * 0.008 * 0.008;
+      out->loglik = it.tdist_loglik + it.prior_loglik;
+    }
+  }
+}
+
+}  // namespace dvo_hip

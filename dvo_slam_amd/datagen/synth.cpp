@@ -1,18 +1,19 @@
 /*
  * synth.cpp -- deterministic synthetic RGB-D frame pairs.
  *
- * TEST INFRASTRUCTURE (see dvo_oracle.h).  There is no TUM dataset on disk and no network, so the
- * parity tests, the bench workload and the CPU baseline all consume these frames.  The generator
+ * A data tool, not part of the alignment path and not part of the oracle: there is no TUM dataset on
+ * disk and no network, so the parity tests, the bench workload and the CPU baseline all consume these
+ * frames (CPU and GPU sides read identical bytes).  Built as libdvo_synth.so by plain g++.  The generator
  * renders the SAME analytic scene from two camera poses (exact re-render by ray/surface root
  * finding, not image warping), then quantises exactly like the reference's ingest does:
  * grey -> u8 (stored as float 0..255 by the caller), depth -> u16 at 5000 counts per metre, 0 = hole
  * (dvo_benchmark/src/benchmark_slam.cpp:46-93, dvo_core/src/core/surface_pyramid.cpp:65-105).
  */
-#include "dvo_oracle.h"
-#include "se3_oracle.h"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -86,6 +87,31 @@ inline uint16_t quantise_depth(double z) {
   return uint16_t(q);
 }
 
+// exp of the twist (upsilon, omega) as a row-major 4x4 (Rodrigues; |omega| here is 0.009..0.03 rad)
+void se3_exp_matrix(const double x[6], double M[16]) {
+  const double* u = x;
+  const double* w = x + 3;
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+  double a, b, c;
+  if (th < 1e-6) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0; }
+  else { a = std::sin(th) / th; b = (1.0 - std::cos(th)) / th2; c = (th - std::sin(th)) / (th2 * th); }
+  const double O[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  double O2[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+  for (int i = 0; i < 3; ++i) {
+    double t = 0;
+    for (int j = 0; j < 3; ++j) {
+      const double I = i == j ? 1.0 : 0.0;
+      M[i * 4 + j] = I + a * O[i * 3 + j] + b * O2[i * 3 + j];
+      t += (I + b * O[i * 3 + j] + c * O2[i * 3 + j]) * u[j];
+    }
+    M[i * 4 + 3] = t;
+  }
+  M[12] = M[13] = M[14] = 0;
+  M[15] = 1;
+}
+
 void punch_holes(uint16_t* depth, int W, int H, Pcg32& rng) {
   for (int by = 0; by < H; by += 8)
     for (int bx = 0; bx < W; bx += 8)
@@ -99,7 +125,7 @@ void punch_holes(uint16_t* depth, int W, int H, Pcg32& rng) {
 
 }  // namespace
 
-extern "C" void oracle_synth_pair(uint64_t seed, int W, int H, const float K[4], uint8_t* grey_ref, uint16_t* depth_ref,
+extern "C" void dvo_synth_pair(uint64_t seed, int W, int H, const float K[4], uint8_t* grey_ref, uint16_t* depth_ref,
                                   uint8_t* grey_cur, uint16_t* depth_cur, double xi_true[6]) {
   Pcg32 rng(seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL, seed + 7);
   Scene sc;
@@ -116,9 +142,8 @@ extern "C" void oracle_synth_pair(uint64_t seed, int W, int H, const float K[4],
     for (int j = 0; j < 3; ++j) xi[part * 3 + j] = d[j] / n * mag;
   }
   for (int i = 0; i < 6; ++i) xi_true[i] = xi[i];
-  const oracle::SE3 T_rc = oracle::se3_exp(xi);   // current -> reference: what match() returns
-  double Mrc[16];
-  oracle::se3_to_matrix(T_rc, Mrc);
+  double Mrc[16];   // current -> reference: the transform match() should return
+  se3_exp_matrix(xi, Mrc);
 
   Pcg32 noise_ref(seed * 31 + 1, 11), noise_cur(seed * 31 + 2, 13);
   Pcg32 holes_ref(seed * 131 + 5, 17), holes_cur(seed * 131 + 6, 19);
@@ -163,4 +188,20 @@ extern "C" void oracle_synth_pair(uint64_t seed, int W, int H, const float K[4],
       depth_cur[size_t(v) * W + u] = quantise_depth(s);
     }
   punch_holes(depth_cur, W, H, holes_cur);
+}
+
+// n pairs with seeds seed0 .. seed0+n-1 into contiguous arrays, generated on `nthreads` host threads
+extern "C" void dvo_synth_batch(uint64_t seed0, int n, int W, int H, const float K[4], uint8_t* grey_ref, uint16_t* depth_ref,
+                                uint8_t* grey_cur, uint16_t* depth_cur, double* xi_true, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  const size_t npx = size_t(W) * H;
+  auto work = [&](int t) {
+    for (int i = t; i < n; i += nthreads)
+      dvo_synth_pair(seed0 + uint64_t(i), W, H, K, grey_ref + i * npx, depth_ref + i * npx, grey_cur + i * npx, depth_cur + i * npx,
+                     xi_true + size_t(i) * 6);
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
 }

@@ -1,0 +1,202 @@
+/*
+ * dvo_hip.h -- C-ABI of libdvo_hip.so: the MI355X (gfx950) implementation of the dense RGB-D
+ * alignment hot path of tum-vision/dvo_slam (dvo::DenseTracker::match and the image data model
+ * that feeds it).
+ *
+ * The reference has no plugin / FFI layer: the drop-in boundary is the C++ class API of dvo_core
+ * (SURVEY.md section 8b).  This header is the thin C layer underneath the header-only C++ facade
+ * `include/dvo/` that reproduces that class API; every entry point cites the reference interface
+ * it replaces (paths relative to /root/reference).  Plain C types only, caller-allocated outputs,
+ * int status return (0 = ok, negative = error, see dvo_hip_last_error), no exceptions cross the
+ * ABI.  A context is thread-compatible (one thread at a time); use one context per host thread,
+ * mirroring "one DenseTracker per thread" (dvo_slam/src/local_tracker.cpp:69-70).
+ *
+ * There is NO CPU fallback: every compute entry point fails with DVO_HIP_ERR_NO_DEVICE when no
+ * gfx950 device is usable.
+ */
+#ifndef DVO_HIP_H_
+#define DVO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVO_HIP_MAX_LEVELS 8
+
+enum {
+  DVO_HIP_OK = 0,
+  DVO_HIP_ERR_NO_DEVICE = -1,
+  DVO_HIP_ERR_INVALID = -2,
+  DVO_HIP_ERR_HIP = -3,
+  DVO_HIP_ERR_CAPACITY = -4
+};
+
+/* dvo::DenseTracker::TerminationCriteria::Enum, dvo_core/include/dvo/dense_tracking.h:71-81 */
+enum {
+  DVO_HIP_ITERATIONS_EXCEEDED = 0,
+  DVO_HIP_INCREMENT_TOO_SMALL = 1,
+  DVO_HIP_LOGLIKELIHOOD_DECREASED = 2,
+  DVO_HIP_TOO_FEW_CONSTRAINTS = 3,
+  DVO_HIP_TERMINATION_UNSET = -1
+};
+
+/* The fields of dvo::DenseTracker::Config that match() reads (dense_tracking.h:42-69; defaults
+ * dvo_core/src/dense_tracking_config.cpp:27-42).  UseWeighting / UseParallel / InfluenceFunction* /
+ * ScaleEstimator* are dead for match() and live only in the C++ facade. */
+typedef struct {
+  int32_t first_level;               /* FirstLevel, default 3 */
+  int32_t last_level;                /* LastLevel, default 1 */
+  int32_t max_iterations_per_level;  /* default 100 */
+  int32_t use_initial_estimate;      /* default 0 */
+  double precision;                  /* default 5e-7 */
+  double mu;                         /* default 0 */
+  float intensity_derivative_threshold; /* default 0 */
+  float depth_derivative_threshold;     /* default 0 */
+} dvo_hip_config;
+
+/* dvo::DenseTracker::IterationStats, dense_tracking.h:83-101 */
+typedef struct {
+  int32_t id;
+  int32_t valid_constraints;
+  double tdist_loglik;               /* TDistributionLogLikelihood (= -ll) */
+  double tdist_mean[2];              /* always 0 */
+  double tdist_precision[4];         /* row-major 2x2 */
+  double prior_loglik;
+  double increment[6];               /* EstimateIncrement, twist (v, omega) */
+  double information[36];            /* EstimateInformation, row-major 6x6, includes mu*I */
+} dvo_hip_iteration_stats;
+
+/* dvo::DenseTracker::LevelStats, dense_tracking.h:104-117 */
+typedef struct {
+  int32_t id;
+  int32_t max_valid_pixels;
+  int32_t valid_pixels;
+  int32_t termination;
+  int32_t n_iterations;
+  int32_t first_iteration_index;     /* index of this level's first record in the iteration array */
+} dvo_hip_level_stats;
+
+/* dvo::DenseTracker::Result, dense_tracking.h:125-140 (Statistics are returned separately) */
+typedef struct {
+  double transformation[16];         /* row-major 4x4. in: initial guess when use_initial_estimate;
+                                        out: estimate^-1 = current -> reference (dense_tracking.cpp:371) */
+  double information[36];            /* A_last * 0.008^2 (dense_tracking.cpp:372) */
+  double loglik;                     /* dense_tracking.cpp:373 */
+  int32_t n_levels;
+  int32_t n_iterations_total;
+} dvo_hip_result;
+
+typedef struct dvo_hip_context dvo_hip_context;
+typedef struct dvo_hip_frame dvo_hip_frame;
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* One context = one device + one HIP stream + scratch.  Replaces the per-tracker scratch vectors
+ * (dense_tracking.h:205-212) and nothing else. */
+int dvo_hip_context_create(int device, dvo_hip_context** out);
+void dvo_hip_context_destroy(dvo_hip_context* ctx);
+/* last error text of this context (or of context creation when ctx == NULL) */
+const char* dvo_hip_last_error(const dvo_hip_context* ctx);
+/* the hipStream_t all work of this context is enqueued on (for HIP-event timing by the caller) */
+void* dvo_hip_context_stream(dvo_hip_context* ctx);
+int dvo_hip_device_count(void);
+
+/* ---- frames: RgbdCameraPyramid::create + RgbdImagePyramid::build + buildAccelerationStructure --
+ * (dvo_core/include/dvo/core/rgbd_image.h:127-147,242-262; rgbd_image.cpp:156-172,283-296,419-543)
+ * Builds the whole device-resident pyramid: 2x2-mean intensity, subsampled depth, halved
+ * intrinsics, clamped central-difference derivatives, interleaved sampling planes.
+ * K = {fx, fy, ox, oy} of level 0.  `levels` = Config::getNumLevels() = FirstLevel + 1. */
+int dvo_hip_frame_create_f32(dvo_hip_context* ctx, int width, int height, const float K[4],
+                             const float* intensity /* 0..255 */, const float* depth /* metres, NaN invalid */,
+                             int levels, dvo_hip_frame** out);
+/* Ingest of raw sensor planes (dvo_benchmark/src/benchmark_slam.cpp:46-93 after BGR2GRAY;
+ * SurfacePyramid::convertRawDepthImageSse, dvo_core/src/core/surface_pyramid.cpp:65-105):
+ * grey u8 -> float 0..255, depth u16 * depth_scale, 0 -> NaN, converted on the device. */
+int dvo_hip_frame_create_raw(dvo_hip_context* ctx, int width, int height, const float K[4],
+                             const uint8_t* grey, const uint16_t* raw_depth, float depth_scale,
+                             int levels, dvo_hip_frame** out);
+/* Same, but the two raw planes are already resident in device memory (HBM). */
+int dvo_hip_frame_create_raw_device(dvo_hip_context* ctx, int width, int height, const float K[4],
+                                    const void* grey_dev, const void* raw_depth_dev, float depth_scale,
+                                    int levels, dvo_hip_frame** out);
+/* Re-ingest new raw planes (device pointers) into an existing frame: no allocation, asynchronous on the
+ * context stream.  The streaming use of RgbdCameraPyramid::create for every camera frame
+ * (dvo_ros/src/camera_dense_tracking.cpp:243); invalidates the frame's cached point selection. */
+int dvo_hip_frame_update_raw_device(dvo_hip_context* ctx, dvo_hip_frame* frame, const void* grey_dev,
+                                    const void* raw_depth_dev, float depth_scale);
+/* The same for n frames of one camera in one launch per pyramid level (blockIdx.z = frame). */
+int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames,
+                                     const void* const* grey_dev, const void* const* raw_depth_dev, float depth_scale);
+void dvo_hip_frame_destroy(dvo_hip_context* ctx, dvo_hip_frame* frame);
+int dvo_hip_frame_info(const dvo_hip_frame* frame, int level, int* width, int* height, float K[4]);
+/* host mirror of one plane of one level (RgbdImage public fields, rgbd_image.h:161-179):
+ * plane 0=intensity 1=depth 2=intensity_dx 3=intensity_dy 4=depth_dx 5=depth_dy */
+int dvo_hip_frame_download_plane(dvo_hip_context* ctx, dvo_hip_frame* frame, int level, int plane, float* out);
+/* PointSelection::select (dvo_core/src/core/point_selection.cpp:89-152): number of reference
+ * pixels that pass ValidPointAndGradientThresholdPredicate (point_selection.h:49-67).  Builds and
+ * caches the reference-side packed plane of that level; optional w*h uint8 mask. */
+int dvo_hip_frame_select(dvo_hip_context* ctx, dvo_hip_frame* frame, int level,
+                         float intensity_threshold, float depth_threshold, int* n_selected, uint8_t* mask_or_null);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* DenseTracker::match(RgbdImagePyramid& reference, RgbdImagePyramid& current, Result&)
+ * (dvo_core/src/dense_tracking.cpp:123-376).  `levels`/`iters` may be NULL (no statistics).
+ * Always returns DVO_HIP_OK on a completed run, like the reference's `return true` (Q16): failure
+ * is signalled by NaNs in the result and by the termination criteria. */
+int dvo_hip_match(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame* current,
+                  const dvo_hip_config* cfg, dvo_hip_result* result,
+                  dvo_hip_level_stats* levels, int cap_levels,
+                  dvo_hip_iteration_stats* iters, int cap_iters);
+
+/* n independent matches in one batched launch sequence (grid = tiles x pairs): the multi-hypothesis
+ * shape of KeyframeGraph::validateKeyframeConstraintsParallel (dvo_slam/src/keyframe_graph.cpp:576-593)
+ * and of LocalTracker::update's two trackers (dvo_slam/src/local_tracker.cpp:180-184).
+ * results[i].transformation is in/out.  Optional stats: levels[i*cap_levels + l],
+ * iters[i*cap_iters + k].  All frames must share width/height/levels. */
+int dvo_hip_match_batch(dvo_hip_context* ctx, int n_pairs,
+                        dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
+                        const dvo_hip_config* cfg, dvo_hip_result* results,
+                        dvo_hip_level_stats* levels, int cap_levels,
+                        dvo_hip_iteration_stats* iters, int cap_iters);
+
+/* One Gauss-Newton linearisation at a given estimate: passes 1-5 of dense_tracking.cpp:271-343
+ * (computeResidualsSse + computeWeightsSse + computeScaleSse + computeCompleteDataLogLikelihood +
+ * NormalEquationsLeastSquares::update) for parity tests against the oracle. */
+typedef struct {
+  int32_t n;                 /* valid constraints */
+  int32_t n_selected;        /* selected reference pixels of the level */
+  float scale_cov[3];        /* C00 C01 C11 = sum w r r^T / (n-3) */
+  float precision[4];        /* P = C^-1, row-major */
+  double neg_loglik;         /* -ll */
+  double A[36];              /* J^T (w P) J, row-major, without mu */
+  double b[6];               /* -J^T (w P) r */
+  double sum_w;              /* reserved (0) */
+} dvo_hip_iteration_out;
+
+int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame* current, int level,
+                            float intensity_threshold, float depth_threshold,
+                            const float T34[12] /* row-major 3x4 float estimate: reference -> current */,
+                            const float P_prev[4], int first_iteration_on_level,
+                            dvo_hip_iteration_out* out,
+                            float* residuals_or_null /* w*h*2 floats, NaN where invalid */);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Launches the dominant kernel (fused warp + residual + weight + Jacobian + reduce) `reps` times for
+ * the given pairs at `level`, bracketed by HIP events on the context stream; returns the average
+ * duration of one launch in milliseconds.  The estimate used is the identity. */
+int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs,
+                                 dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
+                                 int level, int reps, float* avg_ms);
+
+/* Tunables (0 = library default).  key: "rows_per_wave" (1,2,4,8,16), "iters_per_sync" (host
+ * polling cadence of the batched Gauss-Newton loop), "variant" (kernel variant id). */
+int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
+
+const char* dvo_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVO_HIP_H_ */

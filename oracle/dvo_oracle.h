@@ -147,14 +147,6 @@ int oracle_solve6(const double A[36], const double b[6], double x[6]);
  * mode REF_SSE: float sequential blocked accumulation (math_sse.cpp:82-178); MATH: float64. */
 void oracle_rank_update_2x6(const float* J, int n, const float alpha[4], int mode, double A[36]);
 
-/* --- deterministic synthetic RGB-D pairs ---------------------------- */
-/* Renders reference and current frame of the analytic scene. Outputs: grey u8 and raw depth u16
- * (5000 per metre, 0 = hole), plus the true twist xi (v, omega) of the transform that match()
- * should return (current -> reference). */
-void oracle_synth_pair(uint64_t seed, int width, int height, const float K[4],
-                       uint8_t* grey_ref, uint16_t* depth_ref,
-                       uint8_t* grey_cur, uint16_t* depth_cur, double xi_true[6]);
-
 const char* oracle_version(void);
 
 #ifdef __cplusplus

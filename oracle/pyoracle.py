@@ -55,7 +55,7 @@ def build(force=False):
     """Compile liboracle.so with the committed recipe (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("dvo_oracle.cpp", "synth.cpp", "dvo_oracle.h", "se3_oracle.h", "Makefile")):
+            for f in ("dvo_oracle.cpp", "dvo_oracle.h", "se3_oracle.h", "Makefile")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -90,8 +90,6 @@ def lib():
         L.oracle_se3_log.argtypes = [dp, dp]
         L.oracle_solve6.argtypes = [dp, dp, dp]
         L.oracle_rank_update_2x6.argtypes = [fp, C.c_int, fp, C.c_int, dp]
-        L.oracle_synth_pair.argtypes = [C.c_uint64, C.c_int, C.c_int, fp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint16),
-                                        C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), dp]
         L.oracle_version.restype = C.c_char_p
         _lib = L
     return _lib
@@ -161,17 +159,9 @@ def bgr_to_grey(bgr):
 
 
 def synth_pair(seed, w=640, h=480, K=None):
-    """Returns dict(grey_ref u8, depth_ref u16, grey_cur u8, depth_cur u16, xi_true(6), K)."""
-    if K is None:
-        K = FR1_K * (w / 640.0)
-    K = np.ascontiguousarray(K, dtype=np.float32)
-    gr = np.empty((h, w), np.uint8); dr = np.empty((h, w), np.uint16)
-    gc = np.empty((h, w), np.uint8); dc = np.empty((h, w), np.uint16)
-    xi = np.zeros(6)
-    u8 = C.POINTER(C.c_uint8); u16 = C.POINTER(C.c_uint16)
-    lib().oracle_synth_pair(seed, w, h, _fp(K), gr.ctypes.data_as(u8), dr.ctypes.data_as(u16),
-                            gc.ctypes.data_as(u8), dc.ctypes.data_as(u16), _dp(xi))
-    return dict(grey_ref=gr, depth_ref=dr, grey_cur=gc, depth_cur=dc, xi_true=xi, K=K)
+    """Synthetic pair from the package's data generator (dvo_slam_amd/datagen), fr1 intrinsics scaled to the width."""
+    from dvo_slam_amd import datagen
+    return datagen.synth_pair(seed, w, h, FR1_K * (w / 640.0) if K is None else K)
 
 
 def pyramids_from_pair(pair, levels=4):

@@ -1,0 +1,184 @@
+// emul_device.cpp -- TEST-ONLY host emulation of the device code path.
+//
+// Compiles the very headers the gfx950 kernels are built from (pixel_math.h, solver_logic.h,
+// se3_device.h) with the host C++ compiler and drives them pixel by pixel / pair by pair, so that the
+// per-pixel arithmetic and the Gauss-Newton state machine can be checked against the oracle in the
+// CPU-only test tier.  It is never linked into libdvo_hip.so and is not a fallback: the product has none.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../dvo_slam_amd/csrc/solver_logic.h"
+
+using namespace dvo_hip;
+
+extern "C" {
+
+struct emul_level {
+  int w, h;
+  float fx, fy, ox, oy;
+  const float* R;   // w*h*4 {Zsel, I, Idx, Idy}
+  const float* A;   // w*h*4 {I, Z, Idx, Idy}
+  const float* B;   // w*h*2 {Zdx, Zdy}
+  int n_selected;
+};
+
+}  // extern "C"
+
+namespace {
+
+struct LevelCtx {
+  LevelGeom g;
+  std::vector<float> tx, ty;
+  const float4* R;
+  const float4* A;
+  const float2* B;
+};
+
+void make_level(const emul_level& e, LevelCtx& c) {
+  c.tx.resize(e.w);
+  c.ty.resize(e.h);
+  for (int x = 0; x < e.w; ++x) c.tx[x] = (float(x) - e.ox) / e.fx;
+  for (int y = 0; y < e.h; ++y) c.ty[y] = (float(y) - e.oy) / e.fy;
+  c.g.w = e.w; c.g.h = e.h;
+  c.g.fx = e.fx; c.g.fy = e.fy; c.g.ox = e.ox; c.g.oy = e.oy;
+  c.g.wi_x = 0.5f * e.fx / 255.0f; c.g.wi_y = 0.5f * e.fy / 255.0f;
+  c.g.tx = c.tx.data(); c.g.ty = c.ty.data();
+  c.g.tiles_x = (e.w + kTileW - 1) / kTileW;
+  c.g.tiles_y = e.h;
+  c.R = reinterpret_cast<const float4*>(e.R);
+  c.A = reinterpret_cast<const float4*>(e.A);
+  c.B = reinterpret_cast<const float2*>(e.B);
+}
+
+// one sweep of the residual kernel + the log-likelihood sweep: float accumulation per row of 64 pixels
+// (one "wavefront row"), float64 across rows, like the device's per-tile partials
+void sweep(const LevelCtx& c, const float* KT, const float* Pp, bool first, double* sums, std::vector<float>& res) {
+  const int w = c.g.w, h = c.g.h;
+  res.assign(size_t(w) * h * 2, std::nanf(""));
+  for (int i = 0; i < kNumAcc; ++i) sums[i] = 0.0;
+  for (int v = 0; v < h; ++v)
+    for (int u0 = 0; u0 < w; u0 += kTileW) {
+      float acc[kNumAcc];
+      for (int i = 0; i < kNumAcc; ++i) acc[i] = 0.0f;
+      for (int u = u0; u < u0 + kTileW && u < w; ++u) {
+        const int idx = v * w + u;
+        PixelTerms t;
+        if (!pixel_residual(c.g, KT, c.A, c.B, c.R[idx], u, v, t)) continue;
+        res[2 * size_t(idx)] = t.r0;
+        res[2 * size_t(idx) + 1] = t.r1;
+        const float wgt = first ? 1.0f : tdist_weight(t.r0, t.r1, Pp);
+        accumulate_pixel(acc, t, wgt);
+      }
+      for (int i = 0; i < kNumAcc; ++i) sums[i] += double(acc[i]);
+    }
+}
+
+double loglik_sum(const std::vector<float>& res, const double* sums) {
+  const int n = int(sums[kAccN] + 0.5);
+  if (n < 6) return 0.0;
+  float C[3], P[4];
+  const double d = double(n) - 3.0;
+  scale_to_precision(sums[kAccS] / d, sums[kAccS + 1] / d, sums[kAccS + 2] / d, C, P);
+  double total = 0.0;
+  for (size_t i = 0; i < res.size() / 2; ++i)
+    if (res[2 * i] == res[2 * i]) total += std::log(1.0 + 0.2 * double(mahalanobis(res[2 * i], res[2 * i + 1], P)));
+  return total;
+}
+
+}  // namespace
+
+extern "C" {
+
+int emul_level_iteration(const emul_level* L, const float T34[12], const float P_prev[4], int first,
+                         dvo_hip_iteration_out* out, float* residuals) {
+  LevelCtx c;
+  make_level(*L, c);
+  float KT[12];
+  make_KT(c.g.fx, c.g.fy, c.g.ox, c.g.oy, T34, KT);
+  double sums[kNumAcc];
+  std::vector<float> res;
+  sweep(c, KT, P_prev, first != 0, sums, res);
+  const double ll_sum = loglik_sum(res, sums);
+  std::memset(out, 0, sizeof(*out));
+  const int n = int(sums[kAccN] + 0.5);
+  out->n = n;
+  out->n_selected = L->n_selected;
+  if (residuals) std::memcpy(residuals, res.data(), res.size() * sizeof(float));
+  if (n < 6) return 1;
+  float C[3], P[4];
+  const double d = double(n) - 3.0;
+  scale_to_precision(sums[kAccS] / d, sums[kAccS + 1] / d, sums[kAccS + 2] / d, C, P);
+  for (int i = 0; i < 3; ++i) out->scale_cov[i] = C[i];
+  for (int i = 0; i < 4; ++i) out->precision[i] = P[i];
+  const double det = double(P[0]) * double(P[3]) - double(P[1]) * double(P[2]);
+  out->neg_loglik = -(0.5 * double(n) * std::log(det) - 3.5 * ll_sum);
+  const double p00 = P[0], p01 = P[1], p11 = P[3];
+  int o = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) {
+      const double a = p00 * sums[kAccJ00 + o] + p01 * sums[kAccJ01 + o] + p11 * sums[kAccJ11 + o];
+      out->A[i * 6 + j] = a;
+      out->A[j * 6 + i] = a;
+      ++o;
+    }
+  for (int i = 0; i < 6; ++i) out->b[i] = -(p00 * sums[kAccB00 + i] + p01 * sums[kAccB01 + i] + p11 * sums[kAccB11 + i]);
+  return 0;
+}
+
+// the batched driver of capi.hip for one pair, with the kernels replaced by the sweeps above
+int emul_match(const emul_level* levels, const dvo_hip_config* cfg, dvo_hip_result* result,
+               dvo_hip_level_stats* lstats, int cap_levels, dvo_hip_iteration_stats* istats, int cap_iters) {
+  SolverParams prm;
+  prm.max_iterations = cfg->max_iterations_per_level;
+  prm.first_level = cfg->first_level;
+  prm.last_level = cfg->last_level;
+  prm.use_initial_estimate = cfg->use_initial_estimate;
+  prm.precision = cfg->precision;
+  prm.mu = cfg->mu;
+  prm.cap_iters = cap_iters;
+  prm.cap_levels = cap_levels;
+  prm.max_points_level0 = levels[0].w * levels[0].h;
+  PairState st;
+  std::memset(&st, 0, sizeof(st));
+  gn_init_pair(st, prm, result->transformation);
+  for (int level = cfg->first_level; level >= cfg->last_level; --level) {
+    LevelCtx c;
+    make_level(levels[level], c);
+    gn_level_begin(st, prm, c.g, level, levels[level].n_selected, lstats);
+    while (st.active) {
+      double sums[kNumAcc];
+      std::vector<float> res;
+      sweep(c, st.KT, st.P_prev, st.first != 0, sums, res);
+      const double ll_sum = loglik_sum(res, sums);
+      gn_step(st, prm, c.g, sums, ll_sum, lstats, istats);
+    }
+  }
+  gn_finish(st, prm, lstats, istats, result);
+  return 0;
+}
+
+// exposed for unit tests of the device SE(3) / solve code
+void emul_se3_exp(const double x[6], double T[16]) {
+  SE3d S;
+  se3_exp(x, S);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T[i * 4 + j] = S.R[i * 3 + j];
+    T[i * 4 + 3] = S.t[i];
+  }
+  T[12] = T[13] = T[14] = 0;
+  T[15] = 1;
+}
+
+void emul_se3_log(const double T[16], double x[6]) {
+  SE3d S;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) S.R[i * 3 + j] = T[i * 4 + j];
+    S.t[i] = T[i * 4 + 3];
+  }
+  se3_log(S, x);
+}
+
+int emul_solve6(const double A[36], const double b[6], double x[6]) { return solve6(A, b, x) ? 0 : 1; }
+
+}  // extern "C"

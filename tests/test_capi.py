@@ -1,0 +1,70 @@
+"""CPU tier: the C-ABI shared library builds, loads, exports every symbol include/dvo_hip.h declares and
+refuses to compute without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import dvo_slam_amd as d
+from dvo_slam_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "dvo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dvo_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    d.build()
+    L = d.lib()
+    syms = header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(L, s), "libdvo_hip.so does not export %s" % s
+    assert sorted(_lib.EXPORTS) == syms, "dvo_slam_amd/_lib.py EXPORTS is out of sync with include/dvo_hip.h"
+    assert b"gfx950" in L.dvo_hip_version()
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler gives the PODs of include/dvo_hip.h (natural alignment, no packing)
+    assert C.sizeof(_lib.Config) == 4 * 4 + 2 * 8 + 2 * 4
+    assert C.sizeof(_lib.IterationStats) == 8 + 8 * (1 + 2 + 4 + 1 + 6 + 36)
+    assert C.sizeof(_lib.LevelStats) == 24
+    assert C.sizeof(_lib.Result) == 8 * (16 + 36 + 1) + 8
+    assert C.sizeof(_lib.IterationOut) == 8 + 12 + 16 + 4 + 8 * (1 + 36 + 6 + 1)
+
+
+def test_no_cpu_fallback_without_device():
+    L = d.lib()
+    if L.dvo_hip_device_count() > 0:
+        pytest.skip("a GPU is present; the refusal path is for CPU-only boxes")
+    ctx = C.c_void_p()
+    assert L.dvo_hip_context_create(0, C.byref(ctx)) == _lib.ERR_NO_DEVICE
+    assert not ctx.value
+    assert b"no CPU fallback" in L.dvo_hip_last_error(None)
+    with pytest.raises(d.DvoHipError):
+        d.Context(0)
+
+
+def test_product_does_not_import_the_oracle():
+    """The product path must never route through oracle/ (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "dvo_slam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in text and "liboracle" not in text and "dvo_oracle.h" not in text, f
+
+
+def test_config_mirror_defaults():
+    c = d.Config()   # dvo_core/src/dense_tracking_config.cpp:27-42
+    assert (c.FirstLevel, c.LastLevel, c.MaxIterationsPerLevel, c.Precision, c.Mu, c.UseInitialEstimate) == (3, 1, 100, 5e-7, 0.0, False)
+    assert c.getNumLevels() == 4 and c.IsSane() and not c.UseEstimateSmoothing()
+    r = d.Result()
+    assert r.isNaN()
+    r.setIdentity()
+    assert not r.isNaN() and r.LogLikelihood == 0.0

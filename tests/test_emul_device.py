@@ -1,0 +1,105 @@
+"""CPU tier: the device headers (pixel_math.h, solver_logic.h, se3_device.h), compiled for the host by
+tests/emul/emul_device.cpp, against the oracle's MATH mode.  Checks the per-pixel arithmetic and the
+Gauss-Newton state machine the gfx950 kernels are built from, without a GPU.  (The reduction scaffolding and
+the pyramid kernels are only reachable on the GPU: tests/test_gpu_parity.py.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+import common as cm
+import dvo_slam_amd as d
+from oracle import pyoracle as po
+from test_oracle import hat6
+
+
+def test_device_se3_and_solve():
+    L = cm.emul_lib()
+    rng = np.random.default_rng(0)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
+    for scale in (0.0, 1e-9, 1e-6, 1e-3, 0.03, 0.7, 2.0):
+        for _ in range(5):
+            x = rng.uniform(-1, 1, 6) * scale
+            T = np.zeros(16)
+            L.emul_se3_exp(dp(x), dp(T))
+            assert np.allclose(T.reshape(4, 4), scipy.linalg.expm(hat6(x)), atol=1e-13)
+            assert np.allclose(T.reshape(4, 4), po.se3_exp(x), atol=1e-13)     # independent oracle implementation
+            y = np.zeros(6)
+            L.emul_se3_log(dp(T), dp(y))
+            assert np.allclose(y, x, atol=1e-11)
+    for _ in range(20):
+        M = rng.normal(size=(12, 6))
+        A = np.ascontiguousarray(M.T @ M * 10.0 ** rng.uniform(-2, 6))
+        b = rng.normal(size=6)
+        x = np.zeros(6)
+        assert L.emul_solve6(dp(A.reshape(-1)), dp(b), dp(x)) == 0
+        assert np.allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+    x = np.zeros(6)
+    assert L.emul_solve6(dp(np.zeros(36)), dp(np.ones(6)), dp(x)) == 1 and np.isnan(x).all()
+
+
+@pytest.mark.parametrize("level", [2, 1, 0])
+def test_pixel_math_bit_exact_against_oracle(level):
+    pair = cm.synth(31, 320, 240)
+    ref, cur = cm.oracle_pyramids(pair, 3)
+    ep = cm.EmulPair(ref, cur, 3)
+    T34 = po.se3_exp(np.array([0.004, -0.003, 0.002, 0.005, -0.004, 0.003]))[:3]
+    o = po.level_iteration(ref, cur, level, T34, first=True, mode=po.MATH, want_residuals=True)
+    e = ep.level_iteration(level, T34, first=True)
+    assert e["n"] == o["n"] and e["n_selected"] == o["n_selected"]
+    assert np.array_equal(np.isnan(e["residuals"]), np.isnan(o["residuals"]))
+    assert np.array_equal(np.nan_to_num(e["residuals"]), np.nan_to_num(o["residuals"]))     # bit-exact residuals
+    assert np.allclose(e["P"], o["P"], rtol=1e-5)
+    assert abs(e["neg_ll"] - o["neg_ll"]) <= 1e-7 * abs(o["neg_ll"])
+    assert np.abs(e["A"] - o["A"]).max() <= 1e-6 * np.abs(o["A"]).max()
+    assert np.abs(e["b"] - o["b"]).max() <= 1e-6 * np.abs(o["b"]).max()
+    o2 = po.level_iteration(ref, cur, level, T34, P_prev=o["P"], first=False, mode=po.MATH)
+    e2 = ep.level_iteration(level, T34, P_prev=o["P"], first=False)
+    assert e2["n"] == o2["n"]
+    assert np.abs(e2["A"] - o2["A"]).max() <= 1e-6 * np.abs(o2["A"]).max()
+    assert np.abs(e2["b"] - o2["b"]).max() <= 1e-6 * np.abs(o2["b"]).max()
+
+
+@pytest.mark.parametrize("seed,first,last,mu,init,precision", [
+    (1234, 3, 0, 0.0, False, 1e-4), (1234, 3, 0, 0.0, False, 5e-7), (2, 3, 1, 0.05, True, 1e-4), (3, 2, 2, 0.0, False, 5e-7)])
+def test_state_machine_against_oracle_driver(seed, first, last, mu, init, precision):
+    pair = cm.synth(seed, 320, 240)
+    ref, cur = cm.oracle_pyramids(pair, first + 1)
+    ep = cm.EmulPair(ref, cur, first + 1)
+    cfg = d.Config(FirstLevel=first, LastLevel=last, Mu=mu, UseInitialEstimate=init, Precision=precision)
+    T0 = po.se3_exp(0.5 * pair["xi_true"]) if init else None
+    e = ep.match(cfg, T0)
+    o = po.match(ref, cur, cm.oracle_config_from(cfg, po.MATH), T0)
+    s = cm.compare_runs(e, o)
+    assert s["n_mismatch"] == 0 and s["max_x_err"] < 2e-5
+    assert s["max_iter_count_diff"] <= 2
+    assert s["T_err"] < (2e-5 if precision > 1e-6 else 1e-6)
+    if s["structure_mismatch"] == 0:
+        assert np.allclose(e["information"], o["information"], rtol=5e-3, atol=1e-6 * np.abs(o["information"]).max())
+        assert abs(e["loglik"] - o["loglik"]) <= 1e-3 * abs(o["loglik"])
+
+
+def test_state_machine_edge_cases():
+    # no depth at all: one pass, n = 0, criterion overwritten to IncrementTooSmall, identity out, NaN information
+    h, w = 60, 80
+    I = np.random.default_rng(0).uniform(0, 255, (h, w)).astype(np.float32)
+    Z = np.full((h, w), np.nan, np.float32)
+    ref = po.Pyramid(I, Z, po.FR1_K / 8, 1)
+    cur = po.Pyramid(I, Z, po.FR1_K / 8, 1)
+    ep = cm.EmulPair(ref, cur, 1)
+    cfg = d.Config(FirstLevel=0, LastLevel=0)
+    e = ep.match(cfg)
+    o = po.match(ref, cur, cm.oracle_config_from(cfg, po.MATH))
+    assert [L["termination"] for L in e["levels"]] == [L["termination"] for L in o["levels"]] == [1]
+    assert e["levels"][0]["iterations"][0]["n"] == 0
+    assert np.allclose(e["T"], np.eye(4)) and np.isnan(e["information"]).all()
+    # iteration cap
+    pair = cm.synth(4, 160, 120)
+    ref, cur = cm.oracle_pyramids(pair, 3)
+    ep = cm.EmulPair(ref, cur, 3)
+    cfg = d.Config(FirstLevel=2, LastLevel=1, MaxIterationsPerLevel=3, Precision=0.0)
+    e = ep.match(cfg)
+    o = po.match(ref, cur, cm.oracle_config_from(cfg, po.MATH))
+    cm.compare_runs(e, o)
+    assert all(len(L["iterations"]) <= 3 for L in e["levels"])

@@ -1,0 +1,251 @@
+"""GPU tier (-m gpu): the HIP path, called through the C-ABI of libdvo_hip.so, against the CPU oracle's MATH mode
+on identical seeded inputs, against the committed golden fixtures, and -- at the BASELINE sizes -- through
+size-independent properties.
+
+Tolerances (float32 pixel arithmetic, float64 pose arithmetic), all relative to the oracle's MATH mode:
+  image planes, selection masks, valid-pixel counts, residuals   bit-exact
+  precision P, -ll, A, b of one linearisation                    1e-5 relative (tree reduction vs float64 sums)
+  increments x along a full match                                2e-5 absolute
+  final transform (twist of T_gpu^-1 T_oracle)                   1e-6 at Precision 5e-7, 2e-5 at Precision 1e-4
+  vs the quirk-faithful REF_SSE mode                             5e-5 (the oracle's own MATH-vs-REF_SSE delta)
+"""
+import numpy as np
+import pytest
+
+import common as cm
+import dvo_slam_amd as d
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_pyramids(ctx, pair, levels):
+    h, w = pair["grey_ref"].shape
+    cam = d.RgbdCameraPyramid(w, h, pair["K"], ctx)
+    cam.build(levels)
+    return cam.create_raw(pair["grey_ref"], pair["depth_ref"]), cam.create_raw(pair["grey_cur"], pair["depth_cur"])
+
+
+def test_library_loaded_and_device_present(gpu_ctx):
+    assert d.lib().dvo_hip_device_count() >= 1
+    assert gpu_ctx.ptr
+
+
+@pytest.mark.parametrize("w,h,levels", [(640, 480, 4), (160, 120, 3), (100, 76, 2)])
+def test_pyramid_planes_bit_exact(gpu_ctx, w, h, levels):
+    pair = cm.synth(17, w, h)
+    oref, _ = cm.oracle_pyramids(pair, levels)
+    gref, _ = gpu_pyramids(gpu_ctx, pair, levels)
+    names = ["intensity", "depth", "intensity_dx", "intensity_dy", "depth_dx", "depth_dy"]
+    for l in range(levels):
+        img = gref.level(l)
+        for k, name in enumerate(names):
+            o, K = oref.plane(l, k)
+            g = getattr(img, name)
+            assert g.shape == o.shape
+            assert np.array_equal(np.isnan(g), np.isnan(o)), (l, name)
+            assert np.array_equal(np.nan_to_num(g), np.nan_to_num(o)), (l, name)
+        assert np.array_equal(img.K, K)
+        sel = d.PointSelection(gref)
+        n, mask = sel.select(l, want_mask=True)
+        on, omask = oref.select(l)
+        assert n == on and np.array_equal(mask, omask)
+    # f32 ingest path gives the same planes as the raw path
+    cam = d.RgbdCameraPyramid(w, h, pair["K"], gpu_ctx)
+    cam.build(levels)
+    g2 = cam.create(pair["grey_ref"].astype(np.float32), po.convert_raw_depth(pair["depth_ref"]))
+    a, b = g2.level(levels - 1).depth_dx, gref.level(levels - 1).depth_dx
+    assert np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+    # thresholds
+    sel = d.PointSelection(gref, 5.0, 0.02)
+    assert sel.select(0) == oref.select(0, 5.0, 0.02)[0]
+
+
+@pytest.mark.parametrize("w,h,level", [(640, 480, 0), (640, 480, 1), (640, 480, 3), (160, 120, 0), (100, 76, 1)])
+def test_single_linearisation_against_oracle(gpu_ctx, w, h, level):
+    pair = cm.synth(23, w, h)
+    levels = level + 1
+    oref, ocur = cm.oracle_pyramids(pair, levels)
+    gref, gcur = gpu_pyramids(gpu_ctx, pair, levels)
+    trk = d.DenseTracker(d.Config(FirstLevel=level, LastLevel=level), gpu_ctx)
+    T34 = po.se3_exp(np.array([0.004, -0.003, 0.002, 0.005, -0.004, 0.003]))[:3]
+    for rows in (0, 1, 2, 4, 8, 16):            # every tile height must give the same answer
+        gpu_ctx.set_option("rows_per_wave", rows)
+        o = po.level_iteration(oref, ocur, level, T34, first=True, mode=po.MATH, want_residuals=True)
+        g = trk.level_iteration(gref, gcur, level, T34, first=True, want_residuals=True)
+        assert g["n"] == o["n"] and g["n_selected"] == o["n_selected"]
+        assert np.array_equal(np.isnan(g["residuals"]), np.isnan(o["residuals"]))
+        assert np.array_equal(np.nan_to_num(g["residuals"]), np.nan_to_num(o["residuals"]))
+        assert np.allclose(g["P"], o["P"], rtol=1e-5)
+        assert abs(g["neg_ll"] - o["neg_ll"]) <= 1e-6 * abs(o["neg_ll"])
+        assert np.abs(g["A"] - o["A"]).max() <= 1e-5 * np.abs(o["A"]).max()
+        assert np.abs(g["b"] - o["b"]).max() <= 1e-5 * np.abs(o["b"]).max()
+        assert np.array_equal(g["A"], g["A"].T)
+        o2 = po.level_iteration(oref, ocur, level, T34, P_prev=o["P"], first=False, mode=po.MATH)
+        g2 = trk.level_iteration(gref, gcur, level, T34, P_prev=o["P"], first=False)
+        assert g2["n"] == o2["n"]
+        assert np.allclose(g2["P"], o2["P"], rtol=1e-5)
+        assert abs(g2["neg_ll"] - o2["neg_ll"]) <= 1e-6 * abs(o2["neg_ll"])
+        assert np.abs(g2["A"] - o2["A"]).max() <= 1e-5 * np.abs(o2["A"]).max()
+        assert np.abs(g2["b"] - o2["b"]).max() <= 1e-5 * np.abs(o2["b"]).max()
+    gpu_ctx.set_option("rows_per_wave", 0)
+
+
+def test_golden_linearisation(gpu_ctx):
+    g = cm.load_golden("s160_seed7.npz")
+    pair = dict(grey_ref=g["grey_ref"], depth_ref=g["depth_ref"], grey_cur=g["grey_cur"], depth_cur=g["depth_cur"], K=g["K"])
+    gref, gcur = gpu_pyramids(gpu_ctx, pair, 3)
+    trk = d.DenseTracker(d.Config(FirstLevel=0, LastLevel=0), gpu_ctx)
+    a = trk.level_iteration(gref, gcur, 0, g["lin_T34"], first=True)
+    exp = g["lin_math_first"]
+    assert a["n"] == int(exp[0])
+    assert abs(a["neg_ll"] - exp[1]) <= 1e-6 * abs(exp[1])
+    assert np.allclose(a["P"].ravel(), exp[5:9], rtol=1e-5)
+    assert np.abs(a["A"].ravel() - exp[9:45]).max() <= 1e-5 * np.abs(exp[9:45]).max()
+    assert np.abs(a["b"] - exp[45:51]).max() <= 1e-5 * np.abs(exp[45:51]).max()
+    b = trk.level_iteration(gref, gcur, 0, g["lin_T34"], P_prev=exp[5:9], first=False)
+    exp2 = g["lin_math_weighted"]
+    assert b["n"] == int(exp2[0])
+    assert np.abs(b["A"].ravel() - exp2[9:45]).max() <= 1e-5 * np.abs(exp2[9:45]).max()
+
+
+def run_gpu_match(ctx, gref, gcur, cfg, T_init=None):
+    trk = d.DenseTracker(cfg, ctx)
+    r = d.Result()
+    if T_init is not None:
+        r.Transformation = np.array(T_init, dtype=np.float64)
+    assert trk.match(gref, gcur, r) is True
+    return cm.tracker_result_to_dict(r)
+
+
+@pytest.mark.parametrize("seed,w,h,first,last,mu,init,precision", [
+    (1234, 640, 480, 3, 0, 0.0, False, 5e-7),     # BASELINE config 2: single 640x480 pair, 4 levels, finest level 0
+    (1234, 640, 480, 3, 0, 0.0, False, 1e-4),
+    (5, 640, 480, 3, 1, 0.05, True, 1e-4),        # dvo_benchmark/launch/benchmark.yaml
+    (6, 640, 480, 3, 1, 0.0, False, 5e-7),        # reference defaults
+    (7, 160, 120, 2, 0, 0.0, False, 5e-7),
+    (4321, 1280, 960, 4, 0, 0.0, False, 1e-4),    # BASELINE config 5: 1280x960, 5 levels
+])
+def test_full_match_against_oracle(gpu_ctx, seed, w, h, first, last, mu, init, precision):
+    pair = cm.synth(seed, w, h)
+    oref, ocur = cm.oracle_pyramids(pair, first + 1)
+    gref, gcur = gpu_pyramids(gpu_ctx, pair, first + 1)
+    cfg = d.Config(FirstLevel=first, LastLevel=last, Mu=mu, UseInitialEstimate=init, Precision=precision,
+                   MaxIterationsPerLevel=50 if init else 100)
+    T0 = po.se3_exp(0.5 * pair["xi_true"]) if init else None
+    g = run_gpu_match(gpu_ctx, gref, gcur, cfg, T0)
+    o = po.match(oref, ocur, cm.oracle_config_from(cfg, po.MATH), T0)
+    s = cm.compare_runs(g, o)
+    assert s["n_mismatch"] == 0 and s["max_x_err"] < 2e-5, s
+    assert s["max_iter_count_diff"] <= 2, s
+    assert s["T_err"] < (2e-5 if precision > 1e-6 else 1e-6), s
+    if s["structure_mismatch"] == 0:
+        assert np.allclose(g["information"], o["information"], rtol=5e-3, atol=1e-6 * np.abs(o["information"]).max())
+        assert abs(g["loglik"] - o["loglik"]) <= 1e-3 * abs(o["loglik"])
+    # and against the quirk-faithful restatement of the SSE path, and the ground truth of the synthetic pair
+    q = po.match(oref, ocur, cm.oracle_config_from(cfg, po.REF_SSE), T0)
+    assert cm.twist_matrix_error(g["T"], q["T"]) < 5e-5
+    assert np.abs(po.se3_log(g["T"]) - pair["xi_true"]).max() < 1e-4
+
+
+def test_golden_full_match(gpu_ctx):
+    g = cm.load_golden("s160_seed7.npz")
+    pair = dict(grey_ref=g["grey_ref"], depth_ref=g["depth_ref"], grey_cur=g["grey_cur"], depth_cur=g["depth_cur"], K=g["K"])
+    gref, gcur = gpu_pyramids(gpu_ctx, pair, 3)
+    run = run_gpu_match(gpu_ctx, gref, gcur, d.Config(FirstLevel=2, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7))
+    assert cm.twist_matrix_error(run["T"], g["math_T"]) < 1e-6
+    assert cm.twist_matrix_error(run["T"], g["ref_sse_T"]) < 5e-5
+    rows = g["math_iters"]
+    first_level_rows = rows[rows[:, 0] == 2]
+    for it, row in zip(run["levels"][0]["iterations"][:3], first_level_rows[:3]):   # the first passes are far from the noise floor
+        assert it["n"] == int(row[2])
+        assert abs(it["neg_ll"] - row[3]) <= 1e-5 * abs(row[3])
+        assert np.abs(it["x"] - row[8:14]).max() < 1e-6
+
+
+def test_batch_equals_singles_and_is_deterministic(gpu_ctx):
+    pairs = [cm.synth(100 + i, 320, 240) for i in range(6)]
+    pyr = [gpu_pyramids(gpu_ctx, p, 3) for p in pairs]
+    cfg = d.Config(FirstLevel=2, LastLevel=0)
+    trk = d.DenseTracker(cfg, gpu_ctx)
+    singles = []
+    for r, c in pyr:
+        res = d.Result()
+        trk.match(r, c, res)
+        singles.append(res)
+    for rep in range(2):
+        batch = [d.Result() for _ in pyr]
+        trk.match_batch([p[0] for p in pyr], [p[1] for p in pyr], batch, with_stats=True)
+        for s, b in zip(singles, batch):
+            # fixed-order reductions: a pair's result must not depend on what else is in the launch.
+            # (tile height differs between batch sizes, so allow float rounding, not more)
+            assert cm.twist_matrix_error(s.Transformation, b.Transformation) < 1e-6
+        if rep == 0:
+            first = batch
+        else:
+            for a, b in zip(first, batch):   # same launch geometry twice: bit-identical
+                assert np.array_equal(a.Transformation, b.Transformation)
+                assert np.array_equal(a.Information, b.Information)
+    # shared frames in one batch (the LocalTracker pattern: two references against one current frame)
+    res = [d.Result(), d.Result()]
+    trk.match_batch([pyr[0][0], pyr[1][0]], [pyr[0][1], pyr[0][1]], res)
+    assert cm.twist_matrix_error(res[0].Transformation, singles[0].Transformation) < 1e-6
+
+
+def test_properties_at_full_size(gpu_ctx):
+    pair = cm.synth(77)
+    gref, gcur = gpu_pyramids(gpu_ctx, pair, 4)
+    cfg = d.Config(FirstLevel=3, LastLevel=0)
+    trk = d.DenseTracker(cfg, gpu_ctx)
+    # identical frames: the alignment is the identity and the first increment is (numerically) zero
+    r = d.Result()
+    trk.match(gref, gref, r)
+    assert np.abs(po.se3_log(r.Transformation)).max() < 1e-6
+    # swapping the roles inverts the transform (up to the asymmetric hole patterns / occlusion test)
+    a, b = d.Result(), d.Result()
+    trk.match(gref, gcur, a)
+    trk.match(gcur, gref, b)
+    assert cm.twist_matrix_error(a.Transformation, np.linalg.inv(b.Transformation)) < 2e-4
+    # information matrix is symmetric positive definite, statistics are appended not cleared (Q15)
+    assert np.allclose(a.Information, a.Information.T) and np.linalg.eigvalsh(a.Information).min() > 0
+    n_levels = len(a.Statistics.Levels)
+    trk.match(gref, gcur, a)
+    assert len(a.Statistics.Levels) == 2 * n_levels
+    # Affine-matrix overload (dense_tracking.cpp:99-109): in/out 4x4
+    T = np.eye(4)
+    assert trk.match(gref, gcur, T) is True
+    assert cm.twist_matrix_error(T, b.Transformation if False else a.Transformation) < 1e-9
+
+
+def test_edge_cases(gpu_ctx):
+    # no depth at all -> n = 0 on every level, identity out, NaN information, criterion IncrementTooSmall (Q22)
+    h, w = 120, 160
+    I = np.random.default_rng(0).uniform(0, 255, (h, w)).astype(np.float32)
+    Z = np.full((h, w), np.nan, np.float32)
+    cam = d.RgbdCameraPyramid(w, h, po.FR1_K / 4, gpu_ctx)
+    cam.build(3)
+    a, b = cam.create(I, Z), cam.create(I, Z)
+    r = d.Result()
+    d.DenseTracker(d.Config(FirstLevel=2, LastLevel=0), gpu_ctx).match(a, b, r)
+    assert r.isNaN() and np.allclose(r.Transformation, np.eye(4))
+    assert [L.TerminationCriterion for L in r.Statistics.Levels] == [1, 1, 1]
+    assert all(len(L.Iterations) == 1 and L.Iterations[0].ValidConstraints == 0 for L in r.Statistics.Levels)
+    # misuse is rejected with an error code, not a crash
+    with pytest.raises(d.DvoHipError):
+        gpu_ctx.set_option("rows_per_wave", 3)
+    trk = d.DenseTracker(d.Config(FirstLevel=2, LastLevel=0), gpu_ctx)
+    small = d.RgbdCameraPyramid(w // 2, h // 2, po.FR1_K / 8, gpu_ctx)
+    small.build(3)
+    c = small.create(I[::2, ::2].copy(), Z[::2, ::2].copy())
+    with pytest.raises(d.DvoHipError):
+        trk.match(a, c, d.Result())          # frames of different cameras in one match
+    # iteration cap and a ragged (non multiple-of-64) image
+    pair = cm.synth(3, 100, 76)
+    gref, gcur = gpu_pyramids(gpu_ctx, pair, 2)
+    oref, ocur = cm.oracle_pyramids(pair, 2)
+    cfg = d.Config(FirstLevel=1, LastLevel=0, MaxIterationsPerLevel=3, Precision=0.0)
+    g = run_gpu_match(gpu_ctx, gref, gcur, cfg)
+    o = po.match(oref, ocur, cm.oracle_config_from(cfg, po.MATH))
+    s = cm.compare_runs(g, o)
+    assert s["structure_mismatch"] == 0 and s["n_mismatch"] == 0 and s["T_err"] < 1e-6
+    assert all(len(L["iterations"]) <= 3 for L in g["levels"])
