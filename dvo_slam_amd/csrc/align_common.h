@@ -1,0 +1,88 @@
+// align_common.h -- device helpers shared by the alignment kernels: global-address-space loaders and the
+// DPP wavefront reduction.
+#pragma once
+
+#include "launch.h"
+#include "pixel_math.h"
+#include "reduce_scale.h"
+
+namespace dvo_hip {
+
+// Pointers loaded from a table in memory are generic to the compiler; these loaders re-type them as
+// global (address space 1) so the taps compile to global_load_dwordx4 / dwordx2 instead of flat loads.
+typedef float __attribute__((ext_vector_type(4))) vec4f;
+typedef float __attribute__((ext_vector_type(2))) vec2f;
+typedef const __attribute__((address_space(1))) vec4f* GlobalVec4;
+typedef const __attribute__((address_space(1))) vec2f* GlobalVec2;
+
+struct GlobalLoad4 {
+  GlobalVec4 p;
+  __device__ __forceinline__ float4 operator[](int i) const {
+    const vec4f v = p[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+};
+struct GlobalLoad2 {
+  GlobalVec2 p;
+  __device__ __forceinline__ float2 operator[](int i) const {
+    const vec2f v = p[i];
+    return make_float2(v.x, v.y);
+  }
+};
+
+// ---- wavefront reduction of all accumulators with DPP (result valid in lane 63) -------------------------
+// Six DPP stages: row_shr 1,2,4,8 leave each row-of-16 sum in its lane 15; row_bcast:15 folds rows
+// 0->1 and 2->3; row_bcast:31 folds lane 31 into rows 2,3.  Written as inline assembly, five
+// independent accumulators per statement, because (a) hipcc otherwise SLP-packs the adds of adjacent
+// accumulators into v_pk_add_f32, which cannot carry a DPP modifier and costs three moves per add, and
+// (b) a stage applied to five different registers needs one s_nop (VALU write -> DPP read hazard, 2
+// wait states) per statement instead of one per add.
+#define DVO_DPP5(ctrl)                                    \
+  "s_nop 1\n\t"                                           \
+  "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"                 \
+  "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"                 \
+  "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t"                 \
+  "v_add_f32_dpp %3, %3, %3 " ctrl "\n\t"                 \
+  "v_add_f32_dpp %4, %4, %4 " ctrl
+
+template <int STAGE>
+__device__ __forceinline__ void dpp_stage5(float& a, float& b, float& c, float& d, float& e) {
+  if constexpr (STAGE == 0)
+    asm volatile(DVO_DPP5("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+  else if constexpr (STAGE == 1)
+    asm volatile(DVO_DPP5("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+  else if constexpr (STAGE == 2)
+    asm volatile(DVO_DPP5("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+  else if constexpr (STAGE == 3)
+    asm volatile(DVO_DPP5("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+  else if constexpr (STAGE == 4)
+    asm volatile(DVO_DPP5("row_bcast:15 row_mask:0xa bank_mask:0xf") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+  else
+    asm volatile(DVO_DPP5("row_bcast:31 row_mask:0xc bank_mask:0xf") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+}
+
+template <int STAGE, int N>
+__device__ __forceinline__ void dpp_stage_all(float* acc) {
+  static_assert(N % 5 == 0, "accumulators are reduced five at a time (pad the array)");
+#pragma unroll
+  for (int i = 0; i < N; i += 5) dpp_stage5<STAGE>(acc[i], acc[i + 1], acc[i + 2], acc[i + 3], acc[i + 4]);
+}
+
+// sums of N per-lane accumulators over the wavefront; valid in lane 63
+template <int N>
+__device__ __forceinline__ void wave_sum_all_to_lane63(float* acc) {
+  dpp_stage_all<0, N>(acc);
+  dpp_stage_all<1, N>(acc);
+  dpp_stage_all<2, N>(acc);
+  dpp_stage_all<3, N>(acc);
+  dpp_stage_all<4, N>(acc);
+  dpp_stage_all<5, N>(acc);
+}
+
+__device__ __forceinline__ double wave_sum_double(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;   // valid in lane 0
+}
+
+
+}  // namespace dvo_hip

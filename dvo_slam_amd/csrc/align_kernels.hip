@@ -14,93 +14,22 @@
 // streaming of the reference plane, 16-B/8-B gathers of the current planes that stay in L1/L2 thanks
 // to 2-D tiles, XCD-aware tile->workgroup mapping, and a deterministic (atomic-free, fixed-order)
 // wavefront-DPP -> LDS -> per-workgroup-partial reduction.
-#include "launch.h"
-#include "pixel_math.h"
-#include "reduce_scale.h"
+#include "align_common.h"
 
 namespace dvo_hip {
 
-// Pointers loaded from a table in memory are generic to the compiler; these loaders re-type them as
-// global (address space 1) so the taps compile to global_load_dwordx4 / dwordx2 instead of flat loads.
-typedef float __attribute__((ext_vector_type(4))) vec4f;
-typedef float __attribute__((ext_vector_type(2))) vec2f;
-typedef const __attribute__((address_space(1))) vec4f* GlobalVec4;
-typedef const __attribute__((address_space(1))) vec2f* GlobalVec2;
-
-struct GlobalLoad4 {
-  GlobalVec4 p;
-  __device__ __forceinline__ float4 operator[](int i) const {
-    const vec4f v = p[i];
-    return make_float4(v.x, v.y, v.z, v.w);
-  }
-};
-struct GlobalLoad2 {
-  GlobalVec2 p;
-  __device__ __forceinline__ float2 operator[](int i) const {
-    const vec2f v = p[i];
-    return make_float2(v.x, v.y);
-  }
-};
-
-// ---- wavefront reduction of all accumulators with DPP (result valid in lane 63) -------------------------
-// Six DPP stages: row_shr 1,2,4,8 leave each row-of-16 sum in its lane 15; row_bcast:15 folds rows
-// 0->1 and 2->3; row_bcast:31 folds lane 31 into rows 2,3.  Written as inline assembly, five
-// independent accumulators per statement, because (a) hipcc otherwise SLP-packs the adds of adjacent
-// accumulators into v_pk_add_f32, which cannot carry a DPP modifier and costs three moves per add, and
-// (b) a stage applied to five different registers needs one s_nop (VALU write -> DPP read hazard, 2
-// wait states) per statement instead of one per add.
-#define DVO_DPP5(ctrl)                                    \
-  "s_nop 1\n\t"                                           \
-  "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"                 \
-  "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"                 \
-  "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t"                 \
-  "v_add_f32_dpp %3, %3, %3 " ctrl "\n\t"                 \
-  "v_add_f32_dpp %4, %4, %4 " ctrl
-
-template <int STAGE>
-__device__ __forceinline__ void dpp_stage5(float& a, float& b, float& c, float& d, float& e) {
-  if constexpr (STAGE == 0)
-    asm volatile(DVO_DPP5("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
-  else if constexpr (STAGE == 1)
-    asm volatile(DVO_DPP5("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
-  else if constexpr (STAGE == 2)
-    asm volatile(DVO_DPP5("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
-  else if constexpr (STAGE == 3)
-    asm volatile(DVO_DPP5("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
-  else if constexpr (STAGE == 4)
-    asm volatile(DVO_DPP5("row_bcast:15 row_mask:0xa bank_mask:0xf") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
-  else
-    asm volatile(DVO_DPP5("row_bcast:31 row_mask:0xc bank_mask:0xf") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
-}
-
-template <int STAGE>
-__device__ __forceinline__ void dpp_stage_all(float* acc) {
-  static_assert(kNumAcc % 5 == 0, "accumulators are reduced five at a time");
-#pragma unroll
-  for (int i = 0; i < kNumAcc; i += 5) dpp_stage5<STAGE>(acc[i], acc[i + 1], acc[i + 2], acc[i + 3], acc[i + 4]);
-}
-
-__device__ __forceinline__ void wave_sum_all_to_lane63(float* acc) {
-  dpp_stage_all<0>(acc);
-  dpp_stage_all<1>(acc);
-  dpp_stage_all<2>(acc);
-  dpp_stage_all<3>(acc);
-  dpp_stage_all<4>(acc);
-  dpp_stage_all<5>(acc);
-}
-
-__device__ __forceinline__ double wave_sum_double(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;   // valid in lane 0
-}
-
 // FINEST only tags the instantiation that sweeps pyramid level 0 with a distinct symbol, so that a rocprofv3
 // kernel trace reports the finest-level launches (the roofline kernel) separately from the coarser ones.
-template <int RPW, bool FINEST>
-__global__ __launch_bounds__(kBlock) void k_residual_reduce(const LevelGeom g, const PairPtrs* __restrict__ pairs,
-                                                           const PairState* __restrict__ states, int n_pairs,
-                                                           float* __restrict__ partials, float2* __restrict__ scratch,
-                                                           int blocks_per_xcd) {
+// VARIANT selects the schedule of the row loop (same arithmetic, same results):
+//   0  one row at a time (lowest register count)
+//   1  software pipeline: the reference row k+2 and the eight taps of row k+1 are in flight while row k is
+//      blended and accumulated, so each wavefront overlaps its own HBM/L2 latency with its ~1000 cycles of VALU
+//      work instead of relying on the 2-3 co-resident wavefronts the 85 accumulators leave room for
+//   2  as 1, compiled for at least 3 wavefronts per SIMD (<= 168 VGPRs)
+template <int RPW, bool FINEST, int VARIANT>
+__global__ __launch_bounds__(kBlock, (VARIANT == 2 ? 3 : 1)) void k_residual_reduce(
+    const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
+    float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd) {
   // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD one
   // contiguous run of (pair, tile) work items so that a pair's current-frame planes -- re-read by
   // vertically adjacent tiles -- flow through a single L2.
@@ -129,32 +58,63 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce(const LevelGeom g, c
   const int u_r = (tile % g.tiles_x) * kTileW + lane;
   const int row0 = (tile / g.tiles_x) * (kWavesPerBlock * RPW) + wave * RPW;
   const size_t pix_base = size_t(pair) * size_t(g.w) * g.h;
+  const float nanv = __builtin_nanf("");
+  const bool col_ok = u_r < g.w;
 
   float acc[kNumAcc];
 #pragma unroll
   for (int i = 0; i < kNumAcc; ++i) acc[i] = 0.0f;
 
-#pragma unroll 1
-  for (int k = 0; k < RPW; ++k) {
+  // 64 lanes x 16 B = 1 KiB contiguous per wave; rows beyond the image read as "not selected"
+  auto load_ref = [&](int k) -> float4 {
     const int v_r = row0 + k;
-    if (u_r >= g.w || v_r >= g.h) continue;
-    const int idx = v_r * g.w + u_r;
-    const float4 ref = refR[idx];                 // 64 lanes x 16 B = 1 KiB contiguous per wave
-    PixelTerms t;
-    const bool valid = pixel_residual(g, KT, curA, curB, ref, u_r, v_r, t);
-    const float nanv = __builtin_nanf("");
-    scratch[pix_base + idx] = valid ? make_float2(t.r0, t.r1) : make_float2(nanv, nanv);
-    if (!valid) continue;
-
+    if (k < RPW && col_ok && v_r < g.h) return refR[v_r * g.w + u_r];
+    return make_float4(nanv, 0.0f, 0.0f, 0.0f);
+  };
+  // blend, test, store the residual pair for the log-likelihood sweep, weight and accumulate
+  auto finish_row = [&](int k, const float4 ref, const PixelProj& p, const PixelTaps& t) {
+    const int v_r = row0 + k;
+    if (!col_ok || v_r >= g.h) return;
+    PixelTerms o;
+    const bool valid = p.ok && pixel_finish(g, ref, p, t, o);
+    scratch[pix_base + size_t(v_r) * g.w + u_r] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);
+    if (!valid) return;
     // t-distribution weight with the PREVIOUS pass' precision (Q11); first pass on a level: w = 1
-    const float w = first ? 1.0f : tdist_weight(t.r0, t.r1, Pp);
-    accumulate_pixel(acc, t, w);
+    const float w = first ? 1.0f : tdist_weight(o.r0, o.r1, Pp);
+    accumulate_pixel(acc, o, w);
+  };
+
+  if constexpr (VARIANT >= 1) {
+    float4 ref_cur = load_ref(0);
+    float4 ref_next = load_ref(1);
+    PixelProj p_cur = pixel_project(g, KT, ref_cur, col_ok ? u_r : 0, min(row0, g.h - 1));
+    PixelTaps t_cur;
+    if (p_cur.ok) pixel_fetch(g, curA, curB, p_cur, t_cur);
+#pragma unroll 1
+    for (int k = 0; k < RPW; ++k) {
+      const float4 ref_next2 = load_ref(k + 2);                      // stage 1 of row k+2
+      const PixelProj p_next = pixel_project(g, KT, ref_next, col_ok ? u_r : 0, min(row0 + k + 1, g.h - 1));
+      PixelTaps t_next;
+      if (p_next.ok) pixel_fetch(g, curA, curB, p_next, t_next);     // stage 2 of row k+1: eight gathers in flight
+      finish_row(k, ref_cur, p_cur, t_cur);                          // stage 3 of row k
+      ref_cur = ref_next; ref_next = ref_next2;
+      p_cur = p_next; t_cur = t_next;
+    }
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < RPW; ++k) {
+      const float4 ref = load_ref(k);
+      const PixelProj p = pixel_project(g, KT, ref, col_ok ? u_r : 0, min(row0 + k, g.h - 1));
+      PixelTaps t;
+      if (p.ok) pixel_fetch(g, curA, curB, p, t);
+      finish_row(k, ref, p, t);
+    }
   }
 
   // stage 1: DPP reduction inside each wavefront; stage 2: the four wave results through LDS;
   // stage 3 (fixed block order, float64) happens in the per-pair solver kernel.  No float atomics.
   __shared__ float lds[kWavesPerBlock][kAccStride];
-  wave_sum_all_to_lane63(acc);
+  wave_sum_all_to_lane63<kNumAcc>(acc);
   if (lane == 63) {
 #pragma unroll
     for (int i = 0; i < kNumAcc; ++i) lds[wave][i] = acc[i];
@@ -171,12 +131,11 @@ __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const Pair
                                                    double* __restrict__ ll_partials, int blocks_per_pair) {
   const int pair = blockIdx.y;
   if (!states[pair].active) return;
-  __shared__ double sh[4 * kBlock];
+  __shared__ double sh[kWavesPerBlock * kAccStride];
+  __shared__ double sums[kAccStride];
   float C[3], P[4];
-  double s4[4];
-  const int tiles = g.tiles_x * g.tiles_y;
-  const int n = reduce_scale(partials, pair, tiles, sh, s4, C, P);
-  __syncthreads();
+  reduce_partials(partials, pair, g.tiles_x * g.tiles_y, sh, sums);
+  const int n = scale_from_sums(sums, C, P);
   double total = 0.0;
   if (n >= 6) {
     const int npx = g.w * g.h;
@@ -204,25 +163,38 @@ __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const Pair
   if (threadIdx.x == 0) ll_partials[size_t(pair) * blocks_per_pair + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-template <int RPW>
+template <int RPW, int VARIANT>
 static void launch_rr(hipStream_t s, bool finest, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                       float* partials, float2* scratch) {
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   if (finest)
-    k_residual_reduce<RPW, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+    k_residual_reduce<RPW, true, VARIANT><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
   else
-    k_residual_reduce<RPW, false><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+    k_residual_reduce<RPW, false, VARIANT><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
 }
 
-void launch_residual_reduce(hipStream_t s, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
-                            const PairState* states, int n_pairs, float* partials, float2* scratch) {
+template <int VARIANT>
+static void launch_rr_v(hipStream_t s, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
+                        const PairState* states, int n_pairs, float* partials, float2* scratch) {
   switch (rows_per_wave) {
-    case 1: launch_rr<1>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 2: launch_rr<2>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 4: launch_rr<4>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 16: launch_rr<16>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    default: launch_rr<8>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 1: launch_rr<1, VARIANT>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 2: launch_rr<2, VARIANT>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 4: launch_rr<4, VARIANT>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 16: launch_rr<16, VARIANT>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    default: launch_rr<8, VARIANT>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+  }
+}
+
+void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
+                            const PairState* states, int n_pairs, float* partials, float2* scratch) {
+  switch (variant) {
+    case 5: launch_residual_reduce_mfma(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 3: launch_residual_reduce_split(s, false, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 4: launch_residual_reduce_split(s, true, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 1: launch_rr_v<1>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 2: launch_rr_v<2>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    default: launch_rr_v<0>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
   }
 }
 

@@ -1,0 +1,170 @@
+// align_mfma.hip -- the fused residual / Jacobian / reduce sweep with the normal-equation accumulation on the
+// matrix cores (schedule variant 5 of k_residual_reduce; same per-pixel arithmetic, same outputs).
+//
+// Why a matrix instruction in a "memory-bound per-pixel" kernel: measured on MI355X (profiles/r01_*), the
+// all-VALU schedule is NOT memory-bound.  Its 85 per-lane accumulators cost ~125 FMAs per pixel plus a
+// 600-instruction DPP reduction per wavefront, SQ_ACTIVE_INST_VALU shows the vector ALUs 78 % busy, and the
+// kernel stops at 0.50 ms per 128-pair finest-level launch (39 % of the HBM roofline) with 150 VGPRs = 3
+// wavefronts per SIMD.  The accumulation itself is a rank-k update  G += V^T V  of the 16x16 Gram matrix of the
+// per-pixel vectors  v = sqrt(w) * [J0(6), J1(6), r0, r1, 0, 0]  (least_squares.cpp:58-64 contracts exactly this
+// with the 2x2 precision) -- matrix math, four pixels (k = 4) per v_mfma_f32_16x16x4_f32.  That instruction is an
+// exact f32 fmaf chain (no reduced precision), runs on the otherwise idle matrix pipe, keeps the whole Gram
+// matrix in 4 accumulator registers per lane instead of 85, and leaves NO cross-lane reduction to do: the sum
+// over the 64 pixels of a row happens inside the 16 MFMAs.  The per-pixel part (warp, bilinear taps, residual,
+// weights, Jacobian: dense_tracking_impl.cpp:148-281, dense_tracking.cpp:448-476) is unchanged VALU code.
+//
+// Data movement per pixel row of a wavefront: each lane (= pixel) writes its 16-vector to LDS as four
+// conflict-free ds_write_b128; the MFMA operand for pixel group g (lane l <- component l&15 of pixel 4g + l>>4)
+// is one conflict-free ds_read_b32 at a constant offset.  A == B (the sqrt(w)-scaled vector on both sides).
+// The LDS slab is private to the wavefront, so the row loop contains no barrier.
+#include "align_common.h"
+
+namespace dvo_hip {
+
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+
+constexpr int kQuadStride = 264;                 // floats per component quad: 64 pixels x 4 + 8 skew (bank-conflict-free reads)
+constexpr int kSlabFloats = 4 * kQuadStride;     // per-wavefront LDS slab (4224 B)
+
+template <int RPW, bool FINEST>
+__global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
+    const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
+    float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd) {
+  // XCD-aware (pair, tile) -> workgroup mapping, see k_residual_reduce
+  const int tiles = g.tiles_x * g.tiles_y;
+  const int total = tiles * n_pairs;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int item = xcd * blocks_per_xcd + slot;
+  if (item >= total) return;
+  const int pair = item / tiles, tile = item - pair * tiles;
+  const PairState& st = states[pair];
+  if (!st.active) return;
+  const PairPtrs pp = pairs[pair];
+  const GlobalLoad4 refR{(GlobalVec4)pp.refR}, curA{(GlobalVec4)pp.curA};
+  const GlobalLoad2 curB{(GlobalVec2)pp.curB};
+
+  float KT[12], Pp[4];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) KT[i] = st.KT[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) Pp[i] = st.P_prev[i];
+  const bool first = st.first != 0;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u_r = (tile % g.tiles_x) * kTileW + lane;
+  const int row0 = (tile / g.tiles_x) * (kWavesPerBlock * RPW) + wave * RPW;
+  const size_t pix_base = size_t(pair) * size_t(g.w) * g.h;
+  const float nanv = __builtin_nanf("");
+  const bool col_ok = u_r < g.w;
+
+  __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kSlabFloats];
+  __shared__ float gram[kWavesPerBlock][256];
+  __shared__ int counts[kWavesPerBlock];
+  float* my = slab[wave];
+  // write side: component quad q of pixel `lane` at my[q*kQuadStride + lane*4 .. +3]
+  f32x4* wr = reinterpret_cast<f32x4*>(my + lane * 4);
+  // read side: MFMA operand lane l <- component c = l&15 of pixel 4g + (l>>4); g enters as a constant offset of 16 floats
+  const float* rd = my + ((lane >> 2) & 3) * kQuadStride + (lane >> 4) * 4 + (lane & 3);
+
+  f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  int n_valid = 0;
+
+#pragma unroll 1
+  for (int k = 0; k < RPW; ++k) {
+    const int v_r = row0 + k;
+    const bool in_image = col_ok && v_r < g.h;
+    float4 ref = make_float4(nanv, 0.0f, 0.0f, 0.0f);
+    if (in_image) ref = refR[v_r * g.w + u_r];               // 64 lanes x 16 B = 1 KiB contiguous per wave
+    const PixelProj p = pixel_project(g, KT, ref, col_ok ? u_r : 0, min(v_r, g.h - 1));
+    PixelTaps t;
+    if (p.ok) pixel_fetch(g, curA, curB, p, t);
+    PixelTerms o;
+    const bool valid = p.ok && pixel_finish(g, ref, p, t, o);
+    if (in_image) scratch[pix_base + size_t(v_r) * g.w + u_r] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);
+    n_valid += __popcll(__ballot(valid));                    // exact count on the scalar unit
+    f32x4 q0 = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0, q2 = q0, q3 = q0;
+    if (valid) {
+      // t-distribution weight with the PREVIOUS pass' precision (Q11); first pass on a level: w = 1
+      const float sw = first ? 1.0f : __builtin_sqrtf(tdist_weight(o.r0, o.r1, Pp));
+      float J0[6], J1[6];
+      jacobian_rows(o, J0, J1);
+      q0 = f32x4{sw * J0[0], sw * J0[1], sw * J0[2], sw * J0[3]};
+      q1 = f32x4{sw * J0[4], sw * J0[5], sw * J1[0], sw * J1[1]};
+      q2 = f32x4{sw * J1[2], sw * J1[3], sw * J1[4], sw * J1[5]};
+      q3 = f32x4{sw * o.r0, sw * o.r1, 0.0f, 0.0f};
+    }
+    wr[0] = q0;
+    wr[kQuadStride / 4] = q1;
+    wr[2 * (kQuadStride / 4)] = q2;
+    wr[3 * (kQuadStride / 4)] = q3;
+    // the slab is private to this wavefront and LDS executes a wavefront's operations in order: only the
+    // compiler has to be kept from moving the reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int grp = 0; grp < 16; grp += 2) {                  // 4 pixels per MFMA, two independent accumulator chains
+      const float a0 = rd[grp * 16], a1 = rd[grp * 16 + 16];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc1, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // lane l, register i holds G[row (l>>4)*4 + i][col l&15] of this wavefront's rows
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gram[wave][((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
+  if (lane == 0) counts[wave] = n_valid;
+  __syncthreads();
+  // fold the four wavefront Gram matrices into the canonical partial row (device_types.h); vector layout:
+  // components 0..5 = J0, 6..11 = J1, 12 = r0, 13 = r1
+  const int k = threadIdx.x;
+  if (k < kNumAcc) {
+    auto G = [&](int r, int c) {
+      const int e = r * 16 + c;
+      return (gram[0][e] + gram[1][e]) + (gram[2][e] + gram[3][e]);
+    };
+    float v;
+    if (k == kAccN) v = float((counts[0] + counts[1]) + (counts[2] + counts[3]));
+    else if (k == kAccS) v = G(12, 12);
+    else if (k == kAccS + 1) v = G(12, 13);
+    else if (k == kAccS + 2) v = G(13, 13);
+    else if (k < kAccB00) {
+      const int blockId = (k - kAccJ00) / 21;                // 0: J0J0, 1: J1J1, 2: J0J1 symmetrised
+      int o = (k - kAccJ00) % 21, i = 0;
+      while (o >= 6 - i) { o -= 6 - i; ++i; }                // upper-triangular row-major index -> (i, j)
+      const int j = i + o;
+      if (blockId == 0) v = G(i, j);
+      else if (blockId == 1) v = G(6 + i, 6 + j);
+      else v = G(i, 6 + j) + G(j, 6 + i);
+    } else if (k < kAccB01) v = G(k - kAccB00, 12);
+    else if (k < kAccB11) v = G(k - kAccB01, 13) + G(6 + (k - kAccB01), 12);
+    else v = G(6 + (k - kAccB11), 13);
+    partials[(size_t(pair) * tiles + tile) * kAccStride + k] = v;
+  }
+}
+
+template <int RPW>
+static void launch_m(hipStream_t s, bool finest, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
+                     float* partials, float2* scratch) {
+  const int total = g.tiles_x * g.tiles_y * n_pairs;
+  const int per_xcd = (total + 7) / 8;
+  if (finest)
+    k_residual_reduce_mfma<RPW, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+  else
+    k_residual_reduce_mfma<RPW, false><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+}
+
+void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
+                                 const PairState* states, int n_pairs, float* partials, float2* scratch) {
+  switch (rows_per_wave) {
+    case 1: launch_m<1>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 2: launch_m<2>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 4: launch_m<4>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 16: launch_m<16>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    default: launch_m<8>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+  }
+}
+
+}  // namespace dvo_hip

@@ -79,6 +79,7 @@ struct dvo_hip_context {
   std::string err;
   int opt_rows_per_wave = 0;
   int opt_iters_per_sync = 0;
+  int opt_variant = 5;             // schedule of the reduce kernel: 5 = Gram accumulation on the matrix cores (default)
   std::vector<CameraGeom*> cameras;
   // batch workspace
   DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters, misc, build_tbl;
@@ -103,7 +104,7 @@ int fail(dvo_hip_context* ctx, int code, const char* msg) {
   return code;
 }
 
-const int kLlBlocksPerPair = 8;
+const int kLlBlocksPerPair = 32;
 
 // RgbdCameraPyramid::build (rgbd_image.cpp:283-296) + RgbdCamera ctor template (:186-204)
 int get_camera(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, const CameraGeom** out) {
@@ -170,7 +171,7 @@ LevelGeom make_geom(const CameraGeom* cam, int level, int rows_per_wave) {
 // keep all 256 CUs busy when the batch is small
 int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_pairs) {
   if (ctx->opt_rows_per_wave > 0) return ctx->opt_rows_per_wave;
-  const int candidates[4] = {8, 4, 2, 1};
+  const int candidates[5] = {16, 8, 4, 2, 1};
   for (int r : candidates) {
     const int tiles = ((cam->w[level] + kTileW - 1) / kTileW) * ((cam->h[level] + kWavesPerBlock * r - 1) / (kWavesPerBlock * r));
     if (size_t(tiles) * n_pairs >= 1024) return r;
@@ -423,6 +424,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     ctx->opt_iters_per_sync = value;
     return DVO_HIP_OK;
   }
+  if (std::strcmp(key, "variant") == 0) {
+    if (value < 0 || value > 5) return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0..5");
+    ctx->opt_variant = value;
+    return DVO_HIP_OK;
+  }
   return fail(ctx, DVO_HIP_ERR_INVALID, "unknown option");
 }
 
@@ -599,7 +605,7 @@ int dvo_hip_match_batch(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const*
     while (it < cfg->max_iterations_per_level) {
       const int chunk = std::min(per_sync, cfg->max_iterations_per_level - it);
       for (int c = 0; c < chunk; ++c, ++step) {
-        launch_residual_reduce(s, bp.rpw[level], level == 0, g, pp, states, n, ctx->partials.as<float>(), ctx->scratch.as<float2>());
+        launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, ctx->partials.as<float>(), ctx->scratch.as<float2>());
         launch_loglik(s, g, states, n, ctx->partials.as<float>(), ctx->scratch.as<float2>(), ctx->ll_partials.as<double>(), kLlBlocksPerPair);
         launch_solver_step(s, states, n, bp.prm, g, ctx->partials.as<float>(), ctx->ll_partials.as<double>(), kLlBlocksPerPair,
                            d_levels, d_iters, counters + step);
@@ -678,7 +684,7 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
   DVO_HIP_TRY(ctx, hipMemsetAsync(states, 0, sizeof(PairState), s));
   launch_set_fixed_state(s, states, g, d_T, d_P, first_iteration_on_level ? 1 : 0);
   const PairPtrs* pp = bp.pair_ptrs + size_t(level);
-  launch_residual_reduce(s, bp.rpw[level], level == 0, g, pp, states, 1, ctx->partials.as<float>(), ctx->scratch.as<float2>());
+  launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, 1, ctx->partials.as<float>(), ctx->scratch.as<float2>());
   launch_loglik(s, g, states, 1, ctx->partials.as<float>(), ctx->scratch.as<float2>(), ctx->ll_partials.as<double>(), kLlBlocksPerPair);
   int n_sel = 0;
   DVO_HIP_TRY(ctx, hipMemcpyAsync(&n_sel, reference->sel_count + level, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -715,10 +721,10 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs, dvo_hip_fram
   hipEvent_t e0, e1;
   DVO_HIP_TRY(ctx, hipEventCreate(&e0));
   DVO_HIP_TRY(ctx, hipEventCreate(&e1));
-  launch_residual_reduce(s, bp.rpw[level], level == 0, g, pp, states, bp.n, ctx->partials.as<float>(), ctx->scratch.as<float2>());   // warm
+  launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, bp.n, ctx->partials.as<float>(), ctx->scratch.as<float2>());   // warm
   DVO_HIP_TRY(ctx, hipEventRecord(e0, s));
   for (int r = 0; r < reps; ++r)
-    launch_residual_reduce(s, bp.rpw[level], level == 0, g, pp, states, bp.n, ctx->partials.as<float>(), ctx->scratch.as<float2>());
+    launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, bp.n, ctx->partials.as<float>(), ctx->scratch.as<float2>());
   DVO_HIP_TRY(ctx, hipEventRecord(e1, s));
   DVO_HIP_TRY(ctx, hipEventSynchronize(e1));
   float ms = 0;

@@ -15,8 +15,12 @@ void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, 
 void launch_unpack_plane(hipStream_t s, const float4* A, const float2* B, int n, int plane, float* out);
 
 // align_kernels.hip
-void launch_residual_reduce(hipStream_t s, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
+void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
                             const PairState* states, int n_pairs, float* partials, float2* scratch);
+void launch_residual_reduce_split(hipStream_t s, bool pipelined, int rows_per_wave, bool finest_level, const LevelGeom& g,
+                                  const PairPtrs* pairs, const PairState* states, int n_pairs, float* partials, float2* scratch);
+void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
+                                 const PairState* states, int n_pairs, float* partials, float2* scratch);
 void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,
                    const float2* scratch, double* ll_partials, int blocks_per_pair);
 

@@ -64,38 +64,70 @@ DVO_HD void make_KT(float fx, float fy, float ox, float oy, const float* T, floa
   }
 }
 
-// Warp one reference pixel, sample the current frame, form the residual and the gradient rows.
-// Returns false if the pixel contributes no constraint.
-template <typename PtrA, typename PtrB>
-DVO_HD bool pixel_residual(const LevelGeom& g, const float* KT, PtrA curA, PtrB curB, const float4 ref, int u_r, int v_r,
-                           PixelTerms& o) {
+// ---- the residual of one reference pixel, in three stages so that the kernel can software-pipeline them ------
+// (1) pixel_project: warp + projection + bounds test          (dense_tracking_impl.cpp:148-203)
+// (2) pixel_fetch:   the 4 + 4 bilinear taps                   (:212-213, :229-251)
+// (3) pixel_finish:  bilinear blend, NaN / occlusion tests, residual and gradient rows (:256-281)
+struct PixelProj {
+  float X, Y, Z;      // untransformed reference point
+  float qz;           // transformed depth
+  float a1, b1;       // bilinear weights of the +1 taps
+  int base;           // index of tap (u0, v0) in the current-frame planes
+  bool ok;
+};
+
+struct PixelTaps {
+  float4 A00, A10, A01, A11;
+  float2 B00, B10, B01, B11;
+};
+
+DVO_HD PixelProj pixel_project(const LevelGeom& g, const float* KT, const float4 ref, int u_r, int v_r) {
 #pragma clang fp contract(off)
+  PixelProj p;
+  p.ok = false;
+  p.base = 0;
+  p.a1 = p.b1 = 0.0f;
   const float Z = ref.x;
-  if (!(Z == Z)) return false;                      // not selected / no depth (Q19)
+  p.Z = Z;
   const float X = g.tx[u_r] * Z;                    // rgbd_image.cpp:198-201, 258
   const float Y = g.ty[v_r] * Z;
+  p.X = X; p.Y = Y;
   const float qx = (KT[0] * X + KT[1] * Y) + (KT[2] * Z + KT[3]);
   const float qy = (KT[4] * X + KT[5] * Y) + (KT[6] * Z + KT[7]);
   const float qz = (KT[8] * X + KT[9] * Y) + (KT[10] * Z + KT[11]);
+  p.qz = qz;
+  if (!(Z == Z)) return p;                          // not selected / no depth (Q19)
   const float u = qx / qz, v = qy / qz;             // correctly rounded division (MATH semantics, Q1)
-  if (!(u >= 0.0f && u <= float(g.w - 2) && v >= 0.0f && v <= float(g.h - 2))) return false;   // Q4
+  if (!(u >= 0.0f && u <= float(g.w - 2) && v >= 0.0f && v <= float(g.h - 2))) return p;   // Q4
   const float uf = floorf(u), vf = floorf(v);
-  const int u0 = int(uf), v0 = int(vf);
-  const float a1 = u - uf, a0 = 1.0f - a1, b1 = v - vf, b0 = 1.0f - b1;
-  const int base = v0 * g.w + u0;
-  const float4 A00 = curA[base], A10 = curA[base + 1], A01 = curA[base + g.w], A11 = curA[base + g.w + 1];
-  const float2 B00 = curB[base], B10 = curB[base + 1], B01 = curB[base + g.w], B11 = curB[base + g.w + 1];
-#define DVO_BILERP(f) (b0 * (a0 * A00.f + a1 * A10.f) + b1 * (a0 * A01.f + a1 * A11.f))
+  p.a1 = u - uf;
+  p.b1 = v - vf;
+  p.base = int(vf) * g.w + int(uf);
+  p.ok = true;
+  return p;
+}
+
+template <typename PtrA, typename PtrB>
+DVO_HD void pixel_fetch(const LevelGeom& g, PtrA curA, PtrB curB, const PixelProj& p, PixelTaps& t) {
+  const int base = p.base;
+  t.A00 = curA[base]; t.A10 = curA[base + 1]; t.A01 = curA[base + g.w]; t.A11 = curA[base + g.w + 1];
+  t.B00 = curB[base]; t.B10 = curB[base + 1]; t.B01 = curB[base + g.w]; t.B11 = curB[base + g.w + 1];
+}
+
+DVO_HD bool pixel_finish(const LevelGeom& g, const float4 ref, const PixelProj& p, const PixelTaps& t, PixelTerms& o) {
+#pragma clang fp contract(off)
+  const float a1 = p.a1, a0 = 1.0f - a1, b1 = p.b1, b0 = 1.0f - b1;
+#define DVO_BILERP(f) (b0 * (a0 * t.A00.f + a1 * t.A10.f) + b1 * (a0 * t.A01.f + a1 * t.A11.f))
   const float cI = DVO_BILERP(x), cZ = DVO_BILERP(y), cIx = DVO_BILERP(z), cIy = DVO_BILERP(w);
 #undef DVO_BILERP
-  const float cZx = b0 * (a0 * B00.x + a1 * B10.x) + b1 * (a0 * B01.x + a1 * B11.x);
-  const float cZy = b0 * (a0 * B00.y + a1 * B10.y) + b1 * (a0 * B01.y + a1 * B11.y);
+  const float cZx = b0 * (a0 * t.B00.x + a1 * t.B10.x) + b1 * (a0 * t.B01.x + a1 * t.B11.x);
+  const float cZy = b0 * (a0 * t.B00.y + a1 * t.B10.y) + b1 * (a0 * t.B01.y + a1 * t.B11.y);
   if (!(cI == cI && cZ == cZ && cIx == cIx && cIy == cIy && cZx == cZx && cZy == cZy)) return false;   // Q9
   // residual = wcur * interpolated + wref * reference with the weights of dense_tracking.cpp:217-220
   const float inv255 = 1.0f / 255.0f;
   o.r0 = inv255 * cI + (-inv255) * ref.y;
-  o.r1 = 1.0f * cZ + (-1.0f) * qz;                   // reference depth := transformed z (:269)
-  float sigma = Z - 0.4f;                            // dense_tracking_impl.cpp:122-128
+  o.r1 = 1.0f * cZ + (-1.0f) * p.qz;                 // reference depth := transformed z (:269)
+  float sigma = p.Z - 0.4f;                          // dense_tracking_impl.cpp:122-128
   sigma = 0.0012f + 0.0019f * sigma * sigma;
   if (!(o.r1 > -20.0f * sigma)) return false;        // occlusion test (Q5)
   const float wi_x = g.wi_x, wi_y = g.wi_y;          // 0.5 fx / 255, 0.5 fy / 255 (dense_tracking.cpp:219-220)
@@ -103,46 +135,66 @@ DVO_HD bool pixel_residual(const LevelGeom& g, const float* KT, PtrA curA, PtrB 
   o.giy = wi_y * cIy + wi_y * ref.w;
   o.gzx = (1.0f * g.fx) * cZx;                       // wref_zd = 0: current-frame depth gradient only
   o.gzy = (1.0f * g.fy) * cZy;
-  o.X = X; o.Y = Y; o.Z = Z;
+  o.X = p.X; o.Y = p.Y; o.Z = p.Z;
   return true;
 }
 
-// 2x6 Jacobian at the UNtransformed reference point (Q10; dense_tracking.cpp:448-476, :333-340) and the
-// rank update of the P-independent Gram sums (layout in device_types.h).
-DVO_HD void accumulate_pixel(float* acc, const PixelTerms& t, float w) {
+// the three stages back to back
+template <typename PtrA, typename PtrB>
+DVO_HD bool pixel_residual(const LevelGeom& g, const float* KT, PtrA curA, PtrB curB, const float4 ref, int u_r, int v_r,
+                           PixelTerms& o) {
+  const PixelProj p = pixel_project(g, KT, ref, u_r, v_r);
+  if (!p.ok) return false;
+  PixelTaps t;
+  pixel_fetch(g, curA, curB, p, t);
+  return pixel_finish(g, ref, p, t, o);
+}
+
+// 2x6 Jacobian rows at the UNtransformed reference point (Q10; dense_tracking.cpp:448-476, :333-340)
+DVO_HD void jacobian_rows(const PixelTerms& t, float* J0, float* J1) {
   const float iz = fast_rcp(t.Z), iz2 = iz * iz;
   float ja[6], jb[6];
   ja[0] = iz; ja[1] = 0.0f; ja[2] = -t.X * iz2; ja[3] = ja[2] * t.Y; ja[4] = 1.0f - ja[2] * t.X; ja[5] = -t.Y * iz;
   jb[0] = 0.0f; jb[1] = iz; jb[2] = -t.Y * iz2; jb[3] = -1.0f + jb[2] * t.Y; jb[4] = -ja[3]; jb[5] = t.X * iz;
   const float jz[6] = {0.0f, 0.0f, 1.0f, t.Y, -t.X, 0.0f};
-  float J0[6], J1[6], wJ0[6], wJ1[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     J0[i] = t.gix * ja[i] + t.giy * jb[i];
     J1[i] = (t.gzx * ja[i] + t.gzy * jb[i]) - jz[i];
+  }
+}
+
+// Rank update of the P-independent Gram sums (layout in device_types.h) with one pixel's rows.
+DVO_HD void accumulate_pixel(float* acc, const PixelTerms& t, float w) {
+  float J0[6], J1[6], wJ0[6], wJ1[6];
+  jacobian_rows(t, J0, J1);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
     wJ0[i] = w * J0[i];
     wJ1[i] = w * J1[i];
   }
+  // explicit fused multiply-adds: one instruction per accumulated product
+  const float wr0 = w * t.r0, wr1 = w * t.r1;
   acc[kAccN] += 1.0f;
-  acc[kAccS + 0] += w * t.r0 * t.r0;
-  acc[kAccS + 1] += w * t.r0 * t.r1;
-  acc[kAccS + 2] += w * t.r1 * t.r1;
+  acc[kAccS + 0] = fmaf(wr0, t.r0, acc[kAccS + 0]);
+  acc[kAccS + 1] = fmaf(wr0, t.r1, acc[kAccS + 1]);
+  acc[kAccS + 2] = fmaf(wr1, t.r1, acc[kAccS + 2]);
   int o = 0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
 #pragma unroll
     for (int j = i; j < 6; ++j) {
-      acc[kAccJ00 + o] += wJ0[i] * J0[j];
-      acc[kAccJ11 + o] += wJ1[i] * J1[j];
-      acc[kAccJ01 + o] += wJ0[i] * J1[j] + wJ0[j] * J1[i];
+      acc[kAccJ00 + o] = fmaf(wJ0[i], J0[j], acc[kAccJ00 + o]);
+      acc[kAccJ11 + o] = fmaf(wJ1[i], J1[j], acc[kAccJ11 + o]);
+      acc[kAccJ01 + o] = fmaf(wJ0[j], J1[i], fmaf(wJ0[i], J1[j], acc[kAccJ01 + o]));
       ++o;
     }
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    acc[kAccB00 + i] += wJ0[i] * t.r0;
-    acc[kAccB01 + i] += wJ0[i] * t.r1 + wJ1[i] * t.r0;
-    acc[kAccB11 + i] += wJ1[i] * t.r1;
+    acc[kAccB00 + i] = fmaf(wJ0[i], t.r0, acc[kAccB00 + i]);
+    acc[kAccB01 + i] = fmaf(wJ1[i], t.r0, fmaf(wJ0[i], t.r1, acc[kAccB01 + i]));
+    acc[kAccB11 + i] = fmaf(wJ1[i], t.r1, acc[kAccB11 + i]);
   }
 }
 

@@ -35,7 +35,7 @@ __global__ void k_pyr_down(const FrameBuildPtrs* __restrict__ tbl, int level, in
   const float* __restrict__ Z = f.Z[level - 1];
   const int ow = w >> 1, oh = h >> 1;
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= ow || y >= oh) return;
   const float* r0 = I + size_t(2 * y) * w + 2 * x;
   const float* r1 = r0 + w;
@@ -51,7 +51,7 @@ __global__ void k_derive_pack(const FrameBuildPtrs* __restrict__ tbl, int level,
   const float* __restrict__ I = f.I[level];
   const float* __restrict__ Z = f.Z[level];
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
   bool ok = false;
   if (x < w && y < h) {
     const int xp = max(x - 1, 0), xn = min(x + 1, w - 1);
@@ -110,11 +110,11 @@ void launch_ingest_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, f
 
 void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h) {
   const int ow = w / 2, oh = h / 2;
-  k_pyr_down<<<dim3((ow + 63) / 64, oh, n_frames), dim3(64), 0, s>>>(tbl, level, w, h);
+  k_pyr_down<<<dim3((ow + 63) / 64, (oh + 3) / 4, n_frames), dim3(64, 4), 0, s>>>(tbl, level, w, h);
 }
 
 void launch_derive_pack(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr) {
-  k_derive_pack<<<dim3((w + 63) / 64, h, n_frames), dim3(64), 0, s>>>(tbl, level, w, h, ithr, dthr);
+  k_derive_pack<<<dim3((w + 63) / 64, (h + 3) / 4, n_frames), dim3(64, 4), 0, s>>>(tbl, level, w, h, ithr, dthr);
 }
 
 void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float4* R, int* count, uint8_t* mask) {

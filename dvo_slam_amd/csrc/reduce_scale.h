@@ -1,34 +1,42 @@
-// reduce_scale.h -- fixed-order float64 reduction of a pair's four scale accumulators over its tiles.
+// reduce_scale.h -- stage 3 of the deterministic reduction: a pair's per-tile float partials summed in a FIXED
+// order in float64 by one 256-thread workgroup.
 //
-// Both the log-likelihood kernel and the solver kernel need the precision P = (S/(n-3))^-1 of the
-// current pass (dense_tracking.cpp:295).  They call this one routine with the same thread count, so
-// both obtain bit-identical n, S and P regardless of launch geometry elsewhere.
+// Both the log-likelihood kernel and the solver kernel need the precision P = (S/(n-3))^-1 of the current
+// pass (dense_tracking.cpp:295).  They call this one routine with the same thread count, so both obtain
+// bit-identical n, S and P regardless of launch geometry elsewhere.  Order: wavefront w adds tiles
+// w, w+4, w+8, ... (lane k owns accumulator k, lanes 0..23 also own accumulator 64+k: each row of the partial
+// table is read as one coalesced 352-byte line), then the four wave sums are combined as (0+1)+(2+3).
 #pragma once
 
 #include "pixel_math.h"
 
 namespace dvo_hip {
 
-// blockDim.x must be kBlock; sh holds 4*kBlock doubles.  All threads return the same values.
-__device__ inline int reduce_scale(const float* __restrict__ partials, int pair, int tiles, double* sh,
-                                   double* s4, float* C, float* P) {
-  const int tid = threadIdx.x;
-  double s[4] = {0, 0, 0, 0};
-  for (int b = tid; b < tiles; b += kBlock) {
-    const float* p = partials + (size_t(pair) * tiles + b) * kAccStride;
-    s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3];
+// blockDim.x must be kBlock.  sh: kWavesPerBlock * kAccStride doubles of LDS.  sums: kAccStride doubles of LDS,
+// valid for all threads after the call.
+__device__ inline void reduce_partials(const float* __restrict__ partials, int pair, int tiles, double* sh, double* sums) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* row = partials + (size_t(pair) * tiles + wave) * kAccStride;
+  double a0 = 0.0, a1 = 0.0;
+  for (int t = wave; t < tiles; t += kWavesPerBlock, row += size_t(kWavesPerBlock) * kAccStride) {
+    a0 += double(row[lane]);
+    if (lane < kAccStride - 64) a1 += double(row[64 + lane]);
   }
-  for (int k = 0; k < 4; ++k) sh[k * kBlock + tid] = s[k];
+  sh[wave * kAccStride + lane] = a0;
+  if (lane < kAccStride - 64) sh[wave * kAccStride + 64 + lane] = a1;
   __syncthreads();
-  for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
-    if (tid < stride)
-      for (int k = 0; k < 4; ++k) sh[k * kBlock + tid] += sh[k * kBlock + tid + stride];
-    __syncthreads();
+  if (threadIdx.x < kAccStride) {
+    const int k = threadIdx.x;
+    sums[k] = (sh[k] + sh[kAccStride + k]) + (sh[2 * kAccStride + k] + sh[3 * kAccStride + k]);
   }
-  for (int k = 0; k < 4; ++k) s4[k] = sh[k * kBlock];
-  const double d = s4[0] - 3.0;
-  scale_to_precision(s4[1] / d, s4[2] / d, s4[3] / d, C, P);
-  return int(s4[0] + 0.5);
+  __syncthreads();
+}
+
+// n, C = S/(n-3) (float) and P = C^-1 from the reduced sums
+__device__ inline int scale_from_sums(const double* sums, float* C, float* P) {
+  const double d = sums[kAccN] - 3.0;
+  scale_to_precision(sums[kAccS] / d, sums[kAccS + 1] / d, sums[kAccS + 2] / d, C, P);
+  return int(sums[kAccN] + 0.5);
 }
 
 }  // namespace dvo_hip

@@ -33,30 +33,13 @@ __global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n
   const int pair = blockIdx.x;
   PairState& st = states[pair];
   if (!st.active) return;   // uniform
-  __shared__ double sh[4 * kBlock];
+  __shared__ double sh[kWavesPerBlock * kAccStride];
   __shared__ double sums[kAccStride];
-  __shared__ double ll_sum;
-  const int tiles = g.tiles_x * g.tiles_y;
-  float C[3], P[4];
-  double s4[4];
-  reduce_scale(partials, pair, tiles, sh, s4, C, P);
-  const int tid = threadIdx.x;
-  if (tid < kNumAcc) {
-    double s = 0.0;
-    const float* p = partials + size_t(pair) * tiles * kAccStride + tid;
-    for (int b = 0; b < tiles; ++b) s += double(p[size_t(b) * kAccStride]);
-    sums[tid] = s;
-  }
-  if (tid == kBlock - 1) {
-    double s = 0.0;
+  reduce_partials(partials, pair, g.tiles_x * g.tiles_y, sh, sums);   // same routine, same order as k_loglik: identical n, S, P
+  if (threadIdx.x == 0) {
+    double ll_sum = 0.0;
     const double* p = ll_partials + size_t(pair) * ll_blocks_per_pair;
-    for (int b = 0; b < ll_blocks_per_pair; ++b) s += p[b];
-    ll_sum = s;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    // n and S must be the very values the log-likelihood kernel derived P from
-    sums[kAccN] = s4[0]; sums[kAccS] = s4[1]; sums[kAccS + 1] = s4[2]; sums[kAccS + 2] = s4[3];
+    for (int b = 0; b < ll_blocks_per_pair; ++b) ll_sum += p[b];
     gn_step(st, prm, g, sums, ll_sum, levels + size_t(pair) * prm.cap_levels, iters + size_t(pair) * prm.cap_iters);
     if (st.active) atomicAdd(active_counter, 1);
   }
@@ -84,19 +67,12 @@ __global__ void k_set_fixed_state(PairState* states, LevelGeom g, const float* _
 __global__ __launch_bounds__(kBlock) void k_single_shot_out(LevelGeom g, const float* __restrict__ partials,
                                                             const double* __restrict__ ll_partials, int ll_blocks_per_pair,
                                                             int n_selected, dvo_hip_iteration_out* out) {
-  __shared__ double sh[4 * kBlock];
+  __shared__ double sh[kWavesPerBlock * kAccStride];
   __shared__ double sums[kAccStride];
-  const int tiles = g.tiles_x * g.tiles_y;
   float C[3], P[4];
-  double s4[4];
-  const int n = reduce_scale(partials, 0, tiles, sh, s4, C, P);
+  reduce_partials(partials, 0, g.tiles_x * g.tiles_y, sh, sums);
+  const int n = scale_from_sums(sums, C, P);
   const int tid = threadIdx.x;
-  if (tid < kNumAcc) {
-    double s = 0.0;
-    for (int b = 0; b < tiles; ++b) s += double(partials[size_t(b) * kAccStride + tid]);
-    sums[tid] = s;
-  }
-  __syncthreads();
   if (tid != 0) return;
   out->n = n;
   out->n_selected = n_selected;

@@ -10,6 +10,6 @@ echo "== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-5} --warmup 
 if [ "${DO_SWEEP:-1}" = "1" ]; then echo "== sweep"; timeout 900 python scripts/sweep.py ${SWEEP_N:-128} > gpurun_out/sweep.log 2>&1; echo "sweep rc=$?"; tail -40 gpurun_out/sweep.log; fi
 if [ "${DO_PROF:-1}" = "1" ]; then
   echo "== rocprofv3"
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1 ); echo "rocprof rc=$?"
-  find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -20 "$f"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1 ); echo "rocprof rc=$?"
+  find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"; true
 fi

@@ -25,7 +25,18 @@ def main():
     curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(nmax)]
     trk = d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0), ctx)
     rows = []
-    for n in [x for x in (1, 8, 32, 128, 256) if x <= nmax]:
+    for variant in (0, 5):
+        ctx.set_option("variant", variant)
+        for n in [x for x in (1, 128) if x <= nmax]:
+            for level in (0, 1):
+                for rpw in (4, 8, 16):
+                    ctx.set_option("rows_per_wave", rpw)
+                    ms = trk.time_residual_kernel(refs[:n], curs[:n], level, reps=10)
+                    px = (W >> level) * (H >> level) * n
+                    rows.append(dict(kind="variant", variant=variant, pairs=n, level=level, rows_per_wave=rpw, ms=ms, gbps=40.0 * px / (ms * 1e-3) / 1e9))
+                    print("variant=%d pairs=%4d level=%d rpw=%2d  %9.4f ms  %8.1f GB/s (40 B/px)" % (variant, n, level, rpw, ms, rows[-1]["gbps"]), flush=True)
+    ctx.set_option("variant", int(os.environ.get("DVO_VARIANT", "5")))
+    for n in [x for x in (1, 8, 32, 128, 256) if x <= nmax and os.environ.get("FULL_SWEEP", "0") == "1"]:
         for level in (0, 1, 2, 3):
             for rpw in (1, 2, 4, 8, 16):
                 ctx.set_option("rows_per_wave", rpw)
