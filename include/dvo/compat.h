@@ -1,0 +1,128 @@
+// dvo/compat.h -- minimal stand-ins for the third-party types in the reference's public API, used ONLY when the real
+// libraries are not installed (this build image has neither Eigen nor OpenCV nor boost).  With
+// -DDVO_HIP_USE_EIGEN / -DDVO_HIP_USE_OPENCV (or when <Eigen/Geometry> / <opencv2/core/core.hpp> are found) the facade
+// uses Eigen::Affine3d / cv::Mat directly and dvo_benchmark compiles against it unchanged.
+#pragma once
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <vector>
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Geometry>) && !defined(DVO_HIP_NO_EIGEN)
+#define DVO_HIP_USE_EIGEN 1
+#endif
+#if __has_include(<opencv2/core/core.hpp>) && !defined(DVO_HIP_NO_OPENCV)
+#define DVO_HIP_USE_OPENCV 1
+#endif
+#endif
+
+#ifdef DVO_HIP_USE_EIGEN
+#include <Eigen/Geometry>
+#endif
+#ifdef DVO_HIP_USE_OPENCV
+#include <opencv2/core/core.hpp>
+#endif
+
+namespace dvo {
+namespace compat {
+
+#ifdef DVO_HIP_USE_EIGEN
+typedef Eigen::Affine3d Affine3d;
+typedef Eigen::Matrix<double, 6, 1> Vector6d;
+typedef Eigen::Matrix<double, 6, 6> Matrix6d;
+typedef Eigen::Matrix2d Matrix2d;
+typedef Eigen::Vector2d Vector2d;
+inline void affine_to_rowmajor(const Affine3d& T, double* m) {
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m[i * 4 + j] = T.matrix()(i, j);
+}
+inline void affine_from_rowmajor(const double* m, Affine3d& T) {
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T.matrix()(i, j) = m[i * 4 + j];
+}
+#else
+// fixed-size dense matrix with (i, j) access, just enough for Result / Stats
+template <int R, int C>
+struct Mat {
+  double d[R * C];
+  Mat() { for (int i = 0; i < R * C; ++i) d[i] = 0.0; }
+  double& operator()(int i, int j) { return d[i * C + j]; }
+  double operator()(int i, int j) const { return d[i * C + j]; }
+  double& operator()(int i) { return d[i]; }
+  double operator()(int i) const { return d[i]; }
+  void setZero() { for (int i = 0; i < R * C; ++i) d[i] = 0.0; }
+  void setIdentity() { setZero(); for (int i = 0; i < (R < C ? R : C); ++i) d[i * C + i] = 1.0; }
+  void setConstant(double v) { for (int i = 0; i < R * C; ++i) d[i] = v; }
+  double sum() const { double s = 0; for (int i = 0; i < R * C; ++i) s += d[i]; return s; }
+  const double* data() const { return d; }
+  double* data() { return d; }
+};
+typedef Mat<6, 1> Vector6d;
+typedef Mat<6, 6> Matrix6d;
+typedef Mat<2, 2> Matrix2d;
+typedef Mat<2, 1> Vector2d;
+
+// rigid transform with the subset of Eigen::Affine3d the reference's callers use
+struct Affine3d {
+  Mat<4, 4> m;
+  Affine3d() { m.setIdentity(); }
+  Mat<4, 4>& matrix() { return m; }
+  const Mat<4, 4>& matrix() const { return m; }
+  void setIdentity() { m.setIdentity(); }
+  static Affine3d Identity() { return Affine3d(); }
+  Affine3d operator*(const Affine3d& o) const {
+    Affine3d r;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double s = 0;
+        for (int k = 0; k < 4; ++k) s += m(i, k) * o.m(k, j);
+        r.m(i, j) = s;
+      }
+    return r;
+  }
+  Affine3d inverse() const {   // rigid inverse
+    Affine3d r;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) r.m(i, j) = m(j, i);
+    for (int i = 0; i < 3; ++i) r.m(i, 3) = -(r.m(i, 0) * m(0, 3) + r.m(i, 1) * m(1, 3) + r.m(i, 2) * m(2, 3));
+    return r;
+  }
+  double translation(int i) const { return m(i, 3); }
+};
+inline void affine_to_rowmajor(const Affine3d& T, double* out) { std::memcpy(out, T.m.d, sizeof(double) * 16); }
+inline void affine_from_rowmajor(const double* in, Affine3d& T) { std::memcpy(T.m.d, in, sizeof(double) * 16); }
+#endif
+
+#ifdef DVO_HIP_USE_OPENCV
+typedef cv::Mat ImageMat;
+inline const float* image_ptr(const ImageMat& m) { return m.ptr<float>(); }
+inline int image_rows(const ImageMat& m) { return m.rows; }
+inline int image_cols(const ImageMat& m) { return m.cols; }
+inline bool image_is_float1(const ImageMat& m) { return m.type() == CV_32FC1 && m.isContinuous(); }
+inline ImageMat image_create(int rows, int cols) { return ImageMat(rows, cols, CV_32FC1); }
+inline float* image_ptr_mut(ImageMat& m) { return m.ptr<float>(); }
+#else
+// single-channel float image with shared storage (cv::Mat_<float> stand-in)
+struct ImageMat {
+  int rows, cols;
+  std::shared_ptr<std::vector<float> > buf;
+  ImageMat() : rows(0), cols(0) {}
+  ImageMat(int r, int c) : rows(r), cols(c), buf(new std::vector<float>(size_t(r) * c)) {}
+  ImageMat(int r, int c, const float* src) : rows(r), cols(c), buf(new std::vector<float>(src, src + size_t(r) * c)) {}
+  bool empty() const { return rows == 0 || cols == 0; }
+  size_t total() const { return size_t(rows) * cols; }
+  template <typename T> T* ptr() { return reinterpret_cast<T*>(buf->data()); }
+  template <typename T> const T* ptr() const { return reinterpret_cast<const T*>(buf->data()); }
+  template <typename T> T& at(int y, int x) { return ptr<T>()[size_t(y) * cols + x]; }
+};
+inline const float* image_ptr(const ImageMat& m) { return m.ptr<float>(); }
+inline int image_rows(const ImageMat& m) { return m.rows; }
+inline int image_cols(const ImageMat& m) { return m.cols; }
+inline bool image_is_float1(const ImageMat&) { return true; }
+inline ImageMat image_create(int rows, int cols) { return ImageMat(rows, cols); }
+inline float* image_ptr_mut(ImageMat& m) { return m.ptr<float>(); }
+#endif
+
+}  // namespace compat
+}  // namespace dvo

@@ -68,3 +68,21 @@ def test_config_mirror_defaults():
     assert r.isNaN()
     r.setIdentity()
     assert not r.isNaN() and r.LogLikelihood == 0.0
+
+
+def build_facade_example():
+    """g++ only: the facade is header-only C++ over the C-ABI, no hipcc needed on the caller's side."""
+    import subprocess
+    out = os.path.join(ROOT, "tests", "cpp", "facade_example")
+    src = os.path.join(ROOT, "tests", "cpp", "facade_example.cpp")
+    libdir = os.path.join(ROOT, "dvo_slam_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+                           "-L" + libdir, "-ldvo_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+def test_cpp_facade_compiles_against_the_reference_api():
+    """include/dvo/*.h must keep the reference's call pattern compiling (dvo_benchmark/src/benchmark_slam.cpp:384-415, 486)."""
+    d.build()
+    exe = build_facade_example()
+    assert os.path.exists(exe)

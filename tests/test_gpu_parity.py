@@ -251,3 +251,23 @@ def test_edge_cases(gpu_ctx):
     s = cm.compare_runs(g, o)
     assert s["structure_mismatch"] == 0 and s["n_mismatch"] == 0 and s["T_err"] < 1e-6
     assert all(len(L["iterations"]) <= 3 for L in g["levels"])
+
+
+def test_cpp_facade_matches_python_path(gpu_ctx, tmp_path):
+    """The header-only C++ facade (include/dvo/), driven like dvo_benchmark drives dvo_core, gives the same transform."""
+    import subprocess
+    from test_capi import build_facade_example
+    exe = build_facade_example()
+    pair = cm.synth(55, 320, 240)
+    frames = np.stack([pair["grey_ref"].astype(np.float32), po.convert_raw_depth(pair["depth_ref"]),
+                       pair["grey_cur"].astype(np.float32), po.convert_raw_depth(pair["depth_cur"])])
+    raw = tmp_path / "frames.raw"
+    frames.tofile(raw)
+    out = subprocess.check_output([exe, str(raw), "320", "240", "2", "0"], text=True)
+    lines = out.strip().splitlines()
+    assert lines[0].startswith("ok 1 nan 0 levels 3")
+    T = np.array([[float(v) for v in ln.split()] for ln in lines[1:5]])
+    gref, gcur = gpu_pyramids(gpu_ctx, pair, 3)
+    g = run_gpu_match(gpu_ctx, gref, gcur, d.Config(FirstLevel=2, LastLevel=0))
+    assert cm.twist_matrix_error(T, g["T"]) < 1e-9
+    assert np.abs(po.se3_log(T) - pair["xi_true"]).max() < 1e-4
