@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--iters-per-sync", type=int, default=0)
+    ap.add_argument("--groups", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -113,6 +114,8 @@ def main():
         ctx.set_option("rows_per_wave", args.rows_per_wave)
     if args.iters_per_sync:
         ctx.set_option("iters_per_sync", args.iters_per_sync)
+    if args.groups:
+        ctx.set_option("groups", args.groups)
     cam = d.RgbdCameraPyramid(W, H, pairs_np["K"], ctx)
     cam.build(4)
     frames = [cam.create_raw_device(grey_ptrs[i], depth_ptrs[i]) for i in range(2 * B)]
@@ -120,14 +123,15 @@ def main():
     cfg_kwargs = dict(first_level=3, last_level=0, max_iterations=100, precision=5e-7, mu=0.0)
     cfg = d.Config(FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0.0)
     tracker = d.DenseTracker(cfg, ctx)
-    results = [d.Result() for _ in range(B)]
+    last = {}
 
     def step():
-        d.update_raw_device_batch(frames, grey_ptrs, depth_ptrs)       # ingest + pyramids + selection, from HBM-resident raw planes
-        tracker.match_batch(refs, curs, results)                        # synchronous: returns when the twists are on the host
+        d.update_raw_device_batch(frames, grey_ptrs, depth_ptrs)       # ingest + pyramids, from HBM-resident raw planes
+        out = tracker.match_batch_arrays(refs, curs)                    # synchronous: returns when the transforms are on the host
+        last.update(out)
         if world > 1:
-            tw = [_twist(r.Transformation) for r in results]
-            rec = parallel.pack_records(tw, [r.Information for r in results], [r.LogLikelihood for r in results])
+            tw = [_twist(T) for T in out["T"]]
+            rec = parallel.pack_records(tw, out["information"], out["loglik"])
             return parallel.gather_records(rec, n_total, rank, world, device=dev)
         return None
 
@@ -150,10 +154,10 @@ def main():
         elapsed = float(t.item())
 
     # ---- everything below is outside the timed region -------------------------------------------------------
-    twist_err = max(float(np.abs(_twist(r.Transformation) - pairs_np["xi_true"][i]).max()) for i, r in enumerate(results))
-    nan_results = sum(int(r.isNaN()) for r in results)
+    twist_err = max(float(np.abs(_twist(T) - pairs_np["xi_true"][i]).max()) for i, T in enumerate(last["T"]))
+    nan_results = int((~np.isfinite(last["T"]).all(axis=(1, 2)) | ~np.isfinite(last["information"]).all(axis=(1, 2))).sum())
     t_match0 = time.perf_counter()
-    tracker.match_batch(refs, curs, results)
+    tracker.match_batch_arrays(refs, curs)
     match_only_ms = (time.perf_counter() - t_match0) * 1e3
 
     # roofline of the dominant kernel: finest-level fused warp/residual/Jacobian/reduce sweep, HIP events on the context stream

@@ -85,4 +85,36 @@ __device__ __forceinline__ double wave_sum_double(double v) {
 }
 
 
+// sum over a range of stored residual pairs of log(1 + 0.2 r^T P r) (dense_tracking_impl.cpp:413-422), two pixels per
+// 16-B load.  The reference multiplies 50 terms between logs; here a lane multiplies ALL its terms and takes ONE log:
+// after every eight factors the running product is renormalised with frexp (two instructions) and the exponent is
+// summed separately, so the product can neither overflow nor lose precision.  `first_chunk`/`chunk_stride` in units
+// of 4 x blockDim pixel pairs.
+__device__ __forceinline__ double loglik_partial(const float2* __restrict__ res, int npx, const float* P, int first_chunk, int chunk_stride) {
+  typedef const __attribute__((address_space(1))) vec4f* G4;
+  const G4 r = (G4)res;
+  const int npair2 = npx >> 1;
+  double prod = 1.0;
+  int exponent = 0;
+  for (int base = first_chunk * kBlock * 4; base < npair2; base += chunk_stride * kBlock * 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + k * kBlock + threadIdx.x;
+      if (i < npair2) {
+        const vec4f rr = r[i];
+        if (rr.x == rr.x) prod *= 1.0 + 0.2 * double(mahalanobis(rr.x, rr.y, P));
+        if (rr.z == rr.z) prod *= 1.0 + 0.2 * double(mahalanobis(rr.z, rr.w, P));
+      }
+    }
+    int e;
+    prod = frexp(prod, &e);
+    exponent += e;
+  }
+  if ((npx & 1) && first_chunk == 0 && threadIdx.x == 0) {   // odd pixel count: last pixel
+    const float2 rr = res[npx - 1];
+    if (rr.x == rr.x) prod *= 1.0 + 0.2 * double(mahalanobis(rr.x, rr.y, P));
+  }
+  return log(prod) + double(exponent) * 0.6931471805599453094;
+}
+
 }  // namespace dvo_hip

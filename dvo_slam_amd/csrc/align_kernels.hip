@@ -131,30 +131,13 @@ __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const Pair
                                                    double* __restrict__ ll_partials, int blocks_per_pair) {
   const int pair = blockIdx.y;
   if (!states[pair].active) return;
-  __shared__ double sh[kWavesPerBlock * kAccStride];
-  __shared__ double sums[kAccStride];
+  __shared__ double sh[16];
+  __shared__ double sums[4];
   float C[3], P[4];
-  reduce_partials(partials, pair, g.tiles_x * g.tiles_y, sh, sums);
+  reduce_partials_scale(partials, pair, g.tiles_x * g.tiles_y, sh, sums);
   const int n = scale_from_sums(sums, C, P);
   double total = 0.0;
-  if (n >= 6) {
-    const int npx = g.w * g.h;
-    const float2* r = scratch + size_t(pair) * npx;
-    // product of up to 8 terms per lane, one log per lane per chunk (the reference multiplies 50
-    // terms between logs, dense_tracking_impl.cpp:413-422)
-    for (int base = blockIdx.x * kBlock * 8; base < npx; base += blocks_per_pair * kBlock * 8) {
-      double prod = 1.0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = base + k * kBlock + threadIdx.x;
-        if (i < npx) {
-          const float2 rr = r[i];
-          if (rr.x == rr.x) prod *= 1.0 + 0.2 * double(mahalanobis(rr.x, rr.y, P));
-        }
-      }
-      total += log(prod);
-    }
-  }
+  if (n >= 6) total = loglik_partial(scratch + size_t(pair) * g.w * g.h, g.w * g.h, P, blockIdx.x, blocks_per_pair);
   total = wave_sum_double(total);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dvo_hip.h"
@@ -59,7 +60,8 @@ struct FrameLevel {
   float4* A = nullptr;
   float2* B = nullptr;
   float4* R = nullptr;
-  bool selected = false;       // R / count valid for (ithr, dthr)
+  bool has_current = false;    // A, B built (current-frame role)
+  bool selected = false;       // R / count built for (ithr, dthr) (reference role)
   float ithr = 0, dthr = 0;
 };
 
@@ -73,17 +75,32 @@ struct dvo_hip_frame {
   int* sel_count = nullptr;    // device, one int per level
 };
 
+constexpr int kMaxGroups = 8;
+
+// Everything one concurrently running group of pairs needs: its own HIP stream, device scratch and pinned poll word.
+// A large batch is split into groups that run on separate streams (and host threads), so that one group's
+// latency-bound coarse-level iterations overlap another group's bandwidth-bound fine-level sweeps.
+struct Workspace {
+  hipStream_t stream = nullptr;
+  DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters;
+  int* host_counter = nullptr;   // pinned, two poll words (double-buffered)
+  hipEvent_t polled[2] = {nullptr, nullptr};
+  std::string err;
+  bool created = false;
+};
+
 struct dvo_hip_context {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;    // == ws[0].stream: frame builds, single-group matches, measurements
   std::string err;
   int opt_rows_per_wave = 0;
   int opt_iters_per_sync = 0;
   int opt_variant = 5;             // schedule of the reduce kernel: 5 = Gram accumulation on the matrix cores (default)
+  int opt_groups = 0;              // concurrent pair groups of a batched match (0 = default)
   std::vector<CameraGeom*> cameras;
-  // batch workspace
-  DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters, misc, build_tbl;
-  int* host_counter = nullptr;   // pinned
+  Workspace ws[kMaxGroups];
+  hipEvent_t roles_ready = nullptr;
+  DevBuf misc, build_tbl, role_tbl_cur, role_tbl_ref;
 };
 
 namespace {
@@ -97,7 +114,39 @@ namespace {
     }                                                                                             \
   } while (0)
 
+#define DVO_WS_TRY(ws, expr)                                                                     \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess) {                                                                      \
+      (ws).err = std::string(#expr) + ": " + hipGetErrorString(e__);                              \
+      return DVO_HIP_ERR_HIP;                                                                     \
+    }                                                                                             \
+  } while (0)
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int workspace_create(dvo_hip_context* ctx, int g) {
+  Workspace& w = ctx->ws[g];
+  if (w.created) return DVO_HIP_OK;
+  DVO_HIP_TRY(ctx, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+  DVO_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&w.host_counter), 64, hipHostMallocDefault));
+  for (int i = 0; i < 2; ++i) DVO_HIP_TRY(ctx, hipEventCreateWithFlags(&w.polled[i], hipEventDisableTiming));
+  w.created = true;
+  return DVO_HIP_OK;
+}
+
+void workspace_destroy(Workspace& w) {
+  if (!w.created) return;
+  (void)hipStreamSynchronize(w.stream);
+  for (DevBuf* b : {&w.states, &w.pair_ptrs, &w.partials, &w.scratch, &w.ll_partials, &w.lvl_stats, &w.it_stats, &w.results,
+                    &w.t_init, &w.counters})
+    b->release();
+  if (w.host_counter) (void)hipHostFree(w.host_counter);
+  for (int i = 0; i < 2; ++i)
+    if (w.polled[i]) (void)hipEventDestroy(w.polled[i]);
+  (void)hipStreamDestroy(w.stream);
+  w.created = false;
+}
 
 int fail(dvo_hip_context* ctx, int code, const char* msg) {
   if (ctx) ctx->err = msg;
@@ -105,6 +154,9 @@ int fail(dvo_hip_context* ctx, int code, const char* msg) {
 }
 
 const int kLlBlocksPerPair = 32;
+const int kFusedLoglikMaxPixels = 160 * 120;
+const int kDefaultGroups = 2;     // measured: 2 streams +5 %, 4 or 8 streams slower (profiles/r01_d_groups.txt)
+const int kMinPairsPerGroup = 32;
 
 // RgbdCameraPyramid::build (rgbd_image.cpp:283-296) + RgbdCamera ctor template (:186-204)
 int get_camera(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, const CameraGeom** out) {
@@ -171,7 +223,7 @@ LevelGeom make_geom(const CameraGeom* cam, int level, int rows_per_wave) {
 // keep all 256 CUs busy when the batch is small
 int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_pairs) {
   if (ctx->opt_rows_per_wave > 0) return ctx->opt_rows_per_wave;
-  const int candidates[5] = {16, 8, 4, 2, 1};
+  const int candidates[4] = {8, 4, 2, 1};   // measured (profiles/r01_c_tile_sweep.txt): 8 rows is at or near the optimum on every level
   for (int r : candidates) {
     const int tiles = ((cam->w[level] + kTileW - 1) / kTileW) * ((cam->h[level] + kWavesPerBlock * r - 1) / (kWavesPerBlock * r));
     if (size_t(tiles) * n_pairs >= 1024) return r;
@@ -225,9 +277,18 @@ int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels
   return DVO_HIP_OK;
 }
 
-// RgbdImagePyramid::build + buildAccelerationStructure + PointSelection (default thresholds 0/0) for every
-// level of n frames of one camera: one launch per level for the whole batch.  grey/raw may be null arrays for
-// frames whose level-0 float planes were uploaded directly.
+void fill_build_ptrs(dvo_hip_frame* f, FrameBuildPtrs& p) {
+  p.grey = nullptr;
+  p.raw = nullptr;
+  for (int l = 0; l < f->levels; ++l) {
+    p.I[l] = f->lv[l].I; p.Z[l] = f->lv[l].Z; p.A[l] = f->lv[l].A; p.B[l] = f->lv[l].B; p.R[l] = f->lv[l].R;
+  }
+  p.sel_count = f->sel_count;
+}
+
+// RgbdImagePyramid::build (rgbd_image.cpp:156-172) for n frames of one camera: ingest of the raw planes (optional)
+// and the pyr-down chain, one launch per level for the whole batch.  Derived planes are built lazily per role
+// (ensure_roles), like the reference's buildAccelerationStructure / PointSelection caches.
 int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, const void* const* grey, const void* const* raw,
                  float depth_scale) {
   const CameraGeom* cam = frames[0]->cam;
@@ -236,37 +297,52 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
   for (int i = 0; i < n; ++i) {
     dvo_hip_frame* f = frames[i];
     if (f->cam != cam || f->levels != levels) return fail(ctx, DVO_HIP_ERR_INVALID, "frames of one build batch must share camera and levels");
-    FrameBuildPtrs& p = host[i];
-    p.grey = grey ? static_cast<const uint8_t*>(grey[i]) : nullptr;
-    p.raw = raw ? static_cast<const uint16_t*>(raw[i]) : nullptr;
-    for (int l = 0; l < levels; ++l) {
-      p.I[l] = f->lv[l].I; p.Z[l] = f->lv[l].Z; p.A[l] = f->lv[l].A; p.B[l] = f->lv[l].B; p.R[l] = f->lv[l].R;
-      f->lv[l].selected = true;   // built below with the default predicate thresholds
-      f->lv[l].ithr = 0.0f;
-      f->lv[l].dthr = 0.0f;
+    fill_build_ptrs(f, host[i]);
+    host[i].grey = grey ? static_cast<const uint8_t*>(grey[i]) : nullptr;
+    host[i].raw = raw ? static_cast<const uint16_t*>(raw[i]) : nullptr;
+    for (int l = 0; l < levels; ++l) {   // new pixels: every cached role plane is stale (PointSelection::setRgbdImagePyramid)
+      f->lv[l].has_current = false;
+      f->lv[l].selected = false;
     }
-    p.sel_count = f->sel_count;
   }
   DVO_HIP_TRY(ctx, ctx->build_tbl.reserve(size_t(n) * sizeof(FrameBuildPtrs)));
   DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->build_tbl.p, host.data(), size_t(n) * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, ctx->stream));
   const FrameBuildPtrs* tbl = ctx->build_tbl.as<FrameBuildPtrs>();
-  if (grey) launch_ingest_raw(ctx->stream, tbl, n, depth_scale, cam->w[0] * cam->h[0], levels);
-  for (int l = 0; l < levels; ++l) {
-    if (l > 0) launch_pyr_down(ctx->stream, tbl, n, l, cam->w[l - 1], cam->h[l - 1]);
-    launch_derive_pack(ctx->stream, tbl, n, l, cam->w[l], cam->h[l], 0.0f, 0.0f);
-  }
+  if (grey) launch_ingest_raw(ctx->stream, tbl, n, depth_scale, cam->w[0] * cam->h[0]);
+  for (int l = 1; l < levels; ++l) launch_pyr_down(ctx->stream, tbl, n, l, cam->w[l - 1], cam->h[l - 1]);
   DVO_HIP_TRY(ctx, hipGetLastError());
   return DVO_HIP_OK;
 }
 
-int ensure_selection(dvo_hip_context* ctx, dvo_hip_frame* f, int level, float ithr, float dthr, uint8_t* mask_dev) {
-  FrameLevel& L = f->lv[level];
-  if (L.selected && L.ithr == ithr && L.dthr == dthr && !mask_dev) return DVO_HIP_OK;
-  DVO_HIP_TRY(ctx, hipMemsetAsync(f->sel_count + level, 0, sizeof(int), ctx->stream));
-  launch_select_pack(ctx->stream, L.A, L.B, L.w * L.h, ithr, dthr, L.R, f->sel_count + level, mask_dev);
-  L.selected = true;
-  L.ithr = ithr;
-  L.dthr = dthr;
+// Build the missing role planes of a set of frames for levels [l0, l1]: role 0 = current (A, B), role 1 = reference
+// (R + selection count for the given thresholds).  One launch per level for all frames that need it.
+int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int role, int l0, int l1, float ithr, float dthr) {
+  const CameraGeom* cam = frames[0]->cam;
+  std::vector<FrameBuildPtrs> host;
+  const size_t slice = size_t(n) * sizeof(FrameBuildPtrs);
+  DevBuf& table = role == 0 ? ctx->role_tbl_cur : ctx->role_tbl_ref;
+  for (int l = l0; l <= l1; ++l) {
+    host.clear();
+    for (int i = 0; i < n; ++i) {
+      dvo_hip_frame* f = frames[i];
+      FrameLevel& L = f->lv[l];
+      const bool need = role == 0 ? !L.has_current : !(L.selected && L.ithr == ithr && L.dthr == dthr);
+      if (!need) continue;   // also skips the second visit of a frame that is listed twice
+      if (role == 0) L.has_current = true;
+      else { L.selected = true; L.ithr = ithr; L.dthr = dthr; }
+      FrameBuildPtrs p;
+      fill_build_ptrs(f, p);
+      host.push_back(p);
+    }
+    if (host.empty()) continue;
+    // each level has its own slice of the table so that a copy never waits for the previous level's kernel
+    DVO_HIP_TRY(ctx, table.reserve(slice * kMaxLevels));
+    FrameBuildPtrs* tbl = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * l);
+    DVO_HIP_TRY(ctx, hipMemcpyAsync(tbl, host.data(), host.size() * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, ctx->stream));
+    if (role == 0) launch_derive_current(ctx->stream, tbl, int(host.size()), l, cam->w[l], cam->h[l]);
+    else launch_derive_reference(ctx->stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], ithr, dthr);
+  }
+  DVO_HIP_TRY(ctx, hipGetLastError());
   return DVO_HIP_OK;
 }
 
@@ -279,8 +355,7 @@ struct BatchPlan {
   PairPtrs* pair_ptrs = nullptr; // device [levels][n]
 };
 
-int prepare_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
-                  BatchPlan& bp) {
+int validate_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg) {
   if (!ctx || n < 1 || !refs || !curs || !cfg) return fail(ctx, DVO_HIP_ERR_INVALID, "match: null argument");
   if (cfg->first_level < cfg->last_level || cfg->last_level < 0 || cfg->first_level >= kMaxLevels)   // Config::IsSane, DT.cpp:74
     return fail(ctx, DVO_HIP_ERR_INVALID, "match: need 0 <= last_level <= first_level < DVO_HIP_MAX_LEVELS");
@@ -294,7 +369,11 @@ int prepare_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_h
     if (refs[i]->cam != cam || curs[i]->cam != cam)
       return fail(ctx, DVO_HIP_ERR_INVALID, "match: all frames of a batch must share size, intrinsics and level count");
   }
-  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return DVO_HIP_OK;
+}
+
+void make_plan(const dvo_hip_context* ctx, const CameraGeom* cam, const dvo_hip_config* cfg, int n, BatchPlan& bp) {
+  const int need_levels = cfg->first_level + 1;
   bp.n = n;
   bp.cam = cam;
   bp.nlev = cfg->first_level - cfg->last_level + 1;
@@ -311,40 +390,159 @@ int prepare_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_h
   bp.prm.max_points_level0 = cam->w0 * cam->h0;
   bp.rpw.assign(need_levels, 1);
   bp.geom.resize(need_levels);
-  size_t max_tiles = 1;
   for (int l = cfg->last_level; l <= cfg->first_level; ++l) {
     bp.rpw[l] = pick_rows_per_wave(ctx, cam, l, n);
     bp.geom[l] = make_geom(cam, l, bp.rpw[l]);
-    max_tiles = std::max(max_tiles, size_t(bp.geom[l].tiles_x) * bp.geom[l].tiles_y);
   }
-  const size_t npx = size_t(cam->w[cfg->last_level]) * cam->h[cfg->last_level];
-  DVO_HIP_TRY(ctx, ctx->states.reserve(size_t(n) * sizeof(PairState)));
-  DVO_HIP_TRY(ctx, ctx->pair_ptrs.reserve(size_t(n) * need_levels * sizeof(PairPtrs)));
-  DVO_HIP_TRY(ctx, ctx->partials.reserve(size_t(n) * max_tiles * kAccStride * sizeof(float)));
-  DVO_HIP_TRY(ctx, ctx->scratch.reserve(size_t(n) * npx * sizeof(float2)));
-  DVO_HIP_TRY(ctx, ctx->ll_partials.reserve(size_t(n) * kLlBlocksPerPair * sizeof(double)));
-  DVO_HIP_TRY(ctx, ctx->lvl_stats.reserve(size_t(n) * bp.cap_levels * sizeof(dvo_hip_level_stats)));
-  DVO_HIP_TRY(ctx, ctx->it_stats.reserve(size_t(n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats)));
-  DVO_HIP_TRY(ctx, ctx->results.reserve(size_t(n) * sizeof(dvo_hip_result)));
-  DVO_HIP_TRY(ctx, ctx->t_init.reserve(size_t(n) * 16 * sizeof(double)));
-  DVO_HIP_TRY(ctx, ctx->counters.reserve(size_t(bp.cap_iters + 8) * sizeof(int)));
+}
 
-  // PointSelection::select for every reference level (cached per frame), then the pointer tables
+// buildAccelerationStructure for the current frames, PointSelection::select for the reference frames (both cached per
+// frame and level); enqueued on the context's main stream
+int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg) {
+  int rc = ensure_roles(ctx, n, curs, 0, cfg->last_level, cfg->first_level, 0.0f, 0.0f);
+  if (rc == DVO_HIP_OK)
+    rc = ensure_roles(ctx, n, refs, 1, cfg->last_level, cfg->first_level, cfg->intensity_derivative_threshold, cfg->depth_derivative_threshold);
+  return rc;
+}
+
+// device scratch of one group + the per-level pointer tables of its pairs
+int prepare_group(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, BatchPlan& bp) {
+  const int n = bp.n, need_levels = cfg->first_level + 1;
+  size_t max_tiles = 1;
+  for (int l = cfg->last_level; l <= cfg->first_level; ++l) max_tiles = std::max(max_tiles, size_t(bp.geom[l].tiles_x) * bp.geom[l].tiles_y);
+  const size_t npx = size_t(bp.cam->w[cfg->last_level]) * bp.cam->h[cfg->last_level];
+  DVO_WS_TRY(w, w.states.reserve(size_t(n) * sizeof(PairState)));
+  DVO_WS_TRY(w, w.pair_ptrs.reserve(size_t(n) * need_levels * sizeof(PairPtrs)));
+  DVO_WS_TRY(w, w.partials.reserve(size_t(n) * max_tiles * kAccStride * sizeof(float)));
+  DVO_WS_TRY(w, w.scratch.reserve(size_t(n) * npx * sizeof(float2)));
+  DVO_WS_TRY(w, w.ll_partials.reserve(size_t(n) * kLlBlocksPerPair * sizeof(double)));
+  DVO_WS_TRY(w, w.lvl_stats.reserve(size_t(n) * bp.cap_levels * sizeof(dvo_hip_level_stats)));
+  DVO_WS_TRY(w, w.it_stats.reserve(size_t(n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats)));
+  DVO_WS_TRY(w, w.results.reserve(size_t(n) * sizeof(dvo_hip_result)));
+  DVO_WS_TRY(w, w.t_init.reserve(size_t(n) * 16 * sizeof(double)));
+  DVO_WS_TRY(w, w.counters.reserve(size_t(bp.cap_iters + 8) * sizeof(int)));
   std::vector<PairPtrs> host(size_t(n) * need_levels);
   for (int l = cfg->last_level; l <= cfg->first_level; ++l)
     for (int i = 0; i < n; ++i) {
-      int rc = ensure_selection(ctx, refs[i], l, cfg->intensity_derivative_threshold, cfg->depth_derivative_threshold, nullptr);
-      if (rc != DVO_HIP_OK) return rc;
       PairPtrs& p = host[size_t(l) * n + i];
       p.refR = refs[i]->lv[l].R;
       p.curA = curs[i]->lv[l].A;
       p.curB = curs[i]->lv[l].B;
       p.n_selected = refs[i]->sel_count + l;
     }
-  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs), hipMemcpyHostToDevice, ctx->stream));
-  DVO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `host` goes out of scope
-  bp.pair_ptrs = ctx->pair_ptrs.as<PairPtrs>();
+  // pageable source: the runtime stages the bytes before the call returns, so `host` may go out of scope
+  DVO_WS_TRY(w, hipMemcpyAsync(w.pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs), hipMemcpyHostToDevice, w.stream));
+  DVO_WS_TRY(w, hipStreamSynchronize(w.stream));
+  bp.pair_ptrs = w.pair_ptrs.as<PairPtrs>();
   return DVO_HIP_OK;
+}
+
+// The coarse-to-fine Gauss-Newton driver of one group of pairs (dense_tracking.cpp:131-376 for every pair at once).
+int run_group(dvo_hip_context* ctx, Workspace& w, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs,
+              const dvo_hip_config* cfg, dvo_hip_result* results, dvo_hip_level_stats* levels, int cap_levels,
+              dvo_hip_iteration_stats* iters, int cap_iters) {
+  DVO_WS_TRY(w, hipSetDevice(ctx->device));
+  BatchPlan bp;
+  make_plan(ctx, refs[0]->cam, cfg, n, bp);
+  int rc = prepare_group(w, cfg, refs, curs, bp);
+  if (rc != DVO_HIP_OK) return rc;
+  hipStream_t s = w.stream;
+
+  // initial guesses (Result.Transformation is in/out, dense_tracking.cpp:137-147)
+  std::vector<double> tinit(size_t(n) * 16);
+  for (int i = 0; i < n; ++i) std::memcpy(&tinit[size_t(i) * 16], results[i].transformation, 16 * sizeof(double));
+  DVO_WS_TRY(w, hipMemcpyAsync(w.t_init.p, tinit.data(), tinit.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  DVO_WS_TRY(w, hipMemsetAsync(w.counters.p, 0, size_t(bp.cap_iters + 8) * sizeof(int), s));
+
+  PairState* states = w.states.as<PairState>();
+  dvo_hip_level_stats* d_levels = w.lvl_stats.as<dvo_hip_level_stats>();
+  dvo_hip_iteration_stats* d_iters = w.it_stats.as<dvo_hip_iteration_stats>();
+  int* counters = w.counters.as<int>();
+  launch_init_pairs(s, states, n, bp.prm, w.t_init.as<double>());
+
+  const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 2;
+  int step = 0;
+  for (int level = cfg->first_level; level >= cfg->last_level; --level) {
+    const LevelGeom& g = bp.geom[level];
+    const PairPtrs* pp = bp.pair_ptrs + size_t(level) * n;
+    launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels);
+    // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
+    const bool fused_ll = g.w * g.h <= kFusedLoglikMaxPixels;
+    // Chunks of `per_sync` iterations are enqueued ONE AHEAD of the poll: while the host waits for the "pairs still
+    // active" word of chunk k, chunk k+1 is already queued, so the GPU never idles for a host round trip (~40 us).
+    // Iterations enqueued past the end of the level are no-ops (workgroups exit on !active).
+    auto enqueue_chunk = [&](int count) {
+      for (int c = 0; c < count; ++c, ++step) {
+        launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, w.partials.as<float>(), w.scratch.as<float2>());
+        if (!fused_ll)
+          launch_loglik(s, g, states, n, w.partials.as<float>(), w.scratch.as<float2>(), w.ll_partials.as<double>(), kLlBlocksPerPair);
+        launch_solver_step(s, states, n, bp.prm, g, w.partials.as<float>(), w.ll_partials.as<double>(), kLlBlocksPerPair,
+                           fused_ll ? w.scratch.as<float2>() : nullptr, d_levels, d_iters, counters + step);
+      }
+    };
+    int enqueued = std::min(per_sync, cfg->max_iterations_per_level);
+    enqueue_chunk(enqueued);
+    DVO_WS_TRY(w, hipMemcpyAsync(w.host_counter, counters + (step - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+    DVO_WS_TRY(w, hipEventRecord(w.polled[0], s));
+    int slot = 0;
+    for (;;) {
+      const int more = std::min(per_sync, cfg->max_iterations_per_level - enqueued);
+      if (more > 0) {
+        enqueue_chunk(more);
+        enqueued += more;
+        DVO_WS_TRY(w, hipMemcpyAsync(w.host_counter + 1 - slot, counters + (step - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        DVO_WS_TRY(w, hipEventRecord(w.polled[1 - slot], s));
+      }
+      DVO_WS_TRY(w, hipEventSynchronize(w.polled[slot]));
+      if (w.host_counter[slot] == 0 || more <= 0) break;   // every pair left this level (or the iteration cap is reached)
+      slot = 1 - slot;
+    }
+  }
+  launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());
+  DVO_WS_TRY(w, hipMemcpyAsync(results, w.results.p, size_t(n) * sizeof(dvo_hip_result), hipMemcpyDeviceToHost, s));
+  std::vector<dvo_hip_level_stats> hl;
+  std::vector<dvo_hip_iteration_stats> hi;
+  if (levels && cap_levels > 0) {
+    hl.resize(size_t(n) * bp.cap_levels);
+    DVO_WS_TRY(w, hipMemcpyAsync(hl.data(), d_levels, hl.size() * sizeof(dvo_hip_level_stats), hipMemcpyDeviceToHost, s));
+  }
+  if (iters && cap_iters > 0) {
+    hi.resize(size_t(n) * bp.cap_iters);
+    DVO_WS_TRY(w, hipMemcpyAsync(hi.data(), d_iters, hi.size() * sizeof(dvo_hip_iteration_stats), hipMemcpyDeviceToHost, s));
+  }
+  DVO_WS_TRY(w, hipStreamSynchronize(s));
+  DVO_WS_TRY(w, hipGetLastError());
+  bool truncated = false;
+  for (int i = 0; i < n; ++i) {
+    if (!hl.empty()) {
+      const int nl = std::min(results[i].n_levels, std::min(cap_levels, bp.cap_levels));
+      std::memcpy(levels + size_t(i) * cap_levels, &hl[size_t(i) * bp.cap_levels], size_t(nl) * sizeof(dvo_hip_level_stats));
+      truncated |= results[i].n_levels > cap_levels;
+    }
+    if (!hi.empty()) {
+      const int ni = std::min(results[i].n_iterations_total, std::min(cap_iters, bp.cap_iters));
+      std::memcpy(iters + size_t(i) * cap_iters, &hi[size_t(i) * bp.cap_iters], size_t(ni) * sizeof(dvo_hip_iteration_stats));
+      truncated |= results[i].n_iterations_total > cap_iters;
+    }
+  }
+  if (truncated) {
+    w.err = "match: statistics arrays too small (results are valid)";
+    return DVO_HIP_ERR_CAPACITY;
+  }
+  return DVO_HIP_OK;
+}
+
+// single-group preparation on the main stream for the parity / measurement entry points
+int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg, BatchPlan& bp) {
+  int rc = validate_batch(ctx, n, refs, curs, cfg);
+  if (rc != DVO_HIP_OK) return rc;
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  rc = ensure_batch_roles(ctx, n, refs, curs, cfg);
+  if (rc != DVO_HIP_OK) return rc;
+  make_plan(ctx, refs[0]->cam, cfg, n, bp);
+  rc = prepare_group(ctx->ws[0], cfg, refs, curs, bp);
+  if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
+  return rc;
 }
 
 }  // namespace
@@ -379,14 +577,15 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
   }
   dvo_hip_context* ctx = new dvo_hip_context();
   ctx->device = device;
-  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counter), 64, hipHostMallocDefault);
-  if (e != hipSuccess) {
-    g_create_error = std::string("context setup: ") + hipGetErrorString(e);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  int rc = workspace_create(ctx, 0);
+  if (rc == DVO_HIP_OK && hipEventCreateWithFlags(&ctx->roles_ready, hipEventDisableTiming) != hipSuccess) rc = DVO_HIP_ERR_HIP;
+  if (rc != DVO_HIP_OK) {
+    g_create_error = "context setup: " + ctx->err;
+    workspace_destroy(ctx->ws[0]);
     delete ctx;
     return DVO_HIP_ERR_HIP;
   }
+  ctx->stream = ctx->ws[0].stream;
   *out = ctx;
   return DVO_HIP_OK;
 }
@@ -394,16 +593,13 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
 void dvo_hip_context_destroy(dvo_hip_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  for (DevBuf* b : {&ctx->states, &ctx->pair_ptrs, &ctx->partials, &ctx->scratch, &ctx->ll_partials, &ctx->lvl_stats,
-                    &ctx->it_stats, &ctx->results, &ctx->t_init, &ctx->counters, &ctx->misc, &ctx->build_tbl})
-    b->release();
+  for (Workspace& w : ctx->ws) workspace_destroy(w);
+  for (DevBuf* b : {&ctx->misc, &ctx->build_tbl, &ctx->role_tbl_cur, &ctx->role_tbl_ref}) b->release();
   for (CameraGeom* c : ctx->cameras) {
     c->tables.release();
     delete c;
   }
-  if (ctx->host_counter) (void)hipHostFree(ctx->host_counter);
-  (void)hipStreamDestroy(ctx->stream);
+  if (ctx->roles_ready) (void)hipEventDestroy(ctx->roles_ready);
   delete ctx;
 }
 
@@ -422,6 +618,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "iters_per_sync") == 0) {
     if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "iters_per_sync must be >= 0");
     ctx->opt_iters_per_sync = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "groups") == 0) {
+    if (value < 0 || value > kMaxGroups) return fail(ctx, DVO_HIP_ERR_INVALID, "groups must be 0..8");
+    ctx->opt_groups = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "variant") == 0) {
@@ -541,6 +742,9 @@ int dvo_hip_frame_download_plane(dvo_hip_context* ctx, dvo_hip_frame* frame, int
   if (!ctx || !frame || !out || level < 0 || level >= frame->levels || plane < 0 || plane > 5)
     return fail(ctx, DVO_HIP_ERR_INVALID, "frame_download_plane: bad argument");
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dvo_hip_frame* one[1] = {frame};
+  int rc = ensure_roles(ctx, 1, one, 0, level, level, 0.0f, 0.0f);
+  if (rc != DVO_HIP_OK) return rc;
   const FrameLevel& L = frame->lv[level];
   const size_t n = size_t(L.w) * L.h;
   DVO_HIP_TRY(ctx, ctx->misc.reserve(n * 4));
@@ -560,8 +764,15 @@ int dvo_hip_frame_select(dvo_hip_context* ctx, dvo_hip_frame* frame, int level, 
     DVO_HIP_TRY(ctx, ctx->misc.reserve(n));
     mask_dev = ctx->misc.as<uint8_t>();
   }
-  int rc = ensure_selection(ctx, frame, level, ithr, dthr, mask_dev);
+  dvo_hip_frame* one[1] = {frame};
+  int rc = ensure_roles(ctx, 1, one, 1, level, level, ithr, dthr);
+  if (rc == DVO_HIP_OK && mask_dev) rc = ensure_roles(ctx, 1, one, 0, level, level, 0.0f, 0.0f);
   if (rc != DVO_HIP_OK) return rc;
+  if (mask_dev) {   // the mask is not kept on the device: recompute it from the sampling planes
+    FrameLevel& L = frame->lv[level];
+    DVO_HIP_TRY(ctx, hipMemsetAsync(frame->sel_count + level, 0, sizeof(int), ctx->stream));
+    launch_select_pack(ctx->stream, L.A, L.B, L.w * L.h, ithr, dthr, L.R, frame->sel_count + level, mask_dev);
+  }
   int count = 0;
   DVO_HIP_TRY(ctx, hipMemcpyAsync(&count, frame->sel_count + level, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   if (mask_or_null) DVO_HIP_TRY(ctx, hipMemcpyAsync(mask_or_null, mask_dev, n, hipMemcpyDeviceToHost, ctx->stream));
@@ -574,76 +785,48 @@ int dvo_hip_match_batch(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const*
                         const dvo_hip_config* cfg, dvo_hip_result* results, dvo_hip_level_stats* levels, int cap_levels,
                         dvo_hip_iteration_stats* iters, int cap_iters) {
   if (!results) return fail(ctx, DVO_HIP_ERR_INVALID, "match: results is null");
-  BatchPlan bp;
-  int rc = prepare_batch(ctx, n_pairs, references, currents, cfg, bp);
+  int rc = validate_batch(ctx, n_pairs, references, currents, cfg);
   if (rc != DVO_HIP_OK) return rc;
-  hipStream_t s = ctx->stream;
-  const int n = bp.n;
-
-  // initial guesses (Result.Transformation is in/out, dense_tracking.cpp:137-147)
-  std::vector<double> tinit(size_t(n) * 16);
-  for (int i = 0; i < n; ++i) std::memcpy(&tinit[size_t(i) * 16], results[i].transformation, 16 * sizeof(double));
   if (cfg->use_initial_estimate)
-    for (double v : tinit)
-      if (!std::isfinite(v)) return fail(ctx, DVO_HIP_ERR_INVALID, "match: provided initialization is NaN (dense_tracking.cpp:139)");
-  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->t_init.p, tinit.data(), tinit.size() * sizeof(double), hipMemcpyHostToDevice, s));
-  DVO_HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, size_t(bp.cap_iters + 8) * sizeof(int), s));
+    for (int i = 0; i < n_pairs; ++i)
+      for (int k = 0; k < 16; ++k)
+        if (!std::isfinite(results[i].transformation[k]))
+          return fail(ctx, DVO_HIP_ERR_INVALID, "match: provided initialization is NaN (dense_tracking.cpp:139)");
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  rc = ensure_batch_roles(ctx, n_pairs, references, currents, cfg);
+  if (rc != DVO_HIP_OK) return rc;
 
-  PairState* states = ctx->states.as<PairState>();
-  dvo_hip_level_stats* d_levels = ctx->lvl_stats.as<dvo_hip_level_stats>();
-  dvo_hip_iteration_stats* d_iters = ctx->it_stats.as<dvo_hip_iteration_stats>();
-  int* counters = ctx->counters.as<int>();
-  launch_init_pairs(s, states, n, bp.prm, ctx->t_init.as<double>());
-
-  const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 4;
-  int step = 0;
-  for (int level = cfg->first_level; level >= cfg->last_level; --level) {
-    const LevelGeom& g = bp.geom[level];
-    const PairPtrs* pp = bp.pair_ptrs + size_t(level) * n;
-    launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels);
-    int it = 0;
-    while (it < cfg->max_iterations_per_level) {
-      const int chunk = std::min(per_sync, cfg->max_iterations_per_level - it);
-      for (int c = 0; c < chunk; ++c, ++step) {
-        launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, ctx->partials.as<float>(), ctx->scratch.as<float2>());
-        launch_loglik(s, g, states, n, ctx->partials.as<float>(), ctx->scratch.as<float2>(), ctx->ll_partials.as<double>(), kLlBlocksPerPair);
-        launch_solver_step(s, states, n, bp.prm, g, ctx->partials.as<float>(), ctx->ll_partials.as<double>(), kLlBlocksPerPair,
-                           d_levels, d_iters, counters + step);
-      }
-      it += chunk;
-      DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->host_counter, counters + (step - 1), sizeof(int), hipMemcpyDeviceToHost, s));
-      DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
-      if (*ctx->host_counter == 0) break;   // every pair left this level
+  // how many groups: enough pairs per group to fill the chip on the fine levels
+  const int want = ctx->opt_groups > 0 ? ctx->opt_groups : kDefaultGroups;
+  const int groups = std::max(1, std::min(std::min(want, kMaxGroups), n_pairs / kMinPairsPerGroup));
+  if (groups == 1) {
+    rc = run_group(ctx, ctx->ws[0], n_pairs, references, currents, cfg, results, levels, cap_levels, iters, cap_iters);
+    if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
+    return rc;
+  }
+  for (int g = 0; g < groups; ++g) {
+    rc = workspace_create(ctx, g);
+    if (rc != DVO_HIP_OK) return rc;
+  }
+  // the role planes were enqueued on the main stream: every group stream waits for them
+  DVO_HIP_TRY(ctx, hipEventRecord(ctx->roles_ready, ctx->stream));
+  for (int g = 1; g < groups; ++g) DVO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->ws[g].stream, ctx->roles_ready, 0));
+  std::vector<int> rcs(groups, DVO_HIP_OK);
+  std::vector<std::thread> threads;
+  auto work = [&](int g) {
+    const int i0 = int((long long)n_pairs * g / groups), i1 = int((long long)n_pairs * (g + 1) / groups);
+    rcs[g] = run_group(ctx, ctx->ws[g], i1 - i0, references + i0, currents + i0, cfg, results + i0,
+                       levels ? levels + size_t(i0) * cap_levels : nullptr, cap_levels,
+                       iters ? iters + size_t(i0) * cap_iters : nullptr, cap_iters);
+  };
+  for (int g = 1; g < groups; ++g) threads.emplace_back(work, g);
+  work(0);
+  for (std::thread& t : threads) t.join();
+  for (int g = 0; g < groups; ++g)
+    if (rcs[g] != DVO_HIP_OK) {
+      ctx->err = ctx->ws[g].err;
+      return rcs[g];
     }
-  }
-  launch_finish(s, states, n, bp.prm, d_levels, d_iters, ctx->results.as<dvo_hip_result>());
-  DVO_HIP_TRY(ctx, hipMemcpyAsync(results, ctx->results.p, size_t(n) * sizeof(dvo_hip_result), hipMemcpyDeviceToHost, s));
-  std::vector<dvo_hip_level_stats> hl;
-  std::vector<dvo_hip_iteration_stats> hi;
-  if (levels && cap_levels > 0) {
-    hl.resize(size_t(n) * bp.cap_levels);
-    DVO_HIP_TRY(ctx, hipMemcpyAsync(hl.data(), d_levels, hl.size() * sizeof(dvo_hip_level_stats), hipMemcpyDeviceToHost, s));
-  }
-  if (iters && cap_iters > 0) {
-    hi.resize(size_t(n) * bp.cap_iters);
-    DVO_HIP_TRY(ctx, hipMemcpyAsync(hi.data(), d_iters, hi.size() * sizeof(dvo_hip_iteration_stats), hipMemcpyDeviceToHost, s));
-  }
-  DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
-  DVO_HIP_TRY(ctx, hipGetLastError());
-  bool truncated = false;
-  for (int i = 0; i < n; ++i) {
-    if (!hl.empty()) {
-      const int nl = std::min(results[i].n_levels, std::min(cap_levels, bp.cap_levels));
-      std::memcpy(levels + size_t(i) * cap_levels, &hl[size_t(i) * bp.cap_levels], size_t(nl) * sizeof(dvo_hip_level_stats));
-      truncated |= results[i].n_levels > cap_levels;
-    }
-    if (!hi.empty()) {
-      const int ni = std::min(results[i].n_iterations_total, std::min(cap_iters, bp.cap_iters));
-      std::memcpy(iters + size_t(i) * cap_iters, &hi[size_t(i) * bp.cap_iters], size_t(ni) * sizeof(dvo_hip_iteration_stats));
-      truncated |= results[i].n_iterations_total > cap_iters;
-    }
-  }
-  if (truncated) return fail(ctx, DVO_HIP_ERR_CAPACITY, "match: statistics arrays too small (results are valid)");
   return DVO_HIP_OK;
 }
 
@@ -669,7 +852,7 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
   dvo_hip_frame* r[1] = {reference};
   dvo_hip_frame* c[1] = {current};
   BatchPlan bp;
-  int rc = prepare_batch(ctx, 1, r, c, &cfg, bp);
+  int rc = prepare_single(ctx, 1, r, c, &cfg, bp);
   if (rc != DVO_HIP_OK) return rc;
   hipStream_t s = ctx->stream;
   const LevelGeom& g = bp.geom[level];
@@ -680,18 +863,18 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
   dvo_hip_iteration_out* d_out = reinterpret_cast<dvo_hip_iteration_out*>(ctx->misc.as<char>() + 256);
   DVO_HIP_TRY(ctx, hipMemcpyAsync(d_T, T34, 48, hipMemcpyHostToDevice, s));
   DVO_HIP_TRY(ctx, hipMemcpyAsync(d_P, P_prev, 16, hipMemcpyHostToDevice, s));
-  PairState* states = ctx->states.as<PairState>();
+  PairState* states = ctx->ws[0].states.as<PairState>();
   DVO_HIP_TRY(ctx, hipMemsetAsync(states, 0, sizeof(PairState), s));
   launch_set_fixed_state(s, states, g, d_T, d_P, first_iteration_on_level ? 1 : 0);
   const PairPtrs* pp = bp.pair_ptrs + size_t(level);
-  launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, 1, ctx->partials.as<float>(), ctx->scratch.as<float2>());
-  launch_loglik(s, g, states, 1, ctx->partials.as<float>(), ctx->scratch.as<float2>(), ctx->ll_partials.as<double>(), kLlBlocksPerPair);
+  launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>());
+  launch_loglik(s, g, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>(), ctx->ws[0].ll_partials.as<double>(), kLlBlocksPerPair);
   int n_sel = 0;
   DVO_HIP_TRY(ctx, hipMemcpyAsync(&n_sel, reference->sel_count + level, sizeof(int), hipMemcpyDeviceToHost, s));
   DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
-  launch_single_shot_out(s, g, ctx->partials.as<float>(), ctx->ll_partials.as<double>(), kLlBlocksPerPair, n_sel, d_out);
+  launch_single_shot_out(s, g, ctx->ws[0].partials.as<float>(), ctx->ws[0].ll_partials.as<double>(), kLlBlocksPerPair, n_sel, d_out);
   DVO_HIP_TRY(ctx, hipMemcpyAsync(out, d_out, sizeof(dvo_hip_iteration_out), hipMemcpyDeviceToHost, s));
-  if (residuals_or_null) DVO_HIP_TRY(ctx, hipMemcpyAsync(residuals_or_null, ctx->scratch.p, npx * sizeof(float2), hipMemcpyDeviceToHost, s));
+  if (residuals_or_null) DVO_HIP_TRY(ctx, hipMemcpyAsync(residuals_or_null, ctx->ws[0].scratch.p, npx * sizeof(float2), hipMemcpyDeviceToHost, s));
   DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
   DVO_HIP_TRY(ctx, hipGetLastError());
   return DVO_HIP_OK;
@@ -706,7 +889,7 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs, dvo_hip_fram
   cfg.last_level = level;
   cfg.max_iterations_per_level = 1;
   BatchPlan bp;
-  int rc = prepare_batch(ctx, n_pairs, references, currents, &cfg, bp);
+  int rc = prepare_single(ctx, n_pairs, references, currents, &cfg, bp);
   if (rc != DVO_HIP_OK) return rc;
   hipStream_t s = ctx->stream;
   const LevelGeom& g = bp.geom[level];
@@ -714,17 +897,17 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs, dvo_hip_fram
   std::vector<double> tinit(size_t(bp.n) * 16, 0.0);
   for (int i = 0; i < bp.n; ++i)
     for (int k = 0; k < 4; ++k) tinit[size_t(i) * 16 + k * 5] = 1.0;
-  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->t_init.p, tinit.data(), tinit.size() * sizeof(double), hipMemcpyHostToDevice, s));
-  PairState* states = ctx->states.as<PairState>();
-  launch_init_pairs(s, states, bp.n, bp.prm, ctx->t_init.as<double>());
-  launch_level_begin(s, states, bp.n, bp.prm, g, level, pp, ctx->lvl_stats.as<dvo_hip_level_stats>());
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[0].t_init.p, tinit.data(), tinit.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  PairState* states = ctx->ws[0].states.as<PairState>();
+  launch_init_pairs(s, states, bp.n, bp.prm, ctx->ws[0].t_init.as<double>());
+  launch_level_begin(s, states, bp.n, bp.prm, g, level, pp, ctx->ws[0].lvl_stats.as<dvo_hip_level_stats>());
   hipEvent_t e0, e1;
   DVO_HIP_TRY(ctx, hipEventCreate(&e0));
   DVO_HIP_TRY(ctx, hipEventCreate(&e1));
-  launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, bp.n, ctx->partials.as<float>(), ctx->scratch.as<float2>());   // warm
+  launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, bp.n, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>());   // warm
   DVO_HIP_TRY(ctx, hipEventRecord(e0, s));
   for (int r = 0; r < reps; ++r)
-    launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, bp.n, ctx->partials.as<float>(), ctx->scratch.as<float2>());
+    launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, bp.n, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>());
   DVO_HIP_TRY(ctx, hipEventRecord(e1, s));
   DVO_HIP_TRY(ctx, hipEventSynchronize(e1));
   float ms = 0;

@@ -8,9 +8,10 @@
 namespace dvo_hip {
 
 // pyramid_kernels.hip
-void launch_ingest_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int n, int levels);
+void launch_ingest_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int n);
 void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h);
-void launch_derive_pack(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr);
+void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h);
+void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr);
 void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float4* R, int* count, uint8_t* mask);
 void launch_unpack_plane(hipStream_t s, const float4* A, const float2* B, int n, int plane, float* out);
 
@@ -29,7 +30,7 @@ void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverPara
 void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
                         const PairPtrs* pairs, dvo_hip_level_stats* levels);
 void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
-                        const float* partials, const double* ll_partials, int ll_blocks_per_pair,
+                        const float* partials, const double* ll_partials, int ll_blocks_per_pair, const float2* scratch_for_fused_ll,
                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, int* active_counter);
 void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverParams prm,
                    const dvo_hip_level_stats* levels, const dvo_hip_iteration_stats* iters, dvo_hip_result* results);

@@ -8,7 +8,7 @@
 //   selection     dvo_core/src/core/point_selection.cpp:89-152, point_selection.h:49-67
 // is done here on the GPU, one launch per pyramid level for a whole batch of frames (blockIdx.z = frame),
 // so a frame upload is two raw planes and every derived plane stays in HBM.  Layout (all float32):
-//   I, Z          planar, 4 B/pixel each (pyr-down source)
+//   I, Z          planar, 4 B/pixel each (pyr-down and derivative source; built when the frame is ingested)
 //   A             float4 {I, Z, Idx, Idy}  current-side sampling plane, one 16-B tap per bilinear corner
 //   B             float2 {Zdx, Zdy}        current-side sampling plane,  8-B tap
 //   R             float4 {Zsel, I, Idx, Idy} reference-side stream; Zsel = NaN where the selection
@@ -18,10 +18,9 @@
 
 namespace dvo_hip {
 
-__global__ void k_ingest_raw(const FrameBuildPtrs* __restrict__ tbl, float scale, int n, int levels) {
+__global__ void k_ingest_raw(const FrameBuildPtrs* __restrict__ tbl, float scale, int n) {
   const FrameBuildPtrs& f = tbl[blockIdx.z];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < levels) f.sel_count[i] = 0;                  // the selection counters are rebuilt by k_derive_pack
   if (i >= n) return;
   f.I[0][i] = float(f.grey[i]);
   const uint16_t d = f.raw[i];
@@ -43,33 +42,71 @@ __global__ void k_pyr_down(const FrameBuildPtrs* __restrict__ tbl, int level, in
   f.Z[level][size_t(y) * ow + x] = Z[size_t(2 * y) * w + 2 * x];             // top-left sample, NaN holes kept (Q18)
 }
 
-// central differences with clamped borders, the two sampling planes, and the reference-side stream with the
-// selection predicate folded into Z; counts the selected pixels
-__global__ void k_derive_pack(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h, float ithr, float dthr) {
+// Central differences with clamped borders (rgbd_image.cpp:419-489).  The derived planes are built per ROLE, like the
+// reference builds them lazily: a frame that is only ever a current frame gets A + B (buildAccelerationStructure,
+// rgbd_image.cpp:534-543), a frame that is only ever a reference gets R + the selection count (PointSelection::select,
+// point_selection.cpp:89-152).
+struct Derivs {
+  float i0, z0, idx, idy, zdx, zdy;
+};
+
+__device__ __forceinline__ Derivs derive_at(const float* __restrict__ I, const float* __restrict__ Z, int w, int h, int x, int y) {
 #pragma clang fp contract(off)
+  const int xp = max(x - 1, 0), xn = min(x + 1, w - 1);
+  const int yp = max(y - 1, 0), yn = min(y + 1, h - 1);
+  const size_t row = size_t(y) * w;
+  Derivs d;
+  d.i0 = I[row + x];
+  d.z0 = Z[row + x];
+  d.idx = (I[row + xn] - I[row + xp]) * 0.5f;
+  d.idy = (I[size_t(yn) * w + x] - I[size_t(yp) * w + x]) * 0.5f;
+  d.zdx = (Z[row + xn] - Z[row + xp]) * 0.5f;
+  d.zdy = (Z[size_t(yn) * w + x] - Z[size_t(yp) * w + x]) * 0.5f;
+  return d;
+}
+
+// current-frame role: the two sampling planes
+__global__ void k_derive_current(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h) {
   const FrameBuildPtrs& f = tbl[blockIdx.z];
-  const float* __restrict__ I = f.I[level];
-  const float* __restrict__ Z = f.Z[level];
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  bool ok = false;
-  if (x < w && y < h) {
-    const int xp = max(x - 1, 0), xn = min(x + 1, w - 1);
-    const int yp = max(y - 1, 0), yn = min(y + 1, h - 1);
-    const size_t row = size_t(y) * w;
-    const float i0 = I[row + x], z0 = Z[row + x];
-    const float idx = (I[row + xn] - I[row + xp]) * 0.5f;
-    const float idy = (I[size_t(yn) * w + x] - I[size_t(yp) * w + x]) * 0.5f;
-    const float zdx = (Z[row + xn] - Z[row + xp]) * 0.5f;
-    const float zdy = (Z[size_t(yn) * w + x] - Z[size_t(yp) * w + x]) * 0.5f;
-    f.A[level][row + x] = make_float4(i0, z0, idx, idy);
-    f.B[level][row + x] = make_float2(zdx, zdy);
-    ok = z0 == z0 && zdx == zdx && zdy == zdy &&
-         (fabsf(idx) > ithr || fabsf(idy) > ithr || fabsf(zdx) > dthr || fabsf(zdy) > dthr);
-    f.R[level][row + x] = make_float4(ok ? z0 : __builtin_nanf(""), i0, idx, idy);
+  if (x >= w || y >= h) return;
+  const Derivs d = derive_at(f.I[level], f.Z[level], w, h, x, y);
+  f.A[level][size_t(y) * w + x] = make_float4(d.i0, d.z0, d.idx, d.idy);
+  f.B[level][size_t(y) * w + x] = make_float2(d.zdx, d.zdy);
+}
+
+// reference role: the streamed plane with the selection predicate folded into Z; counts the selected pixels.
+// The counter of (frame, level) must have been zeroed on the stream before.  A workgroup sweeps a 64 x 16 pixel
+// tile and issues ONE atomic for it (one atomic per wavefront-row serialised the whole kernel on 128 addresses).
+__global__ void k_derive_reference(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h, float ithr, float dthr) {
+  const FrameBuildPtrs& f = tbl[blockIdx.z];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int count = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = (blockIdx.y * 4 + r) * blockDim.y + threadIdx.y;
+    bool ok = false;
+    if (x < w && y < h) {
+      const Derivs d = derive_at(f.I[level], f.Z[level], w, h, x, y);
+      ok = d.z0 == d.z0 && d.zdx == d.zdx && d.zdy == d.zdy &&
+           (fabsf(d.idx) > ithr || fabsf(d.idy) > ithr || fabsf(d.zdx) > dthr || fabsf(d.zdy) > dthr);
+      f.R[level][size_t(y) * w + x] = make_float4(ok ? d.z0 : __builtin_nanf(""), d.i0, d.idx, d.idy);
+    }
+    count += __popcll(__ballot(ok));      // wave-uniform
   }
-  const unsigned long long ballot = __ballot(ok);
-  if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(f.sel_count + level, __popcll(ballot));
+  __shared__ int wave_counts[4];
+  if (threadIdx.x == 0) wave_counts[threadIdx.y] = count;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    const int total = (wave_counts[0] + wave_counts[1]) + (wave_counts[2] + wave_counts[3]);
+    if (total) atomicAdd(f.sel_count + level, total);
+  }
+}
+
+__global__ void k_zero_counts(const FrameBuildPtrs* __restrict__ tbl, int n_frames, int level) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_frames) tbl[i].sel_count[level] = 0;
 }
 
 // re-selection with other thresholds (PointSelection with a different predicate), one frame
@@ -104,8 +141,8 @@ __global__ void k_unpack_plane(const float4* __restrict__ A, const float2* __res
   out[i] = v;
 }
 
-void launch_ingest_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int n, int levels) {
-  k_ingest_raw<<<dim3((n + 255) / 256, 1, n_frames), dim3(256), 0, s>>>(tbl, scale, n, levels);
+void launch_ingest_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int n) {
+  k_ingest_raw<<<dim3((n + 255) / 256, 1, n_frames), dim3(256), 0, s>>>(tbl, scale, n);
 }
 
 void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h) {
@@ -113,8 +150,13 @@ void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int
   k_pyr_down<<<dim3((ow + 63) / 64, (oh + 3) / 4, n_frames), dim3(64, 4), 0, s>>>(tbl, level, w, h);
 }
 
-void launch_derive_pack(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr) {
-  k_derive_pack<<<dim3((w + 63) / 64, (h + 3) / 4, n_frames), dim3(64, 4), 0, s>>>(tbl, level, w, h, ithr, dthr);
+void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h) {
+  k_derive_current<<<dim3((w + 63) / 64, (h + 3) / 4, n_frames), dim3(64, 4), 0, s>>>(tbl, level, w, h);
+}
+
+void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr) {
+  k_zero_counts<<<dim3((n_frames + 63) / 64), dim3(64), 0, s>>>(tbl, n_frames, level);
+  k_derive_reference<<<dim3((w + 63) / 64, (h + 15) / 16, n_frames), dim3(64, 4), 0, s>>>(tbl, level, w, h, ithr, dthr);
 }
 
 void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float4* R, int* count, uint8_t* mask) {

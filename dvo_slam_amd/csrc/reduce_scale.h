@@ -16,18 +16,62 @@ namespace dvo_hip {
 // valid for all threads after the call.
 __device__ inline void reduce_partials(const float* __restrict__ partials, int pair, int tiles, double* sh, double* sums) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* row = partials + (size_t(pair) * tiles + wave) * kAccStride;
+  const float* base = partials + size_t(pair) * tiles * kAccStride;
+  const bool hi = lane < kAccStride - 64;
   double a0 = 0.0, a1 = 0.0;
-  for (int t = wave; t < tiles; t += kWavesPerBlock, row += size_t(kWavesPerBlock) * kAccStride) {
-    a0 += double(row[lane]);
-    if (lane < kAccStride - 64) a1 += double(row[64 + lane]);
+  // eight independent row loads in flight, then added in tile order (the summation order is part of the contract)
+  for (int t0 = wave; t0 < tiles; t0 += 8 * kWavesPerBlock) {
+    float v0[8], v1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = t0 + j * kWavesPerBlock;
+      const float* row = base + size_t(t < tiles ? t : 0) * kAccStride;
+      v0[j] = t < tiles ? row[lane] : 0.0f;
+      v1[j] = (t < tiles && hi) ? row[64 + lane] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (t0 + j * kWavesPerBlock < tiles) {
+        a0 += double(v0[j]);
+        a1 += double(v1[j]);
+      }
+    }
   }
   sh[wave * kAccStride + lane] = a0;
-  if (lane < kAccStride - 64) sh[wave * kAccStride + 64 + lane] = a1;
+  if (hi) sh[wave * kAccStride + 64 + lane] = a1;
   __syncthreads();
   if (threadIdx.x < kAccStride) {
     const int k = threadIdx.x;
     sums[k] = (sh[k] + sh[kAccStride + k]) + (sh[2 * kAccStride + k] + sh[3 * kAccStride + k]);
+  }
+  __syncthreads();
+}
+
+// The same reduction restricted to the four scale accumulators (n, S00, S01, S11), for kernels that only need P:
+// lane k < 4 of wavefront w adds tiles w, w+4, ... in the same order as reduce_partials, so the result is
+// bit-identical to sums[0..3] of the full reduction while reading 16 B instead of 352 B per tile.
+__device__ inline void reduce_partials_scale(const float* __restrict__ partials, int pair, int tiles, double* sh, double* sums) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < 4) {
+    const float* base = partials + size_t(pair) * tiles * kAccStride;
+    double a0 = 0.0;
+    for (int t0 = wave; t0 < tiles; t0 += 8 * kWavesPerBlock) {
+      float v0[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = t0 + j * kWavesPerBlock;
+        v0[j] = t < tiles ? base[size_t(t) * kAccStride + lane] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (t0 + j * kWavesPerBlock < tiles) a0 += double(v0[j]);
+    }
+    sh[wave * 4 + lane] = a0;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    sums[k] = (sh[k] + sh[4 + k]) + (sh[8 + k] + sh[12 + k]);
   }
   __syncthreads();
 }

@@ -120,9 +120,55 @@ DVO_HD void se3_log(const SE3d& T, double* x) {
   x[3] = w[0]; x[4] = w[1]; x[5] = w[2];
 }
 
+// Symmetric 6x6 solve (Eigen's A.ldlt().solve(b) at dense_tracking.cpp:347).  Fast path: unpivoted LDL^T with
+// compile-time indices only, so the whole factorisation stays in registers (a runtime-indexed 6x7 array lives in
+// scratch memory and made this solve half of the solver kernel's serial time).  A = J^T W J + mu I is symmetric
+// positive definite whenever the alignment is well posed, and LDL^T without pivoting is backward stable for SPD
+// input.  If a pivot is not positive (rank-deficient or indefinite A) the pivoted elimination below takes over.
+DVO_HD bool solve6_pivoted(const double* Ain, const double* bin, double* x);
+
+DVO_HD bool solve6(const double* A, const double* b, double* x) {
+  double L[6][6], D[6], y[6];
+  bool spd = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j * 6 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k] * D[k];
+    D[j] = d;
+    spd = spd && (d > 0.0);
+    const double inv = 1.0 / d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double v = A[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
+      L[i][j] = v * inv;
+    }
+  }
+  if (!spd) return solve6_pivoted(A, b, x);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double v = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] /= D[i];
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double v = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k];
+    x[i] = v;
+  }
+  return true;
+}
+
 // Gaussian elimination with partial pivoting on the 6x6 system; returns false on a singular matrix
 // (x is then NaN, which ends the Gauss-Newton loop exactly like a NaN from Eigen's LDLT would).
-DVO_HD bool solve6(const double* Ain, const double* bin, double* x) {
+DVO_HD bool solve6_pivoted(const double* Ain, const double* bin, double* x) {
   double M[6][7];
   for (int i = 0; i < 6; ++i) {
     for (int j = 0; j < 6; ++j) M[i][j] = Ain[i * 6 + j];

@@ -6,8 +6,7 @@
 // termination (dvo_core/src/dense_tracking.cpp:273-363; logic in solver_logic.h).  Keeping this on the
 // device removes the per-iteration D2H/H2D round trip a host-driven loop would need; the host only
 // polls one integer (pairs still active) every few iterations.
-#include "launch.h"
-#include "reduce_scale.h"
+#include "align_common.h"
 #include "solver_logic.h"
 
 namespace dvo_hip {
@@ -25,24 +24,70 @@ __global__ void k_level_begin(PairState* states, int n_pairs, SolverParams prm, 
   gn_level_begin(states[p], prm, g, level, *pairs[p].n_selected, levels + size_t(p) * prm.cap_levels);
 }
 
+// words of a POD copied cooperatively between global memory and LDS
+template <typename T>
+__device__ __forceinline__ void coop_copy(T* dst, const T* src) {
+  static_assert(sizeof(T) % 4 == 0, "POD must be a multiple of 4 bytes");
+  const unsigned* s = reinterpret_cast<const unsigned*>(src);
+  unsigned* d = reinterpret_cast<unsigned*>(dst);
+  for (int i = threadIdx.x; i < int(sizeof(T) / 4); i += blockDim.x) d[i] = s[i];
+}
+
 __global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
                                                         const float* __restrict__ partials,
                                                         const double* __restrict__ ll_partials, int ll_blocks_per_pair,
+                                                        const float2* __restrict__ scratch_for_fused_ll,
                                                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters,
                                                         int* active_counter) {
   const int pair = blockIdx.x;
-  PairState& st = states[pair];
-  if (!st.active) return;   // uniform
+  if (!states[pair].active) return;   // uniform
+  // The state machine is one lane of serial float64 work; every global access it made used to be a dependent
+  // ~1 us round trip.  Stage the pair's state, its level record and the new iteration record in LDS: loaded and
+  // stored by all 256 lanes at once, touched by lane 0 at LDS latency.
+  __shared__ PairState st;
+  __shared__ dvo_hip_level_stats lvl;
+  __shared__ dvo_hip_iteration_stats rec;
   __shared__ double sh[kWavesPerBlock * kAccStride];
   __shared__ double sums[kAccStride];
+  __shared__ double ll_waves[kWavesPerBlock];
+  __shared__ int rec_index;
+  coop_copy(&st, &states[pair]);
+  __syncthreads();
+  const int level_slot = st.n_levels - 1;
+  dvo_hip_level_stats* lvl_global = levels + size_t(pair) * prm.cap_levels + level_slot;
+  const bool have_level = level_slot >= 0 && level_slot < prm.cap_levels;
+  if (have_level) coop_copy(&lvl, lvl_global);
   reduce_partials(partials, pair, g.tiles_x * g.tiles_y, sh, sums);   // same routine, same order as k_loglik: identical n, S, P
+  if (scratch_for_fused_ll) {
+    // coarse levels: the log-likelihood sweep is small enough for this workgroup, which saves a launch per iteration
+    float C[3], P[4];
+    const int n = scale_from_sums(sums, C, P);
+    double t = 0.0;
+    if (n >= 6) t = loglik_partial(scratch_for_fused_ll + size_t(pair) * g.w * g.h, g.w * g.h, P, 0, 1);
+    t = wave_sum_double(t);
+    if ((threadIdx.x & 63) == 0) ll_waves[threadIdx.x >> 6] = t;
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     double ll_sum = 0.0;
-    const double* p = ll_partials + size_t(pair) * ll_blocks_per_pair;
-    for (int b = 0; b < ll_blocks_per_pair; ++b) ll_sum += p[b];
-    gn_step(st, prm, g, sums, ll_sum, levels + size_t(pair) * prm.cap_levels, iters + size_t(pair) * prm.cap_iters);
+    if (scratch_for_fused_ll) {
+      ll_sum = (ll_waves[0] + ll_waves[1]) + (ll_waves[2] + ll_waves[3]);
+    } else {
+      const double* p = ll_partials + size_t(pair) * ll_blocks_per_pair;
+      for (int b = 0; b < ll_blocks_per_pair; ++b) ll_sum += p[b];
+    }
+    rec_index = st.n_iters_total;
+    // gn_step addresses levels[n_levels - 1] and iters[n_iters_total]: hand it pointers biased so that those land in LDS
+    SolverParams local = prm;
+    local.cap_levels = have_level ? level_slot + 1 : 0;
+    local.cap_iters = rec_index + 1;
+    gn_step(st, local, g, sums, ll_sum, &lvl - level_slot, &rec - rec_index);
     if (st.active) atomicAdd(active_counter, 1);
   }
+  __syncthreads();
+  coop_copy(&states[pair], &st);
+  if (have_level) coop_copy(lvl_global, &lvl);
+  if (rec_index < prm.cap_iters) coop_copy(iters + size_t(pair) * prm.cap_iters + rec_index, &rec);
 }
 
 __global__ void k_finish(const PairState* states, int n_pairs, SolverParams prm, const dvo_hip_level_stats* levels,
@@ -105,10 +150,10 @@ void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverPar
 }
 
 void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
-                        const float* partials, const double* ll_partials, int ll_blocks_per_pair,
+                        const float* partials, const double* ll_partials, int ll_blocks_per_pair, const float2* scratch_for_fused_ll,
                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, int* active_counter) {
   k_solver_step<<<dim3(n_pairs), dim3(kBlock), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
-                                                       levels, iters, active_counter);
+                                                       scratch_for_fused_ll, levels, iters, active_counter);
 }
 
 void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverParams prm,

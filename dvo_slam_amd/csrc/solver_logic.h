@@ -147,10 +147,12 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   const double ll = 0.5 * double(n) * log(det) - 3.5 * ll_sum;                           // :297, impl:424
   rec.tdist_loglik = -ll;
   for (int i = 0; i < 4; ++i) rec.tdist_precision[i] = double(P[i]);
-  double li[6];
-  se3_log(st.initial, li);
+  double li[6] = {0, 0, 0, 0, 0, 0};
   double sq = 0;
-  for (int i = 0; i < 6; ++i) sq += li[i] * li[i];
+  if (prm.mu != 0.0) {                                       // with Mu = 0 the prior terms vanish; skip log(initial)
+    se3_log(st.initial, li);
+    for (int i = 0; i < 6; ++i) sq += li[i] * li[i];
+  }
   rec.prior_loglik = prm.mu * sq;                            // :302
 
   st.last_error = st.error;

@@ -336,6 +336,11 @@ class PointSelection:
         return (n.value, mask) if want_mask else n.value
 
 
+_RESULT_DTYPE = np.dtype([("transformation", np.float64, (16,)), ("information", np.float64, (36,)), ("loglik", np.float64),
+                          ("n_levels", np.int32), ("n_iterations_total", np.int32)])
+assert _RESULT_DTYPE.itemsize == C.sizeof(_lib.Result)
+
+
 def _unpack_stats(res, levels, iters):
     out = []
     for li in range(res.n_levels):
@@ -422,6 +427,29 @@ class DenseTracker:
             if with_stats:   # appended, not cleared
                 r.Statistics.Levels.extend(_unpack_stats(cres[i], levels[i * nl:(i + 1) * nl], iters[i * cap_it:(i + 1) * cap_it]))
         return True
+
+    def match_batch_arrays(self, references, currents, T_init=None):
+        """match_batch without per-pair Python objects: returns dict(T [n,4,4], information [n,6,6], loglik [n],
+        n_iterations [n]).  T_init: optional [n,4,4] initial guesses (used when UseInitialEstimate)."""
+        n = len(references)
+        cfg = self.cfg
+        for r, c in zip(references, currents):
+            r.build(cfg.getNumLevels())
+            c.build(cfg.getNumLevels())
+        cres = (_lib.Result * n)()
+        view = np.frombuffer(cres, dtype=_RESULT_DTYPE)
+        if cfg.UseInitialEstimate:
+            assert T_init is not None and np.isfinite(T_init).all(), "Provided initialization is NaN!"
+            view["transformation"][:] = np.asarray(T_init, dtype=np.float64).reshape(n, 16)
+        else:
+            view["transformation"][:] = np.eye(4).reshape(16)
+        vp = C.c_void_p
+        refs = (vp * n)(*[p.ptr for p in references])
+        curs = (vp * n)(*[p.ptr for p in currents])
+        ccfg = cfg.to_c()
+        self.ctx.check(self.ctx._lib.dvo_hip_match_batch(self.ctx.ptr, n, refs, curs, C.byref(ccfg), cres, None, 0, None, 0))
+        return dict(T=view["transformation"].reshape(n, 4, 4).copy(), information=view["information"].reshape(n, 6, 6).copy(),
+                    loglik=view["loglik"].copy(), n_iterations=view["n_iterations_total"].copy())
 
     def level_iteration(self, reference, current, level, T34, P_prev=None, first=True, want_residuals=False):
         """One Gauss-Newton linearisation at a fixed estimate (parity entry point, dvo_hip_level_iteration)."""

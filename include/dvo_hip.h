@@ -190,8 +190,9 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs,
                                  dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
                                  int level, int reps, float* avg_ms);
 
-/* Tunables (0 = library default).  key: "rows_per_wave" (1,2,4,8,16), "iters_per_sync" (host
- * polling cadence of the batched Gauss-Newton loop), "variant" (kernel variant id). */
+/* Tunables (0 = library default).  key: "rows_per_wave" (1,2,4,8,16: tile height of the reduce kernel),
+ * "iters_per_sync" (host polling cadence of the batched Gauss-Newton loop), "variant" (schedule of the reduce
+ * kernel, 0..5), "groups" (1..8: concurrent pair groups / HIP streams of a batched match). */
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 
 const char* dvo_hip_version(void);
