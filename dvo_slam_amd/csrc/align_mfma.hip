@@ -52,7 +52,9 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int u_r = (tile % g.tiles_x) * kTileW + lane;
-  const int row0 = (tile / g.tiles_x) * (kWavesPerBlock * RPW) + wave * RPW;
+  // wavefront w sweeps rows w, w+4, w+8, ... of the tile: the four waves work on ADJACENT rows at the same time, so the
+  // lower tap row of one wave is the upper tap row of the next and is served by the CU's L1 instead of a second L2 request
+  const int row0 = (tile / g.tiles_x) * (kWavesPerBlock * RPW) + wave;
   const size_t pix_base = size_t(pair) * size_t(g.w) * g.h;
   const float nanv = __builtin_nanf("");
   const bool col_ok = u_r < g.w;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
 
 #pragma unroll 1
   for (int k = 0; k < RPW; ++k) {
-    const int v_r = row0 + k;
+    const int v_r = row0 + k * kWavesPerBlock;
     const bool in_image = col_ok && v_r < g.h;
     float4 ref = make_float4(nanv, 0.0f, 0.0f, 0.0f);
     if (in_image) ref = refR[v_r * g.w + u_r];               // 64 lanes x 16 B = 1 KiB contiguous per wave
@@ -85,12 +87,12 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     f32x4 q0 = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0, q2 = q0, q3 = q0;
     if (valid) {
       // t-distribution weight with the PREVIOUS pass' precision (Q11); first pass on a level: w = 1
-      const float sw = first ? 1.0f : __builtin_sqrtf(tdist_weight(o.r0, o.r1, Pp));
+      const float sw = first ? 1.0f : tdist_weight_sqrt(o.r0, o.r1, Pp);
       float J0[6], J1[6];
-      jacobian_rows(o, J0, J1);
-      q0 = f32x4{sw * J0[0], sw * J0[1], sw * J0[2], sw * J0[3]};
-      q1 = f32x4{sw * J0[4], sw * J0[5], sw * J1[0], sw * J1[1]};
-      q2 = f32x4{sw * J1[2], sw * J1[3], sw * J1[4], sw * J1[5]};
+      jacobian_rows_scaled(o, sw, J0, J1);                   // sqrt(w) folded into the four gradient factors
+      q0 = f32x4{J0[0], J0[1], J0[2], J0[3]};
+      q1 = f32x4{J0[4], J0[5], J1[0], J1[1]};
+      q2 = f32x4{J1[2], J1[3], J1[4], J1[5]};
       q3 = f32x4{sw * o.r0, sw * o.r1, 0.0f, 0.0f};
     }
     wr[0] = q0;

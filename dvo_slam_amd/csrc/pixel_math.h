@@ -23,6 +23,15 @@ DVO_HD float fast_rcp(float x) {
 #endif
 }
 
+// sqrt of the t-distribution weight in two instructions: sqrt(7 / (5 + q)) = sqrt(7) * rsq(5 + q) (v_rsq_f32, 1 ulp)
+DVO_HD float fast_rsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rsqf(x);
+#else
+  return 1.0f / sqrtf(x);
+#endif
+}
+
 struct PixelTerms {
   float r0, r1;       // intensity / depth residual
   float gix, giy;     // intensity gradient row  (0.5 fx (Icx + Irx)/255 , 0.5 fy (Icy + Iry)/255)
@@ -40,6 +49,11 @@ DVO_HD float mahalanobis(float r0, float r1, const float* P) {
 DVO_HD float tdist_weight(float r0, float r1, const float* P) {
 #pragma clang fp contract(off)
   return 7.0f / (5.0f + mahalanobis(r0, r1, P));
+}
+
+// its square root (the matrix-core schedule scales the per-pixel vector by sqrt(w) on both operand sides)
+DVO_HD float tdist_weight_sqrt(float r0, float r1, const float* P) {
+  return 2.6457513110645906f * fast_rsqrt(5.0f + mahalanobis(r0, r1, P));
 }
 
 // C = S/(n-3) rounded to float, P = C^-1 in Eigen's 2x2 inverse order (dense_tracking.cpp:295)
@@ -117,11 +131,17 @@ DVO_HD void pixel_fetch(const LevelGeom& g, PtrA curA, PtrB curB, const PixelPro
 DVO_HD bool pixel_finish(const LevelGeom& g, const float4 ref, const PixelProj& p, const PixelTaps& t, PixelTerms& o) {
 #pragma clang fp contract(off)
   const float a1 = p.a1, a0 = 1.0f - a1, b1 = p.b1, b0 = 1.0f - b1;
+  // intensity and depth feed the residual and the validity tests: reference operation order, no contraction
 #define DVO_BILERP(f) (b0 * (a0 * t.A00.f + a1 * t.A10.f) + b1 * (a0 * t.A01.f + a1 * t.A11.f))
-  const float cI = DVO_BILERP(x), cZ = DVO_BILERP(y), cIx = DVO_BILERP(z), cIy = DVO_BILERP(w);
+  const float cI = DVO_BILERP(x), cZ = DVO_BILERP(y);
 #undef DVO_BILERP
-  const float cZx = b0 * (a0 * t.B00.x + a1 * t.B10.x) + b1 * (a0 * t.B01.x + a1 * t.B11.x);
-  const float cZy = b0 * (a0 * t.B00.y + a1 * t.B10.y) + b1 * (a0 * t.B01.y + a1 * t.B11.y);
+  // the four gradient channels only feed the Jacobian (and the NaN test): same formula with fused multiply-adds
+#define DVO_BILERP_FMA(v00, v10, v01, v11) fmaf(b1, fmaf(a1, v11, a0 * (v01)), b0 * fmaf(a1, v10, a0 * (v00)))
+  const float cIx = DVO_BILERP_FMA(t.A00.z, t.A10.z, t.A01.z, t.A11.z);
+  const float cIy = DVO_BILERP_FMA(t.A00.w, t.A10.w, t.A01.w, t.A11.w);
+  const float cZx = DVO_BILERP_FMA(t.B00.x, t.B10.x, t.B01.x, t.B11.x);
+  const float cZy = DVO_BILERP_FMA(t.B00.y, t.B10.y, t.B01.y, t.B11.y);
+#undef DVO_BILERP_FMA
   if (!(cI == cI && cZ == cZ && cIx == cIx && cIy == cIy && cZx == cZx && cZy == cZy)) return false;   // Q9
   // residual = wcur * interpolated + wref * reference with the weights of dense_tracking.cpp:217-220
   const float inv255 = 1.0f / 255.0f;
@@ -150,19 +170,34 @@ DVO_HD bool pixel_residual(const LevelGeom& g, const float* KT, PtrA curA, PtrB 
   return pixel_finish(g, ref, p, t, o);
 }
 
-// 2x6 Jacobian rows at the UNtransformed reference point (Q10; dense_tracking.cpp:448-476, :333-340)
-DVO_HD void jacobian_rows(const PixelTerms& t, float* J0, float* J1) {
+// 2x6 Jacobian rows at the UNtransformed reference point (Q10; dense_tracking.cpp:448-476, :333-340), scaled by `s`
+// (1 for the plain rows; sqrt(w) for the matrix-core schedule).  Written out term by term: the generic
+// "g.x * Jw(0,k) + g.y * Jw(1,k)" wastes a multiply-add on each of the four structural zeros of Jw.
+//   Jw row 0 = [1/z, 0, -x/z^2, -xy/z^2, 1 + x^2/z^2, -y/z]     Jw row 1 = [0, 1/z, -y/z^2, -(1 + y^2/z^2), xy/z^2, x/z]
+//   J0 = gI . Jw      J1 = gZ . Jw - [0, 0, 1, y, -x, 0]
+DVO_HD void jacobian_rows_scaled(const PixelTerms& t, float s, float* J0, float* J1) {
   const float iz = fast_rcp(t.Z), iz2 = iz * iz;
-  float ja[6], jb[6];
-  ja[0] = iz; ja[1] = 0.0f; ja[2] = -t.X * iz2; ja[3] = ja[2] * t.Y; ja[4] = 1.0f - ja[2] * t.X; ja[5] = -t.Y * iz;
-  jb[0] = 0.0f; jb[1] = iz; jb[2] = -t.Y * iz2; jb[3] = -1.0f + jb[2] * t.Y; jb[4] = -ja[3]; jb[5] = t.X * iz;
-  const float jz[6] = {0.0f, 0.0f, 1.0f, t.Y, -t.X, 0.0f};
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    J0[i] = t.gix * ja[i] + t.giy * jb[i];
-    J1[i] = (t.gzx * ja[i] + t.gzy * jb[i]) - jz[i];
-  }
+  const float a2 = -t.X * iz2, b2 = -t.Y * iz2;
+  const float a3 = a2 * t.Y;                 // Jw(0,3); Jw(1,4) = -a3
+  const float a4 = 1.0f - a2 * t.X;          // Jw(0,4)
+  const float b3 = -1.0f + b2 * t.Y;         // Jw(1,3)
+  const float a5 = -t.Y * iz, b5 = t.X * iz; // Jw(0,5), Jw(1,5)
+  const float gix = s * t.gix, giy = s * t.giy, gzx = s * t.gzx, gzy = s * t.gzy;
+  J0[0] = gix * iz;
+  J0[1] = giy * iz;
+  J0[2] = gix * a2 + giy * b2;
+  J0[3] = gix * a3 + giy * b3;
+  J0[4] = gix * a4 - giy * a3;
+  J0[5] = gix * a5 + giy * b5;
+  J1[0] = gzx * iz;
+  J1[1] = gzy * iz;
+  J1[2] = (gzx * a2 + gzy * b2) - s;
+  J1[3] = (gzx * a3 + gzy * b3) - s * t.Y;
+  J1[4] = (gzx * a4 - gzy * a3) + s * t.X;
+  J1[5] = gzx * a5 + gzy * b5;
 }
+
+DVO_HD void jacobian_rows(const PixelTerms& t, float* J0, float* J1) { jacobian_rows_scaled(t, 1.0f, J0, J1); }
 
 // Rank update of the P-independent Gram sums (layout in device_types.h) with one pixel's rows.
 DVO_HD void accumulate_pixel(float* acc, const PixelTerms& t, float w) {

@@ -22,4 +22,22 @@ for f in sorted(glob.glob('gpurun_out/pmc/*/*counter_collection.csv')):
         if 'residual_reduce' in k:
             print(f.split('/')[-2], k)
             for c, v in agg[k].items(): print("    %-32s total %.4g  per-dispatch %.4g  (n=%d)" % (c, v, v/cnt[(k,c)], cnt[(k,c)]))
+# summary consumed by bench.py (roofline.traffic): FETCH_SIZE is in KB and reports half of a wide coalesced stream on gfx950
+import json
+vals = {}
+for f in glob.glob('gpurun_out/pmc/*/*counter_collection.csv'):
+    per = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if 'residual_reduce' in row['Kernel_Name'] and row['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            per[row['Counter_Name']].append(float(row['Counter_Value']))
+    for c, v in per.items():
+        big = [x for x in v if x > 0.5 * max(v)]
+        vals[c] = sum(big) / len(big)
+if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
+    rec = dict(pairs_per_launch=128, level=0, fetch_size_kb=vals['FETCH_SIZE'], write_size_kb=vals['WRITE_SIZE'],
+               fetch_correction=2.0, traffic_bytes_per_launch=(2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
+               algorithmic_bytes_per_launch=40.0 * 640 * 480 * 128,
+               note="rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (scripts/pmc.sh); FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)")
+    json.dump(rec, open('gpurun_out/pmc/pmc_finest_kernel.json', 'w'), indent=1)
+    print(rec)
 PY
