@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--iters-per-sync", type=int, default=0)
     ap.add_argument("--groups", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU dry runs)")
+    ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses GPU 0 (with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -91,10 +93,16 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and libdvo_hip has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    comm_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
     B = args.pairs_per_gpu
     n_total = B * world
@@ -139,7 +147,7 @@ def main():
         if world > 1:
             tw = [_twist(T) for T in out["T"]]
             rec = parallel.pack_records(tw, out["information"], out["loglik"])
-            return parallel.gather_records(rec, n_total, rank, world, device=dev)
+            return parallel.gather_records(rec, n_total, rank, world, device=comm_dev)
         return None
 
     def barrier():
@@ -156,7 +164,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -25,9 +25,8 @@ namespace dvo_hip {
 //   1  software pipeline: the reference row k+2 and the eight taps of row k+1 are in flight while row k is
 //      blended and accumulated, so each wavefront overlaps its own HBM/L2 latency with its ~1000 cycles of VALU
 //      work instead of relying on the 2-3 co-resident wavefronts the 85 accumulators leave room for
-//   2  as 1, compiled for at least 3 wavefronts per SIMD (<= 168 VGPRs)
 template <int RPW, bool FINEST, int VARIANT>
-__global__ __launch_bounds__(kBlock, (VARIANT == 2 ? 3 : 1)) void k_residual_reduce(
+__global__ __launch_bounds__(kBlock) void k_residual_reduce(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd) {
   // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD one
@@ -176,7 +175,6 @@ void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool 
     case 3: launch_residual_reduce_split(s, false, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
     case 4: launch_residual_reduce_split(s, true, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
     case 1: launch_rr_v<1>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 2: launch_rr_v<2>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
     default: launch_rr_v<0>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
   }
 }

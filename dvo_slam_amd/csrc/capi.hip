@@ -626,7 +626,7 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "variant") == 0) {
-    if (value < 0 || value > 5) return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0..5");
+    if (value < 0 || value > 5 || value == 2) return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0, 1, 3, 4 or 5");
     ctx->opt_variant = value;
     return DVO_HIP_OK;
   }
