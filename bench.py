@@ -76,7 +76,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--iters-per-sync", type=int, default=0)
-    ap.add_argument("--groups", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses GPU 0 (with --backend gloo)")
     args = ap.parse_args()
@@ -129,8 +128,6 @@ def main():
         ctx.set_option("rows_per_wave", args.rows_per_wave)
     if args.iters_per_sync:
         ctx.set_option("iters_per_sync", args.iters_per_sync)
-    if args.groups:
-        ctx.set_option("groups", args.groups)
     cam = d.RgbdCameraPyramid(W, H, pairs_np["K"], ctx)
     cam.build(4)
     frames = [cam.create_raw_device(grey_ptrs[i], depth_ptrs[i]) for i in range(2 * B)]

@@ -10,7 +10,6 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/dvo_hip.h"
@@ -75,11 +74,9 @@ struct dvo_hip_frame {
   int* sel_count = nullptr;    // device, one int per level
 };
 
-constexpr int kMaxGroups = 8;
-
-// Everything one concurrently running group of pairs needs: its own HIP stream, device scratch and pinned poll word.
-// A large batch is split into groups that run on separate streams (and host threads), so that one group's
-// latency-bound coarse-level iterations overlap another group's bandwidth-bound fine-level sweeps.
+// The batch workspace: one HIP stream, device scratch and the pinned poll words of the Gauss-Newton loop.
+// (Splitting a batch into concurrently iterating pair groups on several streams was measured and dropped: the coarse
+// levels are bound by the host's launch rate, which more streams only divide -- profiles/r01_d_groups.txt.)
 struct Workspace {
   hipStream_t stream = nullptr;
   DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters;
@@ -91,15 +88,13 @@ struct Workspace {
 
 struct dvo_hip_context {
   int device = 0;
-  hipStream_t stream = nullptr;    // == ws[0].stream: frame builds, single-group matches, measurements
+  hipStream_t stream = nullptr;    // == ws[0].stream
   std::string err;
   int opt_rows_per_wave = 0;
   int opt_iters_per_sync = 0;
   int opt_variant = 5;             // schedule of the reduce kernel: 5 = Gram accumulation on the matrix cores (default)
-  int opt_groups = 0;              // concurrent pair groups of a batched match (0 = default)
   std::vector<CameraGeom*> cameras;
-  Workspace ws[kMaxGroups];
-  hipEvent_t roles_ready = nullptr;
+  Workspace ws[1];
   DevBuf misc, build_tbl, role_tbl_cur, role_tbl_ref;
 };
 
@@ -155,8 +150,6 @@ int fail(dvo_hip_context* ctx, int code, const char* msg) {
 
 const int kLlBlocksPerPair = 32;
 const int kFusedLoglikMaxPixels = 160 * 120;
-const int kDefaultGroups = 2;     // measured: 2 streams +5 %, 4 or 8 streams slower (profiles/r01_d_groups.txt)
-const int kMinPairsPerGroup = 32;
 
 // RgbdCameraPyramid::build (rgbd_image.cpp:283-296) + RgbdCamera ctor template (:186-204)
 int get_camera(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, const CameraGeom** out) {
@@ -405,8 +398,8 @@ int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, 
   return rc;
 }
 
-// device scratch of one group + the per-level pointer tables of its pairs
-int prepare_group(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, BatchPlan& bp) {
+// Device scratch for n pairs + the per-level pointer tables
+int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, BatchPlan& bp) {
   const int n = bp.n, need_levels = cfg->first_level + 1;
   size_t max_tiles = 1;
   for (int l = cfg->last_level; l <= cfg->first_level; ++l) max_tiles = std::max(max_tiles, size_t(bp.geom[l].tiles_x) * bp.geom[l].tiles_y);
@@ -432,21 +425,19 @@ int prepare_group(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* const*
     }
   // pageable source: the runtime stages the bytes before the call returns, so `host` may go out of scope
   DVO_WS_TRY(w, hipMemcpyAsync(w.pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs), hipMemcpyHostToDevice, w.stream));
-  DVO_WS_TRY(w, hipStreamSynchronize(w.stream));
   bp.pair_ptrs = w.pair_ptrs.as<PairPtrs>();
   return DVO_HIP_OK;
 }
 
-// The coarse-to-fine Gauss-Newton driver of one group of pairs (dense_tracking.cpp:131-376 for every pair at once).
-int run_group(dvo_hip_context* ctx, Workspace& w, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs,
-              const dvo_hip_config* cfg, dvo_hip_result* results, dvo_hip_level_stats* levels, int cap_levels,
-              dvo_hip_iteration_stats* iters, int cap_iters) {
-  DVO_WS_TRY(w, hipSetDevice(ctx->device));
+// The coarse-to-fine Gauss-Newton driver of a batch (dense_tracking.cpp:131-376 for every pair at once).
+int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
+              dvo_hip_result* results, dvo_hip_level_stats* levels, int cap_levels, dvo_hip_iteration_stats* iters, int cap_iters) {
+  Workspace& w = ctx->ws[0];
+  hipStream_t s = w.stream;
   BatchPlan bp;
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
-  int rc = prepare_group(w, cfg, refs, curs, bp);
+  int rc = prepare_buffers(w, cfg, refs, curs, bp);
   if (rc != DVO_HIP_OK) return rc;
-  hipStream_t s = w.stream;
 
   // initial guesses (Result.Transformation is in/out, dense_tracking.cpp:137-147)
   std::vector<double> tinit(size_t(n) * 16);
@@ -457,9 +448,13 @@ int run_group(dvo_hip_context* ctx, Workspace& w, int n, dvo_hip_frame* const* r
   PairState* states = w.states.as<PairState>();
   dvo_hip_level_stats* d_levels = w.lvl_stats.as<dvo_hip_level_stats>();
   dvo_hip_iteration_stats* d_iters = w.it_stats.as<dvo_hip_iteration_stats>();
+  float* partials = w.partials.as<float>();
+  float2* scratch = w.scratch.as<float2>();
+  double* ll_partials = w.ll_partials.as<double>();
   int* counters = w.counters.as<int>();
   launch_init_pairs(s, states, n, bp.prm, w.t_init.as<double>());
 
+  const int per_level = cfg->max_iterations_per_level;
   const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 2;
   int step = 0;
   for (int level = cfg->first_level; level >= cfg->last_level; --level) {
@@ -473,20 +468,19 @@ int run_group(dvo_hip_context* ctx, Workspace& w, int n, dvo_hip_frame* const* r
     // Iterations enqueued past the end of the level are no-ops (workgroups exit on !active).
     auto enqueue_chunk = [&](int count) {
       for (int c = 0; c < count; ++c, ++step) {
-        launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, w.partials.as<float>(), w.scratch.as<float2>());
-        if (!fused_ll)
-          launch_loglik(s, g, states, n, w.partials.as<float>(), w.scratch.as<float2>(), w.ll_partials.as<double>(), kLlBlocksPerPair);
-        launch_solver_step(s, states, n, bp.prm, g, w.partials.as<float>(), w.ll_partials.as<double>(), kLlBlocksPerPair,
-                           fused_ll ? w.scratch.as<float2>() : nullptr, d_levels, d_iters, counters + step);
+        launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch);
+        if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, kLlBlocksPerPair);
+        launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, kLlBlocksPerPair, fused_ll ? scratch : nullptr, d_levels, d_iters,
+                           counters + step);
       }
     };
-    int enqueued = std::min(per_sync, cfg->max_iterations_per_level);
+    int enqueued = std::min(per_sync, per_level);
     enqueue_chunk(enqueued);
     DVO_WS_TRY(w, hipMemcpyAsync(w.host_counter, counters + (step - 1), sizeof(int), hipMemcpyDeviceToHost, s));
     DVO_WS_TRY(w, hipEventRecord(w.polled[0], s));
     int slot = 0;
     for (;;) {
-      const int more = std::min(per_sync, cfg->max_iterations_per_level - enqueued);
+      const int more = std::min(per_sync, per_level - enqueued);
       if (more > 0) {
         enqueue_chunk(more);
         enqueued += more;
@@ -498,6 +492,7 @@ int run_group(dvo_hip_context* ctx, Workspace& w, int n, dvo_hip_frame* const* r
       slot = 1 - slot;
     }
   }
+
   launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());
   DVO_WS_TRY(w, hipMemcpyAsync(results, w.results.p, size_t(n) * sizeof(dvo_hip_result), hipMemcpyDeviceToHost, s));
   std::vector<dvo_hip_level_stats> hl;
@@ -532,7 +527,7 @@ int run_group(dvo_hip_context* ctx, Workspace& w, int n, dvo_hip_frame* const* r
   return DVO_HIP_OK;
 }
 
-// single-group preparation on the main stream for the parity / measurement entry points
+// preparation for the parity / measurement entry points
 int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg, BatchPlan& bp) {
   int rc = validate_batch(ctx, n, refs, curs, cfg);
   if (rc != DVO_HIP_OK) return rc;
@@ -540,7 +535,8 @@ int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_
   rc = ensure_batch_roles(ctx, n, refs, curs, cfg);
   if (rc != DVO_HIP_OK) return rc;
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
-  rc = prepare_group(ctx->ws[0], cfg, refs, curs, bp);
+  rc = prepare_buffers(ctx->ws[0], cfg, refs, curs, bp);
+  if (rc == DVO_HIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = DVO_HIP_ERR_HIP;
   if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
   return rc;
 }
@@ -578,7 +574,6 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
   dvo_hip_context* ctx = new dvo_hip_context();
   ctx->device = device;
   int rc = workspace_create(ctx, 0);
-  if (rc == DVO_HIP_OK && hipEventCreateWithFlags(&ctx->roles_ready, hipEventDisableTiming) != hipSuccess) rc = DVO_HIP_ERR_HIP;
   if (rc != DVO_HIP_OK) {
     g_create_error = "context setup: " + ctx->err;
     workspace_destroy(ctx->ws[0]);
@@ -599,7 +594,6 @@ void dvo_hip_context_destroy(dvo_hip_context* ctx) {
     c->tables.release();
     delete c;
   }
-  if (ctx->roles_ready) (void)hipEventDestroy(ctx->roles_ready);
   delete ctx;
 }
 
@@ -618,11 +612,6 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "iters_per_sync") == 0) {
     if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "iters_per_sync must be >= 0");
     ctx->opt_iters_per_sync = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "groups") == 0) {
-    if (value < 0 || value > kMaxGroups) return fail(ctx, DVO_HIP_ERR_INVALID, "groups must be 0..8");
-    ctx->opt_groups = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "variant") == 0) {
@@ -796,38 +785,9 @@ int dvo_hip_match_batch(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const*
   rc = ensure_batch_roles(ctx, n_pairs, references, currents, cfg);
   if (rc != DVO_HIP_OK) return rc;
 
-  // how many groups: enough pairs per group to fill the chip on the fine levels
-  const int want = ctx->opt_groups > 0 ? ctx->opt_groups : kDefaultGroups;
-  const int groups = std::max(1, std::min(std::min(want, kMaxGroups), n_pairs / kMinPairsPerGroup));
-  if (groups == 1) {
-    rc = run_group(ctx, ctx->ws[0], n_pairs, references, currents, cfg, results, levels, cap_levels, iters, cap_iters);
-    if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
-    return rc;
-  }
-  for (int g = 0; g < groups; ++g) {
-    rc = workspace_create(ctx, g);
-    if (rc != DVO_HIP_OK) return rc;
-  }
-  // the role planes were enqueued on the main stream: every group stream waits for them
-  DVO_HIP_TRY(ctx, hipEventRecord(ctx->roles_ready, ctx->stream));
-  for (int g = 1; g < groups; ++g) DVO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->ws[g].stream, ctx->roles_ready, 0));
-  std::vector<int> rcs(groups, DVO_HIP_OK);
-  std::vector<std::thread> threads;
-  auto work = [&](int g) {
-    const int i0 = int((long long)n_pairs * g / groups), i1 = int((long long)n_pairs * (g + 1) / groups);
-    rcs[g] = run_group(ctx, ctx->ws[g], i1 - i0, references + i0, currents + i0, cfg, results + i0,
-                       levels ? levels + size_t(i0) * cap_levels : nullptr, cap_levels,
-                       iters ? iters + size_t(i0) * cap_iters : nullptr, cap_iters);
-  };
-  for (int g = 1; g < groups; ++g) threads.emplace_back(work, g);
-  work(0);
-  for (std::thread& t : threads) t.join();
-  for (int g = 0; g < groups; ++g)
-    if (rcs[g] != DVO_HIP_OK) {
-      ctx->err = ctx->ws[g].err;
-      return rcs[g];
-    }
-  return DVO_HIP_OK;
+  rc = run_batch(ctx, n_pairs, references, currents, cfg, results, levels, cap_levels, iters, cap_iters);
+  if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
+  return rc;
 }
 
 int dvo_hip_match(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame* current, const dvo_hip_config* cfg,

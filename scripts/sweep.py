@@ -58,19 +58,6 @@ def main():
             rows.append(dict(kind="match", pairs=n, iters_per_sync=ips, ms=float(np.median(ts))))
             print("match  pairs=%4d iters_per_sync=%2d  %9.3f ms  (%.1f alignments/s)" % (n, ips, rows[-1]["ms"], n / rows[-1]["ms"] * 1e3), flush=True)
     ctx.set_option("iters_per_sync", 0)
-    for n in [x for x in (32, 64, 128, 256) if x <= nmax]:
-        res = [d.Result() for _ in range(n)]
-        for groups in (1, 2, 4, 8):
-            ctx.set_option("groups", groups)
-            trk.match_batch(refs[:n], curs[:n], res)
-            ts = []
-            for _ in range(7):
-                t0 = time.perf_counter()
-                trk.match_batch(refs[:n], curs[:n], res)
-                ts.append((time.perf_counter() - t0) * 1e3)
-            rows.append(dict(kind="groups", pairs=n, groups=groups, ms=float(np.median(ts))))
-            print("groups pairs=%4d groups=%d  %9.3f ms  (%.1f alignments/s)" % (n, groups, rows[-1]["ms"], n / rows[-1]["ms"] * 1e3), flush=True)
-    ctx.set_option("groups", 0)
     # iterations actually taken
     res = [d.Result() for _ in range(min(nmax, 16))]
     trk.match_batch(refs[:len(res)], curs[:len(res)], res, with_stats=True)
