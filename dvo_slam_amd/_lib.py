@@ -71,6 +71,8 @@ def build(force=False):
     if force:
         subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
     subprocess.check_call(cmd)
+    # the replay driver (g++ only) links the library just built
+    subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(CSRC), "apps"), "-s"])
     return LIB_PATH
 
 

@@ -34,6 +34,7 @@ def lib():
         u8, u16 = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)
         L.dvo_synth_pair.argtypes = [C.c_uint64, C.c_int, C.c_int, fp, u8, u16, u8, u16, dp]
         L.dvo_synth_batch.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, fp, u8, u16, u8, u16, dp, C.c_int]
+        L.dvo_synth_sequence.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, fp, u8, u16, dp, C.c_int]
         _lib = L
     return _lib
 
@@ -57,3 +58,16 @@ def synth_batch(seed0, n, w=640, h=480, K=None, nthreads=None):
                           gc.ctypes.data_as(u8), dc.ctypes.data_as(u16), xi.ctypes.data_as(C.POINTER(C.c_double)),
                           nthreads or min(8, os.cpu_count() or 1))
     return dict(grey_ref=gr, depth_ref=dr, grey_cur=gc, depth_cur=dc, xi_true=xi, K=K)
+
+
+def synth_sequence(seed, n, w=640, h=480, K=None, nthreads=None):
+    """A camera sweep over one scene: dict(grey [n,h,w] u8, depth [n,h,w] u16, poses [n,4,4] camera->world (frame 0 =
+    identity), K).  match(frame k-1, frame k) should return poses[k-1]^-1 poses[k]."""
+    K = np.ascontiguousarray(FR1_K * (w / 640.0) if K is None else K, dtype=np.float32)
+    grey = np.empty((n, h, w), np.uint8)
+    depth = np.empty((n, h, w), np.uint16)
+    poses = np.zeros((n, 4, 4))
+    lib().dvo_synth_sequence(seed, n, w, h, K.ctypes.data_as(C.POINTER(C.c_float)), grey.ctypes.data_as(C.POINTER(C.c_uint8)),
+                             depth.ctypes.data_as(C.POINTER(C.c_uint16)), poses.ctypes.data_as(C.POINTER(C.c_double)),
+                             nthreads or min(8, os.cpu_count() or 1))
+    return dict(grey=grey, depth=depth, poses=poses, K=K)

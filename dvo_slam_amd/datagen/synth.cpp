@@ -205,3 +205,76 @@ extern "C" void dvo_synth_batch(uint64_t seed0, int n, int W, int H, const float
   work(0);
   for (auto& x : th) x.join();
 }
+
+namespace {
+
+// one view of the scene from the camera whose camera->world transform is Mcw (world = the frame the analytic surface
+// is defined in): intersect each pixel ray with the surface  p.z = depth_at(project(p)),  p = R s d + t
+void render_view(const Scene& sc, const double Mcw[16], Pcg32& noise, Pcg32& holes, uint8_t* grey, uint16_t* depth) {
+  const int W = sc.W, H = sc.H;
+  for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) {
+      const double d[3] = {(u - sc.ox) / sc.fx, (v - sc.oy) / sc.fy, 1.0};
+      double rd[3], t[3] = {Mcw[3], Mcw[7], Mcw[11]};
+      for (int i = 0; i < 3; ++i) rd[i] = Mcw[i * 4 + 0] * d[0] + Mcw[i * 4 + 1] * d[1] + Mcw[i * 4 + 2] * d[2];
+      auto g = [&](double s, double p[3]) {
+        for (int i = 0; i < 3; ++i) p[i] = rd[i] * s + t[i];
+        const double pu = sc.fx * p[0] / p[2] + sc.ox, pv = sc.fy * p[1] / p[2] + sc.oy;
+        return p[2] - sc.depth_at(pu, pv);
+      };
+      double s = sc.depth_at(u, v), p[3];
+      for (int it = 0; it < 30; ++it) {
+        const double g0 = g(s, p);
+        if (std::fabs(g0) < 1e-9) break;
+        double ph[3];
+        const double h = 1e-4;
+        double dg = (g(s + h, ph) - g0) / h;
+        if (std::fabs(dg) < 0.05) dg = dg < 0 ? -0.05 : 0.05;
+        double step = g0 / dg;
+        if (step > 0.2) step = 0.2;
+        if (step < -0.2) step = -0.2;
+        s -= step;
+      }
+      g(s, p);
+      grey[size_t(v) * W + u] = quantise_grey(sc.texture(p) + noise.uniform(-1.5, 1.5));
+      depth[size_t(v) * W + u] = quantise_depth(s);
+    }
+  punch_holes(depth, W, H, holes);
+}
+
+}  // namespace
+
+// A camera sweep over one scene: n frames, frame k seen from the pose  T_k = exp(xi(k)),  xi_i(k) = A_i sin(w_i k + phi_i)
+// (bounded excursion around the scene's defining view, per-frame motion of the order of 30 Hz hand-held footage).
+// poses: n row-major 4x4 camera->world transforms = the ground truth trajectory a replay is evaluated against.
+extern "C" void dvo_synth_sequence(uint64_t seed, int n, int W, int H, const float K[4], uint8_t* grey, uint16_t* depth, double* poses,
+                                   int nthreads) {
+  Pcg32 rng(seed * 0x9E3779B97F4A7C15ULL + 0x7654321ULL, seed + 23);
+  Scene sc;
+  sc.W = W; sc.H = H;
+  sc.fx = K[0]; sc.fy = K[1]; sc.ox = K[2]; sc.oy = K[3];
+  make_scene(sc, rng);
+  double amp[6], freq[6], phase[6];
+  for (int i = 0; i < 6; ++i) {
+    amp[i] = (i < 3 ? 0.12 : 0.10) * rng.uniform(0.5, 1.0);      // metres / radians
+    freq[i] = rng.uniform(0.08, 0.16);                           // rad per frame -> steps of <= ~0.02 per frame
+    phase[i] = rng.uniform(0, 2.0 * M_PI);
+  }
+  for (int k = 0; k < n; ++k) {
+    double xi[6];
+    for (int i = 0; i < 6; ++i) xi[i] = amp[i] * (std::sin(freq[i] * k + phase[i]) - std::sin(phase[i]));   // frame 0 = identity
+    se3_exp_matrix(xi, poses + size_t(k) * 16);
+  }
+  if (nthreads < 1) nthreads = 1;
+  const size_t npx = size_t(W) * H;
+  auto work = [&](int t) {
+    for (int k = t; k < n; k += nthreads) {
+      Pcg32 noise(seed * 977 + 2 * uint64_t(k) + 1, 29), holes(seed * 1543 + 2 * uint64_t(k) + 2, 31);
+      render_view(sc, poses + size_t(k) * 16, noise, holes, grey + k * npx, depth + k * npx);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+}
