@@ -41,6 +41,7 @@ inline void affine_to_rowmajor(const Affine3d& T, double* m) {
 inline void affine_from_rowmajor(const double* m, Affine3d& T) {
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T.matrix()(i, j) = m[i * 4 + j];
 }
+inline double determinant6(const Matrix6d& m) { return m.determinant(); }
 #else
 // fixed-size dense matrix with (i, j) access, just enough for Result / Stats
 template <int R, int C>
@@ -90,6 +91,28 @@ struct Affine3d {
   }
   double translation(int i) const { return m(i, 3); }
 };
+// determinant by LU with partial pivoting (Eigen's Matrix::determinant() for sizes > 4 does the same)
+inline double determinant6(const Mat<6, 6>& m) {
+  double a[36];
+  std::memcpy(a, m.d, sizeof a);
+  double det = 1.0;
+  for (int k = 0; k < 6; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < 6; ++i)
+      if (std::fabs(a[i * 6 + k]) > std::fabs(a[piv * 6 + k])) piv = i;
+    if (a[piv * 6 + k] == 0.0) return 0.0;
+    if (piv != k) {
+      for (int j = 0; j < 6; ++j) { const double t = a[k * 6 + j]; a[k * 6 + j] = a[piv * 6 + j]; a[piv * 6 + j] = t; }
+      det = -det;
+    }
+    det *= a[k * 6 + k];
+    for (int i = k + 1; i < 6; ++i) {
+      const double f = a[i * 6 + k] / a[k * 6 + k];
+      for (int j = k + 1; j < 6; ++j) a[i * 6 + j] -= f * a[k * 6 + j];
+    }
+  }
+  return det;
+}
 inline void affine_to_rowmajor(const Affine3d& T, double* out) { std::memcpy(out, T.m.d, sizeof(double) * 16); }
 inline void affine_from_rowmajor(const double* in, Affine3d& T) { std::memcpy(T.m.d, in, sizeof(double) * 16); }
 #endif

@@ -75,7 +75,12 @@ class DenseTracker {
       assert(HasIterationWithIncrement());
       return TerminationCriterion == TerminationCriteria::LogLikelihoodDecreased ? Iterations[Iterations.size() - 2] : Iterations[Iterations.size() - 1];
     }
+    const IterationStats& LastIterationWithIncrement() const {
+      assert(HasIterationWithIncrement());
+      return TerminationCriterion == TerminationCriteria::LogLikelihoodDecreased ? Iterations[Iterations.size() - 2] : Iterations[Iterations.size() - 1];
+    }
     IterationStats& LastIteration() { return Iterations.back(); }
+    const IterationStats& LastIteration() const { return Iterations.back(); }
   };
   typedef std::vector<LevelStats> LevelStatsVector;
 
@@ -153,15 +158,7 @@ class DenseTracker {
     } else {
       result.setIdentity();
     }
-    dvo_hip_config c;
-    c.first_level = cfg.FirstLevel;
-    c.last_level = cfg.LastLevel;
-    c.max_iterations_per_level = cfg.MaxIterationsPerLevel;
-    c.use_initial_estimate = cfg.UseInitialEstimate ? 1 : 0;
-    c.precision = cfg.Precision;
-    c.mu = cfg.Mu;
-    c.intensity_derivative_threshold = reference.predicate().intensityThreshold();
-    c.depth_derivative_threshold = reference.predicate().depthThreshold();
+    const dvo_hip_config c = c_config(reference.predicate().intensityThreshold(), reference.predicate().depthThreshold());
     const int nl = cfg.FirstLevel - cfg.LastLevel + 1;
     const int cap = nl * cfg.MaxIterationsPerLevel;
     levels_.resize(size_t(nl));
@@ -170,17 +167,74 @@ class DenseTracker {
     dvo::compat::affine_to_rowmajor(result.Transformation, r.transformation);
     dvo_hip_context* ctx = current.device_context();
     core::dvo_hip_check(ctx, dvo_hip_match(ctx, ref.device_frame(), current.device_frame(), &c, &r, levels_.data(), nl, iters_.data(), cap), "dvo_hip_match");
+    unpack(r, levels_.data(), iters_.data(), result);
+    return true;   // dense_tracking.cpp:135, 375
+  }
+
+
+  // ---- extension over the reference API ---------------------------------------------------------------------------
+  // N independent alignments in ONE device batch: what the reference runs as N match() calls on a TBB pool
+  // (dvo_slam/src/keyframe_graph.cpp:576-593) or in a loop (constraint_proposal_validator.cpp:134-146).  Per pair the
+  // semantics are exactly those of match(reference, current, result): results[i].Transformation is in/out, statistics
+  // are appended.  Frames may repeat, in either role.
+  bool matchBatch(const std::vector<core::RgbdImagePyramid*>& references, const std::vector<core::RgbdImagePyramid*>& currents,
+                  const std::vector<Result*>& results) {
+    assert(references.size() == currents.size() && references.size() == results.size());
+    const size_t n = references.size();
+    if (n == 0) return true;
+    std::vector<dvo_hip_frame*> refs(n), curs(n);
+    std::vector<dvo_hip_result> out(n);
+    for (size_t i = 0; i < n; ++i) {
+      references[i]->compute(cfg.getNumLevels());
+      currents[i]->compute(cfg.getNumLevels());
+      refs[i] = references[i]->device_frame();
+      curs[i] = currents[i]->device_frame();
+      if (cfg.UseInitialEstimate) {
+        assert(!results[i]->isNaN() && "Provided initialization is NaN!");
+      } else {
+        results[i]->setIdentity();
+      }
+      dvo::compat::affine_to_rowmajor(results[i]->Transformation, out[i].transformation);
+    }
+    const dvo_hip_config c = c_config(selection_predicate_.intensity_threshold, selection_predicate_.depth_threshold);
+    const int nl = cfg.FirstLevel - cfg.LastLevel + 1;
+    const int cap = nl * cfg.MaxIterationsPerLevel;
+    levels_.resize(n * size_t(nl));
+    iters_.resize(n * size_t(cap));
+    dvo_hip_context* ctx = currents[0]->device_context();
+    core::dvo_hip_check(ctx, dvo_hip_match_batch(ctx, int(n), refs.data(), curs.data(), &c, out.data(), levels_.data(), nl, iters_.data(), cap),
+                        "dvo_hip_match_batch");
+    for (size_t i = 0; i < n; ++i) unpack(out[i], &levels_[i * size_t(nl)], &iters_[i * size_t(cap)], *results[i]);
+    return true;
+  }
+
+ private:
+  dvo_hip_config c_config(float intensity_threshold, float depth_threshold) const {
+    dvo_hip_config c;
+    c.first_level = cfg.FirstLevel;
+    c.last_level = cfg.LastLevel;
+    c.max_iterations_per_level = cfg.MaxIterationsPerLevel;
+    c.use_initial_estimate = cfg.UseInitialEstimate ? 1 : 0;
+    c.precision = cfg.Precision;
+    c.mu = cfg.Mu;
+    c.intensity_derivative_threshold = intensity_threshold;
+    c.depth_derivative_threshold = depth_threshold;
+    return c;
+  }
+
+  // C-ABI result + flat statistics -> Result (statistics appended, not cleared: Q15)
+  static void unpack(const dvo_hip_result& r, const dvo_hip_level_stats* levels, const dvo_hip_iteration_stats* iters, Result& result) {
     dvo::compat::affine_from_rowmajor(r.transformation, result.Transformation);
     for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) result.Information(i, j) = r.information[i * 6 + j];
     result.LogLikelihood = r.loglik;
-    for (int l = 0; l < r.n_levels; ++l) {   // appended, not cleared (Q15)
+    for (int l = 0; l < r.n_levels; ++l) {
       result.Statistics.Levels.push_back(LevelStats());
       LevelStats& ls = result.Statistics.Levels.back();
-      const dvo_hip_level_stats& s = levels_[size_t(l)];
+      const dvo_hip_level_stats& s = levels[l];
       ls.Id = size_t(s.id); ls.MaxValidPixels = size_t(s.max_valid_pixels); ls.ValidPixels = size_t(s.valid_pixels);
       ls.TerminationCriterion = s.termination < 0 ? TerminationCriteria::NumCriteria : TerminationCriteria::Enum(s.termination);
       for (int k = 0; k < s.n_iterations; ++k) {
-        const dvo_hip_iteration_stats& it = iters_[size_t(s.first_iteration_index + k)];
+        const dvo_hip_iteration_stats& it = iters[s.first_iteration_index + k];
         IterationStats o;
         o.Id = size_t(it.id); o.ValidConstraints = size_t(it.valid_constraints);
         o.TDistributionLogLikelihood = it.tdist_loglik;
@@ -192,10 +246,8 @@ class DenseTracker {
         ls.Iterations.push_back(o);
       }
     }
-    return true;   // dense_tracking.cpp:135, 375
   }
 
- private:
   Config cfg;
   core::ValidPointAndGradientThresholdPredicate selection_predicate_;
   core::PointSelection reference_selection_;

@@ -1,0 +1,250 @@
+// validator_check.cpp -- drives include/dvo_slam/constraints/ the way KeyframeGraph drives the reference's validator
+// (dvo_slam/src/keyframe_graph.cpp:500-593) and prints the surviving proposals for tests/test_validation.py.
+//   validator_check table <spec.txt>                    decision logic only: tracking results come from a table (no GPU)
+//   validator_check gpu|gpu_sequential <assoc.txt> <groundtruth.txt>   every frame of a TUM-layout folder is a keyframe; the last one is
+//                                                       validated against all others on the device
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <string>
+#include <tuple>
+
+#include <dvo_benchmark/file_reader.h>
+#include <dvo_benchmark/groundtruth.h>
+#include <dvo_benchmark/image_io.h>
+#include <dvo_benchmark/rgbd_pair.h>
+#include <dvo_benchmark/tools.h>
+#include <dvo_slam/constraints/constraint_proposal_validator.h>
+
+using namespace dvo_slam;
+using namespace dvo_slam::constraints;
+
+namespace {
+
+dvo::core::AffineTransformd from_rowmajor(const double* m) {
+  dvo::core::AffineTransformd T;
+  dvo::compat::affine_from_rowmajor(m, T);
+  return T;
+}
+
+// "O,N,C0.3,E0.03,X1.0" -> voters (O odometry, N NaN, C constraint ratio, E evaluation ratio, X cross validation)
+void add_voters(ConstraintProposalValidator::Stage& stage, const std::string& spec) {
+  std::stringstream ss(spec);
+  std::string tok;
+  while (std::getline(ss, tok, ',')) {
+    const double v = tok.size() > 1 ? std::atof(tok.c_str() + 1) : 0.0;
+    switch (tok[0]) {
+      case 'O': stage.addVoter(new OdometryConstraintVoter()); break;
+      case 'N': stage.addVoter(new NaNResultVoter()); break;
+      case 'C': stage.addVoter(new ConstraintRatioVoter(v)); break;
+      case 'E': stage.addVoter(new TrackingResultEvaluationVoter(v)); break;
+      case 'X': stage.addVoter(new CrossValidationVoter(v)); break;
+    }
+  }
+}
+
+void print_proposals(const ConstraintProposalVector& proposals) {
+  std::printf("%zu\n", proposals.size());
+  for (size_t i = 0; i < proposals.size(); ++i) {
+    const ConstraintProposal& p = *proposals[i];
+    double T[16], I[16];
+    dvo::compat::affine_to_rowmajor(p.TrackingResult.Transformation, T);
+    dvo::compat::affine_to_rowmajor(p.InitialTransformation, I);
+    std::printf("%d %d %.17g", int(p.Reference->id()), int(p.Current->id()), p.TotalScore());
+    for (int k = 0; k < 16; ++k) std::printf(" %.17g", T[k]);
+    for (int k = 0; k < 16; ++k) std::printf(" %.17g", I[k]);
+    std::printf("\n");
+  }
+}
+
+struct TableEntry { double t[3], logdet, ratio; int nan, termination, n_iters; };
+
+dvo::DenseTracker::Result fake_result(const TableEntry& e, int level_id) {
+  dvo::DenseTracker::Result r;
+  double m[16] = {1, 0, 0, e.t[0], 0, 1, 0, e.t[1], 0, 0, 1, e.t[2], 0, 0, 0, 1};
+  if (e.nan) m[3] = std::numeric_limits<double>::quiet_NaN();
+  r.Transformation = from_rowmajor(m);
+  r.Information.setZero();
+  for (int i = 0; i < 6; ++i) r.Information(i, i) = std::exp(e.logdet / 6.0);
+  r.LogLikelihood = 0.0;
+  dvo::DenseTracker::LevelStats ls;
+  ls.Id = size_t(level_id);
+  ls.MaxValidPixels = 1000;
+  ls.ValidPixels = 1000;
+  ls.TerminationCriterion = dvo::DenseTracker::TerminationCriteria::Enum(e.termination);
+  for (int k = 0; k < e.n_iters; ++k) {
+    dvo::DenseTracker::IterationStats it;
+    it.Id = size_t(k);
+    // the very last iteration carries a decoy count: a voter that looks at the wrong iteration is caught
+    it.ValidConstraints = (k == e.n_iters - 1 && e.termination == dvo::DenseTracker::TerminationCriteria::LogLikelihoodDecreased)
+                              ? 1 : size_t(std::lround(e.ratio * 1000.0));
+    it.TDistributionLogLikelihood = 0; it.PriorLogLikelihood = 0;
+    ls.Iterations.push_back(it);
+  }
+  r.Statistics.Levels.push_back(ls);
+  return r;
+}
+
+// decision logic under tabulated tracking results; the stage is recognised by MaxIterationsPerLevel = 10 + stage id
+struct TableValidator : public ConstraintProposalValidator {
+  std::map<std::tuple<int, int, int, int>, TableEntry> table;
+  virtual void track(const dvo::DenseTracker::Config& cfg, ConstraintProposalVector& proposals) {
+    const int stage = cfg.MaxIterationsPerLevel - 10;
+    std::map<std::pair<int, int>, int> seen;
+    for (size_t i = 0; i < proposals.size(); ++i) {
+      ConstraintProposal& p = *proposals[i];
+      const int occurrence = seen[std::make_pair(int(p.Reference->id()), int(p.Current->id()))]++;
+      const auto it = table.find(std::make_tuple(stage, int(p.Reference->id()), int(p.Current->id()), occurrence));
+      if (it == table.end()) { std::fprintf(stderr, "no table entry for stage %d %d->%d #%d\n", stage, p.Reference->id(), p.Current->id(), occurrence); std::exit(3); }
+      p.TrackingResult = fake_result(it->second, cfg.LastLevel);
+    }
+  }
+};
+
+int run_table(const char* path) {
+  std::ifstream in(path);
+  std::string tag;
+  int n;
+  TableValidator validator;
+  std::map<int, KeyframePtr> keyframes;
+  ConstraintProposalVector proposals;
+  while (in >> tag >> n) {
+    for (int i = 0; i < n; ++i) {
+      if (tag == "S") {
+        int id, keep;
+        std::string voters;
+        in >> id >> keep >> voters;
+        dvo::DenseTracker::Config cfg;
+        cfg.MaxIterationsPerLevel = 10 + id;
+        ConstraintProposalValidator::Stage& s = validator.createStage(id).trackingConfig(cfg);
+        if (keep) s.keepBest(); else s.keepAll();
+        add_voters(s, voters);
+      } else if (tag == "K") {
+        int id;
+        double m[16], baseline;
+        in >> id;
+        for (int k = 0; k < 16; ++k) in >> m[k];
+        in >> baseline;
+        TableEntry e = {{0, 0, 0}, baseline, 1.0, 0, 1, 1};
+        KeyframePtr kf(new Keyframe());
+        kf->id(short(id)).pose(from_rowmajor(m)).evaluation(TrackingResultEvaluation::ConstPtr(new EntropyRatioTrackingResultEvaluation(fake_result(e, 0))));
+        keyframes[id] = kf;
+      } else if (tag == "P") {
+        int ref, cur, relative;
+        in >> ref >> cur >> relative;
+        proposals.push_back(relative ? ConstraintProposal::createWithRelative(keyframes[ref], keyframes[cur])
+                                     : ConstraintProposal::createWithIdentity(keyframes[ref], keyframes[cur]));
+      } else if (tag == "T") {
+        int stage, ref, cur, occ;
+        TableEntry e;
+        in >> stage >> ref >> cur >> occ >> e.t[0] >> e.t[1] >> e.t[2] >> e.logdet >> e.ratio >> e.nan >> e.termination >> e.n_iters;
+        validator.table[std::make_tuple(stage, ref, cur, occ)] = e;
+      }
+    }
+  }
+  validator.validate(proposals);
+  print_proposals(proposals);
+  return 0;
+}
+
+dvo::core::RgbdImagePyramidPtr load(dvo::core::RgbdCameraPyramid& camera, const std::string& rgb_file, const std::string& depth_file) {
+  return camera.create(dvo_benchmark::greyFloatFromPng(dvo_benchmark::readPng(rgb_file)),
+                       dvo_benchmark::depthFloatFromPng(dvo_benchmark::readPng(depth_file), 1.0f / 5000.0f));
+}
+
+// the reference's pattern: one match() per proposal (constraint_proposal_validator.cpp:139-146) -- timing comparison only
+struct SequentialValidator : public ConstraintProposalValidator {
+  dvo::DenseTracker one_by_one;
+  virtual void track(const dvo::DenseTracker::Config& cfg, ConstraintProposalVector& proposals) {
+    one_by_one.configure(cfg);
+    for (size_t i = 0; i < proposals.size(); ++i) {
+      ConstraintProposal& p = *proposals[i];
+      p.TrackingResult.Transformation = p.InitialTransformation;
+      one_by_one.match(*p.Reference->image(), *p.Current->image(), p.TrackingResult);
+    }
+  }
+};
+
+int run_gpu(const std::string& assoc, const std::string& gt_file, bool sequential) {
+  dvo_benchmark::FileReader<dvo_benchmark::RgbdPair> pair_reader(assoc);
+  pair_reader.skipComments();
+  std::vector<dvo_benchmark::RgbdPair> pairs;
+  pair_reader.readAllEntries(pairs);
+  const std::string folder = assoc.substr(0, assoc.find_last_of("/") + 1);
+  dvo_benchmark::FileReader<dvo_benchmark::Groundtruth> gt_reader(gt_file);
+  gt_reader.skipComments();
+  gt_reader.next();
+
+  // tracker configurations as KeyframeGraph sets them up (keyframe_graph.cpp:819-838) from launch/benchmark.yaml
+  dvo::DenseTracker::Config odometry = dvo::DenseTracker::getDefaultConfig();
+  odometry.FirstLevel = 3; odometry.LastLevel = 1; odometry.MaxIterationsPerLevel = 50; odometry.Precision = 1e-4; odometry.Mu = 0.05;
+  odometry.UseInitialEstimate = true;
+  dvo::DenseTracker::Config refine = dvo::DenseTracker::getDefaultConfig();
+  refine.FirstLevel = 3; refine.LastLevel = 1; refine.Precision = odometry.Precision; refine.UseInitialEstimate = true; refine.Mu = odometry.Mu;
+  dvo::DenseTracker::Config screen = refine;
+  screen.LastLevel = 3;
+
+  const dvo_benchmark::PngImage first = dvo_benchmark::readPng(folder + pairs[0].RgbFile());
+  const float s = float(first.width) / 640.0f;
+  dvo::core::RgbdCameraPyramid camera(first.width, first.height, dvo::core::IntrinsicMatrix::create(517.3f * s, 516.5f * s, 318.6f * s, 255.3f * s));
+  camera.build(odometry.getNumLevels());
+
+  KeyframeVector keyframes;
+  for (size_t k = 0; k < pairs.size(); ++k) {
+    KeyframePtr kf(new Keyframe());
+    dvo::core::AffineTransformd pose;
+    dvo_benchmark::findClosestEntry(gt_reader, pairs[k].RgbTimestamp());
+    dvo_benchmark::toPoseEigen(gt_reader.entry(), pose);
+    kf->id(short(k)).image(load(camera, folder + pairs[k].RgbFile(), folder + pairs[k].DepthFile())).pose(pose);
+    keyframes.push_back(kf);
+  }
+  // quality baseline of every keyframe: the log-likelihood of its first odometry result (keyframe_tracker.cpp:86-96)
+  dvo::DenseTracker tracker(odometry);
+  for (size_t k = 0; k < keyframes.size(); ++k) {
+    const size_t other = k + 1 < keyframes.size() ? k + 1 : k - 1;
+    dvo::DenseTracker::Result r;
+    r.setIdentity();
+    tracker.match(*keyframes[k]->image(), *keyframes[other]->image(), r);
+    keyframes[k]->evaluation(TrackingResultEvaluation::ConstPtr(new LogLikelihoodTrackingResultEvaluation(r)));
+  }
+
+  // keyframe_graph.cpp:500-522.  Thresholds: launch/benchmark_backend.yaml has 0.3 / 0.03 / 0.6; the synthetic frames carry
+  // 1-pixel depth holes at level 3 (only ~20 % of the selected pixels keep all taps valid), so the test places its
+  // thresholds inside the gaps of THIS scenario's ratios to get a mix of accepted and rejected proposals
+  ConstraintProposalValidator batched;
+  SequentialValidator one_by_one;
+  ConstraintProposalValidator& validator = sequential ? static_cast<ConstraintProposalValidator&>(one_by_one) : batched;
+  add_voters(validator.createStage(1).trackingConfig(screen).keepAll(), "O,N,C0.17,E0.005,X1.0");
+  add_voters(validator.createStage(2).trackingConfig(refine).keepBest(), "N,C0.17,E0.86");
+
+  // keyframe_graph.cpp:576-588: the new keyframe against every candidate, without and with the map's relative pose
+  const KeyframePtr& newest = keyframes.back();
+  ConstraintProposalVector proposals;
+  for (size_t k = 0; k + 1 < keyframes.size(); ++k) {
+    proposals.push_back(ConstraintProposal::createWithIdentity(newest, keyframes[k]));
+    proposals.push_back(ConstraintProposal::createWithRelative(newest, keyframes[k]));
+  }
+  const size_t n_initial = proposals.size();
+  const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  validator.validate(proposals);
+  const double ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::fprintf(stderr, "%s validation: %zu proposals (+ %zu cross-validation twins) in %.3f ms, %zu accepted\n", sequential ? "sequential" : "batched",
+               n_initial, n_initial, ms, proposals.size());
+  print_proposals(proposals);
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc >= 3 && std::string(argv[1]) == "table") return run_table(argv[2]);
+  if (argc >= 4 && std::string(argv[1]) == "gpu") return run_gpu(argv[2], argv[3], false);
+  if (argc >= 4 && std::string(argv[1]) == "gpu_sequential") return run_gpu(argv[2], argv[3], true);
+  std::fprintf(stderr, "usage: %s table spec.txt | gpu assoc.txt groundtruth.txt\n", argv[0]);
+  return 2;
+}
