@@ -47,7 +47,9 @@ class LevelStats(C.Structure):
 
 class Result(C.Structure):
     _fields_ = [("transformation", C.c_double * 16), ("information", C.c_double * 36), ("loglik", C.c_double),
-                ("n_levels", C.c_int32), ("n_iterations_total", C.c_int32)]
+                ("n_levels", C.c_int32), ("n_iterations_total", C.c_int32),
+                ("entropy", C.c_double), ("condition_number", C.c_double), ("constraint_ratio", C.c_double),
+                ("constraint_ratio_accepted", C.c_double)]
 
 
 class IterationOut(C.Structure):

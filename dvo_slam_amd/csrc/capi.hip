@@ -92,6 +92,7 @@ struct dvo_hip_context {
   std::string err;
   int opt_rows_per_wave = 0;
   int opt_iters_per_sync = 0;
+  int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
   int opt_variant = 5;             // schedule of the reduce kernel: 5 = Gram accumulation on the matrix cores (default)
   std::vector<CameraGeom*> cameras;
   Workspace ws[1];
@@ -381,6 +382,7 @@ void make_plan(const dvo_hip_context* ctx, const CameraGeom* cam, const dvo_hip_
   bp.prm.cap_iters = bp.cap_iters;
   bp.prm.cap_levels = bp.cap_levels;
   bp.prm.max_points_level0 = cam->w0 * cam->h0;
+  bp.prm.want_condition_number = ctx->opt_condition_number;
   bp.rpw.assign(need_levels, 1);
   bp.geom.resize(need_levels);
   for (int l = cfg->last_level; l <= cfg->first_level; ++l) {
@@ -617,6 +619,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "variant") == 0) {
     if (value < 0 || value > 5 || value == 2) return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0, 1, 3, 4 or 5");
     ctx->opt_variant = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "condition_number") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "condition_number must be 0 or 1");
+    ctx->opt_condition_number = value;
     return DVO_HIP_OK;
   }
   return fail(ctx, DVO_HIP_ERR_INVALID, "unknown option");

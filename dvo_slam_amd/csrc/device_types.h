@@ -87,6 +87,7 @@ struct SolverParams {
   int cap_iters;                      // per-pair capacity of the iteration record array
   int cap_levels;
   int max_points_level0;
+  int want_condition_number;          // gn_finish also computes the eigenvalue range of the information matrix
 };
 
 }  // namespace dvo_hip

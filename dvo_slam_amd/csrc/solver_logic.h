@@ -212,6 +212,10 @@ DVO_HD void gn_finish(const PairState& st, const SolverParams& prm, const dvo_hi
   out->loglik = dvo_nan();
   out->n_levels = st.n_levels;
   out->n_iterations_total = st.n_iters_total;
+  out->entropy = dvo_nan();
+  out->condition_number = dvo_nan();
+  out->constraint_ratio = dvo_nan();
+  out->constraint_ratio_accepted = 0.0;
   if (st.n_levels >= 1 && st.n_levels - 1 < prm.cap_levels) {
     const dvo_hip_level_stats& ls = levels[st.n_levels - 1];
     int idx = ls.n_iterations - 1;
@@ -222,6 +226,28 @@ DVO_HD void gn_finish(const PairState& st, const SolverParams& prm, const dvo_hi
       for (int i = 0; i < 36; ++i) out->information[i] = it.information[i] * 0.008 * 0.008;
       out->loglik = it.tdist_loglik + it.prior_loglik;
     }
+    // keyframe-selection statistics (dvo_slam/src/keyframe_tracker.cpp:165-196, tracking_result_evaluation.cpp:52-55,
+    // constraints/constraint_proposal_voter.cpp:136-140)
+    const int last = ls.first_iteration_index + ls.n_iterations - 1;
+    if (ls.n_iterations >= 1 && last < prm.cap_iters)
+      out->constraint_ratio = double(iters[last].valid_constraints) / double(ls.valid_pixels);
+    const bool two = ls.termination == DVO_HIP_LOGLIKELIHOOD_DECREASED || ls.termination == DVO_HIP_TOO_FEW_CONSTRAINTS;
+    if (ls.n_iterations >= (two ? 2 : 1)) {                 // LevelStats::HasIterationWithIncrement, dense_tracking_config.cpp:138-150
+      const int acc = ls.termination == DVO_HIP_LOGLIKELIHOOD_DECREASED ? last - 1 : last;
+      if (acc < prm.cap_iters) out->constraint_ratio_accepted = double(iters[acc].valid_constraints) / double(ls.valid_pixels);
+    }
+  }
+  out->entropy = log(sym6_determinant(out->information));   // NaN for a negative determinant like std::log
+  if (prm.want_condition_number) {                          // ~20 us of serial float64 Jacobi sweeps: on request only
+    double ev[6];
+    sym6_eigenvalues(out->information, ev);
+    double lo = ev[0], hi = ev[0], sum = ev[0];
+    for (int i = 1; i < 6; ++i) {
+      lo = ev[i] < lo ? ev[i] : lo;
+      hi = ev[i] > hi ? ev[i] : hi;
+      sum += ev[i];
+    }
+    out->condition_number = sum == sum ? fabs(hi / lo) : dvo_nan();
   }
 }
 

@@ -152,6 +152,8 @@ class Result:
         self.Information = np.eye(6)
         self.LogLikelihood = np.finfo(np.float64).max
         self.Statistics = Stats()
+        self.Entropy = self.ConditionNumber = self.ConstraintRatio = float("nan")
+        self.ConstraintRatioAccepted = 0.0
 
     def isNaN(self):
         return not (np.isfinite(self.Transformation.sum()) and np.isfinite(self.Information.sum()))
@@ -337,7 +339,9 @@ class PointSelection:
 
 
 _RESULT_DTYPE = np.dtype([("transformation", np.float64, (16,)), ("information", np.float64, (36,)), ("loglik", np.float64),
-                          ("n_levels", np.int32), ("n_iterations_total", np.int32)])
+                          ("n_levels", np.int32), ("n_iterations_total", np.int32),
+                          ("entropy", np.float64), ("condition_number", np.float64), ("constraint_ratio", np.float64),
+                          ("constraint_ratio_accepted", np.float64)])
 assert _RESULT_DTYPE.itemsize == C.sizeof(_lib.Result)
 
 
@@ -424,6 +428,9 @@ class DenseTracker:
             r.Transformation = np.array(cres[i].transformation).reshape(4, 4)
             r.Information = np.array(cres[i].information).reshape(6, 6)
             r.LogLikelihood = cres[i].loglik
+            # keyframe-selection statistics computed on the device (extension over the reference's Result)
+            r.Entropy, r.ConditionNumber = cres[i].entropy, cres[i].condition_number
+            r.ConstraintRatio, r.ConstraintRatioAccepted = cres[i].constraint_ratio, cres[i].constraint_ratio_accepted
             if with_stats:   # appended, not cleared
                 r.Statistics.Levels.extend(_unpack_stats(cres[i], levels[i * nl:(i + 1) * nl], iters[i * cap_it:(i + 1) * cap_it]))
         return True
@@ -449,7 +456,9 @@ class DenseTracker:
         ccfg = cfg.to_c()
         self.ctx.check(self.ctx._lib.dvo_hip_match_batch(self.ctx.ptr, n, refs, curs, C.byref(ccfg), cres, None, 0, None, 0))
         return dict(T=view["transformation"].reshape(n, 4, 4).copy(), information=view["information"].reshape(n, 6, 6).copy(),
-                    loglik=view["loglik"].copy(), n_iterations=view["n_iterations_total"].copy())
+                    loglik=view["loglik"].copy(), n_iterations=view["n_iterations_total"].copy(), entropy=view["entropy"].copy(),
+                    condition_number=view["condition_number"].copy(), constraint_ratio=view["constraint_ratio"].copy(),
+                    constraint_ratio_accepted=view["constraint_ratio_accepted"].copy())
 
     def level_iteration(self, reference, current, level, T34, P_prev=None, first=True, want_residuals=False):
         """One Gauss-Newton linearisation at a fixed estimate (parity entry point, dvo_hip_level_iteration)."""

@@ -86,11 +86,23 @@ class DenseTracker {
 
   struct Stats { LevelStatsVector Levels; };
 
+  // Extension over the reference: the statistics its keyframe front-end derives from a Result on the host for every
+  // frame (dvo_slam/src/keyframe_tracker.cpp:165-196, tracking_result_evaluation.cpp:52-55,
+  // constraints/constraint_proposal_voter.cpp:136-140), computed on the device with the result.
+  struct KeyframeStatistics {
+    double Entropy;                   // log det Information
+    double ConditionNumber;           // |lambda_max / lambda_min| of Information
+    double ConstraintRatio;           // ValidConstraints(last iteration) / ValidPixels(last level)
+    double ConstraintRatioAccepted;   // the same for LastIterationWithIncrement, 0 if none
+    KeyframeStatistics() : Entropy(std::numeric_limits<double>::quiet_NaN()), ConditionNumber(Entropy), ConstraintRatio(Entropy), ConstraintRatioAccepted(0.0) {}
+  };
+
   struct Result {
     core::AffineTransformd Transformation;
     core::Matrix6d Information;
     double LogLikelihood;
     Stats Statistics;
+    KeyframeStatistics Keyframe;
     Result() : LogLikelihood(std::numeric_limits<double>::max()) {   // dense_tracking_config.cpp:101-108
       double m[16];
       for (int i = 0; i < 16; ++i) m[i] = std::numeric_limits<double>::quiet_NaN();
@@ -227,6 +239,10 @@ class DenseTracker {
     dvo::compat::affine_from_rowmajor(r.transformation, result.Transformation);
     for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) result.Information(i, j) = r.information[i * 6 + j];
     result.LogLikelihood = r.loglik;
+    result.Keyframe.Entropy = r.entropy;
+    result.Keyframe.ConditionNumber = r.condition_number;
+    result.Keyframe.ConstraintRatio = r.constraint_ratio;
+    result.Keyframe.ConstraintRatioAccepted = r.constraint_ratio_accepted;
     for (int l = 0; l < r.n_levels; ++l) {
       result.Statistics.Levels.push_back(LevelStats());
       LevelStats& ls = result.Statistics.Levels.back();

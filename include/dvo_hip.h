@@ -87,6 +87,15 @@ typedef struct {
   double loglik;                     /* dense_tracking.cpp:373 */
   int32_t n_levels;
   int32_t n_iterations_total;
+  /* Keyframe-selection statistics, by-products of the last normal equations (what the reference's front-end derives on
+   * the host from Information / Statistics for every frame): */
+  double entropy;                    /* log det(information): EntropyRatioTrackingResultEvaluation::value,
+                                        dvo_slam/src/tracking_result_evaluation.cpp:52-55 */
+  double condition_number;           /* |lambda_max / lambda_min| of information, dvo_slam/src/keyframe_tracker.cpp:170-196;
+                                        NaN unless dvo_hip_set_option(ctx, "condition_number", 1) */
+  double constraint_ratio;           /* ValidConstraints(last iteration) / ValidPixels(last level), keyframe_tracker.cpp:165-168 */
+  double constraint_ratio_accepted;  /* same for LastIterationWithIncrement, 0 if there is none
+                                        (dvo_slam/src/constraints/constraint_proposal_voter.cpp:136-140) */
 } dvo_hip_result;
 
 typedef struct dvo_hip_context dvo_hip_context;
@@ -192,7 +201,8 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs,
 
 /* Tunables (0 = library default).  key: "rows_per_wave" (1,2,4,8,16: tile height of the reduce kernel),
  * "iters_per_sync" (host polling cadence of the batched Gauss-Newton loop), "variant" (schedule of the reduce
- * kernel: 0, 1, 3, 4, 5). */
+ * kernel: 0, 1, 3, 4, 5), "condition_number" (1: results carry the condition number of the information
+ * matrix, ~20 us of extra serial work per batch; default 0). */
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 
 const char* dvo_hip_version(void);

@@ -13,9 +13,10 @@ def result_is_nan(r):
 
 
 class LocalTracker:
-    def __init__(self, match, accept_callbacks):
-        """match(ref_image, cur_image, T_init) -> dict(T, information, ...); accept_callbacks: f(r_odometry, r_keyframe) -> bool."""
-        self.match, self.accept = match, accept_callbacks
+    def __init__(self, match, accept_callbacks, on_map_initialized=None):
+        """match(ref_image, cur_image, T_init) -> dict(T, information, ...); accept_callbacks: f(r_odometry, r_keyframe) -> bool;
+        on_map_initialized(r_odometry) is called whenever a local map is opened (local_tracker.cpp:157)."""
+        self.match, self.accept, self.on_map_initialized = match, accept_callbacks, on_map_initialized
         self.force = False
         self.last_keyframe_pose = np.eye(4)
         self.completed_maps = 0
@@ -26,6 +27,8 @@ class LocalTracker:
         self.keyframe, self.keyframe_pose = keyframe, keyframe_pose
         self.current = frame
         self.current_pose = keyframe_pose @ r_odometry["T"]          # addKeyframeMeasurement, local_map.cpp:196-200
+        if self.on_map_initialized:
+            self.on_map_initialized(r_odometry)
 
     def init_new_local_map(self, keyframe, frame, keyframe_pose=None):
         r = self.match(keyframe, frame, np.eye(4))
@@ -49,3 +52,50 @@ class LocalTracker:
             self.last_keyframe_pose = r_odometry["T"]
             switched = True
         return self.current_pose.copy(), switched
+
+
+class KeyframeSelection:
+    """The accept criteria KeyframeTracker installs (dvo_slam/src/keyframe_tracker.cpp:60-72, 86-168), including the in-place
+    overwrite of the results on estimate divergence (:125-151).  Results are dicts with T, information, loglik, levels."""
+
+    def __init__(self, max_translational_distance=0.2, min_entropy_ratio=0.91, min_constraint_ratio=0.33):
+        self.max_dist, self.min_ratio, self.min_constraints = max_translational_distance, min_entropy_ratio, min_constraint_ratio
+        self.last_transform_to_keyframe = np.eye(4)
+        self.first = self.sum = self.n = None
+        self.trace = []
+
+    @staticmethod
+    def value(r):                                      # LogLikelihoodTrackingResultEvaluation, tracking_result_evaluation.cpp:57-60
+        return -float(r["loglik"])
+
+    def on_map_initialized(self, r_odometry):          # keyframe_tracker.cpp:86-96
+        self.last_transform_to_keyframe = r_odometry["T"].copy()
+        self.first = self.sum = self.value(r_odometry)
+        self.n = 1.0
+
+    def callbacks(self):
+        def evaluation(ro, rk):                        # :105-123
+            ratio = self.value(rk) / self.first
+            ok = ratio > self.min_ratio
+            if ok:
+                self.sum += self.value(rk)
+                self.n += 1.0
+            self.trace.append(ratio)
+            return ok
+
+        def divergence(ro, rk):                        # :125-151
+            reject = np.linalg.norm(ro["T"][:3, 3]) > 0.1 or np.linalg.norm(rk["T"][:3, 3]) > 1.5 * self.max_dist
+            if reject:
+                ro["T"] = np.eye(4)
+                ro["information"] = np.eye(6) * 0.008 * 0.008
+                rk["T"] = self.last_transform_to_keyframe.copy()
+            self.last_transform_to_keyframe = rk["T"].copy()
+            return not reject
+
+        def distance(ro, rk):                          # :153-156
+            return bool(np.linalg.norm(rk["T"][:3, 3]) < self.max_dist)
+
+        def constraint_ratio(ro, rk):                  # :165-168
+            level = rk["levels"][-1]
+            return level["iterations"][-1]["n"] / level["valid_pixels"] > self.min_constraints
+        return [evaluation, divergence, distance, constraint_ratio]

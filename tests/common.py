@@ -129,7 +129,24 @@ def result_to_dict(res, levels, iters):
         out_levels.append(dict(id=L.id, max_valid_pixels=L.max_valid_pixels, valid_pixels=L.valid_pixels, termination=L.termination,
                                iterations=its))
     return dict(T=np.array(res.transformation).reshape(4, 4), information=np.array(res.information).reshape(6, 6),
-                loglik=res.loglik, levels=out_levels)
+                loglik=res.loglik, levels=out_levels, entropy=res.entropy, condition_number=res.condition_number,
+                constraint_ratio=res.constraint_ratio, constraint_ratio_accepted=res.constraint_ratio_accepted)
+
+
+def keyframe_statistics_from(result):
+    """The reference's host-side derivations from a Result dict (T, information, levels): keyframe_tracker.cpp:165-196,
+    tracking_result_evaluation.cpp:52-55, constraint_proposal_voter.cpp:136-140, dense_tracking_config.cpp:138-150."""
+    info = result["information"]
+    ev = np.sort(np.linalg.eigvalsh(info)) if np.isfinite(info).all() else np.full(6, np.nan)
+    level = result["levels"][-1]
+    its, term = level["iterations"], level["termination"]
+    need = 2 if term in (2, 3) else 1
+    accepted = 0.0
+    if len(its) >= need:
+        accepted = float((its[-2] if term == 2 else its[-1])["n"]) / level["valid_pixels"]
+    with np.errstate(all="ignore"):
+        return dict(entropy=float(np.log(np.linalg.det(info))), condition_number=float(abs(ev[5] / ev[0])),
+                    constraint_ratio=float(its[-1]["n"]) / level["valid_pixels"], constraint_ratio_accepted=accepted)
 
 
 def tracker_result_to_dict(r):
@@ -140,7 +157,8 @@ def tracker_result_to_dict(r):
                     prior_ll=s.PriorLogLikelihood, x=s.EstimateIncrement, A=s.EstimateInformation) for s in L.Iterations]
         out_levels.append(dict(id=L.Id, max_valid_pixels=L.MaxValidPixels, valid_pixels=L.ValidPixels, termination=L.TerminationCriterion,
                                iterations=its))
-    return dict(T=r.Transformation, information=r.Information, loglik=r.LogLikelihood, levels=out_levels)
+    return dict(T=r.Transformation, information=r.Information, loglik=r.LogLikelihood, levels=out_levels, entropy=r.Entropy,
+                condition_number=r.ConditionNumber, constraint_ratio=r.ConstraintRatio, constraint_ratio_accepted=r.ConstraintRatioAccepted)
 
 
 def oracle_config_from(cfg, mode):

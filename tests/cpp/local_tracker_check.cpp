@@ -2,7 +2,8 @@
 // reference's LocalTracker (dvo_slam/src/keyframe_tracker.cpp:52-72, 216-246): first two frames open a local map, every further
 // frame is update()d; a distance criterion on the keyframe alignment (keyframe_tracker.cpp:153-156) decides when a new keyframe
 // is due.  Prints one line per frame: "<switched> <16 pose numbers>" for tests/test_local_tracker.py.
-//   local_tracker_check <assoc.txt> <max_translational_distance>
+//   local_tracker_check <assoc.txt> <max_translational_distance>            distance criterion + an always-true second slot
+//   local_tracker_check <assoc.txt> <max_translational_distance> selection  the KeyframeTracker criteria (dvo_slam/keyframe_selection.h)
 #include <cmath>
 #include <cstdio>
 #include <string>
@@ -11,6 +12,7 @@
 #include <dvo_benchmark/file_reader.h>
 #include <dvo_benchmark/image_io.h>
 #include <dvo_benchmark/rgbd_pair.h>
+#include <dvo_slam/keyframe_selection.h>
 #include <dvo_slam/local_tracker.h>
 
 int main(int argc, char** argv) {
@@ -38,13 +40,18 @@ int main(int argc, char** argv) {
   dvo_slam::LocalTracker tracker;
   tracker.configure(cfg);
   int completed = 0, votes_cast = 0;
-  tracker.addAcceptCallback([&](const dvo_slam::LocalTracker&, const dvo_slam::LocalTracker::TrackingResult&, const dvo_slam::LocalTracker::TrackingResult& r_keyframe) {
+  const bool use_selection = argc >= 4 && std::string(argv[3]) == "selection";
+  dvo_slam::KeyframeTrackerConfig selection_cfg;
+  selection_cfg.MaxTranslationalDistance = max_distance;
+  dvo_slam::KeyframeSelection selection(selection_cfg);
+  if (use_selection) selection.install(tracker);
+  if (!use_selection) tracker.addAcceptCallback([&](const dvo_slam::LocalTracker&, const dvo_slam::LocalTracker::TrackingResult&, const dvo_slam::LocalTracker::TrackingResult& r_keyframe) {
     double m[16];
     dvo::compat::affine_to_rowmajor(r_keyframe.Transformation, m);
     ++votes_cast;
     return std::sqrt(m[3] * m[3] + m[7] * m[7] + m[11] * m[11]) < max_distance;
   });
-  tracker.addAcceptCallback([&](const dvo_slam::LocalTracker&, const dvo_slam::LocalTracker::TrackingResult&, const dvo_slam::LocalTracker::TrackingResult&) {
+  if (!use_selection) tracker.addAcceptCallback([&](const dvo_slam::LocalTracker&, const dvo_slam::LocalTracker::TrackingResult&, const dvo_slam::LocalTracker::TrackingResult&) {
     ++votes_cast;     // a second slot: must be asked even when the first one already vetoed
     return true;
   });
@@ -68,5 +75,5 @@ int main(int argc, char** argv) {
   }
   std::fprintf(stderr, "local maps completed %d, accept votes cast %d, measurements in the open map %zu\n", completed, votes_cast,
                tracker.getLocalMap()->measurements().size());
-  return votes_cast == 2 * int(frames.size() - 2) ? 0 : 4;
+  return (use_selection || votes_cast == 2 * int(frames.size() - 2)) ? 0 : 4;
 }

@@ -139,6 +139,7 @@ int emul_match(const emul_level* levels, const dvo_hip_config* cfg, dvo_hip_resu
   prm.cap_iters = cap_iters;
   prm.cap_levels = cap_levels;
   prm.max_points_level0 = levels[0].w * levels[0].h;
+  prm.want_condition_number = 1;
   PairState st;
   std::memset(&st, 0, sizeof(st));
   gn_init_pair(st, prm, result->transformation);
@@ -180,5 +181,6 @@ void emul_se3_log(const double T[16], double x[6]) {
 }
 
 int emul_solve6(const double A[36], const double b[6], double x[6]) { return solve6(A, b, x) ? 0 : 1; }
+void emul_sym6_eigenvalues(const double A[36], double ev[6]) { sym6_eigenvalues(A, ev); }
 
 }  // extern "C"

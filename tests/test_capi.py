@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Config) == 4 * 4 + 2 * 8 + 2 * 4
     assert C.sizeof(_lib.IterationStats) == 8 + 8 * (1 + 2 + 4 + 1 + 6 + 36)
     assert C.sizeof(_lib.LevelStats) == 24
-    assert C.sizeof(_lib.Result) == 8 * (16 + 36 + 1) + 8
+    assert C.sizeof(_lib.Result) == 8 * (16 + 36 + 1) + 8 + 8 * 4
     assert C.sizeof(_lib.IterationOut) == 8 + 12 + 16 + 4 + 8 * (1 + 36 + 6 + 1)
 
 

@@ -78,6 +78,30 @@ def test_state_machine_against_oracle_driver(seed, first, last, mu, init, precis
     if s["structure_mismatch"] == 0:
         assert np.abs(e["information"] - o["information"]).max() <= 2e-3 * np.abs(o["information"]).max()
         assert abs(e["loglik"] - o["loglik"]) <= 1e-3 * abs(o["loglik"])
+    # keyframe-selection statistics in the result record = the reference's host-side derivations from the same result
+    k = cm.keyframe_statistics_from(e)
+    assert e["entropy"] == pytest.approx(k["entropy"], rel=1e-12) and e["condition_number"] == pytest.approx(k["condition_number"], rel=1e-9)
+    assert e["constraint_ratio"] == k["constraint_ratio"] and e["constraint_ratio_accepted"] == k["constraint_ratio_accepted"]
+    ko = cm.keyframe_statistics_from(o)          # ... and agree with the oracle run's
+    assert e["entropy"] == pytest.approx(ko["entropy"], abs=2e-2) and e["constraint_ratio"] == pytest.approx(ko["constraint_ratio"], abs=2e-3)
+
+
+def test_sym6_eigenvalues_and_degenerate_statistics():
+    L = cm.emul_lib()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
+    rng = np.random.default_rng(4)
+    for k in range(40):
+        M = rng.normal(size=(8, 6)) * 10.0 ** rng.uniform(-3, 3, size=6)      # badly scaled columns: condition numbers up to ~1e12
+        A = np.ascontiguousarray(M.T @ M)
+        if k % 5 == 0:
+            A -= 0.5 * np.trace(A) / 6 * np.eye(6)                             # indefinite
+        ev = np.zeros(6)
+        L.emul_sym6_eigenvalues(dp(A.reshape(-1)), dp(ev))
+        want = np.linalg.eigvalsh(A)
+        assert np.allclose(np.sort(ev), want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
+    ev = np.zeros(6)
+    L.emul_sym6_eigenvalues(dp(np.full(36, np.nan)), dp(ev))
+    assert np.isnan(ev).all()
 
 
 def test_state_machine_edge_cases():

@@ -112,6 +112,7 @@ def test_golden_linearisation(gpu_ctx):
 
 
 def run_gpu_match(ctx, gref, gcur, cfg, T_init=None):
+    ctx.set_option("condition_number", 1)
     trk = d.DenseTracker(cfg, ctx)
     r = d.Result()
     if T_init is not None:
@@ -144,6 +145,13 @@ def test_full_match_against_oracle(gpu_ctx, seed, w, h, first, last, mu, init, p
     if s["structure_mismatch"] == 0:
         assert np.abs(g["information"] - o["information"]).max() <= 2e-3 * np.abs(o["information"]).max()
         assert abs(g["loglik"] - o["loglik"]) <= 1e-3 * abs(o["loglik"])
+    # keyframe-selection statistics computed on the device = the reference's host-side derivations from the same result
+    k = cm.keyframe_statistics_from(g)
+    assert g["entropy"] == pytest.approx(k["entropy"], rel=1e-12) and g["condition_number"] == pytest.approx(k["condition_number"], rel=1e-9)
+    assert g["constraint_ratio"] == k["constraint_ratio"] and g["constraint_ratio_accepted"] == k["constraint_ratio_accepted"]
+    if s["structure_mismatch"] == 0:
+        ko = cm.keyframe_statistics_from(o)
+        assert g["entropy"] == pytest.approx(ko["entropy"], abs=2e-2) and g["constraint_ratio"] == pytest.approx(ko["constraint_ratio"], abs=1e-3)
     # and against the quirk-faithful restatement of the SSE path, and the ground truth of the synthetic pair
     q = po.match(oref, ocur, cm.oracle_config_from(cfg, po.REF_SSE), T0)
     assert cm.twist_matrix_error(g["T"], q["T"]) < 5e-5
@@ -230,6 +238,7 @@ def test_edge_cases(gpu_ctx):
     r = d.Result()
     d.DenseTracker(d.Config(FirstLevel=2, LastLevel=0), gpu_ctx).match(a, b, r)
     assert r.isNaN() and np.allclose(r.Transformation, np.eye(4))
+    assert np.isnan(r.Entropy) and np.isnan(r.ConditionNumber) and np.isnan(r.ConstraintRatioAccepted)    # 0 constraints / 0 pixels
     assert [L.TerminationCriterion for L in r.Statistics.Levels] == [1, 1, 1]
     assert all(len(L.Iterations) == 1 and L.Iterations[0].ValidConstraints == 0 for L in r.Statistics.Levels)
     # misuse is rejected with an error code, not a crash
