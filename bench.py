@@ -177,7 +177,7 @@ def main():
     algo_bytes = ALGO_BYTES_PER_PIXEL * W * H * B
     achieved = algo_bytes / (k_ms[0] * 1e-3) / 1e9
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                    traffic=_pmc_traffic(B), kernel="dvo_hip::k_residual_reduce<RPW, true> (level 0, %d pairs per launch)" % B,
+                    traffic=_pmc_traffic(B), kernel="dvo_hip::k_residual_reduce_mfma<RPW, true> (pyramid level 0, %d pairs per launch)" % B,
                     kernel_ms=round(k_ms[0], 4), algorithmic_bytes_per_launch=algo_bytes,
                     per_level_kernel_ms={str(k): round(v, 4) for k, v in k_ms.items()})
 

@@ -89,22 +89,28 @@ __device__ __forceinline__ double wave_sum_double(double v) {
 // 16-B load.  The reference multiplies 50 terms between logs; here a lane multiplies ALL its terms and takes ONE log:
 // after every eight factors the running product is renormalised with frexp (two instructions) and the exponent is
 // summed separately, so the product can neither overflow nor lose precision.  `first_chunk`/`chunk_stride` in units
-// of 4 x blockDim pixel pairs.
+// of LOADS x blockDim pixel pairs; LOADS = 16-B loads in flight per lane between renormalisations (frexp only rescales by
+// a power of two, so the value does not depend on LOADS -- only the latency hiding does).
+template <int LOADS>
 __device__ __forceinline__ double loglik_partial(const float2* __restrict__ res, int npx, const float* P, int first_chunk, int chunk_stride) {
   typedef const __attribute__((address_space(1))) vec4f* G4;
   const G4 r = (G4)res;
   const int npair2 = npx >> 1;
   double prod = 1.0;
   int exponent = 0;
-  for (int base = first_chunk * kBlock * 4; base < npair2; base += chunk_stride * kBlock * 4) {
+  for (int base = first_chunk * kBlock * LOADS; base < npair2; base += chunk_stride * kBlock * LOADS) {
+    vec4f rr[LOADS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < LOADS; ++k) {
       const int i = base + k * kBlock + threadIdx.x;
-      if (i < npair2) {
-        const vec4f rr = r[i];
-        if (rr.x == rr.x) prod *= 1.0 + 0.2 * double(mahalanobis(rr.x, rr.y, P));
-        if (rr.z == rr.z) prod *= 1.0 + 0.2 * double(mahalanobis(rr.z, rr.w, P));
-      }
+      const float nanv = __builtin_nanf("");
+      const vec4f v = r[i < npair2 ? i : npair2 - 1];         // unconditional load, selected afterwards (no branch per load)
+      rr[k] = i < npair2 ? v : vec4f{nanv, nanv, nanv, nanv};
+    }
+#pragma unroll
+    for (int k = 0; k < LOADS; ++k) {
+      if (rr[k].x == rr[k].x) prod *= 1.0 + 0.2 * double(mahalanobis(rr[k].x, rr[k].y, P));
+      if (rr[k].z == rr[k].z) prod *= 1.0 + 0.2 * double(mahalanobis(rr[k].z, rr[k].w, P));
     }
     int e;
     prod = frexp(prod, &e);

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const Pair
   reduce_partials_scale(partials, pair, g.tiles_x * g.tiles_y, sh, sums);
   const int n = scale_from_sums(sums, C, P);
   double total = 0.0;
-  if (n >= 6) total = loglik_partial(scratch + size_t(pair) * g.w * g.h, g.w * g.h, P, blockIdx.x, blocks_per_pair);
+  if (n >= 6) total = loglik_partial<4>(scratch + size_t(pair) * g.w * g.h, g.w * g.h, P, blockIdx.x, blocks_per_pair);
   total = wave_sum_double(total);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();

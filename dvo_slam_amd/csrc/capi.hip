@@ -302,8 +302,12 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
   DVO_HIP_TRY(ctx, ctx->build_tbl.reserve(size_t(n) * sizeof(FrameBuildPtrs)));
   DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->build_tbl.p, host.data(), size_t(n) * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, ctx->stream));
   const FrameBuildPtrs* tbl = ctx->build_tbl.as<FrameBuildPtrs>();
-  if (grey) launch_ingest_raw(ctx->stream, tbl, n, depth_scale, cam->w[0] * cam->h[0]);
-  for (int l = 1; l < levels; ++l) launch_pyr_down(ctx->stream, tbl, n, l, cam->w[l - 1], cam->h[l - 1]);
+  int built = 1;                                       // float ingest: level 0 is already in place
+  if (grey) {
+    launch_ingest_pyramid(ctx->stream, tbl, n, depth_scale, cam->w[0], cam->h[0], levels);
+    built = levels < 4 ? levels : 4;
+  }
+  for (int l = built; l < levels; ++l) launch_pyr_down(ctx->stream, tbl, n, l, cam->w[l - 1], cam->h[l - 1]);
   DVO_HIP_TRY(ctx, hipGetLastError());
   return DVO_HIP_OK;
 }

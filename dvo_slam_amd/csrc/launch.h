@@ -8,7 +8,8 @@
 namespace dvo_hip {
 
 // pyramid_kernels.hip
-void launch_ingest_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int n);
+// raw ingest + pyramid levels 1..3 in one pass (levels beyond the fourth: launch_pyr_down)
+void launch_ingest_pyramid(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels);
 void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h);
 void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h);
 void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr);

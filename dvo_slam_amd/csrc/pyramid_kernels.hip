@@ -18,13 +18,70 @@
 
 namespace dvo_hip {
 
-__global__ void k_ingest_raw(const FrameBuildPtrs* __restrict__ tbl, float scale, int n) {
+// Ingest and the first three pyr-down steps in one pass over the raw planes.  A 32 x 8 workgroup owns a 64 x 16 tile of
+// level 0: every thread converts one 2 x 2 quad (level 0), averages it (level 1); levels 2 and 3 are folded through LDS
+// (16 x 4 and 8 x 2 pixels per tile).  Compared with ingest + three pyr-down launches this never re-reads a float plane:
+// 0.9 MB in, 3.2 MB out per 640 x 480 frame instead of 7.3 MB of traffic.  Arithmetic and summation order are those of
+// the reference's ingest and of k_pyr_down (bit-identical planes); `levels` <= 4 levels are produced, deeper ones by k_pyr_down.
+__global__ __launch_bounds__(256) void k_ingest_pyramid(const FrameBuildPtrs* __restrict__ tbl, float scale, int w0, int h0, int levels) {
+#pragma clang fp contract(off)
   const FrameBuildPtrs& f = tbl[blockIdx.z];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  f.I[0][i] = float(f.grey[i]);
-  const uint16_t d = f.raw[i];
-  f.Z[0][i] = d == 0 ? __builtin_nanf("") : float(d) * scale;
+  const int tx = threadIdx.x, ty = threadIdx.y;               // 32 x 8
+  const int x1 = blockIdx.x * 32 + tx, y1 = blockIdx.y * 8 + ty;   // level-1 pixel = level-0 quad
+  const int w1 = w0 >> 1, h1 = h0 >> 1;
+  __shared__ float s1[8][32];
+  __shared__ float s2[4][16];
+  const float nanv = __builtin_nanf("");
+  float q[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, z00 = nanv;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    const int y = 2 * y1 + dy;
+    if (y >= h0) continue;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int x = 2 * x1 + dx;
+      if (x >= w0) continue;
+      const size_t i = size_t(y) * w0 + x;
+      const float g = float(f.grey[i]);
+      const uint16_t d = f.raw[i];
+      const float z = d == 0 ? nanv : float(d) * scale;
+      f.I[0][i] = g;
+      f.Z[0][i] = z;
+      q[dy][dx] = g;
+      if (dx == 0 && dy == 0) z00 = z;
+    }
+  }
+  if (levels < 2) return;
+  const float i1 = (q[0][0] + q[0][1] + q[1][0] + q[1][1]) / 4.0f;   // same summation order as the reference
+  const bool in1 = x1 < w1 && y1 < h1;
+  if (in1) {
+    f.I[1][size_t(y1) * w1 + x1] = i1;
+    f.Z[1][size_t(y1) * w1 + x1] = z00;                       // top-left sample, NaN holes kept (Q18)
+  }
+  if (levels < 3) return;                                      // uniform
+  s1[ty][tx] = i1;
+  __syncthreads();
+  const int w2 = w1 >> 1, h2 = h1 >> 1, w3 = w2 >> 1, h3 = h2 >> 1;
+  float i2 = 0.0f;
+  const bool own2 = (tx & 1) == 0 && (ty & 1) == 0;
+  const int x2 = x1 >> 1, y2 = y1 >> 1;
+  if (own2) {
+    i2 = (s1[ty][tx] + s1[ty][tx + 1] + s1[ty + 1][tx] + s1[ty + 1][tx + 1]) / 4.0f;
+    if (x2 < w2 && y2 < h2) {
+      f.I[2][size_t(y2) * w2 + x2] = i2;
+      f.Z[2][size_t(y2) * w2 + x2] = z00;
+    }
+    s2[ty >> 1][tx >> 1] = i2;
+  }
+  if (levels < 4) return;
+  __syncthreads();
+  if ((tx & 3) == 0 && (ty & 3) == 0) {
+    const int x3 = x1 >> 2, y3 = y1 >> 2, cx = tx >> 1, cy = ty >> 1;
+    if (x3 < w3 && y3 < h3) {
+      f.I[3][size_t(y3) * w3 + x3] = (s2[cy][cx] + s2[cy][cx + 1] + s2[cy + 1][cx] + s2[cy + 1][cx + 1]) / 4.0f;
+      f.Z[3][size_t(y3) * w3 + x3] = z00;
+    }
+  }
 }
 
 __global__ void k_pyr_down(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h) {
@@ -141,8 +198,8 @@ __global__ void k_unpack_plane(const float4* __restrict__ A, const float2* __res
   out[i] = v;
 }
 
-void launch_ingest_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int n) {
-  k_ingest_raw<<<dim3((n + 255) / 256, 1, n_frames), dim3(256), 0, s>>>(tbl, scale, n);
+void launch_ingest_pyramid(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels) {
+  k_ingest_pyramid<<<dim3((w0 + 63) / 64, (h0 + 15) / 16, n_frames), dim3(32, 8), 0, s>>>(tbl, scale, w0, h0, levels < 4 ? levels : 4);
 }
 
 void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h) {

@@ -12,6 +12,12 @@
 
 namespace dvo_hip {
 
+// Rows in flight per lane and round.  The sums are latency-bound, not bandwidth-bound: the partial rows were written
+// by other CUs a kernel ago and every round is a ~2 us trip to HBM/MALL, so a round covers 4 wavefronts x 32 rows = 128
+// tiles (measured: 32 tiles per round cost 100 us per iteration for a single pair's 1200 finest-level tiles).  Only the
+// number of loads in flight changes with this constant, never the order of the additions.
+constexpr int kReduceInFlight = 32;
+
 // blockDim.x must be kBlock.  sh: kWavesPerBlock * kAccStride doubles of LDS.  sums: kAccStride doubles of LDS,
 // valid for all threads after the call.
 __device__ inline void reduce_partials(const float* __restrict__ partials, int pair, int tiles, double* sh, double* sums) {
@@ -19,22 +25,23 @@ __device__ inline void reduce_partials(const float* __restrict__ partials, int p
   const float* base = partials + size_t(pair) * tiles * kAccStride;
   const bool hi = lane < kAccStride - 64;
   double a0 = 0.0, a1 = 0.0;
-  // eight independent row loads in flight, then added in tile order (the summation order is part of the contract)
-  for (int t0 = wave; t0 < tiles; t0 += 8 * kWavesPerBlock) {
-    float v0[8], v1[8];
+  // independent row loads in flight, then added in tile order (the summation order is part of the contract)
+  for (int t0 = wave; t0 < tiles; t0 += kReduceInFlight * kWavesPerBlock) {
+    float v0[kReduceInFlight], v1[kReduceInFlight];
+    // branch-free: every load is issued (out-of-range rows re-read the last row), the selection happens at the add --
+    // a conditional load costs a branch and a full s_waitcnt each, which serialises the round trips
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < kReduceInFlight; ++j) {
       const int t = t0 + j * kWavesPerBlock;
-      const float* row = base + size_t(t < tiles ? t : 0) * kAccStride;
-      v0[j] = t < tiles ? row[lane] : 0.0f;
-      v1[j] = (t < tiles && hi) ? row[64 + lane] : 0.0f;
+      const float* row = base + size_t(t < tiles ? t : tiles - 1) * kAccStride;
+      v0[j] = row[lane];
+      v1[j] = row[hi ? 64 + lane : 64];
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (t0 + j * kWavesPerBlock < tiles) {
-        a0 += double(v0[j]);
-        a1 += double(v1[j]);
-      }
+    for (int j = 0; j < kReduceInFlight; ++j) {
+      const bool in = t0 + j * kWavesPerBlock < tiles;
+      a0 += in ? double(v0[j]) : 0.0;                       // x + 0.0 == x: the masked adds do not perturb the sum
+      a1 += in ? double(v1[j]) : 0.0;
     }
   }
   sh[wave * kAccStride + lane] = a0;
@@ -55,16 +62,15 @@ __device__ inline void reduce_partials_scale(const float* __restrict__ partials,
   if (lane < 4) {
     const float* base = partials + size_t(pair) * tiles * kAccStride;
     double a0 = 0.0;
-    for (int t0 = wave; t0 < tiles; t0 += 8 * kWavesPerBlock) {
-      float v0[8];
+    for (int t0 = wave; t0 < tiles; t0 += kReduceInFlight * kWavesPerBlock) {
+      float v0[kReduceInFlight];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < kReduceInFlight; ++j) {
         const int t = t0 + j * kWavesPerBlock;
-        v0[j] = t < tiles ? base[size_t(t) * kAccStride + lane] : 0.0f;
+        v0[j] = base[size_t(t < tiles ? t : tiles - 1) * kAccStride + lane];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (t0 + j * kWavesPerBlock < tiles) a0 += double(v0[j]);
+      for (int j = 0; j < kReduceInFlight; ++j) a0 += (t0 + j * kWavesPerBlock < tiles) ? double(v0[j]) : 0.0;
     }
     sh[wave * 4 + lane] = a0;
   }
