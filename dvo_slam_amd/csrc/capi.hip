@@ -92,6 +92,7 @@ struct dvo_hip_context {
   std::string err;
   int opt_rows_per_wave = 0;
   int opt_iters_per_sync = 0;
+  int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
   int opt_variant = 5;             // schedule of the reduce kernel: 5 = Gram accumulation on the matrix cores (default)
   std::vector<CameraGeom*> cameras;
@@ -218,9 +219,12 @@ LevelGeom make_geom(const CameraGeom* cam, int level, int rows_per_wave) {
 int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_pairs) {
   if (ctx->opt_rows_per_wave > 0) return ctx->opt_rows_per_wave;
   const int candidates[4] = {8, 4, 2, 1};   // measured (profiles/r01_c_tile_sweep.txt): 8 rows is at or near the optimum on every level
+  // The tallest tile that still yields this many workgroups.  Fewer, taller tiles also mean fewer partial rows for the
+  // bookkeeping kernel, which matters most when there are few pairs (whole-match timings: profiles/r01_f_tile_heuristic.txt).
+  const size_t enough = ctx->opt_min_workgroups > 0 ? size_t(ctx->opt_min_workgroups) : (n_pairs <= 8 ? 512 : n_pairs < 64 ? 1024 : 2048);
   for (int r : candidates) {
     const int tiles = ((cam->w[level] + kTileW - 1) / kTileW) * ((cam->h[level] + kWavesPerBlock * r - 1) / (kWavesPerBlock * r));
-    if (size_t(tiles) * n_pairs >= 1024) return r;
+    if (size_t(tiles) * n_pairs >= enough) return r;
   }
   return 1;
 }
@@ -623,6 +627,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "variant") == 0) {
     if (value < 0 || value > 5 || value == 2) return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0, 1, 3, 4 or 5");
     ctx->opt_variant = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "min_workgroups") == 0) {
+    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "min_workgroups must be >= 0");
+    ctx->opt_min_workgroups = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "condition_number") == 0) {

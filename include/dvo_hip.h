@@ -201,7 +201,8 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs,
 
 /* Tunables (0 = library default).  key: "rows_per_wave" (1,2,4,8,16: tile height of the reduce kernel),
  * "iters_per_sync" (host polling cadence of the batched Gauss-Newton loop), "variant" (schedule of the reduce
- * kernel: 0, 1, 3, 4, 5), "condition_number" (1: results carry the condition number of the information
+ * kernel: 0, 1, 3, 4, 5), "min_workgroups" (tile-height heuristic: smallest launch that
+ * counts as filling the chip; 0 = built-in table), "condition_number" (1: results carry the condition number of the information
  * matrix, ~20 us of extra serial work per batch; default 0). */
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 
