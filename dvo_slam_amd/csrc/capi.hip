@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -80,8 +81,8 @@ struct dvo_hip_frame {
 struct Workspace {
   hipStream_t stream = nullptr;
   DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters;
-  int* host_counter = nullptr;   // pinned, two poll words (double-buffered)
-  hipEvent_t polled[2] = {nullptr, nullptr};
+  int* host_status = nullptr;    // pinned: one word per Gauss-Newton step of a batch, written by the device (k_solver_step)
+  size_t host_status_words = 0;
   std::string err;
   bool created = false;
 };
@@ -126,8 +127,6 @@ int workspace_create(dvo_hip_context* ctx, int g) {
   Workspace& w = ctx->ws[g];
   if (w.created) return DVO_HIP_OK;
   DVO_HIP_TRY(ctx, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-  DVO_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&w.host_counter), 64, hipHostMallocDefault));
-  for (int i = 0; i < 2; ++i) DVO_HIP_TRY(ctx, hipEventCreateWithFlags(&w.polled[i], hipEventDisableTiming));
   w.created = true;
   return DVO_HIP_OK;
 }
@@ -138,9 +137,9 @@ void workspace_destroy(Workspace& w) {
   for (DevBuf* b : {&w.states, &w.pair_ptrs, &w.partials, &w.scratch, &w.ll_partials, &w.lvl_stats, &w.it_stats, &w.results,
                     &w.t_init, &w.counters})
     b->release();
-  if (w.host_counter) (void)hipHostFree(w.host_counter);
-  for (int i = 0; i < 2; ++i)
-    if (w.polled[i]) (void)hipEventDestroy(w.polled[i]);
+  if (w.host_status) (void)hipHostFree(w.host_status);
+  w.host_status = nullptr;
+  w.host_status_words = 0;
   (void)hipStreamDestroy(w.stream);
   w.created = false;
 }
@@ -423,7 +422,7 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
   DVO_WS_TRY(w, w.it_stats.reserve(size_t(n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats)));
   DVO_WS_TRY(w, w.results.reserve(size_t(n) * sizeof(dvo_hip_result)));
   DVO_WS_TRY(w, w.t_init.reserve(size_t(n) * 16 * sizeof(double)));
-  DVO_WS_TRY(w, w.counters.reserve(size_t(bp.cap_iters + 8) * sizeof(int)));
+  DVO_WS_TRY(w, w.counters.reserve(size_t(bp.cap_iters + 8) * sizeof(unsigned long long)));
   std::vector<PairPtrs> host(size_t(n) * need_levels);
   for (int l = cfg->last_level; l <= cfg->first_level; ++l)
     for (int i = 0; i < n; ++i) {
@@ -437,6 +436,32 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
   DVO_WS_TRY(w, hipMemcpyAsync(w.pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs), hipMemcpyHostToDevice, w.stream));
   bp.pair_ptrs = w.pair_ptrs.as<PairPtrs>();
   return DVO_HIP_OK;
+}
+
+// Spin on the pinned status word the device writes when the last workgroup of a step is through (publish_step in
+// solver_kernels.hip).  A host-memory poll sees the word ~2 us after the store; an event synchronisation took ~10 us.
+int wait_for_step(Workspace& w, int step, int* active) {
+  volatile int* word = w.host_status + step;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1;; ++spins) {
+    const int v = *word;
+    if (v & kStepDoneFlag) {
+      *active = v & ~kStepDoneFlag;
+      return DVO_HIP_OK;
+    }
+    if ((spins & 0xfffff) == 0) {                            // every ~1M polls: has the stream died, or are we stuck?
+      const hipError_t q = hipStreamQuery(w.stream);
+      if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();   // "still running" is not an error to keep
+      if (q != hipSuccess && q != hipErrorNotReady) {
+        w.err = std::string("match: stream failed while waiting for a Gauss-Newton step: ") + hipGetErrorString(q);
+        return DVO_HIP_ERR_HIP;
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+        w.err = "match: timed out waiting for a Gauss-Newton step";
+        return DVO_HIP_ERR_HIP;
+      }
+    }
+  }
 }
 
 // The coarse-to-fine Gauss-Newton driver of a batch (dense_tracking.cpp:131-376 for every pair at once).
@@ -453,7 +478,17 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   std::vector<double> tinit(size_t(n) * 16);
   for (int i = 0; i < n; ++i) std::memcpy(&tinit[size_t(i) * 16], results[i].transformation, 16 * sizeof(double));
   DVO_WS_TRY(w, hipMemcpyAsync(w.t_init.p, tinit.data(), tinit.size() * sizeof(double), hipMemcpyHostToDevice, s));
-  DVO_WS_TRY(w, hipMemsetAsync(w.counters.p, 0, size_t(bp.cap_iters + 8) * sizeof(int), s));
+  // per-step tallies (device) and status words (pinned host memory the device writes, see publish_step)
+  const size_t n_steps = size_t(bp.cap_iters) + 8;
+  if (w.host_status_words < n_steps) {
+    if (w.host_status) (void)hipHostFree(w.host_status);
+    w.host_status = nullptr;
+    w.host_status_words = 0;
+    DVO_WS_TRY(w, hipHostMalloc(reinterpret_cast<void**>(&w.host_status), n_steps * sizeof(int), hipHostMallocDefault));
+    w.host_status_words = n_steps;
+  }
+  std::memset(w.host_status, 0, n_steps * sizeof(int));   // the previous batch ended with a stream synchronisation
+  DVO_WS_TRY(w, hipMemsetAsync(w.counters.p, 0, n_steps * sizeof(unsigned long long), s));
 
   PairState* states = w.states.as<PairState>();
   dvo_hip_level_stats* d_levels = w.lvl_stats.as<dvo_hip_level_stats>();
@@ -461,11 +496,11 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   float* partials = w.partials.as<float>();
   float2* scratch = w.scratch.as<float2>();
   double* ll_partials = w.ll_partials.as<double>();
-  int* counters = w.counters.as<int>();
+  unsigned long long* tallies = w.counters.as<unsigned long long>();
   launch_init_pairs(s, states, n, bp.prm, w.t_init.as<double>());
 
   const int per_level = cfg->max_iterations_per_level;
-  const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 2;
+  const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 1;
   int step = 0;
   for (int level = cfg->first_level; level >= cfg->last_level; --level) {
     const LevelGeom& g = bp.geom[level];
@@ -473,33 +508,31 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels);
     // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
     const bool fused_ll = g.w * g.h <= kFusedLoglikMaxPixels;
-    // Chunks of `per_sync` iterations are enqueued ONE AHEAD of the poll: while the host waits for the "pairs still
-    // active" word of chunk k, chunk k+1 is already queued, so the GPU never idles for a host round trip (~40 us).
-    // Iterations enqueued past the end of the level are no-ops (workgroups exit on !active).
+    // Chunks of `per_sync` iterations are enqueued ONE AHEAD of the poll: while the host waits for the status word of
+    // chunk k, chunk k+1 is already queued, so the GPU never idles for a host round trip.  Iterations enqueued past the
+    // end of the level are no-ops (workgroups exit on !active).
     auto enqueue_chunk = [&](int count) {
       for (int c = 0; c < count; ++c, ++step) {
         launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch);
         if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, kLlBlocksPerPair);
         launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, kLlBlocksPerPair, fused_ll ? scratch : nullptr, d_levels, d_iters,
-                           counters + step);
+                           tallies + step, w.host_status + step);
       }
     };
     int enqueued = std::min(per_sync, per_level);
     enqueue_chunk(enqueued);
-    DVO_WS_TRY(w, hipMemcpyAsync(w.host_counter, counters + (step - 1), sizeof(int), hipMemcpyDeviceToHost, s));
-    DVO_WS_TRY(w, hipEventRecord(w.polled[0], s));
-    int slot = 0;
+    int watched = step - 1;                                  // last step of the chunk whose outcome is awaited
     for (;;) {
       const int more = std::min(per_sync, per_level - enqueued);
       if (more > 0) {
         enqueue_chunk(more);
         enqueued += more;
-        DVO_WS_TRY(w, hipMemcpyAsync(w.host_counter + 1 - slot, counters + (step - 1), sizeof(int), hipMemcpyDeviceToHost, s));
-        DVO_WS_TRY(w, hipEventRecord(w.polled[1 - slot], s));
       }
-      DVO_WS_TRY(w, hipEventSynchronize(w.polled[slot]));
-      if (w.host_counter[slot] == 0 || more <= 0) break;   // every pair left this level (or the iteration cap is reached)
-      slot = 1 - slot;
+      int active = 0;
+      rc = wait_for_step(w, watched, &active);
+      if (rc != DVO_HIP_OK) return rc;
+      if (active == 0 || more <= 0) break;                   // every pair left this level (or the iteration cap is reached)
+      watched = step - 1;
     }
   }
 

@@ -78,6 +78,9 @@ struct PairState {
   int pad;
 };
 
+// a step's word in the pinned status array: kStepDoneFlag | number of pairs still active on the level
+constexpr int kStepDoneFlag = 0x40000000;
+
 struct SolverParams {
   int max_iterations;
   int first_level, last_level;
