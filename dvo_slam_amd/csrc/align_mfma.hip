@@ -50,7 +50,9 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   for (int i = 0; i < 4; ++i) Pp[i] = st.P_prev[i];
   const bool first = st.first != 0;
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wavefront index is uniform: keeping it (and every row index derived from it) in scalar registers moves the row
+  // bounds test, the row offsets and the ty table load from the vector ALU to the scalar unit
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int u_r = (tile % g.tiles_x) * kTileW + lane;
   // wavefront w sweeps rows w, w+4, w+8, ... of the tile: the four waves work on ADJACENT rows at the same time, so the
   // lower tap row of one wave is the upper tap row of the next and is served by the CU's L1 instead of a second L2 request
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   const size_t pix_base = size_t(pair) * size_t(g.w) * g.h;
   const float nanv = __builtin_nanf("");
   const bool col_ok = u_r < g.w;
+  const float tx_u = g.tx[col_ok ? u_r : 0];                   // column term of the back-projection: constant over the rows
 
   __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kSlabFloats];
   __shared__ float gram[kWavesPerBlock][256];
@@ -73,32 +76,35 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
 
 #pragma unroll 1
   for (int k = 0; k < RPW; ++k) {
-    const int v_r = row0 + k * kWavesPerBlock;
+    const int v_r = row0 + k * kWavesPerBlock;               // scalar
     const bool in_image = col_ok && v_r < g.h;
     float4 ref = make_float4(nanv, 0.0f, 0.0f, 0.0f);
     if (in_image) ref = refR[v_r * g.w + u_r];               // 64 lanes x 16 B = 1 KiB contiguous per wave
-    const PixelProj p = pixel_project(g, KT, ref, col_ok ? u_r : 0, min(v_r, g.h - 1));
+    const PixelProj p = pixel_project_at(g, KT, ref, tx_u, g.ty[min(v_r, g.h - 1)]);
     PixelTaps t;
     if (p.ok) pixel_fetch(g, curA, curB, p, t);
     PixelTerms o;
     const bool valid = p.ok && pixel_finish(g, ref, p, t, o);
     if (in_image) scratch[pix_base + size_t(v_r) * g.w + u_r] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);
     n_valid += __popcll(__ballot(valid));                    // exact count on the scalar unit
-    f32x4 q0 = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0, q2 = q0, q3 = q0;
     if (valid) {
       // t-distribution weight with the PREVIOUS pass' precision (Q11); first pass on a level: w = 1
       const float sw = first ? 1.0f : tdist_weight_sqrt(o.r0, o.r1, Pp);
       float J0[6], J1[6];
       jacobian_rows_scaled(o, sw, J0, J1);                   // sqrt(w) folded into the four gradient factors
-      q0 = f32x4{J0[0], J0[1], J0[2], J0[3]};
-      q1 = f32x4{J0[4], J0[5], J1[0], J1[1]};
-      q2 = f32x4{J1[2], J1[3], J1[4], J1[5]};
-      q3 = f32x4{sw * o.r0, sw * o.r1, 0.0f, 0.0f};
+      wr[0] = f32x4{J0[0], J0[1], J0[2], J0[3]};
+      wr[kQuadStride / 4] = f32x4{J0[4], J0[5], J1[0], J1[1]};
+      wr[2 * (kQuadStride / 4)] = f32x4{J1[2], J1[3], J1[4], J1[5]};
+      wr[3 * (kQuadStride / 4)] = f32x4{sw * o.r0, sw * o.r1, 0.0f, 0.0f};
+    } else {
+      // a pixel without a constraint contributes a zero vector: four stores of one zero quad instead of clearing the
+      // fourteen component registers on every row
+      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+      wr[0] = zero;
+      wr[kQuadStride / 4] = zero;
+      wr[2 * (kQuadStride / 4)] = zero;
+      wr[3 * (kQuadStride / 4)] = zero;
     }
-    wr[0] = q0;
-    wr[kQuadStride / 4] = q1;
-    wr[2 * (kQuadStride / 4)] = q2;
-    wr[3 * (kQuadStride / 4)] = q3;
     // the slab is private to this wavefront and LDS executes a wavefront's operations in order: only the
     // compiler has to be kept from moving the reads above the writes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

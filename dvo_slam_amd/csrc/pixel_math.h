@@ -95,7 +95,8 @@ struct PixelTaps {
   float2 B00, B10, B01, B11;
 };
 
-DVO_HD PixelProj pixel_project(const LevelGeom& g, const float* KT, const float4 ref, int u_r, int v_r) {
+// tx = (u - ox) / fx and ty = (v - oy) / fy of the pixel, from the per-level tables (rgbd_image.cpp:198-201)
+DVO_HD PixelProj pixel_project_at(const LevelGeom& g, const float* KT, const float4 ref, float tx, float ty) {
 #pragma clang fp contract(off)
   PixelProj p;
   p.ok = false;
@@ -103,8 +104,8 @@ DVO_HD PixelProj pixel_project(const LevelGeom& g, const float* KT, const float4
   p.a1 = p.b1 = 0.0f;
   const float Z = ref.x;
   p.Z = Z;
-  const float X = g.tx[u_r] * Z;                    // rgbd_image.cpp:198-201, 258
-  const float Y = g.ty[v_r] * Z;
+  const float X = tx * Z;                           // rgbd_image.cpp:258
+  const float Y = ty * Z;
   p.X = X; p.Y = Y;
   const float qx = (KT[0] * X + KT[1] * Y) + (KT[2] * Z + KT[3]);
   const float qy = (KT[4] * X + KT[5] * Y) + (KT[6] * Z + KT[7]);
@@ -119,6 +120,10 @@ DVO_HD PixelProj pixel_project(const LevelGeom& g, const float* KT, const float4
   p.base = int(vf) * g.w + int(uf);
   p.ok = true;
   return p;
+}
+
+DVO_HD PixelProj pixel_project(const LevelGeom& g, const float* KT, const float4 ref, int u_r, int v_r) {
+  return pixel_project_at(g, KT, ref, g.tx[u_r], g.ty[v_r]);
 }
 
 template <typename PtrA, typename PtrB>
