@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 
 W, H = 640, 480
 ALGO_BYTES_PER_PIXEL = 40.0          # ref {Z,I,Idx,Idy} 16 B + cur {I,Z,Idx,Idy,Zdx,Zdy} 24 B
+BACKGROUND_BUILD_WORKGROUPS = 0      # cap on the workgroups of background build kernels: measured, no gain (profiles/r01_i_overlap.txt)
 HBM_PEAK_GBPS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -74,6 +75,8 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=64)
     ap.add_argument("--cpu-reps", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--build-workgroups", type=int, default=-1, help="cap on the workgroups of a background build kernel (library option build_workgroups; -1 = bench default)")
+    ap.add_argument("--no-overlap", action="store_true", help="build each batch right before its match on one frame set (no build/match overlap)")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--iters-per-sync", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU dry runs)")
@@ -128,18 +131,37 @@ def main():
         ctx.set_option("rows_per_wave", args.rows_per_wave)
     if args.iters_per_sync:
         ctx.set_option("iters_per_sync", args.iters_per_sync)
+    if not args.no_overlap:
+        # the next batch is built in the background of the current match
+        ctx.set_option("build_workgroups", BACKGROUND_BUILD_WORKGROUPS if args.build_workgroups < 0 else args.build_workgroups)
     cam = d.RgbdCameraPyramid(W, H, pairs_np["K"], ctx)
     cam.build(4)
-    frames = [cam.create_raw_device(grey_ptrs[i], depth_ptrs[i]) for i in range(2 * B)]
+    # two frame sets: while batch k is being aligned, batch k+1 is re-ingested and its pyramids / role planes are built on the
+    # context's build stream (a streaming pipeline's steady state); --no-overlap runs build and match back to back on one set
+    n_sets = 1 if args.no_overlap else 2
+    sets = [[cam.create_raw_device(grey_ptrs[i], depth_ptrs[i]) for i in range(2 * B)] for _ in range(n_sets)]
+    frames = sets[0]
     refs, curs = frames[:B], frames[B:]
     cfg_kwargs = dict(first_level=3, last_level=0, max_iterations=100, precision=5e-7, mu=0.0)
     cfg = d.Config(FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0.0)
     tracker = d.DenseTracker(cfg, ctx)
     last = {}
 
+    counter = [0]
+
+    def build(k):
+        fs = sets[k]
+        d.update_raw_device_batch(fs, grey_ptrs, depth_ptrs)            # ingest + pyramids, from HBM-resident raw planes (asynchronous)
+        if n_sets > 1:                                                  # role planes ahead of the match, on the build stream
+            d.prepare_roles_batch(fs[:B], "reference", cfg)
+            d.prepare_roles_batch(fs[B:], "current", cfg)
+
     def step():
-        d.update_raw_device_batch(frames, grey_ptrs, depth_ptrs)       # ingest + pyramids, from HBM-resident raw planes
-        out = tracker.match_batch_arrays(refs, curs)                    # synchronous: returns when the transforms are on the host
+        k = counter[0] % n_sets
+        counter[0] += 1
+        build((k + 1) % n_sets)                                         # next batch (with one set: this batch, built right before its match)
+        fs = sets[k]
+        out = tracker.match_batch_arrays(fs[:B], fs[B:])                # synchronous: returns when the transforms are on the host
         last.update(out)
         if world > 1:
             tw = [_twist(T) for T in out["T"]]
@@ -152,6 +174,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if n_sets > 1:
+        build(0)                                                        # prime the pipeline: step k aligns set k % 2 and builds the other
     for _ in range(args.warmup):
         step()
     barrier()
@@ -200,7 +224,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "batch of %d independent 640x480 RGB-D frame pairs per GPU (per-GPU shard of BASELINE config 4), "
                                    "4-level pyramid, FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0; "
-                                   "step = re-ingest raw planes from HBM + pyramids + selection + coarse-to-fine match_batch" % B,
+                                   "step = re-ingest one batch of raw planes from HBM (pyramids, sampling planes, point selection) + "
+                                   "coarse-to-fine match_batch of one batch%s" % (
+                                       B, "; build and match run back to back" if args.no_overlap else
+                                       "; the build of batch k+1 (build stream) overlaps the match of batch k, every step does one full build and one full match"),
                        "pairs_per_gpu": B, "global_pairs_per_step": n_total, "width": W, "height": H,
                        "parallelism": "independent pairs sharded round-robin over %d GPU(s), one all-gather of 256-B records per step" % world},
             "roofline": roofline,

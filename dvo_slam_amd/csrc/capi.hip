@@ -73,6 +73,7 @@ struct dvo_hip_frame {
   FrameLevel lv[kMaxLevels];
   DevBuf pool;
   int* sel_count = nullptr;    // device, one int per level
+  unsigned long long built_seq = 0;   // ticket of the last build-stream work that wrote this frame (0 = none pending)
 };
 
 // The batch workspace: one HIP stream, device scratch and the pinned poll words of the Gauss-Newton loop.
@@ -93,12 +94,22 @@ struct dvo_hip_context {
   std::string err;
   int opt_rows_per_wave = 0;
   int opt_iters_per_sync = 0;
+  int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
   int opt_variant = 5;             // schedule of the reduce kernel: 5 = Gram accumulation on the matrix cores (default)
   std::vector<CameraGeom*> cameras;
   Workspace ws[1];
-  DevBuf misc, build_tbl, role_tbl_cur, role_tbl_ref;
+  DevBuf misc, build_tbl, role_tbl_cur, role_tbl_ref, prep_tbl_cur, prep_tbl_ref;
+  // Frame construction (ingest, pyramid, eagerly prepared role planes) runs on its own stream so that the next batch of
+  // frames can be built while the current batch is being aligned: the build is bandwidth-bound, the coarse pyramid levels
+  // of an alignment are latency-bound, and the two overlap.  Every build call takes a ticket and records an event; an
+  // alignment makes the main stream wait for the newest ticket among ITS frames only.
+  hipStream_t build_stream = nullptr;
+  static const int kBuildRing = 16;
+  hipEvent_t build_events[kBuildRing] = {};
+  unsigned long long build_seq = 0;          // last ticket issued
+  unsigned long long main_waited_seq = 0;    // newest ticket the main stream already waits behind
 };
 
 namespace {
@@ -126,7 +137,11 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 int workspace_create(dvo_hip_context* ctx, int g) {
   Workspace& w = ctx->ws[g];
   if (w.created) return DVO_HIP_OK;
-  DVO_HIP_TRY(ctx, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+  // the alignment stream outranks the build stream: its short, dependent kernels must not queue behind the wide
+  // elementwise kernels of a concurrent frame build
+  int prio_least = 0, prio_greatest = 0;
+  DVO_HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+  DVO_HIP_TRY(ctx, hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, prio_greatest));
   w.created = true;
   return DVO_HIP_OK;
 }
@@ -147,6 +162,29 @@ void workspace_destroy(Workspace& w) {
 int fail(dvo_hip_context* ctx, int code, const char* msg) {
   if (ctx) ctx->err = msg;
   return code;
+}
+
+// ticket + event for work just enqueued on the build stream; stamps the frames it wrote
+int stamp_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames) {
+  const unsigned long long seq = ++ctx->build_seq;
+  DVO_HIP_TRY(ctx, hipEventRecord(ctx->build_events[seq % dvo_hip_context::kBuildRing], ctx->build_stream));
+  for (int i = 0; i < n; ++i) frames[i]->built_seq = seq;
+  return DVO_HIP_OK;
+}
+
+// the main stream must not touch these frames before the build-stream work that produced them is done
+int wait_for_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames) {
+  unsigned long long need = 0;
+  for (int i = 0; i < n; ++i)
+    if (frames[i] && frames[i]->built_seq > need) need = frames[i]->built_seq;
+  if (need <= ctx->main_waited_seq) return DVO_HIP_OK;
+  // tickets older than the ring have had their event re-recorded for a newer ticket of the same stream: waiting for the
+  // oldest live one still orders us after `need`
+  const unsigned long long oldest_live = ctx->build_seq >= dvo_hip_context::kBuildRing ? ctx->build_seq - dvo_hip_context::kBuildRing + 1 : 1;
+  const unsigned long long use = need < oldest_live ? oldest_live : need;
+  DVO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->build_events[use % dvo_hip_context::kBuildRing], 0));
+  ctx->main_waited_seq = use;
+  return DVO_HIP_OK;
 }
 
 const int kLlBlocksPerPair = 32;
@@ -303,25 +341,29 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
     }
   }
   DVO_HIP_TRY(ctx, ctx->build_tbl.reserve(size_t(n) * sizeof(FrameBuildPtrs)));
-  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->build_tbl.p, host.data(), size_t(n) * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, ctx->stream));
+  hipStream_t bs = ctx->build_stream;
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->build_tbl.p, host.data(), size_t(n) * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, bs));
   const FrameBuildPtrs* tbl = ctx->build_tbl.as<FrameBuildPtrs>();
   int built = 1;                                       // float ingest: level 0 is already in place
   if (grey) {
-    launch_ingest_pyramid(ctx->stream, tbl, n, depth_scale, cam->w[0], cam->h[0], levels);
+    launch_ingest_pyramid(bs, tbl, n, depth_scale, cam->w[0], cam->h[0], levels, ctx->opt_build_workgroups);
     built = levels < 4 ? levels : 4;
   }
-  for (int l = built; l < levels; ++l) launch_pyr_down(ctx->stream, tbl, n, l, cam->w[l - 1], cam->h[l - 1]);
+  for (int l = built; l < levels; ++l) launch_pyr_down(bs, tbl, n, l, cam->w[l - 1], cam->h[l - 1]);
   DVO_HIP_TRY(ctx, hipGetLastError());
-  return DVO_HIP_OK;
+  return stamp_build(ctx, n, frames);
 }
 
 // Build the missing role planes of a set of frames for levels [l0, l1]: role 0 = current (A, B), role 1 = reference
 // (R + selection count for the given thresholds).  One launch per level for all frames that need it.
-int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int role, int l0, int l1, float ithr, float dthr) {
+// `eager`: on the build stream (dvo_hip_frames_prepare), otherwise on the main stream right before the planes are used.
+int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int role, int l0, int l1, float ithr, float dthr, bool eager = false) {
   const CameraGeom* cam = frames[0]->cam;
   std::vector<FrameBuildPtrs> host;
   const size_t slice = size_t(n) * sizeof(FrameBuildPtrs);
-  DevBuf& table = role == 0 ? ctx->role_tbl_cur : ctx->role_tbl_ref;
+  DevBuf& table = eager ? (role == 0 ? ctx->prep_tbl_cur : ctx->prep_tbl_ref) : (role == 0 ? ctx->role_tbl_cur : ctx->role_tbl_ref);
+  hipStream_t stream = eager ? ctx->build_stream : ctx->stream;
+  bool launched = false;
   for (int l = l0; l <= l1; ++l) {
     host.clear();
     for (int i = 0; i < n; ++i) {
@@ -339,9 +381,15 @@ int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int 
     // each level has its own slice of the table so that a copy never waits for the previous level's kernel
     DVO_HIP_TRY(ctx, table.reserve(slice * kMaxLevels));
     FrameBuildPtrs* tbl = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * l);
-    DVO_HIP_TRY(ctx, hipMemcpyAsync(tbl, host.data(), host.size() * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, ctx->stream));
-    if (role == 0) launch_derive_current(ctx->stream, tbl, int(host.size()), l, cam->w[l], cam->h[l]);
-    else launch_derive_reference(ctx->stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], ithr, dthr);
+    DVO_HIP_TRY(ctx, hipMemcpyAsync(tbl, host.data(), host.size() * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, stream));
+    const int cap = eager ? ctx->opt_build_workgroups : 0;   // planes needed right now are built at full width
+    if (role == 0) launch_derive_current(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], cap);
+    else launch_derive_reference(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], ithr, dthr, cap);
+    launched = true;
+  }
+  if (eager && launched) {
+    const int rc = stamp_build(ctx, n, frames);
+    if (rc != DVO_HIP_OK) return rc;
   }
   DVO_HIP_TRY(ctx, hipGetLastError());
   return DVO_HIP_OK;
@@ -401,7 +449,10 @@ void make_plan(const dvo_hip_context* ctx, const CameraGeom* cam, const dvo_hip_
 // buildAccelerationStructure for the current frames, PointSelection::select for the reference frames (both cached per
 // frame and level); enqueued on the context's main stream
 int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg) {
-  int rc = ensure_roles(ctx, n, curs, 0, cfg->last_level, cfg->first_level, 0.0f, 0.0f);
+  int rc = wait_for_build(ctx, n, refs);
+  if (rc == DVO_HIP_OK) rc = wait_for_build(ctx, n, curs);
+  if (rc != DVO_HIP_OK) return rc;
+  rc = ensure_roles(ctx, n, curs, 0, cfg->last_level, cfg->first_level, 0.0f, 0.0f);
   if (rc == DVO_HIP_OK)
     rc = ensure_roles(ctx, n, refs, 1, cfg->last_level, cfg->first_level, cfg->intensity_derivative_threshold, cfg->depth_derivative_threshold);
   return rc;
@@ -624,6 +675,15 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
     return DVO_HIP_ERR_HIP;
   }
   ctx->stream = ctx->ws[0].stream;
+  int prio_least = 0, prio_greatest = 0;
+  e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->build_stream, hipStreamNonBlocking, prio_least);
+  for (int i = 0; i < dvo_hip_context::kBuildRing && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->build_events[i], hipEventDisableTiming);
+  if (e != hipSuccess) {
+    g_create_error = std::string("context setup (build stream): ") + hipGetErrorString(e);
+    dvo_hip_context_destroy(ctx);
+    return DVO_HIP_ERR_HIP;
+  }
   *out = ctx;
   return DVO_HIP_OK;
 }
@@ -631,8 +691,12 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
 void dvo_hip_context_destroy(dvo_hip_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->build_stream) (void)hipStreamSynchronize(ctx->build_stream);
   for (Workspace& w : ctx->ws) workspace_destroy(w);
-  for (DevBuf* b : {&ctx->misc, &ctx->build_tbl, &ctx->role_tbl_cur, &ctx->role_tbl_ref}) b->release();
+  for (hipEvent_t ev : ctx->build_events)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->build_stream) (void)hipStreamDestroy(ctx->build_stream);
+  for (DevBuf* b : {&ctx->misc, &ctx->build_tbl, &ctx->role_tbl_cur, &ctx->role_tbl_ref, &ctx->prep_tbl_cur, &ctx->prep_tbl_ref}) b->release();
   for (CameraGeom* c : ctx->cameras) {
     c->tables.release();
     delete c;
@@ -662,6 +726,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     ctx->opt_variant = value;
     return DVO_HIP_OK;
   }
+  if (std::strcmp(key, "build_workgroups") == 0) {
+    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "build_workgroups must be >= 0");
+    ctx->opt_build_workgroups = value;
+    return DVO_HIP_OK;
+  }
   if (std::strcmp(key, "min_workgroups") == 0) {
     if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "min_workgroups must be >= 0");
     ctx->opt_min_workgroups = value;
@@ -683,12 +752,12 @@ int dvo_hip_frame_create_f32(dvo_hip_context* ctx, int width, int height, const 
   int rc = frame_alloc(ctx, width, height, K, levels, &f, &raw_off);
   if (rc != DVO_HIP_OK) return rc;
   const size_t n = size_t(width) * height;
-  hipError_t e = hipMemcpyAsync(f->lv[0].I, intensity, n * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(f->lv[0].Z, depth, n * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(f->sel_count, 0, sizeof(int) * kMaxLevels, ctx->stream);
+  hipError_t e = hipMemcpyAsync(f->lv[0].I, intensity, n * 4, hipMemcpyHostToDevice, ctx->build_stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(f->lv[0].Z, depth, n * 4, hipMemcpyHostToDevice, ctx->build_stream);
+  if (e == hipSuccess) e = hipMemsetAsync(f->sel_count, 0, sizeof(int) * kMaxLevels, ctx->build_stream);
   if (e == hipSuccess) {
     rc = frames_build(ctx, 1, &f, nullptr, nullptr, 0.0f);
-    if (rc == DVO_HIP_OK) e = hipStreamSynchronize(ctx->stream);   // the caller's host buffers may go away
+    if (rc == DVO_HIP_OK) e = hipStreamSynchronize(ctx->build_stream);   // the caller's host buffers may go away
   }
   if (e != hipSuccess) ctx->err = std::string("frame_create_f32: ") + hipGetErrorString(e);
   if (e != hipSuccess || rc != DVO_HIP_OK) {
@@ -710,13 +779,13 @@ int dvo_hip_frame_create_raw(dvo_hip_context* ctx, int width, int height, const 
   char* stage = f->pool.as<char>() + raw_off;
   uint16_t* d_raw = reinterpret_cast<uint16_t*>(stage);
   uint8_t* d_grey = reinterpret_cast<uint8_t*>(stage + n * 2);
-  hipError_t e = hipMemcpyAsync(d_raw, raw_depth, n * 2, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_grey, grey, n, hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e = hipMemcpyAsync(d_raw, raw_depth, n * 2, hipMemcpyHostToDevice, ctx->build_stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_grey, grey, n, hipMemcpyHostToDevice, ctx->build_stream);
   if (e == hipSuccess) {
     const void* g[1] = {d_grey};
     const void* r[1] = {d_raw};
     rc = frames_build(ctx, 1, &f, g, r, depth_scale);
-    if (rc == DVO_HIP_OK) e = hipStreamSynchronize(ctx->stream);
+    if (rc == DVO_HIP_OK) e = hipStreamSynchronize(ctx->build_stream);
   }
   if (e != hipSuccess) ctx->err = std::string("frame_create_raw: ") + hipGetErrorString(e);
   if (e != hipSuccess || rc != DVO_HIP_OK) {
@@ -741,7 +810,7 @@ int dvo_hip_frame_create_raw_device(dvo_hip_context* ctx, int width, int height,
     dvo_hip_frame_destroy(ctx, f);
     return rc;
   }
-  *out = f;   // asynchronous: later work on this context's stream is ordered after the build
+  *out = f;   // asynchronous (build stream): every later use of the frame is ordered after the build
   return DVO_HIP_OK;
 }
 
@@ -752,6 +821,25 @@ int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip
     if (!frames[i] || !grey_dev[i] || !raw_depth_dev[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device: null entry");
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   return frames_build(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale);
+}
+
+int dvo_hip_frames_prepare(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, int role, const dvo_hip_config* cfg) {
+  if (!ctx || n_frames < 1 || !frames || !cfg || (role != DVO_HIP_ROLE_CURRENT && role != DVO_HIP_ROLE_REFERENCE))
+    return fail(ctx, DVO_HIP_ERR_INVALID, "frames_prepare: bad argument");
+  if (cfg->first_level < cfg->last_level || cfg->last_level < 0 || cfg->first_level >= kMaxLevels)
+    return fail(ctx, DVO_HIP_ERR_INVALID, "frames_prepare: need 0 <= last_level <= first_level < DVO_HIP_MAX_LEVELS");
+  for (int i = 0; i < n_frames; ++i) {
+    if (!frames[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_prepare: null frame");
+    if (frames[i]->cam != frames[0]->cam || frames[i]->levels <= cfg->first_level)
+      return fail(ctx, DVO_HIP_ERR_INVALID, "frames_prepare: frames must share the camera and have first_level + 1 levels");
+  }
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const bool ref = role == DVO_HIP_ROLE_REFERENCE;
+  const int rc = ensure_roles(ctx, n_frames, frames, ref ? 1 : 0, cfg->last_level, cfg->first_level, ref ? cfg->intensity_derivative_threshold : 0.0f,
+                              ref ? cfg->depth_derivative_threshold : 0.0f, /*eager=*/true);
+  if (rc != DVO_HIP_OK) return rc;
+  DVO_HIP_TRY(ctx, hipGetLastError());
+  return DVO_HIP_OK;
 }
 
 int dvo_hip_frame_update_raw_device(dvo_hip_context* ctx, dvo_hip_frame* frame, const void* grey_dev, const void* raw_depth_dev,
@@ -767,6 +855,7 @@ void dvo_hip_frame_destroy(dvo_hip_context* ctx, dvo_hip_frame* frame) {
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->build_stream) (void)hipStreamSynchronize(ctx->build_stream);
   }
   frame->pool.release();
   delete frame;
@@ -785,7 +874,8 @@ int dvo_hip_frame_download_plane(dvo_hip_context* ctx, dvo_hip_frame* frame, int
     return fail(ctx, DVO_HIP_ERR_INVALID, "frame_download_plane: bad argument");
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   dvo_hip_frame* one[1] = {frame};
-  int rc = ensure_roles(ctx, 1, one, 0, level, level, 0.0f, 0.0f);
+  int rc = wait_for_build(ctx, 1, one);
+  if (rc == DVO_HIP_OK) rc = ensure_roles(ctx, 1, one, 0, level, level, 0.0f, 0.0f);
   if (rc != DVO_HIP_OK) return rc;
   const FrameLevel& L = frame->lv[level];
   const size_t n = size_t(L.w) * L.h;
@@ -807,7 +897,8 @@ int dvo_hip_frame_select(dvo_hip_context* ctx, dvo_hip_frame* frame, int level, 
     mask_dev = ctx->misc.as<uint8_t>();
   }
   dvo_hip_frame* one[1] = {frame};
-  int rc = ensure_roles(ctx, 1, one, 1, level, level, ithr, dthr);
+  int rc = wait_for_build(ctx, 1, one);
+  if (rc == DVO_HIP_OK) rc = ensure_roles(ctx, 1, one, 1, level, level, ithr, dthr);
   if (rc == DVO_HIP_OK && mask_dev) rc = ensure_roles(ctx, 1, one, 0, level, level, 0.0f, 0.0f);
   if (rc != DVO_HIP_OK) return rc;
   if (mask_dev) {   // the mask is not kept on the device: recompute it from the sampling planes

@@ -9,10 +9,12 @@ namespace dvo_hip {
 
 // pyramid_kernels.hip
 // raw ingest + pyramid levels 1..3 in one pass (levels beyond the fourth: launch_pyr_down)
-void launch_ingest_pyramid(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels);
+void launch_ingest_pyramid(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int max_workgroups);
 void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h);
-void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h);
-void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr);
+// max_workgroups > 0 caps the grid (the kernels walk the tiles with a grid stride): background build next to an alignment
+void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int max_workgroups);
+void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr,
+                             int max_workgroups);
 void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float4* R, int* count, uint8_t* mask);
 void launch_unpack_plane(hipStream_t s, const float4* A, const float2* B, int n, int plane, float* out);
 

@@ -23,65 +23,79 @@ namespace dvo_hip {
 // (16 x 4 and 8 x 2 pixels per tile).  Compared with ingest + three pyr-down launches this never re-reads a float plane:
 // 0.9 MB in, 3.2 MB out per 640 x 480 frame instead of 7.3 MB of traffic.  Arithmetic and summation order are those of
 // the reference's ingest and of k_pyr_down (bit-identical planes); `levels` <= 4 levels are produced, deeper ones by k_pyr_down.
-__global__ __launch_bounds__(256) void k_ingest_pyramid(const FrameBuildPtrs* __restrict__ tbl, float scale, int w0, int h0, int levels) {
+// Work distribution of the frame-build kernels: a linear index over (tile, frame) walked with a grid stride.  Launched with
+// one workgroup per tile this is the plain one-tile-per-workgroup kernel; launched with FEWER workgroups (option
+// "build_workgroups_per_cu") the same kernel becomes a background job that leaves most wave slots of every CU free, so the
+// short dependent kernels of an alignment running concurrently on the other stream are dispatched at once instead of queueing
+// behind tens of thousands of elementwise workgroups.
+template <typename Body>
+__device__ __forceinline__ void for_each_tile(int tiles_x, int tiles_y, int n_frames, Body body) {
+  const int per_frame = tiles_x * tiles_y, total = per_frame * n_frames;
+  for (int i = blockIdx.x; i < total; i += gridDim.x) {
+    const int frame = i / per_frame, t = i - frame * per_frame;
+    body(t % tiles_x, t / tiles_x, frame);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ingest_pyramid(const FrameBuildPtrs* __restrict__ tbl, float scale, int w0, int h0, int levels,
+                                                        int tiles_x, int tiles_y, int n_frames) {
 #pragma clang fp contract(off)
-  const FrameBuildPtrs& f = tbl[blockIdx.z];
-  const int tx = threadIdx.x, ty = threadIdx.y;               // 32 x 8
-  const int x1 = blockIdx.x * 32 + tx, y1 = blockIdx.y * 8 + ty;   // level-1 pixel = level-0 quad
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
   const int w1 = w0 >> 1, h1 = h0 >> 1;
+  const int w2 = w1 >> 1, h2 = h1 >> 1, w3 = w2 >> 1, h3 = h2 >> 1;
   __shared__ float s1[8][32];
   __shared__ float s2[4][16];
   const float nanv = __builtin_nanf("");
-  float q[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, z00 = nanv;
+  for_each_tile(tiles_x, tiles_y, n_frames, [&](int bx, int by, int frame) {
+    const FrameBuildPtrs& f = tbl[frame];
+    const int x1 = bx * 32 + tx, y1 = by * 8 + ty;              // level-1 pixel = level-0 quad
+    float q[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, z00 = nanv;
 #pragma unroll
-  for (int dy = 0; dy < 2; ++dy) {
-    const int y = 2 * y1 + dy;
-    if (y >= h0) continue;
+    for (int dy = 0; dy < 2; ++dy) {
+      const int y = 2 * y1 + dy;
+      if (y >= h0) continue;
 #pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int x = 2 * x1 + dx;
-      if (x >= w0) continue;
-      const size_t i = size_t(y) * w0 + x;
-      const float g = float(f.grey[i]);
-      const uint16_t d = f.raw[i];
-      const float z = d == 0 ? nanv : float(d) * scale;
-      f.I[0][i] = g;
-      f.Z[0][i] = z;
-      q[dy][dx] = g;
-      if (dx == 0 && dy == 0) z00 = z;
+      for (int dx = 0; dx < 2; ++dx) {
+        const int x = 2 * x1 + dx;
+        if (x >= w0) continue;
+        const size_t i = size_t(y) * w0 + x;
+        const float g = float(f.grey[i]);
+        const uint16_t d = f.raw[i];
+        const float z = d == 0 ? nanv : float(d) * scale;
+        f.I[0][i] = g;
+        f.Z[0][i] = z;
+        q[dy][dx] = g;
+        if (dx == 0 && dy == 0) z00 = z;
+      }
     }
-  }
-  if (levels < 2) return;
-  const float i1 = (q[0][0] + q[0][1] + q[1][0] + q[1][1]) / 4.0f;   // same summation order as the reference
-  const bool in1 = x1 < w1 && y1 < h1;
-  if (in1) {
-    f.I[1][size_t(y1) * w1 + x1] = i1;
-    f.Z[1][size_t(y1) * w1 + x1] = z00;                       // top-left sample, NaN holes kept (Q18)
-  }
-  if (levels < 3) return;                                      // uniform
-  s1[ty][tx] = i1;
-  __syncthreads();
-  const int w2 = w1 >> 1, h2 = h1 >> 1, w3 = w2 >> 1, h3 = h2 >> 1;
-  float i2 = 0.0f;
-  const bool own2 = (tx & 1) == 0 && (ty & 1) == 0;
-  const int x2 = x1 >> 1, y2 = y1 >> 1;
-  if (own2) {
-    i2 = (s1[ty][tx] + s1[ty][tx + 1] + s1[ty + 1][tx] + s1[ty + 1][tx + 1]) / 4.0f;
-    if (x2 < w2 && y2 < h2) {
-      f.I[2][size_t(y2) * w2 + x2] = i2;
-      f.Z[2][size_t(y2) * w2 + x2] = z00;
+    if (levels < 2) return;                                      // uniform
+    const float i1 = (q[0][0] + q[0][1] + q[1][0] + q[1][1]) / 4.0f;   // same summation order as the reference
+    if (x1 < w1 && y1 < h1) {
+      f.I[1][size_t(y1) * w1 + x1] = i1;
+      f.Z[1][size_t(y1) * w1 + x1] = z00;                       // top-left sample, NaN holes kept (Q18)
     }
-    s2[ty >> 1][tx >> 1] = i2;
-  }
-  if (levels < 4) return;
-  __syncthreads();
-  if ((tx & 3) == 0 && (ty & 3) == 0) {
-    const int x3 = x1 >> 2, y3 = y1 >> 2, cx = tx >> 1, cy = ty >> 1;
-    if (x3 < w3 && y3 < h3) {
-      f.I[3][size_t(y3) * w3 + x3] = (s2[cy][cx] + s2[cy][cx + 1] + s2[cy + 1][cx] + s2[cy + 1][cx + 1]) / 4.0f;
-      f.Z[3][size_t(y3) * w3 + x3] = z00;
+    if (levels < 3) return;
+    s1[ty][tx] = i1;
+    __syncthreads();
+    const int x2 = x1 >> 1, y2 = y1 >> 1;
+    if ((tx & 1) == 0 && (ty & 1) == 0) {
+      const float i2 = (s1[ty][tx] + s1[ty][tx + 1] + s1[ty + 1][tx] + s1[ty + 1][tx + 1]) / 4.0f;
+      if (x2 < w2 && y2 < h2) {
+        f.I[2][size_t(y2) * w2 + x2] = i2;
+        f.Z[2][size_t(y2) * w2 + x2] = z00;
+      }
+      s2[ty >> 1][tx >> 1] = i2;
     }
-  }
+    __syncthreads();                                             // also: nobody overwrites s1 of this tile before it was read
+    if (levels >= 4 && (tx & 3) == 0 && (ty & 3) == 0) {
+      const int x3 = x1 >> 2, y3 = y1 >> 2, cx = tx >> 1, cy = ty >> 1;
+      if (x3 < w3 && y3 < h3) {
+        f.I[3][size_t(y3) * w3 + x3] = (s2[cy][cx] + s2[cy][cx + 1] + s2[cy + 1][cx] + s2[cy + 1][cx + 1]) / 4.0f;
+        f.Z[3][size_t(y3) * w3 + x3] = z00;
+      }
+    }
+    __syncthreads();                                             // s2 is free again for the next tile of this workgroup
+  });
 }
 
 __global__ void k_pyr_down(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h) {
@@ -123,42 +137,48 @@ __device__ __forceinline__ Derivs derive_at(const float* __restrict__ I, const f
 }
 
 // current-frame role: the two sampling planes
-__global__ void k_derive_current(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h) {
-  const FrameBuildPtrs& f = tbl[blockIdx.z];
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= w || y >= h) return;
-  const Derivs d = derive_at(f.I[level], f.Z[level], w, h, x, y);
-  f.A[level][size_t(y) * w + x] = make_float4(d.i0, d.z0, d.idx, d.idy);
-  f.B[level][size_t(y) * w + x] = make_float2(d.zdx, d.zdy);
+__global__ void k_derive_current(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h, int tiles_x, int tiles_y, int n_frames) {
+  for_each_tile(tiles_x, tiles_y, n_frames, [&](int bx, int by, int frame) {
+    const FrameBuildPtrs& f = tbl[frame];
+    const int x = bx * 64 + threadIdx.x;
+    const int y = by * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const Derivs d = derive_at(f.I[level], f.Z[level], w, h, x, y);
+    f.A[level][size_t(y) * w + x] = make_float4(d.i0, d.z0, d.idx, d.idy);
+    f.B[level][size_t(y) * w + x] = make_float2(d.zdx, d.zdy);
+  });
 }
 
 // reference role: the streamed plane with the selection predicate folded into Z; counts the selected pixels.
 // The counter of (frame, level) must have been zeroed on the stream before.  A workgroup sweeps a 64 x 16 pixel
 // tile and issues ONE atomic for it (one atomic per wavefront-row serialised the whole kernel on 128 addresses).
-__global__ void k_derive_reference(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h, float ithr, float dthr) {
-  const FrameBuildPtrs& f = tbl[blockIdx.z];
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  int count = 0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int y = (blockIdx.y * 4 + r) * blockDim.y + threadIdx.y;
-    bool ok = false;
-    if (x < w && y < h) {
-      const Derivs d = derive_at(f.I[level], f.Z[level], w, h, x, y);
-      ok = d.z0 == d.z0 && d.zdx == d.zdx && d.zdy == d.zdy &&
-           (fabsf(d.idx) > ithr || fabsf(d.idy) > ithr || fabsf(d.zdx) > dthr || fabsf(d.zdy) > dthr);
-      f.R[level][size_t(y) * w + x] = make_float4(ok ? d.z0 : __builtin_nanf(""), d.i0, d.idx, d.idy);
-    }
-    count += __popcll(__ballot(ok));      // wave-uniform
-  }
+__global__ void k_derive_reference(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h, float ithr, float dthr,
+                                   int tiles_x, int tiles_y, int n_frames) {
   __shared__ int wave_counts[4];
-  if (threadIdx.x == 0) wave_counts[threadIdx.y] = count;
-  __syncthreads();
-  if (threadIdx.x == 0 && threadIdx.y == 0) {
-    const int total = (wave_counts[0] + wave_counts[1]) + (wave_counts[2] + wave_counts[3]);
-    if (total) atomicAdd(f.sel_count + level, total);
-  }
+  for_each_tile(tiles_x, tiles_y, n_frames, [&](int bx, int by, int frame) {
+    const FrameBuildPtrs& f = tbl[frame];
+    const int x = bx * 64 + threadIdx.x;
+    int count = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = (by * 4 + r) * 4 + threadIdx.y;
+      bool ok = false;
+      if (x < w && y < h) {
+        const Derivs d = derive_at(f.I[level], f.Z[level], w, h, x, y);
+        ok = d.z0 == d.z0 && d.zdx == d.zdx && d.zdy == d.zdy &&
+             (fabsf(d.idx) > ithr || fabsf(d.idy) > ithr || fabsf(d.zdx) > dthr || fabsf(d.zdy) > dthr);
+        f.R[level][size_t(y) * w + x] = make_float4(ok ? d.z0 : __builtin_nanf(""), d.i0, d.idx, d.idy);
+      }
+      count += __popcll(__ballot(ok));      // wave-uniform
+    }
+    if (threadIdx.x == 0) wave_counts[threadIdx.y] = count;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+      const int total = (wave_counts[0] + wave_counts[1]) + (wave_counts[2] + wave_counts[3]);
+      if (total) atomicAdd(f.sel_count + level, total);
+    }
+    __syncthreads();                        // wave_counts is rewritten by the next tile
+  });
 }
 
 __global__ void k_zero_counts(const FrameBuildPtrs* __restrict__ tbl, int n_frames, int level) {
@@ -198,8 +218,15 @@ __global__ void k_unpack_plane(const float4* __restrict__ A, const float2* __res
   out[i] = v;
 }
 
-void launch_ingest_pyramid(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels) {
-  k_ingest_pyramid<<<dim3((w0 + 63) / 64, (h0 + 15) / 16, n_frames), dim3(32, 8), 0, s>>>(tbl, scale, w0, h0, levels < 4 ? levels : 4);
+// grid of a frame-build kernel: one workgroup per tile unless a cap is given (background build)
+static int capped_grid(int tiles_x, int tiles_y, int n_frames, int max_workgroups) {
+  const long long total = (long long)tiles_x * tiles_y * n_frames;
+  return int(max_workgroups > 0 && total > max_workgroups ? max_workgroups : total);
+}
+
+void launch_ingest_pyramid(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int max_workgroups) {
+  const int tx = (w0 + 63) / 64, ty = (h0 + 15) / 16;
+  k_ingest_pyramid<<<dim3(capped_grid(tx, ty, n_frames, max_workgroups)), dim3(256), 0, s>>>(tbl, scale, w0, h0, levels < 4 ? levels : 4, tx, ty, n_frames);
 }
 
 void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h) {
@@ -207,13 +234,16 @@ void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int
   k_pyr_down<<<dim3((ow + 63) / 64, (oh + 3) / 4, n_frames), dim3(64, 4), 0, s>>>(tbl, level, w, h);
 }
 
-void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h) {
-  k_derive_current<<<dim3((w + 63) / 64, (h + 3) / 4, n_frames), dim3(64, 4), 0, s>>>(tbl, level, w, h);
+void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int max_workgroups) {
+  const int tx = (w + 63) / 64, ty = (h + 3) / 4;
+  k_derive_current<<<dim3(capped_grid(tx, ty, n_frames, max_workgroups)), dim3(64, 4), 0, s>>>(tbl, level, w, h, tx, ty, n_frames);
 }
 
-void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr) {
+void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr,
+                             int max_workgroups) {
   k_zero_counts<<<dim3((n_frames + 63) / 64), dim3(64), 0, s>>>(tbl, n_frames, level);
-  k_derive_reference<<<dim3((w + 63) / 64, (h + 15) / 16, n_frames), dim3(64, 4), 0, s>>>(tbl, level, w, h, ithr, dthr);
+  const int tx = (w + 63) / 64, ty = (h + 15) / 16;
+  k_derive_reference<<<dim3(capped_grid(tx, ty, n_frames, max_workgroups)), dim3(64, 4), 0, s>>>(tbl, level, w, h, ithr, dthr, tx, ty, n_frames);
 }
 
 void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float4* R, int* count, uint8_t* mask) {

@@ -302,6 +302,18 @@ def update_raw_device_batch(pyramids, grey_dev_ptrs, depth_dev_ptrs, depth_scale
     ctx.check(ctx._lib.dvo_hip_frames_update_raw_device(ctx.ptr, n, fr, g, z, depth_scale))
 
 
+def prepare_roles_batch(pyramids, role, config):
+    """Build the role planes of n pyramids ahead of time and asynchronously (dvo_hip_frames_prepare): role "current" = sampling
+    planes, "reference" = point selection for config's thresholds.  Together with update_raw_device_batch this runs on the
+    context's build stream, concurrently with a match started afterwards on other frames."""
+    n = len(pyramids)
+    ctx = pyramids[0].ctx
+    vp = C.c_void_p
+    fr = (vp * n)(*[p.ptr for p in pyramids])
+    ccfg = config.to_c()
+    ctx.check(ctx._lib.dvo_hip_frames_prepare(ctx.ptr, n, fr, {"current": 0, "reference": 1}[role], C.byref(ccfg)))
+
+
 class PointSelection:
     """Reference-side selection cache (point_selection.h:69-99).  The selected list itself never leaves the GPU."""
 

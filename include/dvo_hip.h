@@ -131,13 +131,25 @@ int dvo_hip_frame_create_raw_device(dvo_hip_context* ctx, int width, int height,
                                     const void* grey_dev, const void* raw_depth_dev, float depth_scale,
                                     int levels, dvo_hip_frame** out);
 /* Re-ingest new raw planes (device pointers) into an existing frame: no allocation, asynchronous on the
- * context stream.  The streaming use of RgbdCameraPyramid::create for every camera frame
+ * context's build stream.  The streaming use of RgbdCameraPyramid::create for every camera frame
  * (dvo_ros/src/camera_dense_tracking.cpp:243); invalidates the frame's cached point selection. */
 int dvo_hip_frame_update_raw_device(dvo_hip_context* ctx, dvo_hip_frame* frame, const void* grey_dev,
                                     const void* raw_depth_dev, float depth_scale);
 /* The same for n frames of one camera in one launch per pyramid level (blockIdx.z = frame). */
 int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames,
                                      const void* const* grey_dev, const void* const* raw_depth_dev, float depth_scale);
+/* Build the role planes of n frames ahead of time, asynchronously: role CURRENT = the sampling planes of
+ * RgbdImage::buildAccelerationStructure (dvo_core/src/core/rgbd_image.cpp:534-543), role REFERENCE = the point selection of
+ * PointSelection::select for cfg's thresholds (dvo_core/src/core/point_selection.cpp:89-152), levels cfg->last_level ..
+ * cfg->first_level.  This is what the reference's LocalTracker does with a new image BEFORE handing it to its trackers
+ * (dvo_slam/src/local_tracker.cpp:159-170).  Optional: dvo_hip_match* builds whatever is missing.
+ * Frame construction (create / update / prepare) runs on a stream of its own, concurrently with an alignment that was
+ * started afterwards on other frames -- build the next batch, then align the current one, and the two overlap.  A frame
+ * must not be updated while a match that uses it is in progress (matches are blocking calls, so this only concerns other
+ * host threads). */
+#define DVO_HIP_ROLE_CURRENT 0
+#define DVO_HIP_ROLE_REFERENCE 1
+int dvo_hip_frames_prepare(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, int role, const dvo_hip_config* cfg);
 void dvo_hip_frame_destroy(dvo_hip_context* ctx, dvo_hip_frame* frame);
 int dvo_hip_frame_info(const dvo_hip_frame* frame, int level, int* width, int* height, float K[4]);
 /* host mirror of one plane of one level (RgbdImage public fields, rgbd_image.h:161-179):
