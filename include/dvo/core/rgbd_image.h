@@ -3,9 +3,9 @@
 //
 // Differences a caller can observe: derived planes (derivatives, point cloud, "acceleration structure") live on the
 // GPU; the public cv::Mat-like fields of RgbdImage are HOST MIRRORS filled on first access through the accessor
-// functions of the same name (intensity(), depth(), intensity_dx() ...).  buildPointCloud() /
-// buildAccelerationStructure() / calculateDerivatives() are kept as no-ops (the device build already did the work),
-// so dvo_slam/src/local_tracker.cpp:163-169 compiles and behaves unchanged.
+// functions of the same name (intensity(), depth(), intensity_dx() ...).  buildPointCloud() / calculateDerivatives() are kept
+// as no-ops (by-products of the device kernels) and buildAccelerationStructure() starts the asynchronous device build of the
+// level's sampling planes, so dvo_slam/src/local_tracker.cpp:163-169 compiles and behaves unchanged.
 #pragma once
 
 #include <cassert>
@@ -103,10 +103,13 @@ class RgbdImage {
   const dvo::compat::ImageMat& intensity_dy() { return plane(3); }
   const dvo::compat::ImageMat& depth_dx() { return plane(4); }
   const dvo::compat::ImageMat& depth_dy() { return plane(5); }
-  // all three are done by the device build when the pyramid is created; kept so callers compile unchanged
+  // derivatives and the 3-D points are by-products of the device kernels; kept so callers compile unchanged
   void calculateDerivatives() {}
   void buildPointCloud() {}
-  void buildAccelerationStructure() {}
+  // rgbd_image.cpp:534-543.  On the device: the current-frame sampling planes of this level, built asynchronously on the
+  // context's build stream (dvo_hip_frames_prepare) -- what LocalTracker does with a new image before handing it to its
+  // trackers (local_tracker.cpp:163-169).  Optional: match() builds whatever is missing.
+  inline void buildAccelerationStructure();
 
  private:
   inline const dvo::compat::ImageMat& plane(int idx);
@@ -169,6 +172,14 @@ class RgbdImagePyramid {
 
 inline RgbdImagePyramidPtr RgbdCameraPyramid::create(const dvo::compat::ImageMat& base_intensity, const dvo::compat::ImageMat& base_depth) {
   return RgbdImagePyramidPtr(new RgbdImagePyramid(*this, base_intensity, base_depth));
+}
+
+inline void RgbdImage::buildAccelerationStructure() {
+  dvo_hip_config c = {};
+  c.first_level = c.last_level = level_;
+  c.max_iterations_per_level = 1;
+  dvo_hip_frame* one[1] = {owner_->device_frame()};
+  dvo_hip_check(owner_->device_context(), dvo_hip_frames_prepare(owner_->device_context(), 1, one, DVO_HIP_ROLE_CURRENT, &c), "dvo_hip_frames_prepare");
 }
 
 inline const dvo::compat::ImageMat& RgbdImage::plane(int idx) {

@@ -49,6 +49,14 @@ class LocalTracker {
   }
 
   void update(const dvo::core::RgbdImagePyramid::Ptr& image, dvo::core::AffineTransformd& pose) {
+    // prepare the image (local_tracker.cpp:159-170): pyramid, then per level the sampling planes -- asynchronous on the device
+    const dvo::DenseTracker::Config& config = tracker_.configuration();
+    image->build(config.getNumLevels());
+    for (int idx = config.LastLevel; idx <= config.FirstLevel; ++idx) {
+      image->level(size_t(idx)).buildPointCloud();
+      image->level(size_t(idx)).buildAccelerationStructure();
+    }
+
     TrackingResult r_odometry, r_keyframe;
     r_odometry.Transformation.setIdentity();
     r_keyframe.Transformation = last_keyframe_pose_.inverse();

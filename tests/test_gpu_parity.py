@@ -14,6 +14,7 @@ import pytest
 
 import common as cm
 import dvo_slam_amd as d
+from dvo_slam_amd import datagen
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -280,3 +281,76 @@ def test_cpp_facade_matches_python_path(gpu_ctx, tmp_path):
     g = run_gpu_match(gpu_ctx, gref, gcur, d.Config(FirstLevel=2, LastLevel=0))
     assert cm.twist_matrix_error(T, g["T"]) < 1e-9
     assert np.abs(po.se3_log(T) - pair["xi_true"]).max() < 1e-4
+
+
+def test_device_ingest_prepare_and_background_build(gpu_ctx):
+    """Frames ingested from device-resident raw planes, role planes prepared ahead of time, and a build of OTHER frames in
+    flight on the build stream while a batch is aligned: none of it may change a single bit of the results."""
+    import ctypes as C
+    hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")       # the runtime the library itself uses: plain device buffers for the raw planes
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def to_device(arr):
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), arr.nbytes) == 0
+        assert hip.hipMemcpy(p, arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1) == 0
+        return p.value
+    n, w, h = 6, 320, 240
+    cfg = d.Config(FirstLevel=2, LastLevel=0)
+    trk = d.DenseTracker(cfg, gpu_ctx)
+    cam = d.RgbdCameraPyramid(w, h, po.FR1_K * 0.5, gpu_ctx)
+    cam.build(3)
+    batches = [datagen.synth_batch(seed, n, w, h) for seed in (100, 200)]
+
+    def host_frames(b):
+        return ([cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)],
+                [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)])
+
+    def raw(out):
+        return b"".join(np.ascontiguousarray(out[k]).tobytes() for k in ("T", "information", "loglik", "n_iterations", "entropy"))
+    base = []
+    for b in batches:
+        refs, curs = host_frames(b)
+        base.append(raw(trk.match_batch_arrays(refs, curs)))
+    assert base[0] != base[1]
+
+    dev = []
+    for b in batches:
+        g = to_device(np.concatenate([b["grey_ref"], b["grey_cur"]]))
+        z = to_device(np.concatenate([b["depth_ref"], b["depth_cur"]]))
+        dev.append((g, z, [g + i * w * h for i in range(2 * n)], [z + 2 * i * w * h for i in range(2 * n)]))
+    sets = [[cam.create_raw_device(dev[k][2][i], dev[k][3][i]) for i in range(2 * n)] for k in range(2)]
+    for k in range(2):   # device ingest == host ingest
+        assert raw(trk.match_batch_arrays(sets[k][:n], sets[k][n:])) == base[k]
+    # re-ingest + eager role planes, then match
+    d.update_raw_device_batch(sets[0], dev[0][2], dev[0][3])
+    d.prepare_roles_batch(sets[0][:n], "reference", cfg)
+    d.prepare_roles_batch(sets[0][n:], "current", cfg)
+    assert raw(trk.match_batch_arrays(sets[0][:n], sets[0][n:])) == base[0]
+    # a frame that is prepared for both roles can be used in either (the inverse pairing just has to run)
+    d.prepare_roles_batch(sets[0][:n], "current", cfg)
+    assert np.isfinite(trk.match_batch_arrays(sets[0][n:], sets[0][:n])["T"]).all()
+    # set 1 is rebuilt (with set 0's data!) while set 0 is aligned: set 0's result is untouched, set 1 now gives set 0's result
+    for _ in range(3):
+        d.update_raw_device_batch(sets[1], dev[0][2], dev[0][3])
+        d.prepare_roles_batch(sets[1][:n], "reference", cfg)
+        d.prepare_roles_batch(sets[1][n:], "current", cfg)
+        assert raw(trk.match_batch_arrays(sets[0][:n], sets[0][n:])) == base[0]
+        assert raw(trk.match_batch_arrays(sets[1][:n], sets[1][n:])) == base[0]
+        d.update_raw_device_batch(sets[1], dev[1][2], dev[1][3])         # back to its own data, roles built lazily by the match
+        assert raw(trk.match_batch_arrays(sets[1][:n], sets[1][n:])) == base[1]
+    # a narrow background build (grid-stride kernels) writes the same planes
+    gpu_ctx.set_option("build_workgroups", 64)
+    d.update_raw_device_batch(sets[1], dev[0][2], dev[0][3])
+    d.prepare_roles_batch(sets[1][:n], "reference", cfg)
+    d.prepare_roles_batch(sets[1][n:], "current", cfg)
+    gpu_ctx.set_option("build_workgroups", 0)
+    assert raw(trk.match_batch_arrays(sets[1][:n], sets[1][n:])) == base[0]
+    with pytest.raises(d.DvoHipError):
+        d.prepare_roles_batch(sets[0][:n], "reference", d.Config(FirstLevel=5, LastLevel=0))   # more levels than the frames have
+    del sets
+    for g, z, _, _ in dev:
+        hip.hipFree(C.c_void_p(g))
+        hip.hipFree(C.c_void_p(z))
