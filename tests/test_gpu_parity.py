@@ -287,7 +287,11 @@ def test_device_ingest_prepare_and_background_build(gpu_ctx):
     """Frames ingested from device-resident raw planes, role planes prepared ahead of time, and a build of OTHER frames in
     flight on the build stream while a batch is aligned: none of it may change a single bit of the results."""
     import ctypes as C
-    hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")       # the runtime the library itself uses: plain device buffers for the raw planes
+    # plain device buffers for the raw planes, from the HIP runtime this process already has loaded (the library's own, or
+    # torch's bundled copy when another test module imported torch first)
+    loaded = sorted({line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line})
+    assert loaded, "libdvo_hip.so should have pulled in the HIP runtime"
+    hip = C.CDLL(loaded[0])
     hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 
