@@ -74,12 +74,20 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   int n_valid = 0;
 
+  // the reference row of iteration k+1 is requested before row k is processed: one of the two dependent memory round trips
+  // of a row (reference pixel -> projected tap addresses) is taken off the critical path for 4 registers
+  auto load_ref = [&](int v_r) {
+    float4 r = make_float4(nanv, 0.0f, 0.0f, 0.0f);
+    if (col_ok && v_r < g.h) r = refR[v_r * g.w + u_r];       // 64 lanes x 16 B = 1 KiB contiguous per wave
+    return r;
+  };
+  float4 ref_next = load_ref(row0);
 #pragma unroll 1
   for (int k = 0; k < RPW; ++k) {
     const int v_r = row0 + k * kWavesPerBlock;               // scalar
     const bool in_image = col_ok && v_r < g.h;
-    float4 ref = make_float4(nanv, 0.0f, 0.0f, 0.0f);
-    if (in_image) ref = refR[v_r * g.w + u_r];               // 64 lanes x 16 B = 1 KiB contiguous per wave
+    const float4 ref = ref_next;
+    if (k + 1 < RPW) ref_next = load_ref(v_r + kWavesPerBlock);
     const PixelProj p = pixel_project_at(g, KT, ref, tx_u, g.ty[min(v_r, g.h - 1)]);
     PixelTaps t;
     if (p.ok) pixel_fetch(g, curA, curB, p, t);
