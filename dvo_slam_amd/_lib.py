@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdvo_hip.so")
+LIB_PATH = os.environ.get("DVO_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libdvo_hip.so")   # override: A/B measurements of two builds
 CSRC = os.path.join(_HERE, "csrc")
 
 MAX_LEVELS = 8

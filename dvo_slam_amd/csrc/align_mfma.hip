@@ -26,7 +26,9 @@ typedef float __attribute__((ext_vector_type(4))) f32x4;
 constexpr int kQuadStride = 264;                 // floats per component quad: 64 pixels x 4 + 8 skew (bank-conflict-free reads)
 constexpr int kSlabFloats = 4 * kQuadStride;     // per-wavefront LDS slab (4224 B)
 
-template <int RPW, bool FINEST>
+// LINEAR: the level is walked as one row of w*h pixels in 64-pixel segments (LevelGeom::linear) -- same per-pixel arithmetic,
+// the pixel coordinates come from a division instead of the tile position.
+template <int RPW, bool FINEST, bool LINEAR>
 __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd) {
@@ -38,29 +40,43 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   if (item >= total) return;
   const int pair = item / tiles, tile = item - pair * tiles;
   const PairState& st = states[pair];
-  if (!st.active) return;
+  if constexpr (RPW <= 2) {
+    // Short tiles (coarse levels, small batches): the prologue is most of a workgroup's life.  The pair's plane pointers
+    // are requested together with the activity flag and pinned above the branch, so the scalar loads travel together
+    // instead of as a chain of dependent round trips (the compiler otherwise sinks each to its first use).  Tall tiles run
+    // measurably better with the lazy order.
+    const PairPtrs early = pairs[pair];
+    const int active = st.active;
+    asm volatile("" ::"s"(early.refR), "s"(early.curA), "s"(early.curB), "s"(active));
+    if (!active) return;
+  } else {
+    if (!st.active) return;
+  }
   const PairPtrs pp = pairs[pair];
-  const GlobalLoad4 refR{(GlobalVec4)pp.refR}, curA{(GlobalVec4)pp.curA};
-  const GlobalLoad2 curB{(GlobalVec2)pp.curB};
-
   float KT[12], Pp[4];
 #pragma unroll
   for (int i = 0; i < 12; ++i) KT[i] = st.KT[i];
 #pragma unroll
   for (int i = 0; i < 4; ++i) Pp[i] = st.P_prev[i];
   const bool first = st.first != 0;
+  const GlobalLoad4 refR{(GlobalVec4)pp.refR}, curA{(GlobalVec4)pp.curA};
+  const GlobalLoad2 curB{(GlobalVec2)pp.curB};
 
   // the wavefront index is uniform: keeping it (and every row index derived from it) in scalar registers moves the row
   // bounds test, the row offsets and the ty table load from the vector ALU to the scalar unit
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int u_r = (tile % g.tiles_x) * kTileW + lane;
+  // tiled: lane = column u_r of the tile, rows row0, row0 + 4, ...;  linear: 64-pixel segments row0, row0 + 4, ... of the
+  // flattened level, lane = offset in the segment
+  const int u_r = LINEAR ? lane : (tile % g.tiles_x) * kTileW + lane;
   // wavefront w sweeps rows w, w+4, w+8, ... of the tile: the four waves work on ADJACENT rows at the same time, so the
   // lower tap row of one wave is the upper tap row of the next and is served by the CU's L1 instead of a second L2 request
   const int row0 = (tile / g.tiles_x) * (kWavesPerBlock * RPW) + wave;
   const size_t pix_base = size_t(pair) * size_t(g.w) * g.h;
   const float nanv = __builtin_nanf("");
-  const bool col_ok = u_r < g.w;
-  const float tx_u = g.tx[col_ok ? u_r : 0];                   // column term of the back-projection: constant over the rows
+  const bool col_ok = LINEAR || u_r < g.w;
+  const int n_px = g.w * g.h;
+  const float inv_w = 1.0f / float(g.w);
+  const float tx_u = LINEAR ? 0.0f : g.tx[col_ok ? u_r : 0];  // column term of the back-projection: constant over the rows
 
   __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kSlabFloats];
   __shared__ float gram[kWavesPerBlock][256];
@@ -78,22 +94,46 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   // of a row (reference pixel -> projected tap addresses) is taken off the critical path for 4 registers
   auto load_ref = [&](int v_r) {
     float4 r = make_float4(nanv, 0.0f, 0.0f, 0.0f);
-    if (col_ok && v_r < g.h) r = refR[v_r * g.w + u_r];       // 64 lanes x 16 B = 1 KiB contiguous per wave
+    if (LINEAR) {
+      if (v_r * kTileW + lane < n_px) r = refR[v_r * kTileW + lane];
+    } else {
+      if (col_ok && v_r < g.h) r = refR[v_r * g.w + u_r];     // 64 lanes x 16 B = 1 KiB contiguous per wave
+    }
     return r;
   };
   float4 ref_next = load_ref(row0);
 #pragma unroll 1
   for (int k = 0; k < RPW; ++k) {
-    const int v_r = row0 + k * kWavesPerBlock;               // scalar
-    const bool in_image = col_ok && v_r < g.h;
+    const int v_r = row0 + k * kWavesPerBlock;               // scalar: image row (tiled) or segment (linear)
     const float4 ref = ref_next;
     if (k + 1 < RPW) ref_next = load_ref(v_r + kWavesPerBlock);
-    const PixelProj p = pixel_project_at(g, KT, ref, tx_u, g.ty[min(v_r, g.h - 1)]);
+    bool in_image;
+    size_t pix;                                               // index of this lane's pixel in the level
+    float tx_p, ty_p;
+    if constexpr (LINEAR) {
+      const int idx = v_r * kTileW + lane;
+      in_image = idx < n_px;
+      pix = size_t(idx);
+      // row and column of the pixel: idx < 2^24, so one float multiply lands within one row of the quotient
+      const int pc = in_image ? idx : 0;
+      int row = int(float(pc) * inv_w);
+      int col = pc - row * g.w;
+      if (col < 0) { col += g.w; row -= 1; }
+      if (col >= g.w) { col -= g.w; row += 1; }
+      tx_p = g.tx[col];
+      ty_p = g.ty[row];
+    } else {
+      in_image = col_ok && v_r < g.h;
+      pix = size_t(v_r) * g.w + u_r;                          // scalar row offset + lane
+      tx_p = tx_u;
+      ty_p = g.ty[min(v_r, g.h - 1)];
+    }
+    const PixelProj p = pixel_project_at(g, KT, ref, tx_p, ty_p);
     PixelTaps t;
     if (p.ok) pixel_fetch(g, curA, curB, p, t);
     PixelTerms o;
     const bool valid = p.ok && pixel_finish(g, ref, p, t, o);
-    if (in_image) scratch[pix_base + size_t(v_r) * g.w + u_r] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);
+    if (in_image) scratch[pix_base + pix] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);
     n_valid += __popcll(__ballot(valid));                    // exact count on the scalar unit
     if (valid) {
       // t-distribution weight with the PREVIOUS pass' precision (Q11); first pass on a level: w = 1
@@ -166,10 +206,14 @@ static void launch_m(hipStream_t s, bool finest, const LevelGeom& g, const PairP
                      float* partials, float2* scratch) {
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
-  if (finest)
-    k_residual_reduce_mfma<RPW, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
-  else
-    k_residual_reduce_mfma<RPW, false><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+  const dim3 grid(per_xcd * 8), block(kBlock);
+  if (g.linear) {
+    if (finest) k_residual_reduce_mfma<RPW, true, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+    else k_residual_reduce_mfma<RPW, false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+  } else {
+    if (finest) k_residual_reduce_mfma<RPW, true, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+    else k_residual_reduce_mfma<RPW, false, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+  }
 }
 
 void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,

@@ -239,15 +239,29 @@ int get_camera(dvo_hip_context* ctx, int w, int h, const float K[4], int levels,
   return DVO_HIP_OK;
 }
 
-LevelGeom make_geom(const CameraGeom* cam, int level, int rows_per_wave) {
+// tiles of the sweep kernel for one pair (see LevelGeom::linear)
+void level_tiles(int w, int h, int rows_per_wave, bool linear, int* tiles_x, int* tiles_y) {
+  const int th = kWavesPerBlock * rows_per_wave;
+  if (linear) {
+    const int segments = (w * h + kTileW - 1) / kTileW;
+    *tiles_x = 1;
+    *tiles_y = (segments + th - 1) / th;
+  } else {
+    *tiles_x = (w + kTileW - 1) / kTileW;
+    *tiles_y = (h + th - 1) / th;
+  }
+}
+
+bool level_is_linear(const dvo_hip_context* ctx, int w) { return ctx->opt_variant == 5 && w % kTileW != 0; }
+
+LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int rows_per_wave) {
   LevelGeom g;
   g.w = cam->w[level]; g.h = cam->h[level];
   g.fx = cam->K[level][0]; g.fy = cam->K[level][1]; g.ox = cam->K[level][2]; g.oy = cam->K[level][3];
   g.wi_x = 0.5f * g.fx / 255.0f; g.wi_y = 0.5f * g.fy / 255.0f;
   g.tx = cam->tx[level]; g.ty = cam->ty[level];
-  g.tiles_x = (g.w + kTileW - 1) / kTileW;
-  const int th = kWavesPerBlock * rows_per_wave;
-  g.tiles_y = (g.h + th - 1) / th;
+  g.linear = level_is_linear(ctx, g.w) ? 1 : 0;
+  level_tiles(g.w, g.h, rows_per_wave, g.linear != 0, &g.tiles_x, &g.tiles_y);
   return g;
 }
 
@@ -260,8 +274,9 @@ int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int le
   // bookkeeping kernel, which matters most when there are few pairs (whole-match timings: profiles/r01_f_tile_heuristic.txt).
   const size_t enough = ctx->opt_min_workgroups > 0 ? size_t(ctx->opt_min_workgroups) : (n_pairs <= 8 ? 512 : n_pairs < 64 ? 1024 : 2048);
   for (int r : candidates) {
-    const int tiles = ((cam->w[level] + kTileW - 1) / kTileW) * ((cam->h[level] + kWavesPerBlock * r - 1) / (kWavesPerBlock * r));
-    if (size_t(tiles) * n_pairs >= enough) return r;
+    int tx, ty;
+    level_tiles(cam->w[level], cam->h[level], r, level_is_linear(ctx, cam->w[level]), &tx, &ty);
+    if (size_t(tx) * ty * n_pairs >= enough) return r;
   }
   return 1;
 }
@@ -442,7 +457,7 @@ void make_plan(const dvo_hip_context* ctx, const CameraGeom* cam, const dvo_hip_
   bp.geom.resize(need_levels);
   for (int l = cfg->last_level; l <= cfg->first_level; ++l) {
     bp.rpw[l] = pick_rows_per_wave(ctx, cam, l, n);
-    bp.geom[l] = make_geom(cam, l, bp.rpw[l]);
+    bp.geom[l] = make_geom(ctx, cam, l, bp.rpw[l]);
   }
 }
 

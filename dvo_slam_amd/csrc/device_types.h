@@ -36,6 +36,10 @@ struct LevelGeom {                    // identical for every pair of a batch (on
   const float* tx;                    // (u - ox)/fx per column, the reference's pointcloud_template_
   const float* ty;                    // (v - oy)/fy per row
   int tiles_x, tiles_y;
+  // 1: the sweep kernel walks the level as ONE row of w*h pixels in 64-pixel segments (tiles_x = 1) instead of 64-column
+  // tiles.  Used when w is not a multiple of 64: an 80-pixel-wide level otherwise runs every second wavefront-row with 16
+  // of its 64 lanes (37 % of the issue slots wasted), a 160-wide one with 32 (17 %).
+  int linear;
 };
 
 struct PairPtrs {                     // device planes of one pair at one level

@@ -46,6 +46,7 @@ void make_level(const emul_level& e, LevelCtx& c) {
   c.g.tx = c.tx.data(); c.g.ty = c.ty.data();
   c.g.tiles_x = (e.w + kTileW - 1) / kTileW;
   c.g.tiles_y = e.h;
+  c.g.linear = 0;
   c.R = reinterpret_cast<const float4*>(e.R);
   c.A = reinterpret_cast<const float4*>(e.A);
   c.B = reinterpret_cast<const float2*>(e.B);
