@@ -1,5 +1,6 @@
 /*
- * dvo_oracle.cpp -- CPU ORACLE (test infrastructure, see dvo_oracle.h; "parity unpinned").
+ * dvo_oracle.cpp -- CPU ORACLE (test infrastructure; parity status: dvo_oracle.h -- the SSE passes are pinned
+ * against the reference's own code, the driver is "parity unpinned").
  *
  * A from-scratch restatement of the reference's dense RGB-D alignment path.  Every function cites
  * the reference lines (relative to /root/reference) whose behaviour it reproduces.  Build with
@@ -640,7 +641,7 @@ using namespace oracle;
 
 extern "C" {
 
-const char* oracle_version(void) { return "dvo-oracle 1 (parity unpinned: reference has no tests/fixtures)"; }
+const char* oracle_version(void) { return "dvo-oracle 2 (SSE passes pinned against oracle/_ref; driver parity unpinned: the reference has no tests/fixtures)"; }
 
 oracle_pyramid* oracle_pyramid_create(int width, int height, const float K[4], const float* intensity, const float* depth, int levels) {
   if (width <= 0 || height <= 0 || levels < 1) return nullptr;
@@ -771,6 +772,46 @@ int oracle_level_iteration(oracle_pyramid* ref, oracle_pyramid* cur, int level, 
   normal_equations(S.points_error.p, S.weights.p, n, out->precision, mode, out->A, out->b);
   return 0;
 }
+
+// ---- the passes one by one on caller-supplied arrays (pinning against oracle/_ref, tests/test_oracle_ref.py) ----------
+int oracle_pass_residuals(int mode, int n, const float* points, const float* accel, int w, int h, const float K[4], const float T[12],
+                          float* out_points, float* out_residuals) {
+  Level cur;
+  cur.w = w; cur.h = h;
+  cur.K = Intrinsics{K[0], K[1], K[2], K[3]};
+  cur.accel.resize(size_t(w) * h * 8);
+  std::memcpy(cur.accel.p, accel, size_t(w) * h * 8 * sizeof(float));
+  AlignedBuf<RefPoint> pts;
+  pts.resize(size_t(n) + 1);
+  for (int i = 0; i < n; ++i) {
+    std::memcpy(pts.p[i].p, points + size_t(i) * 12, 4 * sizeof(float));
+    std::memcpy(pts.p[i].v, points + size_t(i) * 12 + 4, 8 * sizeof(float));
+  }
+  Scratch S;
+  ensure_scratch(S, size_t(n) + 2, false);
+  const Weights8 W = make_weights(cur.K);
+  const int n_out = mode == DVO_ORACLE_REF_SSE ? residual_pass_ref(pts.p, n, cur, T, W, S, nullptr, false)
+                                               : residual_pass_math(pts.p, n, cur, T, W, S, nullptr, false);
+  for (int i = 0; i < n_out; ++i) {
+    std::memcpy(out_points + size_t(i) * 12, S.points_error.p[i].p, 4 * sizeof(float));
+    std::memcpy(out_points + size_t(i) * 12 + 4, S.points_error.p[i].v, 8 * sizeof(float));
+    out_residuals[2 * i] = S.residuals.p[2 * i];
+    out_residuals[2 * i + 1] = S.residuals.p[2 * i + 1];
+  }
+  return n_out;
+}
+
+void oracle_pass_weight_vectors(const float K[4], float reference_weight[8], float current_weight[8]) {
+  const Weights8 W = make_weights(Intrinsics{K[0], K[1], K[2], K[3]});
+  std::memcpy(reference_weight, W.wref, sizeof(W.wref));
+  std::memcpy(current_weight, W.wcur, sizeof(W.wcur));
+}
+
+void oracle_pass_weights(int mode, int n, const float* residuals, const float P[4], float* weights) { weights_pass(residuals, n, P, weights, mode); }
+
+void oracle_pass_scale(int mode, int n, const float* residuals, const float* weights, float C[3]) { scale_pass(residuals, weights, n, mode, C); }
+
+double oracle_pass_loglik(int mode, int n, const float* residuals, const float P[4]) { return loglik_pass(residuals, n, P, mode); }
 
 void oracle_se3_exp(const double x[6], double T[16]) { se3_to_matrix(se3_exp(x), T); }
 void oracle_se3_log(const double T[16], double x[6]) { se3_log(se3_from_matrix(T), x); }

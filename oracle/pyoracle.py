@@ -53,10 +53,9 @@ class IterationOut(C.Structure):
 
 def build(force=False):
     """Compile liboracle.so with the committed recipe (oracle/Makefile)."""
-    if force or not os.path.exists(_LIB_PATH) or any(
-            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("dvo_oracle.cpp", "dvo_oracle.h", "se3_oracle.h", "Makefile")):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
+    subprocess.check_call(["make", "-C", _HERE, "-s"])      # also builds _ref/libdvo_ref.so when /root/reference is present
     return _LIB_PATH
 
 
@@ -91,8 +90,40 @@ def lib():
         L.oracle_solve6.argtypes = [dp, dp, dp]
         L.oracle_rank_update_2x6.argtypes = [fp, C.c_int, fp, C.c_int, dp]
         L.oracle_version.restype = C.c_char_p
+        L.oracle_pass_residuals.argtypes = [C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp]
+        L.oracle_pass_weight_vectors.argtypes = [fp, fp, fp]
+        L.oracle_pass_weights.argtypes = [C.c_int, C.c_int, fp, fp, fp]
+        L.oracle_pass_scale.argtypes = [C.c_int, C.c_int, fp, fp, fp]
+        L.oracle_pass_loglik.restype = C.c_double
+        L.oracle_pass_loglik.argtypes = [C.c_int, C.c_int, fp, fp]
         _lib = L
     return _lib
+
+
+REF_LIB_PATH = os.path.join(_HERE, "_ref", "libdvo_ref.so")
+_ref = None
+
+
+def ref_lib():
+    """oracle/_ref/libdvo_ref.so: the reference's own SSE passes (see oracle/ref_bridge.cpp), or None when it could not be
+    built (no reference tree and no prebuilt library)."""
+    global _ref
+    if _ref is None:
+        build()
+        if not os.path.exists(REF_LIB_PATH):
+            return None
+        L = C.CDLL(REF_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.ref_compute_residuals.argtypes = [C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp]
+        L.ref_compute_weights.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp]
+        L.ref_compute_scale.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp]
+        L.ref_loglik.restype = C.c_float
+        L.ref_loglik.argtypes = [C.c_int, fp, fp, fp, fp]
+        L.ref_rank_update_2x6.argtypes = [C.c_int, fp, fp, fp]
+        L.ref_intrinsics_scale.argtypes = [fp, C.c_float, fp]
+        L.ref_convert_raw_depth.argtypes = [C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_float, fp]
+        _ref = L
+    return _ref
 
 
 def _fp(a):

@@ -1,5 +1,6 @@
 """CPU tier: pins the oracle (oracle/) against analytic identities, scipy / numpy restatements and the committed
-golden fixtures.  The reference has no tests of its own: "parity unpinned"."""
+golden fixtures.  The reference has no tests of its own; what can be pinned against the reference's own
+code is in tests/test_oracle_ref.py, the rest (driver, Jacobian, image model, SE(3)) is "parity unpinned"."""
 import numpy as np
 import pytest
 import scipy.linalg
