@@ -1,6 +1,6 @@
 /*
- * dvo_oracle.cpp -- CPU ORACLE (test infrastructure; parity status: dvo_oracle.h -- the SSE passes are pinned
- * against the reference's own code, the driver is "parity unpinned").
+ * dvo_oracle.cpp -- CPU ORACLE (test infrastructure; parity status: dvo_oracle.h -- the REF_SSE mode is pinned
+ * bit for bit against the reference's own translation units, oracle/_ref).
  *
  * A from-scratch restatement of the reference's dense RGB-D alignment path.  Every function cites
  * the reference lines (relative to /root/reference) whose behaviour it reproduces.  Build with
@@ -347,8 +347,10 @@ static void weights_pass(const float* res, int n, const float P[4], float* w, in
   for (; i < n; ++i) w[i] = float((2.0 + 5.0f) / (5.0f + mahalanobis(res + 2 * i, P)));
 }
 
-// Pass 3 (dense_tracking_impl.cpp:566-638): C = sum w r r^T / (n-3)
-static void scale_pass(const float* res, const float* w, int n, int mode, float C[3]) {
+// Pass 3 (dense_tracking_impl.cpp:566-638): C = sum w r r^T / (n-3).  C = {c00, c01, c11, c10}: the reference's scalar tail
+// (odd n) adds the full outer product (w d) d^T coefficient by coefficient, so c10 = (w y) x can differ from c01 = (w x) y
+// in the last bit; the SSE part writes one value to both.
+static void scale_pass(const float* res, const float* w, int n, int mode, float C[4]) {
   if (mode == DVO_ORACLE_REF_SSE) {
     const float scale = 1.0f / float(size_t(n) - 2 - 1);
     float a0 = 0, a1 = 0, a3 = 0;
@@ -360,13 +362,15 @@ static void scale_pass(const float* res, const float* w, int n, int mode, float 
       a1 = a1 + (scale * (w[i] * yx) + scale * (w[i + 1] * yx));
       a3 = a3 + (scale * (w[i] * yy) + scale * (w[i + 1] * yy));
     }
+    float a2 = a1;                              // covariance(1,0) = tmp[1]  (:629)
     if (n & 1) {
       const float x = res[2 * n2], y = res[2 * n2 + 1], ww = w[n2];
       a0 += scale * ((ww * x) * x);
       a1 += scale * ((ww * x) * y);
+      a2 += scale * ((ww * y) * x);
       a3 += scale * ((ww * y) * y);
     }
-    C[0] = a0; C[1] = a1; C[2] = a3;
+    C[0] = a0; C[1] = a1; C[2] = a3; C[3] = a2;
   } else {
     double s0 = 0, s1 = 0, s3 = 0;
     for (int i = 0; i < n; ++i) {
@@ -374,17 +378,17 @@ static void scale_pass(const float* res, const float* w, int n, int mode, float 
       s0 += ww * x * x; s1 += ww * x * y; s3 += ww * y * y;
     }
     const double d = double(n) - 3.0;
-    C[0] = float(s0 / d); C[1] = float(s1 / d); C[2] = float(s3 / d);
+    C[0] = float(s0 / d); C[1] = float(s1 / d); C[2] = float(s3 / d); C[3] = C[1];
   }
 }
 
-// Eigen 2x2 inverse (dense_tracking.cpp:295)
-static void invert2(const float C[3], float P[4]) {
-  const float det = C[0] * C[2] - C[1] * C[1];
+// Eigen 2x2 inverse (dense_tracking.cpp:295) of {c00, c01, c11, c10}; P row-major
+static void invert2(const float C[4], float P[4]) {
+  const float det = C[0] * C[2] - C[3] * C[1];
   const float inv = 1.0f / det;
   P[0] = C[2] * inv;
   P[1] = -C[1] * inv;
-  P[2] = -C[1] * inv;
+  P[2] = -C[3] * inv;
   P[3] = C[0] * inv;
 }
 
@@ -577,7 +581,7 @@ static int match_impl(oracle_pyramid* ref, oracle_pyramid* cur, const oracle_con
       }
       if (iteration == 0) std::fill(S.weights.p, S.weights.p + n, 1.0f);   // :286-289
       else weights_pass(S.residuals.p, n, P, S.weights.p, cfg.mode);
-      float Cv[3];
+      float Cv[4];
       scale_pass(S.residuals.p, S.weights.p, n, cfg.mode, Cv);
       invert2(Cv, P);                                           // :295
       const double ll = loglik_pass(S.residuals.p, n, P, cfg.mode);
@@ -641,7 +645,7 @@ using namespace oracle;
 
 extern "C" {
 
-const char* oracle_version(void) { return "dvo-oracle 2 (SSE passes pinned against oracle/_ref; driver parity unpinned: the reference has no tests/fixtures)"; }
+const char* oracle_version(void) { return "dvo-oracle 3 (REF_SSE pinned bit-exactly against the reference's own translation units, oracle/_ref)"; }
 
 oracle_pyramid* oracle_pyramid_create(int width, int height, const float K[4], const float* intensity, const float* depth, int levels) {
   if (width <= 0 || height <= 0 || levels < 1) return nullptr;
@@ -766,8 +770,10 @@ int oracle_level_iteration(oracle_pyramid* ref, oracle_pyramid* cur, int level, 
   double sw = 0;
   for (int i = 0; i < n; ++i) sw += S.weights.p[i];
   out->sum_w = sw;
-  scale_pass(S.residuals.p, S.weights.p, n, mode, out->scale_cov);
-  invert2(out->scale_cov, out->precision);
+  float Cv[4];
+  scale_pass(S.residuals.p, S.weights.p, n, mode, Cv);
+  invert2(Cv, out->precision);
+  std::memcpy(out->scale_cov, Cv, 3 * sizeof(float));
   out->neg_loglik = -loglik_pass(S.residuals.p, n, out->precision, mode);
   normal_equations(S.points_error.p, S.weights.p, n, out->precision, mode, out->A, out->b);
   return 0;
@@ -809,7 +815,7 @@ void oracle_pass_weight_vectors(const float K[4], float reference_weight[8], flo
 
 void oracle_pass_weights(int mode, int n, const float* residuals, const float P[4], float* weights) { weights_pass(residuals, n, P, weights, mode); }
 
-void oracle_pass_scale(int mode, int n, const float* residuals, const float* weights, float C[3]) { scale_pass(residuals, weights, n, mode, C); }
+void oracle_pass_scale(int mode, int n, const float* residuals, const float* weights, float C[4]) { scale_pass(residuals, weights, n, mode, C); }
 
 double oracle_pass_loglik(int mode, int n, const float* residuals, const float P[4]) { return loglik_pass(residuals, n, P, mode); }
 

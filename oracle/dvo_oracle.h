@@ -20,18 +20,15 @@
  *   SE(3) exp/log   Sophus (un-vendored, unpinned: sophus/Makefile:5-8) -- closed forms restated
  *
  * PARITY STATUS.  The reference ships no tests, golden vectors or fixtures for this path (SURVEY.md
- * section 4 / 8c) and cannot be built as a whole here (needs ROS, Eigen, OpenCV, Sophus, TBB, boost).
- *   PINNED against the reference's own code: the REF_SSE passes -- residuals (pass 1), weights (2),
- *     scale (3), log-likelihood (4), the 2x6 rank update of the normal equations (5b) -- plus
- *     IntrinsicMatrix::scale and the raw-depth ingest.  The reference translation units
- *     dense_tracking_impl.cpp, core/math_sse.cpp, core/intrinsic_matrix.cpp, core/surface_pyramid.cpp
- *     are compiled unmodified from /root/reference against stand-in headers for Eigen / OpenCV / boost
- *     (oracle/shim/, oracle/ref_bridge.cpp -> oracle/_ref/libdvo_ref.so) and
- *     tests/test_oracle_ref.py demands bit-identical outputs from the restatement.
- *   UNPINNED ("parity unpinned" for these): the Gauss-Newton driver, the Jacobian, the pyramid /
- *     derivative / selection code and SE(3) -- their translation units need Sophus, Eigen's solvers and
- *     OpenCV's image functions.  They are pinned only against analytic identities, scipy (expm/logm,
- *     solve), independent numpy restatements and the oracle's own two modes.
+ * section 4 / 8c) and cannot be built with its own build system here (needs ROS, Eigen, OpenCV, Sophus,
+ * TBB, boost).  The REF_SSE mode IS PINNED against the reference's own code: twelve dvo_core translation
+ * units (driver, SSE passes, normal equations, selection, image model, intrinsics, depth ingest) are
+ * compiled unmodified from /root/reference against stand-in headers for those libraries (oracle/shim/,
+ * oracle/ref_bridge.cpp -> oracle/_ref/libdvo_ref.so), and tests/test_oracle_ref.py demands bit-identical
+ * outputs pass by pass, for the image model, and for whole DenseTracker::match() runs.  SE(3) exp/log and
+ * the 6x6 solve are external dependencies of the reference (Sophus, Eigen: un-vendored, unpinned) -- the
+ * stand-ins use this oracle's closed forms for them, which are pinned against scipy instead.  The MATH mode
+ * (below) is REF_SSE minus its order-/ISA-dependent quirks and cannot be pinned against reference code.
  *
  * Two semantic modes:
  *   DVO_ORACLE_REF_SSE  quirk-faithful: approximate reciprocal (_mm_rcp_ps) in projection and
@@ -158,12 +155,12 @@ void oracle_rank_update_2x6(const float* J, int n, const float alpha[4], int mod
 
 /* The passes of one iteration on caller-supplied arrays, so that each can be pinned against the reference's own function
  * (oracle/_ref, tests/test_oracle_ref.py).  points: n x 12 floats (xyz1 + 8 channel values), accel: h x w x 8 floats,
- * T: row-major 3x4, P: row-major 2x2, C: {c00, c01, c11}. */
+ * T: row-major 3x4, P: row-major 2x2, C: {c00, c01, c11, c10}. */
 int oracle_pass_residuals(int mode, int n, const float* points, const float* accel, int w, int h, const float K[4], const float T[12],
                           float* out_points, float* out_residuals);
 void oracle_pass_weight_vectors(const float K[4], float reference_weight[8], float current_weight[8]);
 void oracle_pass_weights(int mode, int n, const float* residuals, const float P[4], float* weights);
-void oracle_pass_scale(int mode, int n, const float* residuals, const float* weights, float C[3]);
+void oracle_pass_scale(int mode, int n, const float* residuals, const float* weights, float C[4] /* c00 c01 c11 c10 */);
 double oracle_pass_loglik(int mode, int n, const float* residuals, const float P[4]);
 
 const char* oracle_version(void);

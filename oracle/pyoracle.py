@@ -122,6 +122,12 @@ def ref_lib():
         L.ref_rank_update_2x6.argtypes = [C.c_int, fp, fp, fp]
         L.ref_intrinsics_scale.argtypes = [fp, C.c_float, fp]
         L.ref_convert_raw_depth.argtypes = [C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_float, fp]
+        L.ref_match.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, fp, C.POINTER(Config), C.POINTER(Result), C.POINTER(LevelStats), C.c_int,
+                                C.POINTER(IterationStats), C.c_int]
+        L.ref_match_batch.restype = C.c_double
+        L.ref_match_batch.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), C.POINTER(Config),
+                                      C.POINTER(Result), C.c_int, C.c_int]
+        L.ref_level_planes.argtypes = [C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, C.POINTER(C.c_uint8), fp, fp]
         _ref = L
     return _ref
 
@@ -292,3 +298,60 @@ def rank_update_2x6(J, alpha, mode=MATH):
     A = np.zeros(36)
     lib().oracle_rank_update_2x6(_fp(J), J.shape[0], _fp(alpha), mode, _dp(A))
     return A.reshape(6, 6)
+
+
+def ref_match(intensity_ref, depth_ref, intensity_cur, depth_cur, K, cfg, T_init=None):
+    """The REFERENCE's DenseTracker::match (oracle/_ref), same dict layout as match()."""
+    L = ref_lib()
+    I0, Z0, I1, Z1 = [np.ascontiguousarray(a, dtype=np.float32) for a in (intensity_ref, depth_ref, intensity_cur, depth_cur)]
+    h, w = I0.shape
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    res = Result()
+    T0 = np.eye(4) if T_init is None else np.asarray(T_init, dtype=np.float64)
+    for i, v in enumerate(T0.reshape(-1)):
+        res.transformation[i] = v
+    nl = cfg.first_level - cfg.last_level + 1
+    cap_it = nl * (cfg.max_iterations_per_level + 1)
+    levels = (LevelStats * nl)()
+    iters = (IterationStats * cap_it)()
+    rc = L.ref_match(w, h, _fp(K), _fp(I0), _fp(Z0), _fp(I1), _fp(Z1), C.byref(cfg), C.byref(res), levels, nl, iters, cap_it)
+    if rc != 0:
+        raise RuntimeError("ref_match rc=%d" % rc)
+    return dict(T=np.array(res.transformation).reshape(4, 4), information=np.array(res.information).reshape(6, 6),
+                loglik=res.loglik, levels=_unpack_stats(res, levels, iters))
+
+
+def ref_level_planes(intensity, depth, K, level, want_points=False):
+    """Planes [6,h,w], selection mask, level intrinsics (and the selected points [n,12]) of the REFERENCE's image model."""
+    L = ref_lib()
+    I, Z = np.ascontiguousarray(intensity, np.float32), np.ascontiguousarray(depth, np.float32)
+    h, w = I.shape
+    lh, lw = h >> level, w >> level
+    planes = np.zeros((6, lh, lw), np.float32)
+    mask = np.zeros((lh, lw), np.uint8)
+    Kl = np.zeros(4, np.float32)
+    pts = np.zeros((lh * lw, 12), np.float32) if want_points else None
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    n = L.ref_level_planes(w, h, _fp(K), _fp(I), _fp(Z), level, _fp(planes), mask.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(Kl),
+                           _fp(pts) if want_points else None)
+    return dict(planes=planes, mask=mask, K=Kl, n_selected=n, points=None if pts is None else pts[:n])
+
+
+def ref_match_batch(planes, K, cfg, n_matches=None, nthreads=1, T_inits=None):
+    """Throughput of the REFERENCE's DenseTracker::match (oracle/_ref): planes = list of (I_ref, Z_ref, I_cur, Z_cur) float32
+    arrays; n_matches >= len(planes) matches are run round-robin on `nthreads` threads.  -> (T [n,4,4], seconds)."""
+    L = ref_lib()
+    n = len(planes)
+    n_matches = n_matches or n
+    keep = [[np.ascontiguousarray(p[k], dtype=np.float32) for p in planes] for k in range(4)]
+    h, w = keep[0][0].shape
+    fp = C.POINTER(C.c_float)
+    arrs = [(fp * n)(*[_fp(a) for a in keep[k]]) for k in range(4)]
+    results = (Result * n)()
+    for i in range(n):
+        T0 = np.eye(4) if T_inits is None else np.asarray(T_inits[i], dtype=np.float64)
+        for k, v in enumerate(T0.reshape(-1)):
+            results[i].transformation[k] = v
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    secs = L.ref_match_batch(n, w, h, _fp(K), arrs[0], arrs[1], arrs[2], arrs[3], C.byref(cfg), results, n_matches, nthreads)
+    return np.stack([np.array(results[i].transformation).reshape(4, 4) for i in range(n)]), secs

@@ -1,33 +1,26 @@
-// oracle/ref_bridge.cpp -- TEST INFRASTRUCTURE.  C entry points around the REFERENCE's own hot-path functions.
+// oracle/ref_bridge.cpp -- TEST INFRASTRUCTURE.  C entry points around the REFERENCE's own alignment code.
 //
-// oracle/_ref/libdvo_ref.so = the reference translation units dvo_core/src/dense_tracking_impl.cpp, core/math_sse.cpp,
-// core/intrinsic_matrix.cpp and core/surface_pyramid.cpp, compiled unmodified from /root/reference (never copied) against the stand-in headers in
-// oracle/shim/ (Eigen / OpenCV / boost are not installed here), plus this file.  It exists to PIN the oracle's REF_SSE mode:
-// tests/test_oracle_ref.py feeds both the same arrays and demands bit-identical outputs.  Nothing but tests may load it.
+// oracle/_ref/libdvo_ref.so = twelve translation units of dvo_core (oracle/Makefile: REF_UNITS -- the DenseTracker driver, its SSE
+// passes, the normal equations, point selection, the RGB-D image model, intrinsics, raw-depth ingest), compiled unmodified
+// from /root/reference (never copied) against the stand-in headers in oracle/shim/, plus this file.  It exists to PIN the
+// oracle: tests/test_oracle_ref.py feeds both the same arrays and compares.  Nothing but tests may load it.
 //
-// What is the reference's: every SSE pass (computeResidualsSse, computeWeightsSse, computeScaleSse), the scalar
-// computeCompleteDataLogLikelihood / computeWeights / computeScale, OptimizedSelfAdjointMatrix6x6f::rankUpdate / toEigen,
-// IntrinsicMatrix.  What the stand-ins supply inside those functions: the 3x3 * 3x4 float product K*T, 2x2 determinant, the
-// tiny fixed-size expression algebra of the scalar functions (oracle/shim/Eigen/Core).  What THIS file supplies: the five
-// trivial members of RgbdCamera / RgbdImage below, whose own translation unit (rgbd_image.cpp) needs all of OpenCV.
+// What is the reference's: every line of control flow and every float operation of DenseTracker::match(), the SSE passes,
+// pyramid / derivative / point-cloud / acceleration-structure / selection code.  What the stand-ins supply (none of it is in
+// /root/reference: Eigen, OpenCV, Sophus, boost, TBB are external, un-vendored dependencies): containers (cv::Mat,
+// fixed-size Eigen matrices, cv::merge), the small fixed-size algebra (K*T, 2x2 inverse / determinant, 1x2 * 2x6 products,
+// the b-vector update), SE(3) exp / log / compose and the 6x6 LDL^T solve -- the last two are the oracle's own
+// (oracle/se3_oracle.h), so a whole-match comparison isolates the driver's control flow and the float passes.
+#include <atomic>
+#include <chrono>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include <dvo/dense_tracking_impl.h>
 #include <dvo/core/surface_pyramid.h>
 
-namespace dvo {
-namespace core {
-// dvo_core/src/core/rgbd_image.cpp:186-208, without the point-cloud template (not used by the functions under test)
-RgbdCamera::RgbdCamera(size_t width, size_t height, const IntrinsicMatrix& intrinsics) : width_(width), height_(height), intrinsics_(intrinsics) {}
-RgbdCamera::~RgbdCamera() {}
-// dvo_core/src/core/rgbd_image.cpp:320-332
-RgbdImage::RgbdImage(const RgbdCamera& camera)
-    : width(0), height(0), intensity_requires_calculation_(true), depth_requires_calculation_(true), pointcloud_requires_build_(true), camera_(camera) {}
-RgbdImage::~RgbdImage() {}
-// dvo_core/src/core/rgbd_image.cpp:783-786
-bool RgbdImage::inImage(const float& x, const float& y) const { return x >= 0 && x < width && y >= 0 && y < height; }
-}  // namespace core
-}  // namespace dvo
+#include "dvo_oracle.h"   // result / statistics records shared with the oracle's C API
 
 using namespace dvo::core;
 
@@ -151,6 +144,188 @@ void ref_intrinsics_scale(const float K[4], float factor, float out[4]) {
   IntrinsicMatrix m = IntrinsicMatrix::create(K[0], K[1], K[2], K[3]);
   m.scale(factor);
   out[0] = m.fx(); out[1] = m.fy(); out[2] = m.ox(); out[3] = m.oy();
+}
+
+// DenseTracker::match(RgbdImagePyramid&, RgbdImagePyramid&, Result&) of the reference, dvo_core/src/dense_tracking.cpp:123-376, on
+// float planes (intensity 0..255, depth in metres, NaN = hole).  result->transformation is in/out.  cfg->mode is ignored.
+int ref_match(int w, int h, const float K[4], const float* ref_intensity, const float* ref_depth, const float* cur_intensity,
+              const float* cur_depth, const oracle_config* cfg, oracle_result* result, oracle_level_stats* levels, int cap_levels,
+              oracle_iteration_stats* iters, int cap_iters) {
+  IntrinsicMatrix intrinsics = IntrinsicMatrix::create(K[0], K[1], K[2], K[3]);
+  RgbdCameraPyramid camera(size_t(w), size_t(h), intrinsics);
+  dvo::DenseTracker::Config c = dvo::DenseTracker::getDefaultConfig();
+  c.FirstLevel = cfg->first_level;
+  c.LastLevel = cfg->last_level;
+  c.MaxIterationsPerLevel = cfg->max_iterations_per_level;
+  c.UseInitialEstimate = cfg->use_initial_estimate != 0;
+  c.Precision = cfg->precision;
+  c.Mu = cfg->mu;
+  c.IntensityDerivativeThreshold = cfg->intensity_derivative_threshold;
+  c.DepthDerivativeThreshold = cfg->depth_derivative_threshold;
+  camera.build(c.getNumLevels());
+  auto image = [&](const float* p) {
+    cv::Mat m(h, w, CV_32FC1);
+    std::memcpy(m.data, p, size_t(w) * h * sizeof(float));
+    return m;
+  };
+  RgbdImagePyramidPtr reference = camera.create(image(ref_intensity), image(ref_depth));
+  RgbdImagePyramidPtr current = camera.create(image(cur_intensity), image(cur_depth));
+
+  dvo::DenseTracker tracker(c);
+  dvo::DenseTracker::Result r;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) r.Transformation.matrix()(i, j) = result->transformation[i * 4 + j];
+  tracker.match(*reference, *current, r);
+
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) result->transformation[i * 4 + j] = r.Transformation.matrix()(i, j);
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) result->information[i * 6 + j] = r.Information(i, j);
+  result->loglik = r.LogLikelihood;
+  result->n_levels = int(r.Statistics.Levels.size());
+  int n_it = 0;
+  for (size_t l = 0; l < r.Statistics.Levels.size(); ++l) {
+    const dvo::DenseTracker::LevelStats& L = r.Statistics.Levels[l];
+    if (int(l) < cap_levels) {
+      oracle_level_stats& o = levels[l];
+      o.id = int(L.Id);
+      o.max_valid_pixels = int(L.MaxValidPixels);
+      o.valid_pixels = int(L.ValidPixels);
+      o.termination = int(L.TerminationCriterion);
+      o.n_iterations = int(L.Iterations.size());
+      o.first_iteration_index = n_it;
+    }
+    for (size_t k = 0; k < L.Iterations.size(); ++k, ++n_it) {
+      if (n_it >= cap_iters) continue;
+      const dvo::DenseTracker::IterationStats& I = L.Iterations[k];
+      oracle_iteration_stats& o = iters[n_it];
+      o.id = int(I.Id);
+      o.valid_constraints = int(I.ValidConstraints);
+      o.tdist_loglik = I.TDistributionLogLikelihood;
+      o.tdist_mean[0] = I.TDistributionMean(0);
+      o.tdist_mean[1] = I.TDistributionMean(1);
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) o.tdist_precision[a * 2 + b] = I.TDistributionPrecision(a, b);
+      o.prior_loglik = I.PriorLogLikelihood;
+      for (int a = 0; a < 6; ++a) o.increment[a] = I.EstimateIncrement(a);
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) o.information[a * 6 + b] = I.EstimateInformation(a, b);
+    }
+  }
+  result->n_iterations_total = n_it;
+  return 0;
+}
+
+// Throughput of the reference: n_matches DenseTracker::match() calls (match k aligns pair k % n_pairs) on `nthreads` host threads,
+// one tracker per thread, one match per thread at a time -- the reference's own threading model
+// (dvo_slam/src/keyframe_graph.cpp:576-593).  Pyramids, derivative planes and acceleration structures are built beforehand and
+// shared read-only; the point selection of the reference frame is part of every match, as in the reference.  Returns the wall
+// seconds of the match phase; results[k] (k < n_pairs) = last result of pair k.
+double ref_match_batch(int n_pairs, int w, int h, const float K[4], const float* const* ref_intensity, const float* const* ref_depth,
+                       const float* const* cur_intensity, const float* const* cur_depth, const oracle_config* cfg, oracle_result* results,
+                       int n_matches, int nthreads) {
+  IntrinsicMatrix intrinsics = IntrinsicMatrix::create(K[0], K[1], K[2], K[3]);
+  RgbdCameraPyramid camera(size_t(w), size_t(h), intrinsics);
+  dvo::DenseTracker::Config c = dvo::DenseTracker::getDefaultConfig();
+  c.FirstLevel = cfg->first_level;
+  c.LastLevel = cfg->last_level;
+  c.MaxIterationsPerLevel = cfg->max_iterations_per_level;
+  c.UseInitialEstimate = cfg->use_initial_estimate != 0;
+  c.Precision = cfg->precision;
+  c.Mu = cfg->mu;
+  c.IntensityDerivativeThreshold = cfg->intensity_derivative_threshold;
+  c.DepthDerivativeThreshold = cfg->depth_derivative_threshold;
+  camera.build(c.getNumLevels());
+  auto pyramid = [&](const float* I, const float* Z) {
+    cv::Mat mi(h, w, CV_32FC1), mz(h, w, CV_32FC1);
+    std::memcpy(mi.data, I, size_t(w) * h * sizeof(float));
+    std::memcpy(mz.data, Z, size_t(w) * h * sizeof(float));
+    RgbdImagePyramidPtr p = camera.create(mi, mz);
+    p->build(c.getNumLevels());
+    for (size_t l = 0; l < c.getNumLevels(); ++l) {
+      p->level(l).buildPointCloud();
+      p->level(l).buildAccelerationStructure();
+    }
+    return p;
+  };
+  std::vector<RgbdImagePyramidPtr> refs, curs;
+  for (int i = 0; i < n_pairs; ++i) {
+    refs.push_back(pyramid(ref_intensity[i], ref_depth[i]));
+    curs.push_back(pyramid(cur_intensity[i], cur_depth[i]));
+  }
+  std::vector<dvo::DenseTracker::Result> init(static_cast<size_t>(n_pairs)), last(static_cast<size_t>(n_pairs));
+  for (int p = 0; p < n_pairs; ++p)
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) init[size_t(p)].Transformation.matrix()(i, j) = results[p].transformation[i * 4 + j];
+  if (nthreads < 1) nthreads = 1;
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    dvo::DenseTracker tracker(c);
+    for (int k = next.fetch_add(1); k < n_matches; k = next.fetch_add(1)) {
+      const size_t p = size_t(k % n_pairs);
+      dvo::DenseTracker::Result r;
+      r.Transformation = init[p].Transformation;
+      tracker.match(*refs[p], *curs[p], r);
+      if (k >= n_matches - n_pairs) last[p] = r;          // exactly one writer per pair
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> threads;
+  for (int t = 1; t < nthreads; ++t) threads.emplace_back(work);
+  work();
+  for (auto& t : threads) t.join();
+  const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int p = 0; p < n_pairs && p < n_matches; ++p) {
+    const dvo::DenseTracker::Result& r = last[size_t(p)];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) results[p].transformation[i * 4 + j] = r.Transformation.matrix()(i, j);
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) results[p].information[i * 6 + j] = r.Information(i, j);
+    results[p].loglik = r.LogLikelihood;
+    results[p].n_levels = int(r.Statistics.Levels.size());
+    int n_it = 0;
+    for (size_t l = 0; l < r.Statistics.Levels.size(); ++l) n_it += int(r.Statistics.Levels[l].Iterations.size());
+    results[p].n_iterations_total = n_it;
+  }
+  return seconds;
+}
+
+// one level of the reference's image model (rgbd_image.cpp:156-172, 419-543; point_selection.cpp:89-152): the six planes
+// [6][h_l][w_l], the selection mask and (optionally) the selected points of pyramid level `level`; returns their number
+int ref_level_planes(int w, int h, const float K[4], const float* intensity, const float* depth, int level, float* planes,
+                     unsigned char* mask, float K_level[4], float* points /* n x 12 or null */) {
+  IntrinsicMatrix intrinsics = IntrinsicMatrix::create(K[0], K[1], K[2], K[3]);
+  RgbdCameraPyramid camera(size_t(w), size_t(h), intrinsics);
+  camera.build(size_t(level) + 1);
+  cv::Mat I(h, w, CV_32FC1), Z(h, w, CV_32FC1);
+  std::memcpy(I.data, intensity, size_t(w) * h * sizeof(float));
+  std::memcpy(Z.data, depth, size_t(w) * h * sizeof(float));
+  RgbdImagePyramidPtr pyramid = camera.create(I, Z);
+  pyramid->build(size_t(level) + 1);
+  RgbdImage& img = pyramid->level(size_t(level));
+  img.buildPointCloud();
+  img.buildAccelerationStructure();
+  const int lw = int(img.width), lh = int(img.height);
+  const cv::Mat* src[6] = {&img.intensity, &img.depth, &img.intensity_dx, &img.intensity_dy, &img.depth_dx, &img.depth_dy};
+  for (int p = 0; p < 6; ++p) std::memcpy(planes + size_t(p) * lw * lh, src[p]->data, size_t(lw) * lh * sizeof(float));
+  const IntrinsicMatrix& Kl = camera.level(size_t(level)).intrinsics();
+  K_level[0] = Kl.fx(); K_level[1] = Kl.fy(); K_level[2] = Kl.ox(); K_level[3] = Kl.oy();
+  // selection with the tracker's predicate at thresholds 0 (point_selection.h:49-67); the debug index marks the selected pixels
+  ValidPointAndGradientThresholdPredicate predicate;
+  PointSelection selection(*pyramid, predicate);
+  selection.debug(true);
+  PointSelection::PointIterator first, last;
+  selection.select(size_t(level), first, last);
+  const int n_selected = int(last - first);
+  cv::Mat index;
+  selection.getDebugIndex(size_t(level), index);
+  std::memcpy(mask, index.data, size_t(lw) * lh);
+  if (points)
+    for (int i = 0; i < n_selected; ++i) {
+      std::memcpy(points + size_t(i) * 12, (first + i)->point.data, 4 * sizeof(float));
+      std::memcpy(points + size_t(i) * 12 + 4, (first + i)->intensity_and_depth.data, 8 * sizeof(float));
+    }
+  return n_selected;
 }
 
 }  // extern "C"

@@ -1,0 +1,2 @@
+#pragma once
+#include "blocked_range.h"

@@ -1,6 +1,7 @@
 """CPU tier: pins the oracle (oracle/) against analytic identities, scipy / numpy restatements and the committed
-golden fixtures.  The reference has no tests of its own; what can be pinned against the reference's own
-code is in tests/test_oracle_ref.py, the rest (driver, Jacobian, image model, SE(3)) is "parity unpinned"."""
+golden fixtures.  The reference has no tests of its own; tests/test_oracle_ref.py pins the oracle's REF_SSE
+mode bit for bit against the reference's own translation units (oracle/_ref) -- this file covers what that cannot: SE(3) and
+the 6x6 solve (external dependencies of the reference), the MATH mode and its distance to REF_SSE."""
 import numpy as np
 import pytest
 import scipy.linalg
