@@ -127,6 +127,8 @@ def ref_lib():
         L.ref_match_batch.restype = C.c_double
         L.ref_match_batch.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), C.POINTER(Config),
                                       C.POINTER(Result), C.c_int, C.c_int]
+        L.ref_validate.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.POINTER(fp), C.POINTER(fp), C.POINTER(C.c_double), C.POINTER(Config), C.c_double,
+                                   C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int]
         L.ref_level_planes.argtypes = [C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, C.POINTER(C.c_uint8), fp, fp]
         _ref = L
     return _ref
@@ -355,3 +357,22 @@ def ref_match_batch(planes, K, cfg, n_matches=None, nthreads=1, T_inits=None):
     K = np.ascontiguousarray(K, dtype=np.float32)
     secs = L.ref_match_batch(n, w, h, _fp(K), arrs[0], arrs[1], arrs[2], arrs[3], C.byref(cfg), results, n_matches, nthreads)
     return np.stack([np.array(results[i].transformation).reshape(4, 4) for i in range(n)]), secs
+
+
+def ref_validate(intensity, depth, K, poses, odometry_cfg, min_constraint_ratio, min_entropy_coarse, min_entropy_fine, cross_threshold=1.0):
+    """The REFERENCE's ConstraintProposalValidator (oracle/_ref, see ref_bridge.cpp::ref_validate): the last keyframe against all
+    others.  -> list of dict(ref, cur, score, T) for the surviving proposals."""
+    L = ref_lib()
+    n = len(intensity)
+    keepI = [np.ascontiguousarray(a, np.float32) for a in intensity]
+    keepZ = [np.ascontiguousarray(a, np.float32) for a in depth]
+    h, w = keepI[0].shape
+    fp = C.POINTER(C.c_float)
+    I = (fp * n)(*[_fp(a) for a in keepI])
+    Z = (fp * n)(*[_fp(a) for a in keepZ])
+    P = np.ascontiguousarray(np.asarray(poses, np.float64).reshape(n, 16))
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    out = np.zeros((4 * n, 19))
+    m = L.ref_validate(n, w, h, _fp(K), I, Z, P.ctypes.data_as(C.POINTER(C.c_double)), C.byref(odometry_cfg), min_constraint_ratio,
+                       min_entropy_coarse, min_entropy_fine, cross_threshold, out.ctypes.data_as(C.POINTER(C.c_double)), 4 * n)
+    return [dict(ref=int(o[0]), cur=int(o[1]), score=float(o[2]), T=o[3:].reshape(4, 4).copy()) for o in out[:m]]

@@ -20,6 +20,8 @@
 #include <dvo/dense_tracking_impl.h>
 #include <dvo/core/surface_pyramid.h>
 
+#include <dvo_slam/constraints/constraint_proposal_validator.h>
+
 #include "dvo_oracle.h"   // result / statistics records shared with the oracle's C API
 
 using namespace dvo::core;
@@ -288,6 +290,87 @@ double ref_match_batch(int n_pairs, int w, int h, const float K[4], const float*
     results[p].n_iterations_total = n_it;
   }
   return seconds;
+}
+
+// The reference's ConstraintProposalValidator (dvo_slam/src/constraints/*.cpp) set up as KeyframeGraph does it
+// (dvo_slam/src/keyframe_graph.cpp:500-522, 819-838) on n_kf keyframes given as float planes: stage 1 = level first_level only
+// with the five voters, stage 2 = first_level -> 1 with three, thresholds passed in.  Every keyframe's evaluation baseline is the
+// log-likelihood of its own odometry to the neighbouring keyframe (keyframe_tracker.cpp:86-96).  Proposals: the LAST keyframe
+// against every other, with identity and with the relative map pose as initial guess (keyframe_graph.cpp:576-588).
+// out: per surviving proposal {reference id, current id, total score, T[16]} = 19 doubles.  Returns their number.
+int ref_validate(int n_kf, int w, int h, const float K[4], const float* const* intensity, const float* const* depth, const double* poses /* n x 16 */,
+                 const oracle_config* odometry_cfg, double min_constraint_ratio, double min_entropy_coarse, double min_entropy_fine,
+                 double cross_validation_threshold, double* out, int cap) {
+  using namespace dvo_slam;
+  using namespace dvo_slam::constraints;
+  auto config = [&](int first, int last) {
+    dvo::DenseTracker::Config c = dvo::DenseTracker::getDefaultConfig();
+    c.FirstLevel = first;
+    c.LastLevel = last;
+    c.Precision = odometry_cfg->precision;
+    c.UseInitialEstimate = true;
+    c.Mu = odometry_cfg->mu;
+    c.IntensityDerivativeThreshold = odometry_cfg->intensity_derivative_threshold;
+    c.DepthDerivativeThreshold = odometry_cfg->depth_derivative_threshold;
+    return c;
+  };
+  dvo::DenseTracker::Config odometry = config(odometry_cfg->first_level, odometry_cfg->last_level);
+  odometry.MaxIterationsPerLevel = odometry_cfg->max_iterations_per_level;
+  IntrinsicMatrix intrinsics = IntrinsicMatrix::create(K[0], K[1], K[2], K[3]);
+  RgbdCameraPyramid camera(size_t(w), size_t(h), intrinsics);
+  camera.build(odometry.getNumLevels());
+  std::vector<KeyframePtr> keyframes;
+  for (int k = 0; k < n_kf; ++k) {
+    cv::Mat mi(h, w, CV_32FC1), mz(h, w, CV_32FC1);
+    std::memcpy(mi.data, intensity[k], size_t(w) * h * sizeof(float));
+    std::memcpy(mz.data, depth[k], size_t(w) * h * sizeof(float));
+    KeyframePtr kf(new Keyframe());
+    Eigen::Affine3d pose;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) pose.matrix()(i, j) = poses[size_t(k) * 16 + i * 4 + j];
+    kf->id(short(k)).image(camera.create(mi, mz)).pose(pose);
+    keyframes.push_back(kf);
+  }
+  dvo::DenseTracker tracker(odometry);
+  for (int k = 0; k < n_kf; ++k) {
+    const int other = k + 1 < n_kf ? k + 1 : k - 1;
+    dvo::DenseTracker::Result r;
+    r.setIdentity();
+    tracker.match(*keyframes[size_t(k)]->image(), *keyframes[size_t(other)]->image(), r);
+    keyframes[size_t(k)]->evaluation(TrackingResultEvaluation::ConstPtr(new LogLikelihoodTrackingResultEvaluation(r)));
+  }
+  ConstraintProposalValidator validator;
+  validator.createStage(1)
+      .trackingConfig(config(odometry_cfg->first_level, odometry_cfg->first_level))
+      .keepAll()
+      .addVoter(new OdometryConstraintVoter())
+      .addVoter(new NaNResultVoter())
+      .addVoter(new ConstraintRatioVoter(min_constraint_ratio))
+      .addVoter(new TrackingResultEvaluationVoter(min_entropy_coarse))
+      .addVoter(new CrossValidationVoter(cross_validation_threshold));
+  validator.createStage(2)
+      .trackingConfig(config(odometry_cfg->first_level, 1))
+      .keepBest()
+      .addVoter(new NaNResultVoter())
+      .addVoter(new ConstraintRatioVoter(min_constraint_ratio))
+      .addVoter(new TrackingResultEvaluationVoter(min_entropy_fine));
+  ConstraintProposalVector proposals;
+  const KeyframePtr& newest = keyframes.back();
+  for (int k = 0; k + 1 < n_kf; ++k) {
+    proposals.push_back(ConstraintProposal::createWithIdentity(newest, keyframes[size_t(k)]));
+    proposals.push_back(ConstraintProposal::createWithRelative(newest, keyframes[size_t(k)]));
+  }
+  validator.validate(proposals);
+  int n_out = 0;
+  for (size_t i = 0; i < proposals.size() && n_out < cap; ++i, ++n_out) {
+    double* o = out + size_t(n_out) * 19;
+    o[0] = proposals[i]->Reference->id();
+    o[1] = proposals[i]->Current->id();
+    o[2] = proposals[i]->TotalScore();
+    for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < 4; ++b) o[3 + a * 4 + b] = proposals[i]->TrackingResult.Transformation.matrix()(a, b);
+  }
+  return n_out;
 }
 
 // one level of the reference's image model (rgbd_image.cpp:156-172, 419-543; point_selection.cpp:89-152): the six planes

@@ -4,6 +4,8 @@
 // closed forms (oracle/se3_oracle.h: unit quaternion + translation like Sophus::SO3/SE3, twist order (upsilon, omega)).
 #pragma once
 
+#include <sstream>   // (pulled in transitively by the real header; the reference relies on that)
+
 #include <Eigen/Core>
 #include <Eigen/Geometry>
 
@@ -17,6 +19,11 @@ class SE3d {
   SE3d() {}
   SE3d(const Eigen::Matrix3d& R, const Eigen::Vector3d& t) {
     double M[16] = {R(0, 0), R(0, 1), R(0, 2), t(0), R(1, 0), R(1, 1), R(1, 2), t(1), R(2, 0), R(2, 1), R(2, 2), t(2), 0, 0, 0, 1};
+    T_ = oracle::se3_from_matrix(M);
+  }
+  explicit SE3d(const Eigen::Matrix4d& m) {
+    double M[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) M[i * 4 + j] = m(i, j);
     T_ = oracle::se3_from_matrix(M);
   }
   static SE3d exp(const Tangent& x) {

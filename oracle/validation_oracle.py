@@ -4,7 +4,8 @@ Follows dvo_slam/src/constraints/constraint_proposal_validator.cpp:69-165 (stage
 abort, rejected-proposal removal, keepBest, initial-transformation hand-over), constraint_proposal_voter.cpp:34-211 (the
 five voters), constraint_proposal.cpp:30-110 and tracking_result_evaluation.cpp:27-62, one proposal at a time in list
 order exactly like the reference; `track` is injected (the oracle's sequential match(), or a table in the logic tests).
-Parity unpinned: the reference has no tests or fixtures for this code.
+Pinned: tests/test_oracle_ref.py::test_proposal_validation_restatement_is_the_references runs the reference's own validator,
+voters and evaluation classes (compiled into oracle/_ref) on a synthetic keyframe set and gets the same survivors, order and scores.
 """
 import numpy as np
 

@@ -213,3 +213,40 @@ def test_degenerate_matches_follow_the_reference_driver():
     o = po.match(po.Pyramid(Ig, Zg, pair["K"], 3), po.Pyramid(Ig, Zg, pair["K"], 3), cfg)
     assert [(L["termination"], len(L["iterations"])) for L in r["levels"]] == [(L["termination"], len(L["iterations"])) for L in o["levels"]]
     assert np.array_equal(r["T"], o["T"])
+
+
+def test_proposal_validation_restatement_is_the_references():
+    """oracle/validation_oracle.py (the sequential restatement the C++ facade's batched validator is tested against) vs the
+    reference's own ConstraintProposalValidator + voters + tracking-result evaluation (dvo_slam/src/constraints/*.cpp,
+    tracking_result_evaluation.cpp, compiled into oracle/_ref) driving the reference's own tracker: same survivors, same order,
+    same scores, same transforms."""
+    from dvo_slam_amd import datagen
+    from oracle import validation_oracle as vo
+    n, w, h = 9, 320, 240
+    seq = datagen.synth_sequence(9, n, w, h)
+    K = (np.array([517.3, 516.5, 318.6, 255.3]) * 0.5).astype(np.float32)
+    I = [seq["grey"][k].astype(np.float32) for k in range(n)]
+    Z = [po.convert_raw_depth(seq["depth"][k]) for k in range(n)]
+    thresholds = dict(min_constraint_ratio=0.17, min_entropy_coarse=0.005, min_entropy_fine=0.86)   # as in tests/test_validation.py
+    odometry = po.make_config(3, 1, 50, 1e-4, 0.05, True, mode=po.REF_SSE)
+    got = po.ref_validate(I, Z, K, seq["poses"], odometry, **thresholds)
+
+    kfs = [vo.Keyframe(k, po.Pyramid(I[k], Z[k], K, 4), seq["poses"][k]) for k in range(n)]
+    refine = po.make_config(3, 1, 100, 1e-4, 0.05, True, mode=po.REF_SSE)
+    screen = po.make_config(3, 3, 100, 1e-4, 0.05, True, mode=po.REF_SSE)
+    for k, kf in enumerate(kfs):
+        kf.evaluation = vo.LogLikelihoodEvaluation(po.match(kf.image, kfs[k + 1 if k + 1 < n else k - 1].image, odometry, np.eye(4)))
+    stages = [vo.Stage(1, screen, False, [vo.OdometryConstraintVoter(), vo.NaNResultVoter(), vo.ConstraintRatioVoter(0.17),
+                                          vo.TrackingResultEvaluationVoter(0.005), vo.CrossValidationVoter(1.0)]),
+              vo.Stage(2, refine, True, [vo.NaNResultVoter(), vo.ConstraintRatioVoter(0.17), vo.TrackingResultEvaluationVoter(0.86)])]
+    proposals = []
+    for k in range(n - 1):
+        proposals += [vo.Proposal.with_identity(kfs[-1], kfs[k]), vo.Proposal.with_relative(kfs[-1], kfs[k])]
+    want = vo.validate(stages, proposals, lambda stage, p: po.match(p.reference.image, p.current.image, stage.cfg, p.initial))
+    assert len(want) >= 3
+    assert [(g["ref"], g["cur"]) for g in got] == [(p.reference.id, p.current.id) for p in want]
+    for g, p in zip(got, want):
+        assert g["score"] == p.total_score()
+        # the stage hand-over inverts the transform with Eigen's Affine3d::inverse (a stand-in there, numpy's LU inverse here):
+        # the two runs start stage 2 a rounding error apart
+        assert np.abs(g["T"] - p.result["T"]).max() < 1e-12
