@@ -157,6 +157,14 @@ def test_full_match_against_oracle(gpu_ctx, seed, w, h, first, last, mu, init, p
     q = po.match(oref, ocur, cm.oracle_config_from(cfg, po.REF_SSE), T0)
     assert cm.twist_matrix_error(g["T"], q["T"]) < 5e-5
     assert np.abs(po.se3_log(g["T"]) - pair["xi_true"]).max() < 1e-4
+    # ... and against the REFERENCE ITSELF: its own DenseTracker::match(), compiled from /root/reference into oracle/_ref (the built
+    # library travels to the GPU box), on the same frames.  REF_SSE reproduces it bit for bit; the GPU within the quirk distance.
+    if po.ref_lib() is not None:
+        r = po.ref_match(pair["grey_ref"].astype(np.float32), po.convert_raw_depth(pair["depth_ref"]),
+                         pair["grey_cur"].astype(np.float32), po.convert_raw_depth(pair["depth_cur"]), pair["K"],
+                         cm.oracle_config_from(cfg, po.REF_SSE), T0)
+        assert np.array_equal(r["T"], q["T"]) and [len(L["iterations"]) for L in r["levels"]] == [len(L["iterations"]) for L in q["levels"]]
+        assert cm.twist_matrix_error(g["T"], r["T"]) < 5e-5
 
 
 def test_golden_full_match(gpu_ctx):
