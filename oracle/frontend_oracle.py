@@ -3,7 +3,8 @@
 Follows dvo_slam/src/local_tracker.cpp:133-216 (initNewLocalMap, update: keyframe + odometry alignment of every frame,
 accept callbacks with the all-must-agree combiner of local_tracker.h:46-70, keyframe hand-over) and the pose bookkeeping of
 dvo_slam/src/local_map.cpp:170-200, with the two alignments run one after the other through an injected `match`.
-Parity unpinned: the reference has no tests for this code.
+Pinned: tests/test_oracle_ref.py runs the reference's own keyframe_tracker.cpp + local_tracker.cpp + local_map.cpp (compiled unmodified
+into oracle/_ref) on the same frames and demands the same keyframe switches and poses.
 """
 import numpy as np
 

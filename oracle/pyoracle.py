@@ -376,3 +376,24 @@ def ref_validate(intensity, depth, K, poses, odometry_cfg, min_constraint_ratio,
     m = L.ref_validate(n, w, h, _fp(K), I, Z, P.ctypes.data_as(C.POINTER(C.c_double)), C.byref(odometry_cfg), min_constraint_ratio,
                        min_entropy_coarse, min_entropy_fine, cross_threshold, out.ctypes.data_as(C.POINTER(C.c_double)), 4 * n)
     return [dict(ref=int(o[0]), cur=int(o[1]), score=float(o[2]), T=o[3:].reshape(4, 4).copy()) for o in out[:m]]
+
+
+def ref_frontend(intensity, depth, K, tracking_cfg, max_translational_distance=0.2, min_entropy_ratio=0.91, min_constraint_ratio=0.33):
+    """The REFERENCE's tracking front end (oracle/_ref, see ref_bridge.cpp::ref_frontend): KeyframeTracker::update() frame by frame.
+    -> (poses [n,4,4], completed local maps after each frame [n])."""
+    L = ref_lib()
+    n = len(intensity)
+    keepI = [np.ascontiguousarray(a, np.float32) for a in intensity]
+    keepZ = [np.ascontiguousarray(a, np.float32) for a in depth]
+    h, w = keepI[0].shape
+    fp = C.POINTER(C.c_float)
+    I = (fp * n)(*[_fp(a) for a in keepI])
+    Z = (fp * n)(*[_fp(a) for a in keepZ])
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    poses = np.zeros((n, 16))
+    maps = np.zeros(n, np.int32)
+    L.ref_frontend.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.POINTER(fp), C.POINTER(fp), C.c_void_p, C.c_double, C.c_double, C.c_double,
+                               C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.ref_frontend(n, w, h, _fp(K), I, Z, C.cast(C.byref(tracking_cfg), C.c_void_p), max_translational_distance, min_entropy_ratio,
+                   min_constraint_ratio, poses.ctypes.data_as(C.POINTER(C.c_double)), maps.ctypes.data_as(C.POINTER(C.c_int)))
+    return poses.reshape(n, 4, 4), maps

@@ -21,6 +21,7 @@
 #include <dvo/core/surface_pyramid.h>
 
 #include <dvo_slam/constraints/constraint_proposal_validator.h>
+#include <dvo_slam/keyframe_tracker.h>
 
 #include "dvo_oracle.h"   // result / statistics records shared with the oracle's C API
 
@@ -409,6 +410,48 @@ int ref_level_planes(int w, int h, const float K[4], const float* intensity, con
       std::memcpy(points + size_t(i) * 12 + 4, (first + i)->intensity_and_depth.data, 8 * sizeof(float));
     }
   return n_selected;
+}
+
+// The reference's tracking front end, run as dvo_slam/src/camera_keyframe_tracking.cpp / benchmark_slam.cpp:327-383 run it:
+// KeyframeTracker::update() per frame (keyframe_tracker.cpp:225-245 -> LocalTracker, local_tracker.cpp:133-216 -> LocalMap,
+// local_map.cpp) with the five accept criteria of keyframe_tracker.cpp:60-72.  The pose-graph back end it hands completed local
+// maps to is a counting sink (ref_graph_stub.cpp).  out_pose: n x 16, out_maps: completed local maps after each frame.
+extern int g_ref_completed_local_maps;
+int ref_frontend(int n, int w, int h, const float K[4], const float* const* intensity, const float* const* depth, const oracle_config* tracking,
+                 double max_translational_distance, double min_entropy_ratio, double min_constraint_ratio, double* out_pose, int* out_maps) {
+  dvo::DenseTracker::Config cfg = dvo::DenseTracker::getDefaultConfig();
+  cfg.FirstLevel = tracking->first_level;
+  cfg.LastLevel = tracking->last_level;
+  cfg.MaxIterationsPerLevel = tracking->max_iterations_per_level;
+  cfg.Precision = tracking->precision;
+  cfg.UseInitialEstimate = tracking->use_initial_estimate != 0;
+  cfg.Mu = tracking->mu;
+  cfg.IntensityDerivativeThreshold = tracking->intensity_derivative_threshold;
+  cfg.DepthDerivativeThreshold = tracking->depth_derivative_threshold;
+  dvo_slam::KeyframeTrackerConfig selection;
+  selection.MaxTranslationalDistance = max_translational_distance;
+  selection.MinEntropyRatio = min_entropy_ratio;
+  selection.MinEquationSystemConstraintRatio = min_constraint_ratio;
+  IntrinsicMatrix intrinsics = IntrinsicMatrix::create(K[0], K[1], K[2], K[3]);
+  RgbdCameraPyramid camera(size_t(w), size_t(h), intrinsics);
+  camera.build(cfg.getNumLevels());
+  dvo_slam::KeyframeTracker tracker;
+  tracker.configureTracking(cfg);
+  tracker.configureKeyframeSelection(selection);
+  tracker.init();
+  g_ref_completed_local_maps = 0;
+  for (int k = 0; k < n; ++k) {
+    cv::Mat mi(h, w, CV_32FC1), mz(h, w, CV_32FC1);
+    std::memcpy(mi.data, intensity[k], size_t(w) * h * sizeof(float));
+    std::memcpy(mz.data, depth[k], size_t(w) * h * sizeof(float));
+    Eigen::Affine3d pose;
+    pose.setIdentity();
+    tracker.update(camera.create(mi, mz), ros::Time(double(k + 1) / 30.0), pose);
+    for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < 4; ++b) out_pose[size_t(k) * 16 + a * 4 + b] = pose.matrix()(a, b);
+    out_maps[k] = g_ref_completed_local_maps;
+  }
+  return 0;
 }
 
 }  // extern "C"

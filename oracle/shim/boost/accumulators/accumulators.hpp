@@ -1,6 +1,7 @@
 // oracle/shim/boost/accumulators/accumulators.hpp -- TEST INFRASTRUCTURE, see oracle/shim/Eigen/Core.  A running mean, all the
 // reference's stopwatch (dvo/util/stopwatch.h) asks of boost.accumulators.
 #pragma once
+#include <sstream>
 namespace boost {
 namespace accumulators {
 namespace tag { struct mean {}; }

@@ -1,0 +1,11 @@
+#pragma once
+#include "block_solver.h"
+namespace g2o {
+class OptimizationAlgorithmLevenberg : public OptimizationAlgorithm {
+ public:
+  explicit OptimizationAlgorithmLevenberg(Solver* s) : s_(s) {}
+  ~OptimizationAlgorithmLevenberg() { delete s_; }
+ private:
+  Solver* s_;
+};
+}  // namespace g2o

@@ -250,3 +250,33 @@ def test_proposal_validation_restatement_is_the_references():
         # the stage hand-over inverts the transform with Eigen's Affine3d::inverse (a stand-in there, numpy's LU inverse here):
         # the two runs start stage 2 a rounding error apart
         assert np.abs(g["T"] - p.result["T"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("max_distance,what", [(0.04, "distance and quality both bite"), (0.012, "the divergence overwrite fires on every frame")])
+def test_tracking_front_end_restatement_is_the_references(max_distance, what, capfd):
+    """oracle/frontend_oracle.py (LocalTracker + the KeyframeTracker accept criteria, the sequential restatement the C++ facade's
+    batched front end is tested against) vs the reference's own KeyframeTracker -> LocalTracker -> LocalMap
+    (dvo_slam/src/keyframe_tracker.cpp, local_tracker.cpp, local_map.cpp compiled into oracle/_ref) driving the reference's own
+    tracker: same keyframe switches, same poses."""
+    from dvo_slam_amd import datagen
+    from oracle import frontend_oracle as fo
+    n, w, h = 14, 192, 144
+    seq = datagen.synth_sequence(31, n, w, h)
+    K = (np.array([517.3, 516.5, 318.6, 255.3]) * (w / 640.0)).astype(np.float32)
+    I = [seq["grey"][k].astype(np.float32) for k in range(n)]
+    Z = [po.convert_raw_depth(seq["depth"][k]) for k in range(n)]
+    cfg = po.make_config(3, 1, 50, 1e-4, 0.05, True, mode=po.REF_SSE)
+    poses, maps = po.ref_frontend(I, Z, K, cfg, max_translational_distance=max_distance)
+    capfd.readouterr()                       # the reference narrates its divergence overwrite on stderr
+
+    frames = [po.Pyramid(I[k], Z[k], K, 4) for k in range(n)]
+    sel = fo.KeyframeSelection(max_translational_distance=max_distance)
+    lt = fo.LocalTracker(lambda a, b, T0: po.match(a, b, cfg, T0), sel.callbacks(), sel.on_map_initialized)
+    lt.init_new_local_map(frames[0], frames[1])
+    want = [(np.eye(4), False), (lt.current_pose.copy(), False)] + [lt.update(frames[k]) for k in range(2, n)]
+    completed = np.cumsum([int(s) for _, s in want])
+    print(what, completed)
+    assert 2 <= completed[-1] <= n - 2
+    assert np.array_equal(maps, completed)
+    # pose composition and the inverse of the keyframe estimate run through the Eigen stand-in there and numpy here
+    assert max(np.abs(p - q).max() for p, (q, _) in zip(poses, want)) < 1e-12
