@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--build-workgroups", type=int, default=-1, help="cap on the workgroups of a background build kernel (library option build_workgroups; -1 = bench default)")
     ap.add_argument("--no-overlap", action="store_true", help="build each batch right before its match on one frame set (no build/match overlap)")
+    ap.add_argument("--no-from-host", action="store_true", help="skip the PCIe-inclusive leg (raw planes handed over in pinned host memory)")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--iters-per-sync", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU dry runs)")
@@ -225,6 +226,52 @@ def main():
         lat.append((time.perf_counter() - t1) * 1e3)
     single_pair_ms = float(np.median(lat[2:]))
 
+    # PCIe-inclusive leg (never `value`): the same pipeline, but every step's raw planes are handed over in pinned HOST memory
+    # (SURVEY.md 8d config 4 "incl. H2D of 2 planes per frame") -- DMA on the upload stream, build on the build stream, match on
+    # the main stream, three batches in flight
+    from_host = None
+    if not args.no_from_host:
+        pinned = d.PinnedRawPlanes(ctx, 2 * B, W, H)
+        for i in range(B):
+            pinned.grey[i][:] = pairs_np["grey_ref"][i]
+            pinned.grey[B + i][:] = pairs_np["grey_cur"][i]
+            pinned.depth[i][:] = pairs_np["depth_ref"][i]
+            pinned.depth[B + i][:] = pairs_np["depth_cur"][i]
+
+        def host_build(k):
+            d.update_raw_host_batch(sets[k], pinned.grey, pinned.depth)
+            if n_sets > 1:
+                d.prepare_roles_batch(sets[k][:B], "reference", cfg)
+                d.prepare_roles_batch(sets[k][B:], "current", cfg)
+
+        def host_step(j):
+            host_build((j + 1) % n_sets)
+            out_h = tracker.match_batch_arrays(sets[j % n_sets][:B], sets[j % n_sets][B:])
+            return out_h
+
+        if n_sets > 1:
+            host_build(0)
+        for j in range(2):
+            host_step(j)
+        barrier()
+        t_h = time.perf_counter()
+        for j in range(args.steps):
+            out_h = host_step(j)
+        barrier()
+        el_h = time.perf_counter() - t_h
+        if world > 1:
+            t = torch.tensor([el_h], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_h = float(t.item())
+        bytes_step = 2 * B * W * H * 3
+        from_host = {"value": round(n_total * args.steps / el_h, 2), "unit": "alignments/s", "ms_per_step": round(el_h / args.steps * 1e3, 3),
+                     "h2d_bytes_per_step_per_gpu": bytes_step, "h2d_GBps_per_gpu": round(bytes_step * args.steps / el_h / 1e9, 2),
+                     "same_results": bool(np.array_equal(out_h["T"], last["T"])),
+                     "note": "raw planes (u8 grey + u16 depth of both frames of every pair, 1.84 MB per pair) DMA-ed from pinned host "
+                             "memory every step; reported beside `value`, never as it"}
+        d.upload_wait(ctx)
+        pinned.close()
+
     out = None
     if rank == 0:
         value = n_total * args.steps / elapsed
@@ -244,6 +291,7 @@ def main():
             "roofline": roofline,
             "match_only_ms_per_batch": round(match_only_ms, 3),
             "single_pair_ms": round(single_pair_ms, 3),
+            "from_host": from_host,
             "max_twist_error_vs_truth": twist_err, "nan_results": nan_results,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -110,6 +110,17 @@ struct dvo_hip_context {
   hipEvent_t build_events[kBuildRing] = {};
   unsigned long long build_seq = 0;          // last ticket issued
   unsigned long long main_waited_seq = 0;    // newest ticket the main stream already waits behind
+  // Host -> device transfers of raw planes (dvo_hip_frames_update_raw) have a stream of their own, so that the DMA of batch
+  // k+2 runs while batch k+1 is being built and batch k aligned.
+  // The planes land in one of kUploadRing contiguous device buffers (not in the frames' own staging areas), so that host planes
+  // that are adjacent in memory move in ONE transfer: a 0.9 MB copy per frame reaches ~30 GB/s, a whole batch per copy the link rate.
+  hipStream_t upload_stream = nullptr;
+  hipEvent_t upload_done = nullptr;
+  static const int kUploadRing = 3;
+  DevBuf upload_buf[kUploadRing];
+  unsigned long long upload_buf_seq[kUploadRing] = {};   // ticket of the build that reads the buffer's current contents
+  unsigned upload_next = 0;
+  unsigned long long upload_waited_seq = 0;  // newest build ticket the upload stream already waits behind
 };
 
 namespace {
@@ -172,19 +183,26 @@ int stamp_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames) {
   return DVO_HIP_OK;
 }
 
+// make `stream` (the main stream, or the upload stream about to overwrite a transfer buffer) wait for build ticket `need`
+int wait_for_ticket(dvo_hip_context* ctx, unsigned long long need, bool upload) {
+  unsigned long long& waited = upload ? ctx->upload_waited_seq : ctx->main_waited_seq;
+  hipStream_t stream = upload ? ctx->upload_stream : ctx->stream;
+  if (need <= waited) return DVO_HIP_OK;
+  // tickets older than the ring have had their event re-recorded for a newer ticket of the same stream: waiting for the
+  // oldest live one still orders us after `need`
+  const unsigned long long oldest_live = ctx->build_seq >= dvo_hip_context::kBuildRing ? ctx->build_seq - dvo_hip_context::kBuildRing + 1 : 1;
+  const unsigned long long use = need < oldest_live ? oldest_live : need;
+  DVO_HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->build_events[use % dvo_hip_context::kBuildRing], 0));
+  waited = use;
+  return DVO_HIP_OK;
+}
+
 // the main stream must not touch these frames before the build-stream work that produced them is done
 int wait_for_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames) {
   unsigned long long need = 0;
   for (int i = 0; i < n; ++i)
     if (frames[i] && frames[i]->built_seq > need) need = frames[i]->built_seq;
-  if (need <= ctx->main_waited_seq) return DVO_HIP_OK;
-  // tickets older than the ring have had their event re-recorded for a newer ticket of the same stream: waiting for the
-  // oldest live one still orders us after `need`
-  const unsigned long long oldest_live = ctx->build_seq >= dvo_hip_context::kBuildRing ? ctx->build_seq - dvo_hip_context::kBuildRing + 1 : 1;
-  const unsigned long long use = need < oldest_live ? oldest_live : need;
-  DVO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->build_events[use % dvo_hip_context::kBuildRing], 0));
-  ctx->main_waited_seq = use;
-  return DVO_HIP_OK;
+  return wait_for_ticket(ctx, need, /*upload=*/false);
 }
 
 const int kLlBlocksPerPair = 32;
@@ -694,6 +712,8 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
   e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->build_stream, hipStreamNonBlocking, prio_least);
   for (int i = 0; i < dvo_hip_context::kBuildRing && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->build_events[i], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->upload_done, hipEventDisableTiming);
   if (e != hipSuccess) {
     g_create_error = std::string("context setup (build stream): ") + hipGetErrorString(e);
     dvo_hip_context_destroy(ctx);
@@ -706,12 +726,16 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
 void dvo_hip_context_destroy(dvo_hip_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
   if (ctx->build_stream) (void)hipStreamSynchronize(ctx->build_stream);
   for (Workspace& w : ctx->ws) workspace_destroy(w);
+  if (ctx->upload_done) (void)hipEventDestroy(ctx->upload_done);
+  if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
   for (hipEvent_t ev : ctx->build_events)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->build_stream) (void)hipStreamDestroy(ctx->build_stream);
   for (DevBuf* b : {&ctx->misc, &ctx->build_tbl, &ctx->role_tbl_cur, &ctx->role_tbl_ref, &ctx->prep_tbl_cur, &ctx->prep_tbl_ref}) b->release();
+  for (DevBuf& b : ctx->upload_buf) b.release();
   for (CameraGeom* c : ctx->cameras) {
     c->tables.release();
     delete c;
@@ -838,6 +862,76 @@ int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip
   return frames_build(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale);
 }
 
+// Streaming ingest from HOST memory: DMA of the raw planes into a transfer buffer on the upload stream, then the batched
+// build on the build stream.  Returns at once; from pinned memory (dvo_hip_host_alloc) the transfers are truly asynchronous,
+// from pageable memory the runtime stages them (correct, but the call then blocks for most of the copy).
+int dvo_hip_frames_update_raw(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const uint8_t* const* grey,
+                              const uint16_t* const* raw_depth, float depth_scale) {
+  if (!ctx || n_frames < 1 || !frames || !grey || !raw_depth) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw: null argument");
+  for (int i = 0; i < n_frames; ++i) {
+    if (!frames[i] || !grey[i] || !raw_depth[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw: null entry");
+    if (frames[i]->cam != frames[0]->cam) return fail(ctx, DVO_HIP_ERR_INVALID, "frames of one build batch must share camera and levels");
+  }
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n = size_t(frames[0]->lv[0].w) * frames[0]->lv[0].h;
+  const size_t slot_bytes = (n * 3 + 1) & ~size_t(1);           // per frame: [u16 depth][u8 grey], padded to an even size
+  const unsigned b = ctx->upload_next++ % dvo_hip_context::kUploadRing;
+  DevBuf& buf = ctx->upload_buf[b];
+  // the previous contents of this buffer may still be read by the build they were uploaded for
+  int rc = wait_for_ticket(ctx, ctx->upload_buf_seq[b], /*upload=*/true);
+  if (rc != DVO_HIP_OK) return rc;
+  if (buf.bytes < slot_bytes * size_t(n_frames)) {
+    DVO_HIP_TRY(ctx, hipStreamSynchronize(ctx->build_stream));   // growing = free + malloc
+    DVO_HIP_TRY(ctx, buf.reserve(slot_bytes * size_t(n_frames)));
+  }
+  char* base = buf.as<char>();
+  std::vector<const void*> g(static_cast<size_t>(n_frames)), r(static_cast<size_t>(n_frames));
+  for (int i = 0; i < n_frames;) {
+    const char* hd = reinterpret_cast<const char*>(raw_depth[i]);
+    if (reinterpret_cast<const char*>(grey[i]) != hd + n * 2) {   // separate planes: two transfers for this frame
+      DVO_HIP_TRY(ctx, hipMemcpyAsync(base + slot_bytes * i, hd, n * 2, hipMemcpyHostToDevice, ctx->upload_stream));
+      DVO_HIP_TRY(ctx, hipMemcpyAsync(base + slot_bytes * i + n * 2, grey[i], n, hipMemcpyHostToDevice, ctx->upload_stream));
+      ++i;
+      continue;
+    }
+    int j = i + 1;                                               // frames in the slot layout that follow each other in host memory
+    while (j < n_frames && reinterpret_cast<const char*>(raw_depth[j]) == hd + slot_bytes * size_t(j - i) &&
+           reinterpret_cast<const char*>(grey[j]) == reinterpret_cast<const char*>(raw_depth[j]) + n * 2)
+      ++j;
+    DVO_HIP_TRY(ctx, hipMemcpyAsync(base + slot_bytes * i, hd, slot_bytes * size_t(j - i), hipMemcpyHostToDevice, ctx->upload_stream));
+    i = j;
+  }
+  for (int i = 0; i < n_frames; ++i) {
+    r[size_t(i)] = base + slot_bytes * i;
+    g[size_t(i)] = base + slot_bytes * i + n * 2;
+  }
+  DVO_HIP_TRY(ctx, hipEventRecord(ctx->upload_done, ctx->upload_stream));
+  DVO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->build_stream, ctx->upload_done, 0));
+  rc = frames_build(ctx, n_frames, frames, g.data(), r.data(), depth_scale);
+  if (rc == DVO_HIP_OK) ctx->upload_buf_seq[b] = ctx->build_seq;
+  return rc;
+}
+
+int dvo_hip_upload_wait(dvo_hip_context* ctx) {
+  if (!ctx) return DVO_HIP_ERR_INVALID;
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DVO_HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_stream));
+  return DVO_HIP_OK;
+}
+
+int dvo_hip_host_alloc(dvo_hip_context* ctx, size_t bytes, void** out) {
+  if (!ctx || !out || bytes == 0) return fail(ctx, DVO_HIP_ERR_INVALID, "host_alloc: bad argument");
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DVO_HIP_TRY(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return DVO_HIP_OK;
+}
+
+void dvo_hip_host_free(dvo_hip_context* ctx, void* p) {
+  if (!p) return;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  (void)hipHostFree(p);
+}
+
 int dvo_hip_frames_prepare(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, int role, const dvo_hip_config* cfg) {
   if (!ctx || n_frames < 1 || !frames || !cfg || (role != DVO_HIP_ROLE_CURRENT && role != DVO_HIP_ROLE_REFERENCE))
     return fail(ctx, DVO_HIP_ERR_INVALID, "frames_prepare: bad argument");
@@ -870,6 +964,7 @@ void dvo_hip_frame_destroy(dvo_hip_context* ctx, dvo_hip_frame* frame) {
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
     if (ctx->build_stream) (void)hipStreamSynchronize(ctx->build_stream);
   }
   frame->pool.release();

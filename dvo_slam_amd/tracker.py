@@ -302,6 +302,47 @@ def update_raw_device_batch(pyramids, grey_dev_ptrs, depth_dev_ptrs, depth_scale
     ctx.check(ctx._lib.dvo_hip_frames_update_raw_device(ctx.ptr, n, fr, g, z, depth_scale))
 
 
+class PinnedRawPlanes:
+    """Page-locked host memory for the raw planes of n frames (dvo_hip_host_alloc), laid out per frame as [u16 depth][u8 grey]
+    so that a frame moves to the device in one transfer.  `depth[i]` / `grey[i]` are numpy views a decoder writes into."""
+
+    def __init__(self, ctx, n, width, height):
+        self.ctx, self.n, self.npx = ctx, n, width * height
+        stride = (self.npx * 3 + 1) & ~1                     # frames that follow each other at this stride move in one transfer
+        ptr = C.c_void_p()
+        ctx.check(ctx._lib.dvo_hip_host_alloc(ctx.ptr, n * stride, C.byref(ptr)))
+        self.ptr = ptr
+        raw = (C.c_uint8 * (n * stride)).from_address(ptr.value)
+        block = np.frombuffer(raw, dtype=np.uint8).reshape(n, stride)
+        self.depth = [block[i, :self.npx * 2].view(np.uint16).reshape(height, width) for i in range(n)]
+        self.grey = [block[i, self.npx * 2:self.npx * 3].reshape(height, width) for i in range(n)]
+
+    def close(self):
+        if self.ptr is not None:
+            self.depth = self.grey = None
+            self.ctx._lib.dvo_hip_host_free(self.ctx.ptr, self.ptr)
+            self.ptr = None
+
+
+def update_raw_host_batch(pyramids, grey_host, depth_host, depth_scale=1.0 / 5000.0):
+    """Re-ingest raw planes from HOST arrays (uint8 / uint16, C-contiguous) into n existing pyramids: asynchronous DMA on the
+    context's upload stream, then the batched build (dvo_hip_frames_update_raw).  The arrays must stay unchanged until
+    upload_wait() or until a match on these pyramids has returned."""
+    n = len(pyramids)
+    ctx = pyramids[0].ctx
+    vp = C.c_void_p
+    for g, z in zip(grey_host, depth_host):
+        assert g.dtype == np.uint8 and z.dtype == np.uint16 and g.flags.c_contiguous and z.flags.c_contiguous
+    fr = (vp * n)(*[p.ptr for p in pyramids])
+    g = (vp * n)(*[vp(a.ctypes.data) for a in grey_host])
+    z = (vp * n)(*[vp(a.ctypes.data) for a in depth_host])
+    ctx.check(ctx._lib.dvo_hip_frames_update_raw(ctx.ptr, n, fr, g, z, depth_scale))
+
+
+def upload_wait(ctx):
+    ctx.check(ctx._lib.dvo_hip_upload_wait(ctx.ptr))
+
+
 def prepare_roles_batch(pyramids, role, config):
     """Build the role planes of n pyramids ahead of time and asynchronously (dvo_hip_frames_prepare): role "current" = sampling
     planes, "reference" = point selection for config's thresholds.  Together with update_raw_device_batch this runs on the

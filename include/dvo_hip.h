@@ -138,6 +138,21 @@ int dvo_hip_frame_update_raw_device(dvo_hip_context* ctx, dvo_hip_frame* frame, 
 /* The same for n frames of one camera in one launch per pyramid level (blockIdx.z = frame). */
 int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames,
                                      const void* const* grey_dev, const void* const* raw_depth_dev, float depth_scale);
+/* The same from HOST memory: the raw planes are transferred on an upload stream of the context (DMA), the build follows on
+ * the build stream; the call returns at once.  With planes in pinned memory (dvo_hip_host_alloc) the transfer of the next
+ * batch overlaps the build and the alignment of earlier ones.  A frame whose grey plane directly follows its depth plane
+ * (grey == (uint8_t*)(raw_depth + w*h)) moves in one transfer, and so does a run of such frames that follow each other in
+ * host memory at a stride of 3*w*h bytes rounded up to even (one 0.9 MB transfer per 640x480 frame reaches ~30 GB/s, a
+ * whole batch per transfer the link rate).  The host planes must stay unchanged until
+ * dvo_hip_upload_wait() returns (or until a dvo_hip_match* call that uses the frames has returned).
+ * Replaces the per-frame cv::imread -> convert -> RgbdCameraPyramid::create hand-over (dvo_benchmark/src/benchmark_slam.cpp:46-93,
+ * dvo_ros/src/camera_dense_tracking.cpp:243) for a stream of frames. */
+int dvo_hip_frames_update_raw(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames,
+                              const uint8_t* const* grey, const uint16_t* const* raw_depth, float depth_scale);
+int dvo_hip_upload_wait(dvo_hip_context* ctx);
+/* pinned (page-locked) host memory for raw planes: decoders / camera drivers write here, uploads from it are asynchronous */
+int dvo_hip_host_alloc(dvo_hip_context* ctx, size_t bytes, void** out);
+void dvo_hip_host_free(dvo_hip_context* ctx, void* p);
 /* Build the role planes of n frames ahead of time, asynchronously: role CURRENT = the sampling planes of
  * RgbdImage::buildAccelerationStructure (dvo_core/src/core/rgbd_image.cpp:534-543), role REFERENCE = the point selection of
  * PointSelection::select for cfg's thresholds (dvo_core/src/core/point_selection.cpp:89-152), levels cfg->last_level ..

@@ -366,3 +366,57 @@ def test_device_ingest_prepare_and_background_build(gpu_ctx):
     for g, z, _, _ in dev:
         hip.hipFree(C.c_void_p(g))
         hip.hipFree(C.c_void_p(z))
+
+
+@pytest.mark.gpu
+def test_streaming_upload_from_host_memory(gpu_ctx):
+    """dvo_hip_frames_update_raw: raw planes handed over in host memory (pinned block in the frame layout, pinned but separate
+    planes, plain pageable numpy arrays) and DMA-ed on the upload stream while OTHER frames are aligned -- bit-identical results
+    to frames created synchronously from the same planes, batch after batch on the same frame objects."""
+    n, w, h = 5, 320, 240
+    cfg = d.Config(FirstLevel=2, LastLevel=0)
+    trk = d.DenseTracker(cfg, gpu_ctx)
+    cam = d.RgbdCameraPyramid(w, h, po.FR1_K * 0.5, gpu_ctx)
+    cam.build(3)
+    batches = [datagen.synth_batch(seed, n, w, h) for seed in (300, 400, 500)]
+
+    def raw(out):
+        return b"".join(np.ascontiguousarray(out[k]).tobytes() for k in ("T", "information", "loglik", "n_iterations", "entropy"))
+    base = []
+    for b in batches:
+        refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)]
+        curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)]
+        base.append(raw(trk.match_batch_arrays(refs, curs)))
+    assert len(set(base)) == 3
+
+    pinned = [d.PinnedRawPlanes(gpu_ctx, 2 * n, w, h) for _ in batches]
+    for P, b in zip(pinned, batches):
+        for i in range(n):
+            P.grey[i][:], P.depth[i][:] = b["grey_ref"][i], b["depth_ref"][i]
+            P.grey[n + i][:], P.depth[n + i][:] = b["grey_cur"][i], b["depth_cur"][i]
+    sets = [[cam.create_raw(batches[0]["grey_ref"][0], batches[0]["depth_ref"][0]) for _ in range(2 * n)] for _ in range(2)]
+    # pipeline: upload + build batch k+1 into one frame set while batch k is aligned on the other
+    d.update_raw_host_batch(sets[0], pinned[0].grey, pinned[0].depth)
+    for rounds in range(2):
+        for k in range(3):
+            nxt = (k + 1) % 3
+            j = (rounds * 3 + k) % 2
+            d.update_raw_host_batch(sets[1 - j], pinned[nxt].grey, pinned[nxt].depth)
+            d.prepare_roles_batch(sets[1 - j][:n], "reference", cfg)
+            d.prepare_roles_batch(sets[1 - j][n:], "current", cfg)
+            assert raw(trk.match_batch_arrays(sets[j][:n], sets[j][n:])) == base[k]
+    d.upload_wait(gpu_ctx)
+    # separate (non-adjacent) planes take the two-transfer path; pageable memory is staged by the runtime
+    b = batches[1]
+    grey = [np.ascontiguousarray(a) for a in list(b["grey_ref"]) + list(b["grey_cur"])]
+    depth = [np.ascontiguousarray(a) for a in list(b["depth_ref"]) + list(b["depth_cur"])]
+    d.update_raw_host_batch(sets[0], grey, depth)
+    d.upload_wait(gpu_ctx)
+    assert raw(trk.match_batch_arrays(sets[0][:n], sets[0][n:])) == base[1]
+    d.update_raw_host_batch(sets[0], pinned[2].grey[::-1][:2 * n][::-1], pinned[2].depth)     # same planes, list rebuilt
+    assert raw(trk.match_batch_arrays(sets[0][:n], sets[0][n:])) == base[2]
+    with pytest.raises(AssertionError):
+        d.update_raw_host_batch(sets[0], [g.astype(np.float32) for g in grey], depth)
+    del sets
+    for P in pinned:
+        P.close()
