@@ -77,6 +77,8 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   const int n_px = g.w * g.h;
   const float inv_w = 1.0f / float(g.w);
   const float tx_u = LINEAR ? 0.0f : g.tx[col_ok ? u_r : 0];  // column term of the back-projection: constant over the rows
+  const float cx_u = fmaf(tx_u, tx_u, 1.0f);
+  const float P2x = Pp[1] + Pp[2];
 
   __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kSlabFloats];
   __shared__ float gram[kWavesPerBlock][256];
@@ -90,56 +92,55 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   int n_valid = 0;
 
-  // the reference row of iteration k+1 is requested before row k is processed: one of the two dependent memory round trips
-  // of a row (reference pixel -> projected tap addresses) is taken off the critical path for 4 registers
-  auto load_ref = [&](int v_r) {
-    float4 r = make_float4(nanv, 0.0f, 0.0f, 0.0f);
-    if (LINEAR) {
-      if (v_r * kTileW + lane < n_px) r = refR[v_r * kTileW + lane];
-    } else {
-      if (col_ok && v_r < g.h) r = refR[v_r * g.w + u_r];     // 64 lanes x 16 B = 1 KiB contiguous per wave
-    }
-    return r;
+  // The row is straight-line code with two divergent regions (tap fetch; constraint / no constraint): no nested early exits
+  // and no per-exit default values (pixel_math.h, the *_flat stages); the reference rows alternate between two register quads
+  // (rows are processed in pairs) instead of being copied.  The reference row of iteration k+1 is requested before row k is
+  // processed: one of the two dependent memory round trips of a row (reference pixel -> projected tap addresses) is off the
+  // critical path.  (Measured and dropped: reading all sixteen matrix operands of a row behind a scheduling barrier before
+  // the first matrix instruction, +15 %; one residual store per branch instead of a select, no gain; tap fetches of lanes
+  // without a usable projection redirected to tap 0 instead of branched around, no gain.)
+  const float P00 = Pp[0], P11 = Pp[3];
+  const int u_c = LINEAR ? lane : min(u_r, g.w - 1);
+  auto load_ref = [&](int v_r) {                              // clamped: rows / segments past the end are masked by in_image
+    const int idx = LINEAR ? min(v_r * kTileW + lane, n_px - 1) : min(v_r, g.h - 1) * g.w + u_c;
+    return refR[idx];                                         // tiled: 64 lanes x 16 B = 1 KiB contiguous per wave
   };
-  float4 ref_next = load_ref(row0);
-#pragma unroll 1
-  for (int k = 0; k < RPW; ++k) {
-    const int v_r = row0 + k * kWavesPerBlock;               // scalar: image row (tiled) or segment (linear)
-    const float4 ref = ref_next;
-    if (k + 1 < RPW) ref_next = load_ref(v_r + kWavesPerBlock);
+  auto sweep_row = [&](int v_r, const float4 ref) __attribute__((always_inline)) {
     bool in_image;
     size_t pix;                                               // index of this lane's pixel in the level
-    float tx_p, ty_p;
+    float tx_p, ty_p, cx;
     if constexpr (LINEAR) {
       const int idx = v_r * kTileW + lane;
       in_image = idx < n_px;
       pix = size_t(idx);
-      // row and column of the pixel: idx < 2^24, so one float multiply lands within one row of the quotient
       const int pc = in_image ? idx : 0;
-      int row = int(float(pc) * inv_w);
+      int row = int(float(pc) * inv_w);                       // idx < 2^24: one float multiply lands within one row of the quotient
       int col = pc - row * g.w;
       if (col < 0) { col += g.w; row -= 1; }
       if (col >= g.w) { col -= g.w; row += 1; }
       tx_p = g.tx[col];
       ty_p = g.ty[row];
+      cx = fmaf(tx_p, tx_p, 1.0f);
     } else {
       in_image = col_ok && v_r < g.h;
       pix = size_t(v_r) * g.w + u_r;                          // scalar row offset + lane
       tx_p = tx_u;
       ty_p = g.ty[min(v_r, g.h - 1)];
+      cx = cx_u;
     }
-    const PixelProj p = pixel_project_at(g, KT, ref, tx_p, ty_p);
+    const PixelProj p = pixel_project_flat(g, KT, in_image ? ref.x : nanv, tx_p, ty_p);
     PixelTaps t;
-    if (p.ok) pixel_fetch(g, curA, curB, p, t);
+    if (p.ok) pixel_fetch(g, curA, curB, p, t);               // lanes without a usable projection are masked out of `valid`
     PixelTerms o;
-    const bool valid = p.ok && pixel_finish(g, ref, p, t, o);
-    if (in_image) scratch[pix_base + pix] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);
-    n_valid += __popcll(__ballot(valid));                    // exact count on the scalar unit
+    const bool valid = pixel_finish_flat(g, ref, p, t, o) && p.ok;
+    n_valid += __popcll(__ballot(valid));                     // exact count on the scalar unit
+    if (in_image) scratch[pix_base + pix] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);   // one full-width store
     if (valid) {
-      // t-distribution weight with the PREVIOUS pass' precision (Q11); first pass on a level: w = 1
-      const float sw = first ? 1.0f : tdist_weight_sqrt(o.r0, o.r1, Pp);
+      // t-distribution weight with the PREVIOUS pass' precision (Q11); first pass on a level: w = 1.  sqrt(w) is folded into
+      // the four gradient factors of the Jacobian rows.
+      const float sw = first ? 1.0f : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
       float J0[6], J1[6];
-      jacobian_rows_scaled(o, sw, J0, J1);                   // sqrt(w) folded into the four gradient factors
+      jacobian_rows_fast(o, sw, tx_p, ty_p, cx, fmaf(ty_p, ty_p, 1.0f), J0, J1);
       wr[0] = f32x4{J0[0], J0[1], J0[2], J0[3]};
       wr[kQuadStride / 4] = f32x4{J0[4], J0[5], J1[0], J1[1]};
       wr[2 * (kQuadStride / 4)] = f32x4{J1[2], J1[3], J1[4], J1[5]};
@@ -153,19 +154,30 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
       wr[2 * (kQuadStride / 4)] = zero;
       wr[3 * (kQuadStride / 4)] = zero;
     }
-    // the slab is private to this wavefront and LDS executes a wavefront's operations in order: only the
-    // compiler has to be kept from moving the reads above the writes
+    // the slab is private to this wavefront and LDS executes a wavefront's operations in order: only the compiler has to
+    // be kept from moving the reads above the writes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int grp = 0; grp < 16; grp += 2) {                  // 4 pixels per MFMA, two independent accumulator chains
+    for (int grp = 0; grp < 16; grp += 2) {                   // 4 pixels per MFMA, two independent accumulator chains
       const float a0 = rd[grp * 16], a1 = rd[grp * 16 + 16];
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc1, 0, 0, 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  };
+  float4 ref_a = load_ref(row0), ref_b = ref_a;
+#pragma unroll 1
+  for (int k = 0; k < RPW; k += 2) {
+    const int v_r = row0 + k * kWavesPerBlock;                // scalar: image row (tiled) or segment (linear)
+    if (k + 1 < RPW) ref_b = load_ref(v_r + kWavesPerBlock);
+    sweep_row(v_r, ref_a);
+    if (k + 1 < RPW) {
+      if (k + 2 < RPW) ref_a = load_ref(v_r + 2 * kWavesPerBlock);
+      sweep_row(v_r + kWavesPerBlock, ref_b);
+    }
   }
 
   // lane l, register i holds G[row (l>>4)*4 + i][col l&15] of this wavefront's rows

@@ -204,6 +204,88 @@ DVO_HD void jacobian_rows_scaled(const PixelTerms& t, float s, float* J0, float*
 
 DVO_HD void jacobian_rows(const PixelTerms& t, float* J0, float* J1) { jacobian_rows_scaled(t, 1.0f, J0, J1); }
 
+// ---- the same stages as straight-line code (what the matrix-core sweep runs) ------------------------------------------------
+// No early exits: every lane computes everything and carries one predicate, so the row has no nested divergent regions and
+// no per-exit default values.  The arithmetic is that of the stages above, bit for bit (valid count and residuals equal the
+// oracle's MATH mode: correctly rounded divisions, no contraction, the reference's operation order) -- tests/emul checks the
+// two forms against each other.  (Measured and dropped: fused multiply-adds throughout, u = qx * rcp(qz), the blend as four
+// shared tap weights -- 35 fewer vector instructions per pixel, not a microsecond faster in the sweep, which is not bound by
+// vector-ALU issue)
+DVO_HD PixelProj pixel_project_flat(const LevelGeom& g, const float* KT, float Z, float tx, float ty) {
+#pragma clang fp contract(off)
+  PixelProj p;
+  p.Z = Z;                                          // NaN = not selected / no depth / outside the image (Q19): fails the bounds test
+  const float X = tx * Z, Y = ty * Z;               // rgbd_image.cpp:258
+  p.X = X; p.Y = Y;
+  const float qx = (KT[0] * X + KT[1] * Y) + (KT[2] * Z + KT[3]);
+  const float qy = (KT[4] * X + KT[5] * Y) + (KT[6] * Z + KT[7]);
+  const float qz = (KT[8] * X + KT[9] * Y) + (KT[10] * Z + KT[11]);
+  p.qz = qz;
+  const float u = qx / qz, v = qy / qz;             // correctly rounded division (MATH semantics, Q1)
+  p.ok = u >= 0.0f && u <= float(g.w - 2) && v >= 0.0f && v <= float(g.h - 2);   // Q4; false for NaN
+  const float uf = floorf(u), vf = floorf(v);
+  p.a1 = u - uf;
+  p.b1 = v - vf;
+  p.base = int(vf) * g.w + int(uf);                 // meaningless unless ok
+  return p;
+}
+
+// blend, NaN / occlusion tests, residual and gradient rows of a lane whose taps were fetched; everything is computed, the
+// return value says whether the pixel is a constraint
+DVO_HD bool pixel_finish_flat(const LevelGeom& g, const float4 ref, const PixelProj& p, const PixelTaps& t, PixelTerms& o) {
+#pragma clang fp contract(off)
+  const float a1 = p.a1, a0 = 1.0f - a1, b1 = p.b1, b0 = 1.0f - b1;
+#define DVO_BILERP(f) (b0 * (a0 * t.A00.f + a1 * t.A10.f) + b1 * (a0 * t.A01.f + a1 * t.A11.f))
+  const float cI = DVO_BILERP(x), cZ = DVO_BILERP(y);
+#undef DVO_BILERP
+#define DVO_BILERP_FMA(v00, v10, v01, v11) fmaf(b1, fmaf(a1, v11, a0 * (v01)), b0 * fmaf(a1, v10, a0 * (v00)))
+  const float cIx = DVO_BILERP_FMA(t.A00.z, t.A10.z, t.A01.z, t.A11.z);
+  const float cIy = DVO_BILERP_FMA(t.A00.w, t.A10.w, t.A01.w, t.A11.w);
+  const float cZx = DVO_BILERP_FMA(t.B00.x, t.B10.x, t.B01.x, t.B11.x);
+  const float cZy = DVO_BILERP_FMA(t.B00.y, t.B10.y, t.B01.y, t.B11.y);
+#undef DVO_BILERP_FMA
+  const float inv255 = 1.0f / 255.0f;
+  o.r0 = inv255 * cI + (-inv255) * ref.y;
+  o.r1 = 1.0f * cZ + (-1.0f) * p.qz;
+  float sigma = p.Z - 0.4f;
+  sigma = 0.0012f + 0.0019f * sigma * sigma;
+  o.gix = g.wi_x * cIx + g.wi_x * ref.z;
+  o.giy = g.wi_y * cIy + g.wi_y * ref.w;
+  o.gzx = (1.0f * g.fx) * cZx;
+  o.gzy = (1.0f * g.fy) * cZy;
+  o.X = p.X; o.Y = p.Y; o.Z = p.Z;
+  return (cI == cI && cZ == cZ) && (cIx == cIx && cIy == cIy) && (cZx == cZx && cZy == cZy) && o.r1 > -20.0f * sigma;   // Q9, Q5
+}
+
+// sqrt(7 / (5 + r^T P r)) through the symmetric form, P2x = P01 + P10 (the weight only scales the normal equations; it does not
+// decide validity or enter the stored residuals)
+DVO_HD float tdist_weight_sqrt_fast(float r0, float r1, float P00, float P2x, float P11) {
+  const float t = fmaf(P2x, r1, P00 * r0);
+  return 2.6457513110645906f * fast_rsqrt(fmaf(t, r0, fmaf(P11 * r1, r1, 5.0f)));
+}
+
+// The scaled Jacobian rows in normalised coordinates: with x = tx z, y = ty z the warp Jacobian is
+//   Jw row 0 = [1/z, 0, -tx/z, -tx ty, 1 + tx^2, -ty]     Jw row 1 = [0, 1/z, -ty/z, -(1 + ty^2), tx ty, tx]
+// cx = 1 + tx^2 (a constant of the column), cy = 1 + ty^2 (of the row).
+DVO_HD void jacobian_rows_fast(const PixelTerms& t, float s, float tx, float ty, float cx, float cy, float* J0, float* J1) {
+  const float iz = fast_rcp(t.Z);
+  const float txy = tx * ty;
+  const float gix = s * t.gix, giy = s * t.giy, gzx = s * t.gzx, gzy = s * t.gzy;
+  // negations are written on the operands (source modifiers), not on the results (an extra instruction each)
+  J0[0] = gix * iz;
+  J0[1] = giy * iz;
+  J0[2] = fmaf(-ty, J0[1], -tx * J0[0]);
+  J0[3] = fmaf(-giy, cy, -gix * txy);
+  J0[4] = fmaf(gix, cx, giy * txy);
+  J0[5] = fmaf(giy, tx, -gix * ty);
+  J1[0] = gzx * iz;
+  J1[1] = gzy * iz;
+  J1[2] = fmaf(-ty, J1[1], fmaf(-tx, J1[0], -s));
+  J1[3] = fmaf(-gzy, cy, fmaf(-gzx, txy, -s * t.Y));
+  J1[4] = fmaf(gzx, cx, fmaf(gzy, txy, s * t.X));
+  J1[5] = fmaf(gzy, tx, -gzx * ty);
+}
+
 // Rank update of the P-independent Gram sums (layout in device_types.h) with one pixel's rows.
 DVO_HD void accumulate_pixel(float* acc, const PixelTerms& t, float w) {
   float J0[6], J1[6], wJ0[6], wJ1[6];

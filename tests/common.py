@@ -59,6 +59,8 @@ def emul_lib():
         L.emul_level_iteration.argtypes = [C.POINTER(EmulLevel), fp, fp, C.c_int, C.POINTER(hl.IterationOut), fp]
         L.emul_match.argtypes = [C.POINTER(EmulLevel), C.POINTER(hl.Config), C.POINTER(hl.Result), C.POINTER(hl.LevelStats), C.c_int,
                                  C.POINTER(hl.IterationStats), C.c_int]
+        L.emul_set_schedule.argtypes = [C.c_int]
+        L.emul_set_schedule.restype = None
         L.emul_se3_exp.argtypes = [dp, dp]
         L.emul_se3_log.argtypes = [dp, dp]
         L.emul_solve6.argtypes = [dp, dp, dp]

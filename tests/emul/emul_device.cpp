@@ -52,6 +52,49 @@ void make_level(const emul_level& e, LevelCtx& c) {
   c.B = reinterpret_cast<const float2*>(e.B);
 }
 
+// 0: the staged forms (pixel_residual, tdist_weight, accumulate_pixel); 1: what the matrix-core sweep runs -- the straight-line
+// stages, sqrt(w)-scaled rows from jacobian_rows_fast, Gram accumulation of the 14-vector
+int g_schedule = 0;
+
+// G += v v^T of v = [J0(6), J1(6), r0, r1] (already scaled by sqrt(w)), written into the canonical accumulator layout
+void accumulate_vector(float* acc, const float* J0, const float* J1, float r0, float r1) {
+  float v[14];
+  for (int i = 0; i < 6; ++i) { v[i] = J0[i]; v[6 + i] = J1[i]; }
+  v[12] = r0; v[13] = r1;
+  auto G = [&](int r, int c) { return v[r] * v[c]; };
+  acc[kAccN] += 1.0f;
+  acc[kAccS] += G(12, 12); acc[kAccS + 1] += G(12, 13); acc[kAccS + 2] += G(13, 13);
+  int o = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j, ++o) {
+      acc[kAccJ00 + o] += G(i, j);
+      acc[kAccJ11 + o] += G(6 + i, 6 + j);
+      acc[kAccJ01 + o] += G(i, 6 + j) + G(j, 6 + i);
+    }
+  for (int k = 0; k < 6; ++k) {
+    acc[kAccB00 + k] += G(k, 12);
+    acc[kAccB01 + k] += G(k, 13) + G(6 + k, 12);
+    acc[kAccB11 + k] += G(6 + k, 13);
+  }
+}
+
+bool flat_pixel(const LevelCtx& c, const float* KT, const float* Pp, bool first, int u, int v, float* acc, float* r) {
+  const float4 ref = c.R[v * c.g.w + u];
+  const float tx = c.g.tx[u], ty = c.g.ty[v];
+  const PixelProj p = pixel_project_flat(c.g, KT, ref.x, tx, ty);
+  if (!p.ok) return false;
+  PixelTaps t;
+  pixel_fetch(c.g, c.A, c.B, p, t);
+  PixelTerms o;
+  if (!pixel_finish_flat(c.g, ref, p, t, o)) return false;
+  r[0] = o.r0; r[1] = o.r1;
+  const float sw = first ? 1.0f : tdist_weight_sqrt_fast(o.r0, o.r1, Pp[0], Pp[1] + Pp[2], Pp[3]);
+  float J0[6], J1[6];
+  jacobian_rows_fast(o, sw, tx, ty, fmaf(tx, tx, 1.0f), fmaf(ty, ty, 1.0f), J0, J1);
+  accumulate_vector(acc, J0, J1, sw * o.r0, sw * o.r1);
+  return true;
+}
+
 // one sweep of the residual kernel + the log-likelihood sweep: float accumulation per row of 64 pixels
 // (one "wavefront row"), float64 across rows, like the device's per-tile partials
 void sweep(const LevelCtx& c, const float* KT, const float* Pp, bool first, double* sums, std::vector<float>& res) {
@@ -64,6 +107,10 @@ void sweep(const LevelCtx& c, const float* KT, const float* Pp, bool first, doub
       for (int i = 0; i < kNumAcc; ++i) acc[i] = 0.0f;
       for (int u = u0; u < u0 + kTileW && u < w; ++u) {
         const int idx = v * w + u;
+        if (g_schedule != 0) {
+          flat_pixel(c, KT, Pp, first, u, v, acc, &res[2 * size_t(idx)]);
+          continue;
+        }
         PixelTerms t;
         if (!pixel_residual(c.g, KT, c.A, c.B, c.R[idx], u, v, t)) continue;
         res[2 * size_t(idx)] = t.r0;
@@ -90,6 +137,8 @@ double loglik_sum(const std::vector<float>& res, const double* sums) {
 }  // namespace
 
 extern "C" {
+
+void emul_set_schedule(int schedule) { g_schedule = schedule; }
 
 int emul_level_iteration(const emul_level* L, const float T34[12], const float P_prev[4], int first,
                          dvo_hip_iteration_out* out, float* residuals) {

@@ -39,8 +39,20 @@ def test_device_se3_and_solve():
     assert L.emul_solve6(dp(np.zeros(36)), dp(np.ones(6)), dp(x)) == 1 and np.isnan(x).all()
 
 
+@pytest.fixture
+def schedule():
+    """selects which form of the per-pixel stages the emulation runs (tests/emul/emul_device.cpp::g_schedule)"""
+    L = cm.emul_lib()
+    yield L.emul_set_schedule
+    L.emul_set_schedule(0)
+
+
 @pytest.mark.parametrize("level", [2, 1, 0])
-def test_pixel_math_bit_exact_against_oracle(level):
+@pytest.mark.parametrize("form", [0, 1])
+def test_pixel_math_bit_exact_against_oracle(level, form, schedule):
+    """form 0: the staged stage functions; 1: the straight-line stages the matrix-core sweep runs (with the
+    short weight / Jacobian forms and Gram accumulation of the sqrt(w)-scaled vector)."""
+    schedule(form)
     pair = cm.synth(31, 320, 240)
     ref, cur = cm.oracle_pyramids(pair, 3)
     ep = cm.EmulPair(ref, cur, 3)
@@ -59,6 +71,7 @@ def test_pixel_math_bit_exact_against_oracle(level):
     assert e2["n"] == o2["n"]
     assert np.abs(e2["A"] - o2["A"]).max() <= 1e-6 * np.abs(o2["A"]).max()
     assert np.abs(e2["b"] - o2["b"]).max() <= 1e-6 * np.abs(o2["b"]).max()
+
 
 
 @pytest.mark.parametrize("seed,first,last,mu,init,precision", [
