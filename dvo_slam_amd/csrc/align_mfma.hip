@@ -81,7 +81,6 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   const float P2x = Pp[1] + Pp[2];
 
   __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kSlabFloats];
-  __shared__ float gram[kWavesPerBlock][256];
   __shared__ int counts[kWavesPerBlock];
   float* my = slab[wave];
   // write side: component quad q of pixel `lane` at my[q*kQuadStride + lane*4 .. +3]
@@ -98,7 +97,8 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   // processed: one of the two dependent memory round trips of a row (reference pixel -> projected tap addresses) is off the
   // critical path.  (Measured and dropped: reading all sixteen matrix operands of a row behind a scheduling barrier before
   // the first matrix instruction, +15 %; one residual store per branch instead of a select, no gain; tap fetches of lanes
-  // without a usable projection redirected to tap 0 instead of branched around, no gain.)
+  // without a usable projection redirected to tap 0 instead of branched around, no gain; the three stages of a row software-
+  // pipelined over rows (taps of row k+1 in flight during the second half of row k): 104 registers, 4 waves per SIMD, +10 %.)
   const float P00 = Pp[0], P11 = Pp[3];
   const int u_c = LINEAR ? lane : min(u_r, g.w - 1);
   auto load_ref = [&](int v_r) {                              // clamped: rows / segments past the end are masked by in_image
@@ -182,7 +182,8 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
 
   // lane l, register i holds G[row (l>>4)*4 + i][col l&15] of this wavefront's rows
 #pragma unroll
-  for (int i = 0; i < 4; ++i) gram[wave][((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
+  // (the wavefront is done with its slab: its Gram matrix goes into the first 256 floats)
+  for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
   if (lane == 0) counts[wave] = n_valid;
   __syncthreads();
   // fold the four wavefront Gram matrices into the canonical partial row (device_types.h); vector layout:
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   if (k < kNumAcc) {
     auto G = [&](int r, int c) {
       const int e = r * 16 + c;
-      return (gram[0][e] + gram[1][e]) + (gram[2][e] + gram[3][e]);
+      return (slab[0][e] + slab[1][e]) + (slab[2][e] + slab[3][e]);
     };
     float v;
     if (k == kAccN) v = float((counts[0] + counts[1]) + (counts[2] + counts[3]));
