@@ -162,11 +162,10 @@ def main():
     counter = [0]
 
     def build(k):
+        # ingest + pyramids + the planes of the role each frame plays, from HBM-resident raw planes, on the build stream (asynchronous)
         fs = sets[k]
-        d.update_raw_device_batch(fs, grey_ptrs, depth_ptrs)            # ingest + pyramids, from HBM-resident raw planes (asynchronous)
-        if n_sets > 1:                                                  # role planes ahead of the match, on the build stream
-            d.prepare_roles_batch(fs[:B], "reference", cfg)
-            d.prepare_roles_batch(fs[B:], "current", cfg)
+        d.update_raw_device_batch(fs[:B], grey_ptrs[:B], depth_ptrs[:B], role="reference", config=cfg)
+        d.update_raw_device_batch(fs[B:], grey_ptrs[B:], depth_ptrs[B:], role="current", config=cfg)
 
     def step():
         k = counter[0] % n_sets
@@ -239,10 +238,8 @@ def main():
             pinned.depth[B + i][:] = pairs_np["depth_cur"][i]
 
         def host_build(k):
-            d.update_raw_host_batch(sets[k], pinned.grey, pinned.depth)
-            if n_sets > 1:
-                d.prepare_roles_batch(sets[k][:B], "reference", cfg)
-                d.prepare_roles_batch(sets[k][B:], "current", cfg)
+            d.update_raw_host_batch(sets[k][:B], pinned.grey[:B], pinned.depth[:B], role="reference", config=cfg)
+            d.update_raw_host_batch(sets[k][B:], pinned.grey[B:], pinned.depth[B:], role="current", config=cfg)
 
         def host_step(j):
             host_build((j + 1) % n_sets)

@@ -61,7 +61,7 @@ class IterationOut(C.Structure):
 EXPORTS = [
     "dvo_hip_context_create", "dvo_hip_context_destroy", "dvo_hip_last_error", "dvo_hip_context_stream",
     "dvo_hip_device_count", "dvo_hip_frame_create_f32", "dvo_hip_frame_create_raw", "dvo_hip_frame_create_raw_device",
-    "dvo_hip_frame_update_raw_device", "dvo_hip_frames_update_raw_device", "dvo_hip_frames_update_raw", "dvo_hip_upload_wait",
+    "dvo_hip_frame_update_raw_device", "dvo_hip_frames_update_raw_device", "dvo_hip_frames_update_raw", "dvo_hip_frames_update_raw_device_as", "dvo_hip_frames_update_raw_as", "dvo_hip_upload_wait",
     "dvo_hip_host_alloc", "dvo_hip_host_free", "dvo_hip_frames_prepare", "dvo_hip_frame_destroy", "dvo_hip_frame_info", "dvo_hip_frame_download_plane", "dvo_hip_frame_select",
     "dvo_hip_match", "dvo_hip_match_batch", "dvo_hip_level_iteration", "dvo_hip_time_residual_kernel",
     "dvo_hip_set_option", "dvo_hip_version",
@@ -106,6 +106,8 @@ def lib():
     L.dvo_hip_frame_update_raw_device.argtypes = [vp, vp, vp, vp, C.c_float]
     L.dvo_hip_frames_update_raw_device.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_float]
     L.dvo_hip_frames_update_raw.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_float]
+    L.dvo_hip_frames_update_raw_device_as.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_float, C.c_int, C.POINTER(Config)]
+    L.dvo_hip_frames_update_raw_as.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_float, C.c_int, C.POINTER(Config)]
     L.dvo_hip_upload_wait.argtypes = [vp]
     L.dvo_hip_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.dvo_hip_host_free.argtypes = [vp, vp]

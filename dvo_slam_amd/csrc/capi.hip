@@ -74,6 +74,12 @@ struct dvo_hip_frame {
   DevBuf pool;
   int* sel_count = nullptr;    // device, one int per level
   unsigned long long built_seq = 0;   // ticket of the last build-stream work that wrote this frame (0 = none pending)
+  // Frames ingested from raw sensor planes have no float I / Z planes at level 0 (k_build_from_raw writes the role planes
+  // straight from the raw data).  What level 0 can later be derived from: the current-role planes A + B if they exist (they
+  // hold everything), else the 3-B copy of the raw planes in the frame's staging area.
+  bool raw0 = false;
+  bool raw_copy = false;
+  float depth_scale = 0.0f;
 };
 
 // The batch workspace: one HIP stream, device scratch and the pinned poll words of the Gauss-Newton loop.
@@ -348,30 +354,56 @@ int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels
 void fill_build_ptrs(dvo_hip_frame* f, FrameBuildPtrs& p) {
   p.grey = nullptr;
   p.raw = nullptr;
+  p.keep_grey = nullptr;
+  p.keep_raw = nullptr;
   for (int l = 0; l < f->levels; ++l) {
     p.I[l] = f->lv[l].I; p.Z[l] = f->lv[l].Z; p.A[l] = f->lv[l].A; p.B[l] = f->lv[l].B; p.R[l] = f->lv[l].R;
   }
   p.sel_count = f->sel_count;
 }
 
-// RgbdImagePyramid::build (rgbd_image.cpp:156-172) for n frames of one camera: ingest of the raw planes (optional)
-// and the pyr-down chain, one launch per level for the whole batch.  Derived planes are built lazily per role
-// (ensure_roles), like the reference's buildAccelerationStructure / PointSelection caches.
+// the frame's own staging area: [u16 depth][u8 grey], see frame_alloc
+uint16_t* staging_depth(dvo_hip_frame* f) { return f->pool.as<uint16_t>(); }
+uint8_t* staging_grey(dvo_hip_frame* f) { return f->pool.as<uint8_t>() + size_t(f->lv[0].w) * f->lv[0].h * 2; }
+
+bool aligned_to(const void* p, size_t a) { return reinterpret_cast<uintptr_t>(p) % a == 0; }
+
+// RgbdImagePyramid::build (rgbd_image.cpp:156-172) for n frames of one camera.  From float planes (grey == null: level 0 is
+// already in place): the pyr-down chain, one launch per level for the whole batch; derived planes are built lazily per role
+// (ensure_roles), like the reference's buildAccelerationStructure / PointSelection caches.  From raw planes: one fused pass
+// (k_build_from_raw) that also writes level 0 in role `role` (-1: not known yet, 0: current, 1: reference with the given
+// thresholds) and leaves a copy of the raw planes in the frame unless the current-role planes make it redundant.
 int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, const void* const* grey, const void* const* raw,
-                 float depth_scale) {
+                 float depth_scale, int role = -1, float ithr = 0.0f, float dthr = 0.0f) {
   const CameraGeom* cam = frames[0]->cam;
   const int levels = frames[0]->levels;
   std::vector<FrameBuildPtrs> host(n);
+  bool wide = cam->w[0] % 4 == 0;
   for (int i = 0; i < n; ++i) {
     dvo_hip_frame* f = frames[i];
     if (f->cam != cam || f->levels != levels) return fail(ctx, DVO_HIP_ERR_INVALID, "frames of one build batch must share camera and levels");
     fill_build_ptrs(f, host[i]);
-    host[i].grey = grey ? static_cast<const uint8_t*>(grey[i]) : nullptr;
-    host[i].raw = raw ? static_cast<const uint16_t*>(raw[i]) : nullptr;
     for (int l = 0; l < levels; ++l) {   // new pixels: every cached role plane is stale (PointSelection::setRgbdImagePyramid)
       f->lv[l].has_current = false;
       f->lv[l].selected = false;
     }
+    f->raw0 = grey != nullptr;
+    f->raw_copy = false;
+    f->depth_scale = depth_scale;
+    if (!grey) continue;
+    host[i].grey = static_cast<const uint8_t*>(grey[i]);
+    host[i].raw = static_cast<const uint16_t*>(raw[i]);
+    const bool in_place = host[i].raw == staging_depth(f) && host[i].grey == staging_grey(f);
+    if (in_place) {
+      f->raw_copy = true;
+    } else if (role != 0) {
+      host[i].keep_grey = staging_grey(f);
+      host[i].keep_raw = staging_depth(f);
+      f->raw_copy = true;
+    }
+    wide = wide && aligned_to(host[i].grey, 4) && aligned_to(host[i].raw, 8) && aligned_to(staging_grey(f), 4);
+    if (role == 0) f->lv[0].has_current = true;
+    if (role == 1) { f->lv[0].selected = true; f->lv[0].ithr = ithr; f->lv[0].dthr = dthr; }
   }
   DVO_HIP_TRY(ctx, ctx->build_tbl.reserve(size_t(n) * sizeof(FrameBuildPtrs)));
   hipStream_t bs = ctx->build_stream;
@@ -379,7 +411,7 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
   const FrameBuildPtrs* tbl = ctx->build_tbl.as<FrameBuildPtrs>();
   int built = 1;                                       // float ingest: level 0 is already in place
   if (grey) {
-    launch_ingest_pyramid(bs, tbl, n, depth_scale, cam->w[0], cam->h[0], levels, ctx->opt_build_workgroups);
+    launch_build_from_raw(bs, tbl, n, depth_scale, cam->w[0], cam->h[0], levels, role, wide, ithr, dthr, ctx->opt_build_workgroups);
     built = levels < 4 ? levels : 4;
   }
   for (int l = built; l < levels; ++l) launch_pyr_down(bs, tbl, n, l, cam->w[l - 1], cam->h[l - 1]);
@@ -397,28 +429,77 @@ int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int 
   DevBuf& table = eager ? (role == 0 ? ctx->prep_tbl_cur : ctx->prep_tbl_ref) : (role == 0 ? ctx->role_tbl_cur : ctx->role_tbl_ref);
   hipStream_t stream = eager ? ctx->build_stream : ctx->stream;
   bool launched = false;
+  std::vector<FrameBuildPtrs> from_raw;      // level 0 of frames ingested from raw planes: derived from their raw copy
+  std::vector<dvo_hip_frame*> from_planes;   // ... or (reference role only) from their current-role planes
   for (int l = l0; l <= l1; ++l) {
     host.clear();
+    from_raw.clear();
+    from_planes.clear();
+    float raw_scale = 0.0f;
     for (int i = 0; i < n; ++i) {
       dvo_hip_frame* f = frames[i];
       FrameLevel& L = f->lv[l];
       const bool need = role == 0 ? !L.has_current : !(L.selected && L.ithr == ithr && L.dthr == dthr);
       if (!need) continue;   // also skips the second visit of a frame that is listed twice
-      if (role == 0) L.has_current = true;
-      else { L.selected = true; L.ithr = ithr; L.dthr = dthr; }
       FrameBuildPtrs p;
       fill_build_ptrs(f, p);
-      host.push_back(p);
+      if (l == 0 && f->raw0) {
+        if (role == 1 && L.has_current) {
+          from_planes.push_back(f);
+        } else if (f->raw_copy && (from_raw.empty() || f->depth_scale == raw_scale)) {
+          raw_scale = f->depth_scale;
+          p.grey = staging_grey(f);
+          p.raw = staging_depth(f);
+          from_raw.push_back(p);
+        } else if (f->raw_copy) {
+          continue;            // another depth scale than the frames gathered so far: picked up by the pass below
+        } else {
+          return fail(ctx, DVO_HIP_ERR_INVALID, "frame has neither sampling planes nor a raw copy at level 0");
+        }
+      } else {
+        host.push_back(p);
+      }
+      if (role == 0) L.has_current = true;
+      else { L.selected = true; L.ithr = ithr; L.dthr = dthr; }
     }
-    if (host.empty()) continue;
-    // each level has its own slice of the table so that a copy never waits for the previous level's kernel
-    DVO_HIP_TRY(ctx, table.reserve(slice * kMaxLevels));
-    FrameBuildPtrs* tbl = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * l);
-    DVO_HIP_TRY(ctx, hipMemcpyAsync(tbl, host.data(), host.size() * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, stream));
     const int cap = eager ? ctx->opt_build_workgroups : 0;   // planes needed right now are built at full width
-    if (role == 0) launch_derive_current(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], cap);
-    else launch_derive_reference(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], ithr, dthr, cap);
-    launched = true;
+    if (!host.empty()) {
+      // each level has its own slice of the table so that a copy never waits for the previous level's kernel
+      DVO_HIP_TRY(ctx, table.reserve(slice * (kMaxLevels + 1)));
+      FrameBuildPtrs* tbl = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * l);
+      DVO_HIP_TRY(ctx, hipMemcpyAsync(tbl, host.data(), host.size() * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, stream));
+      if (role == 0) launch_derive_current(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], cap);
+      else launch_derive_reference(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], ithr, dthr, cap);
+      launched = true;
+    }
+    if (!from_raw.empty()) {
+      DVO_HIP_TRY(ctx, table.reserve(slice * (kMaxLevels + 1)));
+      FrameBuildPtrs* tbl = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * kMaxLevels);
+      DVO_HIP_TRY(ctx, hipMemcpyAsync(tbl, from_raw.data(), from_raw.size() * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, stream));
+      launch_build_from_raw(stream, tbl, int(from_raw.size()), raw_scale, cam->w[0], cam->h[0], /*levels=*/1, role, cam->w[0] % 4 == 0, ithr, dthr, cap);
+      launched = true;
+    }
+    for (dvo_hip_frame* f : from_planes) {   // PointSelection over a frame that has been a current frame so far
+      FrameLevel& L = f->lv[0];
+      DVO_HIP_TRY(ctx, hipMemsetAsync(f->sel_count, 0, sizeof(int), stream));
+      launch_select_pack(stream, L.A, L.B, L.w * L.h, ithr, dthr, L.R, f->sel_count, nullptr);
+      launched = true;
+    }
+    if (l == 0) {   // frames of a second depth scale (one kernel launch takes one scale): rare, one more pass each
+      bool again = false;
+      for (int i = 0; i < n; ++i) {
+        const FrameLevel& L = frames[i]->lv[0];
+        again = again || (role == 0 ? !L.has_current : !(L.selected && L.ithr == ithr && L.dthr == dthr));
+      }
+      if (again) {
+        if (eager && launched) {
+          const int rc = stamp_build(ctx, n, frames);
+          if (rc != DVO_HIP_OK) return rc;
+        }
+        DVO_HIP_TRY(ctx, hipStreamSynchronize(stream));   // the table slice is reused
+        return ensure_roles(ctx, n, frames, role, l0, l1, ithr, dthr, eager);
+      }
+    }
   }
   if (eager && launched) {
     const int rc = stamp_build(ctx, n, frames);
@@ -853,20 +934,69 @@ int dvo_hip_frame_create_raw_device(dvo_hip_context* ctx, int width, int height,
   return DVO_HIP_OK;
 }
 
+namespace {
+
+int check_prepare_args(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, int role, const dvo_hip_config* cfg, const char* who) {
+  if (!ctx || n_frames < 1 || !frames || !cfg || (role != DVO_HIP_ROLE_CURRENT && role != DVO_HIP_ROLE_REFERENCE))
+    return fail(ctx, DVO_HIP_ERR_INVALID, who);
+  if (cfg->first_level < cfg->last_level || cfg->last_level < 0 || cfg->first_level >= kMaxLevels)
+    return fail(ctx, DVO_HIP_ERR_INVALID, "need 0 <= last_level <= first_level < DVO_HIP_MAX_LEVELS");
+  for (int i = 0; i < n_frames; ++i) {
+    if (!frames[i]) return fail(ctx, DVO_HIP_ERR_INVALID, who);
+    if (frames[i]->cam != frames[0]->cam || frames[i]->levels <= cfg->first_level)
+      return fail(ctx, DVO_HIP_ERR_INVALID, "frames must share the camera and have first_level + 1 levels");
+  }
+  return DVO_HIP_OK;
+}
+
+// role planes of levels cfg->last_level .. cfg->first_level on the build stream (what is already there is skipped)
+int prepare_roles(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, int role, const dvo_hip_config* cfg) {
+  const bool ref = role == DVO_HIP_ROLE_REFERENCE;
+  const int rc = ensure_roles(ctx, n_frames, frames, ref ? 1 : 0, cfg->last_level, cfg->first_level, ref ? cfg->intensity_derivative_threshold : 0.0f,
+                              ref ? cfg->depth_derivative_threshold : 0.0f, /*eager=*/true);
+  if (rc != DVO_HIP_OK) return rc;
+  DVO_HIP_TRY(ctx, hipGetLastError());
+  return DVO_HIP_OK;
+}
+
+// ingest of device-resident raw planes, optionally straight into a role (role < 0: none)
+int update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
+                      const void* const* raw_depth_dev, float depth_scale, int role, const dvo_hip_config* cfg) {
+  const bool ref = role == DVO_HIP_ROLE_REFERENCE;
+  const int fused = role >= 0 && cfg->last_level == 0 ? (ref ? 1 : 0) : -1;   // level 0 is built in the same pass if it is used at all
+  int rc = frames_build(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, fused, ref ? cfg->intensity_derivative_threshold : 0.0f,
+                        ref ? cfg->depth_derivative_threshold : 0.0f);
+  if (rc == DVO_HIP_OK && role >= 0) rc = prepare_roles(ctx, n_frames, frames, role, cfg);
+  return rc;
+}
+
+}  // namespace
+
 int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
                                      const void* const* raw_depth_dev, float depth_scale) {
   if (!ctx || n_frames < 1 || !frames || !grey_dev || !raw_depth_dev) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device: null argument");
   for (int i = 0; i < n_frames; ++i)
     if (!frames[i] || !grey_dev[i] || !raw_depth_dev[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device: null entry");
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return frames_build(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale);
+  return update_raw_device(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, -1, nullptr);
+}
+
+int dvo_hip_frames_update_raw_device_as(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
+                                        const void* const* raw_depth_dev, float depth_scale, int role, const dvo_hip_config* cfg) {
+  int rc = check_prepare_args(ctx, n_frames, frames, role, cfg, "frames_update_raw_device_as: bad argument");
+  if (rc != DVO_HIP_OK) return rc;
+  if (!grey_dev || !raw_depth_dev) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device_as: null argument");
+  for (int i = 0; i < n_frames; ++i)
+    if (!grey_dev[i] || !raw_depth_dev[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device_as: null entry");
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return update_raw_device(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, role, cfg);
 }
 
 // Streaming ingest from HOST memory: DMA of the raw planes into a transfer buffer on the upload stream, then the batched
 // build on the build stream.  Returns at once; from pinned memory (dvo_hip_host_alloc) the transfers are truly asynchronous,
 // from pageable memory the runtime stages them (correct, but the call then blocks for most of the copy).
-int dvo_hip_frames_update_raw(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const uint8_t* const* grey,
-                              const uint16_t* const* raw_depth, float depth_scale) {
+static int update_raw_host(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const uint8_t* const* grey,
+                           const uint16_t* const* raw_depth, float depth_scale, int role, const dvo_hip_config* cfg) {
   if (!ctx || n_frames < 1 || !frames || !grey || !raw_depth) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw: null argument");
   for (int i = 0; i < n_frames; ++i) {
     if (!frames[i] || !grey[i] || !raw_depth[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw: null entry");
@@ -907,9 +1037,21 @@ int dvo_hip_frames_update_raw(dvo_hip_context* ctx, int n_frames, dvo_hip_frame*
   }
   DVO_HIP_TRY(ctx, hipEventRecord(ctx->upload_done, ctx->upload_stream));
   DVO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->build_stream, ctx->upload_done, 0));
-  rc = frames_build(ctx, n_frames, frames, g.data(), r.data(), depth_scale);
-  if (rc == DVO_HIP_OK) ctx->upload_buf_seq[b] = ctx->build_seq;
+  rc = update_raw_device(ctx, n_frames, frames, g.data(), r.data(), depth_scale, role, cfg);
+  ctx->upload_buf_seq[b] = ctx->build_seq;          // the newest ticket is behind every reader of the buffer
   return rc;
+}
+
+int dvo_hip_frames_update_raw(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const uint8_t* const* grey,
+                              const uint16_t* const* raw_depth, float depth_scale) {
+  return update_raw_host(ctx, n_frames, frames, grey, raw_depth, depth_scale, -1, nullptr);
+}
+
+int dvo_hip_frames_update_raw_as(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const uint8_t* const* grey,
+                                 const uint16_t* const* raw_depth, float depth_scale, int role, const dvo_hip_config* cfg) {
+  const int rc = check_prepare_args(ctx, n_frames, frames, role, cfg, "frames_update_raw_as: bad argument");
+  if (rc != DVO_HIP_OK) return rc;
+  return update_raw_host(ctx, n_frames, frames, grey, raw_depth, depth_scale, role, cfg);
 }
 
 int dvo_hip_upload_wait(dvo_hip_context* ctx) {
@@ -933,22 +1075,10 @@ void dvo_hip_host_free(dvo_hip_context* ctx, void* p) {
 }
 
 int dvo_hip_frames_prepare(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, int role, const dvo_hip_config* cfg) {
-  if (!ctx || n_frames < 1 || !frames || !cfg || (role != DVO_HIP_ROLE_CURRENT && role != DVO_HIP_ROLE_REFERENCE))
-    return fail(ctx, DVO_HIP_ERR_INVALID, "frames_prepare: bad argument");
-  if (cfg->first_level < cfg->last_level || cfg->last_level < 0 || cfg->first_level >= kMaxLevels)
-    return fail(ctx, DVO_HIP_ERR_INVALID, "frames_prepare: need 0 <= last_level <= first_level < DVO_HIP_MAX_LEVELS");
-  for (int i = 0; i < n_frames; ++i) {
-    if (!frames[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_prepare: null frame");
-    if (frames[i]->cam != frames[0]->cam || frames[i]->levels <= cfg->first_level)
-      return fail(ctx, DVO_HIP_ERR_INVALID, "frames_prepare: frames must share the camera and have first_level + 1 levels");
-  }
-  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const bool ref = role == DVO_HIP_ROLE_REFERENCE;
-  const int rc = ensure_roles(ctx, n_frames, frames, ref ? 1 : 0, cfg->last_level, cfg->first_level, ref ? cfg->intensity_derivative_threshold : 0.0f,
-                              ref ? cfg->depth_derivative_threshold : 0.0f, /*eager=*/true);
+  const int rc = check_prepare_args(ctx, n_frames, frames, role, cfg, "frames_prepare: bad argument");
   if (rc != DVO_HIP_OK) return rc;
-  DVO_HIP_TRY(ctx, hipGetLastError());
-  return DVO_HIP_OK;
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return prepare_roles(ctx, n_frames, frames, role, cfg);
 }
 
 int dvo_hip_frame_update_raw_device(dvo_hip_context* ctx, dvo_hip_frame* frame, const void* grey_dev, const void* raw_depth_dev,

@@ -52,6 +52,8 @@ struct PairPtrs {                     // device planes of one pair at one level
 struct FrameBuildPtrs {                // one frame of a batched pyramid build
   const uint8_t* grey;                 // raw planes (device), may be null for the float ingest path
   const uint16_t* raw;
+  uint8_t* keep_grey;                  // where k_build_from_raw leaves a copy of the raw planes (the frame's own staging area), or null
+  uint16_t* keep_raw;
   float* I[kMaxLevels];
   float* Z[kMaxLevels];
   float4* A[kMaxLevels];

@@ -9,9 +9,11 @@ namespace dvo_hip {
 
 // pyramid_kernels.hip
 // raw ingest + pyramid levels 1..3 in one pass (levels beyond the fourth: launch_pyr_down)
-void launch_ingest_pyramid(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int max_workgroups);
 void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h);
 // max_workgroups > 0 caps the grid (the kernels walk the tiles with a grid stride): background build next to an alignment
+// level 0 in role `role` (-1 none, 0 current, 1 reference) + pyramid levels 1..3 straight from raw planes; `wide`: 4-pixel aligned rows
+void launch_build_from_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int role, bool wide,
+                           float ithr, float dthr, int max_workgroups);
 void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int max_workgroups);
 void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr,
                              int max_workgroups);

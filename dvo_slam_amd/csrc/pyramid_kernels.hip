@@ -18,14 +18,9 @@
 
 namespace dvo_hip {
 
-// Ingest and the first three pyr-down steps in one pass over the raw planes.  A 32 x 8 workgroup owns a 64 x 16 tile of
-// level 0: every thread converts one 2 x 2 quad (level 0), averages it (level 1); levels 2 and 3 are folded through LDS
-// (16 x 4 and 8 x 2 pixels per tile).  Compared with ingest + three pyr-down launches this never re-reads a float plane:
-// 0.9 MB in, 3.2 MB out per 640 x 480 frame instead of 7.3 MB of traffic.  Arithmetic and summation order are those of
-// the reference's ingest and of k_pyr_down (bit-identical planes); `levels` <= 4 levels are produced, deeper ones by k_pyr_down.
 // Work distribution of the frame-build kernels: a linear index over (tile, frame) walked with a grid stride.  Launched with
 // one workgroup per tile this is the plain one-tile-per-workgroup kernel; launched with FEWER workgroups (option
-// "build_workgroups_per_cu") the same kernel becomes a background job that leaves most wave slots of every CU free, so the
+// "build_workgroups") the same kernel becomes a background job that leaves most wave slots of every CU free, so the
 // short dependent kernels of an alignment running concurrently on the other stream are dispatched at once instead of queueing
 // behind tens of thousands of elementwise workgroups.
 template <typename Body>
@@ -37,56 +32,142 @@ __device__ __forceinline__ void for_each_tile(int tiles_x, int tiles_y, int n_fr
   }
 }
 
-__global__ __launch_bounds__(256) void k_ingest_pyramid(const FrameBuildPtrs* __restrict__ tbl, float scale, int w0, int h0, int levels,
-                                                        int tiles_x, int tiles_y, int n_frames) {
+// Level 0 straight from the raw planes, in the role the frame is about to play, plus pyramid levels 1-3: one pass over
+// 3 B per pixel instead of  raw -> float I, Z (8 B written)  followed by  I, Z (+ halo) -> role planes (8 B read again).
+// A 32 x 8 workgroup owns a 64 x 16 tile; the tile and its one-pixel border are converted into LDS with 4- and 8-byte
+// loads (WIDE: rows and plane addresses are 4-pixel aligned), border coordinates clamped like the reference's derivative
+// code (rgbd_image.cpp:419-489), so pixels past the image edge hold the edge value.  Then every thread derives its 2 x 2
+// quad from LDS and folds pyramid levels 1-3 (2 x 2 means through LDS, same summation order as k_pyr_down).  Float I / Z planes
+// of level 0 are never written:
+// a frame built this way keeps either its current-role planes (which hold everything) or a 3-B copy of the raw planes
+// (keep_grey / keep_raw) from which the other role can be derived later by the same kernel.
+// ROLE: -1 = none (copy + pyramid only), 0 = current (A, B), 1 = reference (R + selection count, counter zeroed before).
+// Arithmetic = the reference's ingest (surface_pyramid.cpp:65-105), k_pyr_down and derive_at: bit-identical planes.
+constexpr int kB0W = 64, kB0H = 16, kB0Stride = 68;
+
+template <int ROLE, bool WIDE>
+__global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __restrict__ tbl, float scale, int w0, int h0, int levels,
+                                                        float ithr, float dthr, int tiles_x, int tiles_y, int n_frames) {
 #pragma clang fp contract(off)
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8 threads, one 2 x 2 quad each
   const int w1 = w0 >> 1, h1 = h0 >> 1;
   const int w2 = w1 >> 1, h2 = h1 >> 1, w3 = w2 >> 1, h3 = h2 >> 1;
+  __shared__ float sI[kB0H + 2][kB0Stride];
+  __shared__ float sZ[kB0H + 2][kB0Stride];
   __shared__ float s1[8][32];
   __shared__ float s2[4][16];
+  __shared__ int wave_counts[4];
   const float nanv = __builtin_nanf("");
   for_each_tile(tiles_x, tiles_y, n_frames, [&](int bx, int by, int frame) {
     const FrameBuildPtrs& f = tbl[frame];
-    const int x1 = bx * 32 + tx, y1 = by * 8 + ty;              // level-1 pixel = level-0 quad
-    float q[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, z00 = nanv;
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-      const int y = 2 * y1 + dy;
-      if (y >= h0) continue;
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int x = 2 * x1 + dx;
-        if (x >= w0) continue;
-        const size_t i = size_t(y) * w0 + x;
-        const float g = float(f.grey[i]);
-        const uint16_t d = f.raw[i];
-        const float z = d == 0 ? nanv : float(d) * scale;
-        f.I[0][i] = g;
-        f.Z[0][i] = z;
-        q[dy][dx] = g;
-        if (dx == 0 && dy == 0) z00 = z;
+    const int x0 = bx * kB0W, y0 = by * kB0H;
+    auto depth_of = [&](uint16_t d) { return d == 0 ? nanv : float(d) * scale; };
+    // ---- tile + border into LDS (column c of the slab = image column x0 - 1 + c, row r = image row y0 - 1 + r, clamped) ----
+    if (WIDE) {
+      for (int i = threadIdx.x; i < (kB0H + 2) * (kB0W / 4); i += 256) {
+        const int r = i / (kB0W / 4), qd = i - r * (kB0W / 4);
+        const int yy = y0 - 1 + r, y = min(max(yy, 0), h0 - 1);
+        const int x = x0 + 4 * qd;
+        const size_t at = size_t(y) * w0 + x;
+        if (x + 3 < w0) {
+          const uchar4 gq = *reinterpret_cast<const uchar4*>(f.grey + at);
+          const ushort4 dq = *reinterpret_cast<const ushort4*>(f.raw + at);
+          float* di = &sI[r][1 + 4 * qd];
+          float* dz = &sZ[r][1 + 4 * qd];
+          di[0] = float(gq.x); di[1] = float(gq.y); di[2] = float(gq.z); di[3] = float(gq.w);
+          dz[0] = depth_of(dq.x); dz[1] = depth_of(dq.y); dz[2] = depth_of(dq.z); dz[3] = depth_of(dq.w);
+          if (f.keep_grey && yy == y && r >= 1 && r <= kB0H) {
+            *reinterpret_cast<uchar4*>(f.keep_grey + at) = gq;
+            *reinterpret_cast<ushort4*>(f.keep_raw + at) = dq;
+          }
+        } else {
+          for (int k = 0; k < 4; ++k) {
+            const int xc = min(x + k, w0 - 1);
+            const uint8_t gv = f.grey[size_t(y) * w0 + xc];
+            const uint16_t dv = f.raw[size_t(y) * w0 + xc];
+            sI[r][1 + 4 * qd + k] = float(gv);
+            sZ[r][1 + 4 * qd + k] = depth_of(dv);
+            if (f.keep_grey && yy == y && r >= 1 && r <= kB0H && x + k < w0) {
+              f.keep_grey[size_t(y) * w0 + xc] = gv;
+              f.keep_raw[size_t(y) * w0 + xc] = dv;
+            }
+          }
+        }
+      }
+      if (threadIdx.x < 2 * (kB0H + 2)) {                       // the two border columns
+        const int r = threadIdx.x >> 1, side = threadIdx.x & 1;
+        const int y = min(max(y0 - 1 + r, 0), h0 - 1);
+        const int x = side ? min(x0 + kB0W, w0 - 1) : max(x0 - 1, 0);
+        sI[r][side ? kB0W + 1 : 0] = float(f.grey[size_t(y) * w0 + x]);
+        sZ[r][side ? kB0W + 1 : 0] = depth_of(f.raw[size_t(y) * w0 + x]);
+      }
+    } else {
+      for (int i = threadIdx.x; i < (kB0H + 2) * (kB0W + 2); i += 256) {
+        const int r = i / (kB0W + 2), c = i - r * (kB0W + 2);
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        const int y = min(max(yy, 0), h0 - 1), x = min(max(xx, 0), w0 - 1);
+        const uint8_t gv = f.grey[size_t(y) * w0 + x];
+        const uint16_t dv = f.raw[size_t(y) * w0 + x];
+        sI[r][c] = float(gv);
+        sZ[r][c] = depth_of(dv);
+        if (f.keep_grey && yy == y && xx == x && r >= 1 && r <= kB0H && c >= 1 && c <= kB0W) {
+          f.keep_grey[size_t(y) * w0 + x] = gv;
+          f.keep_raw[size_t(y) * w0 + x] = dv;
+        }
       }
     }
-    if (levels < 2) return;                                      // uniform
-    const float i1 = (q[0][0] + q[0][1] + q[1][0] + q[1][1]) / 4.0f;   // same summation order as the reference
-    if (x1 < w1 && y1 < h1) {
+    __syncthreads();
+    // ---- level 0 in the frame's role ----
+    const int x1 = bx * 32 + tx, y1 = by * 8 + ty;              // level-1 pixel = level-0 quad
+    int count = 0;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int x = 2 * x1 + dx, y = 2 * y1 + dy;
+        const int r = 2 * ty + dy + 1, c = 2 * tx + dx + 1;
+        bool ok = false;
+        if (ROLE >= 0 && x < w0 && y < h0) {
+          const float i0 = sI[r][c], z0 = sZ[r][c];
+          const float idx = (sI[r][c + 1] - sI[r][c - 1]) * 0.5f, idy = (sI[r + 1][c] - sI[r - 1][c]) * 0.5f;
+          const float zdx = (sZ[r][c + 1] - sZ[r][c - 1]) * 0.5f, zdy = (sZ[r + 1][c] - sZ[r - 1][c]) * 0.5f;
+          const size_t at = size_t(y) * w0 + x;
+          if (ROLE == 0) {
+            f.A[0][at] = make_float4(i0, z0, idx, idy);
+            f.B[0][at] = make_float2(zdx, zdy);
+          } else {
+            ok = z0 == z0 && zdx == zdx && zdy == zdy && (fabsf(idx) > ithr || fabsf(idy) > ithr || fabsf(zdx) > dthr || fabsf(zdy) > dthr);
+            f.R[0][at] = make_float4(ok ? z0 : nanv, i0, idx, idy);
+          }
+        }
+        if (ROLE == 1) count += __popcll(__ballot(ok));         // wave-uniform
+      }
+    }
+    if (ROLE == 1 && (threadIdx.x & 63) == 0) wave_counts[threadIdx.x >> 6] = count;
+    // ---- pyramid levels 1-3 (16 x 4 and 8 x 2 pixels of levels 2 and 3 per tile; an out-of-image quad is never written) ----
+    const int r = 2 * ty + 1, c = 2 * tx + 1;
+    const float i1 = (sI[r][c] + sI[r][c + 1] + sI[r + 1][c] + sI[r + 1][c + 1]) / 4.0f;   // same summation order as the reference
+    const float z00 = sZ[r][c];
+    if (levels >= 2 && x1 < w1 && y1 < h1) {
       f.I[1][size_t(y1) * w1 + x1] = i1;
       f.Z[1][size_t(y1) * w1 + x1] = z00;                       // top-left sample, NaN holes kept (Q18)
     }
-    if (levels < 3) return;
     s1[ty][tx] = i1;
-    __syncthreads();
+    __syncthreads();                                             // s1 and wave_counts complete; sI / sZ free for the next tile
+    if (ROLE == 1 && threadIdx.x == 0) {
+      const int total = (wave_counts[0] + wave_counts[1]) + (wave_counts[2] + wave_counts[3]);
+      if (total) atomicAdd(f.sel_count, total);
+    }
     const int x2 = x1 >> 1, y2 = y1 >> 1;
     if ((tx & 1) == 0 && (ty & 1) == 0) {
       const float i2 = (s1[ty][tx] + s1[ty][tx + 1] + s1[ty + 1][tx] + s1[ty + 1][tx + 1]) / 4.0f;
-      if (x2 < w2 && y2 < h2) {
+      if (levels >= 3 && x2 < w2 && y2 < h2) {
         f.I[2][size_t(y2) * w2 + x2] = i2;
         f.Z[2][size_t(y2) * w2 + x2] = z00;
       }
       s2[ty >> 1][tx >> 1] = i2;
     }
-    __syncthreads();                                             // also: nobody overwrites s1 of this tile before it was read
+    __syncthreads();
     if (levels >= 4 && (tx & 3) == 0 && (ty & 3) == 0) {
       const int x3 = x1 >> 2, y3 = y1 >> 2, cx = tx >> 1, cy = ty >> 1;
       if (x3 < w3 && y3 < h3) {
@@ -94,7 +175,7 @@ __global__ __launch_bounds__(256) void k_ingest_pyramid(const FrameBuildPtrs* __
         f.Z[3][size_t(y3) * w3 + x3] = z00;
       }
     }
-    __syncthreads();                                             // s2 is free again for the next tile of this workgroup
+    __syncthreads();                                             // s1, s2, wave_counts free for the next tile of this workgroup
   });
 }
 
@@ -224,9 +305,19 @@ static int capped_grid(int tiles_x, int tiles_y, int n_frames, int max_workgroup
   return int(max_workgroups > 0 && total > max_workgroups ? max_workgroups : total);
 }
 
-void launch_ingest_pyramid(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int max_workgroups) {
-  const int tx = (w0 + 63) / 64, ty = (h0 + 15) / 16;
-  k_ingest_pyramid<<<dim3(capped_grid(tx, ty, n_frames, max_workgroups)), dim3(256), 0, s>>>(tbl, scale, w0, h0, levels < 4 ? levels : 4, tx, ty, n_frames);
+void launch_build_from_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int role, bool wide,
+                           float ithr, float dthr, int max_workgroups) {
+  const int tx = (w0 + kB0W - 1) / kB0W, ty = (h0 + kB0H - 1) / kB0H;
+  const dim3 grid(capped_grid(tx, ty, n_frames, max_workgroups)), block(256);
+  const int lv = levels < 4 ? levels : 4;
+  if (role == 1) k_zero_counts<<<dim3((n_frames + 63) / 64), dim3(64), 0, s>>>(tbl, n_frames, 0);
+#define DVO_LAUNCH_B0(ROLE, WIDE) k_build_from_raw<ROLE, WIDE><<<grid, block, 0, s>>>(tbl, scale, w0, h0, lv, ithr, dthr, tx, ty, n_frames)
+  if (wide) {
+    if (role == 0) DVO_LAUNCH_B0(0, true); else if (role == 1) DVO_LAUNCH_B0(1, true); else DVO_LAUNCH_B0(-1, true);
+  } else {
+    if (role == 0) DVO_LAUNCH_B0(0, false); else if (role == 1) DVO_LAUNCH_B0(1, false); else DVO_LAUNCH_B0(-1, false);
+  }
+#undef DVO_LAUNCH_B0
 }
 
 void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h) {

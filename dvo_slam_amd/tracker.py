@@ -291,15 +291,23 @@ class RgbdCameraPyramid:
         return RgbdImagePyramid(self, make, self.levels, timestamp)
 
 
-def update_raw_device_batch(pyramids, grey_dev_ptrs, depth_dev_ptrs, depth_scale=1.0 / 5000.0):
-    """Re-ingest raw planes (device pointers) into n existing pyramids of one camera: one launch per level for the batch."""
+_ROLES = {"current": 0, "reference": 1}
+
+
+def update_raw_device_batch(pyramids, grey_dev_ptrs, depth_dev_ptrs, depth_scale=1.0 / 5000.0, role=None, config=None):
+    """Re-ingest raw planes (device pointers) into n existing pyramids of one camera, batched.  With role ("current" /
+    "reference") and config: ingest and prepare_roles_batch in one pass over the raw planes (dvo_hip_frames_update_raw_device_as)."""
     n = len(pyramids)
     ctx = pyramids[0].ctx
     vp = C.c_void_p
     fr = (vp * n)(*[p.ptr for p in pyramids])
     g = (vp * n)(*[vp(int(x)) for x in grey_dev_ptrs])
     z = (vp * n)(*[vp(int(x)) for x in depth_dev_ptrs])
-    ctx.check(ctx._lib.dvo_hip_frames_update_raw_device(ctx.ptr, n, fr, g, z, depth_scale))
+    if role is None:
+        ctx.check(ctx._lib.dvo_hip_frames_update_raw_device(ctx.ptr, n, fr, g, z, depth_scale))
+    else:
+        ccfg = config.to_c()
+        ctx.check(ctx._lib.dvo_hip_frames_update_raw_device_as(ctx.ptr, n, fr, g, z, depth_scale, _ROLES[role], C.byref(ccfg)))
 
 
 class PinnedRawPlanes:
@@ -324,7 +332,7 @@ class PinnedRawPlanes:
             self.ptr = None
 
 
-def update_raw_host_batch(pyramids, grey_host, depth_host, depth_scale=1.0 / 5000.0):
+def update_raw_host_batch(pyramids, grey_host, depth_host, depth_scale=1.0 / 5000.0, role=None, config=None):
     """Re-ingest raw planes from HOST arrays (uint8 / uint16, C-contiguous) into n existing pyramids: asynchronous DMA on the
     context's upload stream, then the batched build (dvo_hip_frames_update_raw).  The arrays must stay unchanged until
     upload_wait() or until a match on these pyramids has returned."""
@@ -336,7 +344,11 @@ def update_raw_host_batch(pyramids, grey_host, depth_host, depth_scale=1.0 / 500
     fr = (vp * n)(*[p.ptr for p in pyramids])
     g = (vp * n)(*[vp(a.ctypes.data) for a in grey_host])
     z = (vp * n)(*[vp(a.ctypes.data) for a in depth_host])
-    ctx.check(ctx._lib.dvo_hip_frames_update_raw(ctx.ptr, n, fr, g, z, depth_scale))
+    if role is None:
+        ctx.check(ctx._lib.dvo_hip_frames_update_raw(ctx.ptr, n, fr, g, z, depth_scale))
+    else:
+        ccfg = config.to_c()
+        ctx.check(ctx._lib.dvo_hip_frames_update_raw_as(ctx.ptr, n, fr, g, z, depth_scale, _ROLES[role], C.byref(ccfg)))
 
 
 def upload_wait(ctx):
@@ -352,7 +364,7 @@ def prepare_roles_batch(pyramids, role, config):
     vp = C.c_void_p
     fr = (vp * n)(*[p.ptr for p in pyramids])
     ccfg = config.to_c()
-    ctx.check(ctx._lib.dvo_hip_frames_prepare(ctx.ptr, n, fr, {"current": 0, "reference": 1}[role], C.byref(ccfg)))
+    ctx.check(ctx._lib.dvo_hip_frames_prepare(ctx.ptr, n, fr, _ROLES[role], C.byref(ccfg)))
 
 
 class PointSelection:

@@ -98,6 +98,10 @@ typedef struct {
                                         (dvo_slam/src/constraints/constraint_proposal_voter.cpp:136-140) */
 } dvo_hip_result;
 
+/* the two roles of a frame in an alignment (dvo_hip_frames_prepare, dvo_hip_frames_update_raw*_as) */
+#define DVO_HIP_ROLE_CURRENT 0
+#define DVO_HIP_ROLE_REFERENCE 1
+
 typedef struct dvo_hip_context dvo_hip_context;
 typedef struct dvo_hip_frame dvo_hip_frame;
 
@@ -138,6 +142,13 @@ int dvo_hip_frame_update_raw_device(dvo_hip_context* ctx, dvo_hip_frame* frame, 
 /* The same for n frames of one camera in one launch per pyramid level (blockIdx.z = frame). */
 int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames,
                                      const void* const* grey_dev, const void* const* raw_depth_dev, float depth_scale);
+/* Update + dvo_hip_frames_prepare(role, cfg) in ONE pass over the raw planes: the frames are about to be used in that role
+ * (DVO_HIP_ROLE_*), so level 0 is written straight into the role's planes instead of float planes that the prepare step would
+ * have to read back (40 instead of 56 B of traffic per pixel for a current frame, 33 instead of 45 for a reference).
+ * A frame can still be used in the other role later. */
+int dvo_hip_frames_update_raw_device_as(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames,
+                                        const void* const* grey_dev, const void* const* raw_depth_dev, float depth_scale,
+                                        int role, const dvo_hip_config* cfg);
 /* The same from HOST memory: the raw planes are transferred on an upload stream of the context (DMA), the build follows on
  * the build stream; the call returns at once.  With planes in pinned memory (dvo_hip_host_alloc) the transfer of the next
  * batch overlaps the build and the alignment of earlier ones.  A frame whose grey plane directly follows its depth plane
@@ -149,6 +160,9 @@ int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip
  * dvo_ros/src/camera_dense_tracking.cpp:243) for a stream of frames. */
 int dvo_hip_frames_update_raw(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames,
                               const uint8_t* const* grey, const uint16_t* const* raw_depth, float depth_scale);
+int dvo_hip_frames_update_raw_as(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames,
+                                 const uint8_t* const* grey, const uint16_t* const* raw_depth, float depth_scale,
+                                 int role, const dvo_hip_config* cfg);
 int dvo_hip_upload_wait(dvo_hip_context* ctx);
 /* pinned (page-locked) host memory for raw planes: decoders / camera drivers write here, uploads from it are asynchronous */
 int dvo_hip_host_alloc(dvo_hip_context* ctx, size_t bytes, void** out);
@@ -162,8 +176,6 @@ void dvo_hip_host_free(dvo_hip_context* ctx, void* p);
  * started afterwards on other frames -- build the next batch, then align the current one, and the two overlap.  A frame
  * must not be updated while a match that uses it is in progress (matches are blocking calls, so this only concerns other
  * host threads). */
-#define DVO_HIP_ROLE_CURRENT 0
-#define DVO_HIP_ROLE_REFERENCE 1
 int dvo_hip_frames_prepare(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, int role, const dvo_hip_config* cfg);
 void dvo_hip_frame_destroy(dvo_hip_context* ctx, dvo_hip_frame* frame);
 int dvo_hip_frame_info(const dvo_hip_frame* frame, int level, int* width, int* height, float K[4]);

@@ -420,3 +420,62 @@ def test_streaming_upload_from_host_memory(gpu_ctx):
     del sets
     for P in pinned:
         P.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,levels", [(320, 240, 3), (102, 78, 3), (640, 480, 4)])
+def test_role_aware_ingest_is_bit_identical(gpu_ctx, w, h, levels):
+    """dvo_hip_frames_update_raw_as: level 0 written straight from the raw planes into the role's planes (no float planes at
+    level 0, 4-pixel-wide loads when the rows allow it).  Same planes, same selection, same alignment results as frames built
+    the long way -- also when a frame is later used in the OTHER role (reference from its sampling planes, current from the
+    raw copy it kept)."""
+    n = 4
+    cfg = d.Config(FirstLevel=levels - 1, LastLevel=0)
+    trk = d.DenseTracker(cfg, gpu_ctx)
+    K = po.FR1_K * (w / 640.0)
+    cam = d.RgbdCameraPyramid(w, h, K, gpu_ctx)
+    cam.build(levels)
+    b = datagen.synth_batch(77, n, w, h)
+
+    def raw(out):
+        return b"".join(np.ascontiguousarray(out[k]).tobytes() for k in ("T", "information", "loglik", "n_iterations", "entropy"))
+    refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)]
+    curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)]
+    forward, backward = raw(trk.match_batch_arrays(refs, curs)), raw(trk.match_batch_arrays(curs, refs))
+    assert forward != backward
+    names = ("intensity", "depth", "intensity_dx", "intensity_dy", "depth_dx", "depth_dy")
+
+    def all_planes(f):
+        return [np.array(getattr(f.level(l), k)) for l in range(levels) for k in names]
+
+    def count(f, level, ithr=0.0, dthr=0.0):
+        return d.PointSelection(f, ithr, dthr).select(level)
+    planes = [all_planes(f) for f in (refs[0], curs[0])]
+    counts = [count(refs[0], l) for l in range(levels)]
+
+    dummy = np.zeros((h, w), np.uint8), np.full((h, w), 5000, np.uint16)
+    R = [cam.create_raw(*dummy) for _ in range(n)]
+    Cu = [cam.create_raw(*dummy) for _ in range(n)]
+    gr = [np.ascontiguousarray(a) for a in b["grey_ref"]]
+    zr = [np.ascontiguousarray(a) for a in b["depth_ref"]]
+    gc = [np.ascontiguousarray(a) for a in b["grey_cur"]]
+    zc = [np.ascontiguousarray(a) for a in b["depth_cur"]]
+    for rounds in range(2):
+        d.update_raw_host_batch(R, gr, zr, role="reference", config=cfg)
+        d.update_raw_host_batch(Cu, gc, zc, role="current", config=cfg)
+        assert raw(trk.match_batch_arrays(R, Cu)) == forward
+        assert raw(trk.match_batch_arrays(Cu, R)) == backward          # each frame in the role it was NOT built for
+        assert raw(trk.match_batch_arrays(R, Cu)) == forward
+    for want_f, got_f in zip(planes, [all_planes(f) for f in (R[0], Cu[0])]):
+        for a, c in zip(want_f, got_f):
+            assert np.array_equal(a, c, equal_nan=True)
+    assert [count(R[0], l) for l in range(levels)] == counts
+    # other thresholds on a role-ingested frame, then back
+    n_tight = count(R[1], 0, 8.0, 0.02)
+    assert 0 < n_tight < count(refs[1], 0) and n_tight == count(refs[1], 0, 8.0, 0.02)
+    assert raw(trk.match_batch_arrays(R, Cu)) == forward
+    # a configuration that does not use level 0: nothing of level 0 is built at ingest, the match of the full pyramid still agrees
+    coarse = d.Config(FirstLevel=levels - 1, LastLevel=1)
+    d.update_raw_host_batch(R, gr, zr, role="reference", config=coarse)
+    d.update_raw_host_batch(Cu, gc, zc, role="current", config=coarse)
+    assert raw(trk.match_batch_arrays(R, Cu)) == forward
