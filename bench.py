@@ -209,11 +209,15 @@ def main():
 
     # roofline of the dominant kernel: finest-level fused warp/residual/Jacobian/reduce sweep, HIP events on the context stream
     k_ms = {lvl: tracker.time_residual_kernel(refs, curs, lvl, reps=20) for lvl in (0, 1, 2, 3)}
+    stream_ms = tracker.time_stream_mix(refs, curs, 0, reps=20)     # the same planes streamed in pixel order, nothing else
     algo_bytes = ALGO_BYTES_PER_PIXEL * W * H * B
     achieved = algo_bytes / (k_ms[0] * 1e-3) / 1e9
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
                     traffic=_pmc_traffic(B), kernel="dvo_hip::k_residual_reduce_mfma<RPW, true> (pyramid level 0, %d pairs per launch)" % B,
                     kernel_ms=round(k_ms[0], 4), algorithmic_bytes_per_launch=algo_bytes,
+                    bare_stream_ms=round(stream_ms, 4), bare_stream_frac=round(algo_bytes / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    bare_stream_note="a kernel that only reads the same planes in pixel order and writes the 8-B pair (no gather, "
+                                     "arithmetic or reduction), timed the same way: what this part's memory system needs for the same bytes",
                     per_level_kernel_ms={str(k): round(v, 4) for k, v in k_ms.items()})
 
     # latency of BASELINE config 2: one 640x480 pair, 4 levels

@@ -63,7 +63,7 @@ EXPORTS = [
     "dvo_hip_device_count", "dvo_hip_frame_create_f32", "dvo_hip_frame_create_raw", "dvo_hip_frame_create_raw_device",
     "dvo_hip_frame_update_raw_device", "dvo_hip_frames_update_raw_device", "dvo_hip_frames_update_raw", "dvo_hip_frames_update_raw_device_as", "dvo_hip_frames_update_raw_as", "dvo_hip_upload_wait",
     "dvo_hip_host_alloc", "dvo_hip_host_free", "dvo_hip_frames_prepare", "dvo_hip_frame_destroy", "dvo_hip_frame_info", "dvo_hip_frame_download_plane", "dvo_hip_frame_select",
-    "dvo_hip_match", "dvo_hip_match_batch", "dvo_hip_level_iteration", "dvo_hip_time_residual_kernel",
+    "dvo_hip_match", "dvo_hip_match_batch", "dvo_hip_level_iteration", "dvo_hip_time_residual_kernel", "dvo_hip_time_stream_mix",
     "dvo_hip_set_option", "dvo_hip_version",
 ]
 
@@ -125,6 +125,7 @@ def lib():
     L.dvo_hip_level_iteration.argtypes = [vp, vp, vp, C.c_int, C.c_float, C.c_float, fp, fp, C.c_int,
                                           C.POINTER(IterationOut), fp]
     L.dvo_hip_time_residual_kernel.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, fp]
+    L.dvo_hip_time_stream_mix.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, fp]
     L.dvo_hip_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.dvo_hip_version.restype = C.c_char_p
     _lib = L

@@ -179,6 +179,24 @@ void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool 
   }
 }
 
+// The sweep's bytes without the sweep: every pixel's reference quad, current-frame quad and gradient pair are read in
+// pixel order and an 8-byte pair is written where the sweep writes its residuals.  No gather, no arithmetic, no reduction:
+// the time of this kernel is what the memory system needs for the sweep's algorithmic traffic (dvo_hip_time_stream_mix).
+__global__ __launch_bounds__(kBlock) void k_stream_mix(const PairPtrs* __restrict__ pairs, int n_px, float2* __restrict__ scratch) {
+  const PairPtrs pp = pairs[blockIdx.y];
+  float2* out = scratch + size_t(blockIdx.y) * n_px;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_px; i += gridDim.x * kBlock) {
+    const float4 r = pp.refR[i], a = pp.curA[i];
+    const float2 b = pp.curB[i];
+    out[i] = make_float2(r.x + a.y + b.x, r.w + a.z + b.y);
+  }
+}
+
+void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch) {
+  const int per_pair = (n_px + kBlock * 8 - 1) / (kBlock * 8);
+  k_stream_mix<<<dim3(per_pair, n_pairs), dim3(kBlock), 0, s>>>(pairs, n_px, scratch);
+}
+
 void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,
                    const float2* scratch, double* ll_partials, int blocks_per_pair) {
   k_loglik<<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, blocks_per_pair);

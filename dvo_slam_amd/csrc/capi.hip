@@ -1263,4 +1263,36 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs, dvo_hip_fram
   return DVO_HIP_OK;
 }
 
+int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
+                            int level, int reps, float* avg_ms) {
+  if (!avg_ms || reps < 1) return fail(ctx, DVO_HIP_ERR_INVALID, "time_stream_mix: bad argument");
+  dvo_hip_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.first_level = level;
+  cfg.last_level = level;
+  cfg.max_iterations_per_level = 1;
+  BatchPlan bp;
+  int rc = prepare_single(ctx, n_pairs, references, currents, &cfg, bp);
+  if (rc != DVO_HIP_OK) return rc;
+  hipStream_t s = ctx->stream;
+  const LevelGeom& g = bp.geom[level];
+  const PairPtrs* pp = bp.pair_ptrs + size_t(level) * bp.n;
+  float2* scratch = ctx->ws[0].scratch.as<float2>();
+  hipEvent_t e0, e1;
+  DVO_HIP_TRY(ctx, hipEventCreate(&e0));
+  DVO_HIP_TRY(ctx, hipEventCreate(&e1));
+  launch_stream_mix(s, pp, bp.n, g.w * g.h, scratch);   // warm
+  DVO_HIP_TRY(ctx, hipEventRecord(e0, s));
+  for (int r = 0; r < reps; ++r) launch_stream_mix(s, pp, bp.n, g.w * g.h, scratch);
+  DVO_HIP_TRY(ctx, hipEventRecord(e1, s));
+  DVO_HIP_TRY(ctx, hipEventSynchronize(e1));
+  float ms = 0;
+  DVO_HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  DVO_HIP_TRY(ctx, hipGetLastError());
+  *avg_ms = ms / float(reps);
+  return DVO_HIP_OK;
+}
+
 }  // extern "C"

@@ -27,6 +27,7 @@ void launch_residual_reduce_split(hipStream_t s, bool pipelined, int rows_per_wa
                                   const PairPtrs* pairs, const PairState* states, int n_pairs, float* partials, float2* scratch);
 void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
                                  const PairState* states, int n_pairs, float* partials, float2* scratch);
+void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch);
 void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,
                    const float2* scratch, double* ll_partials, int blocks_per_pair);
 

@@ -550,3 +550,13 @@ class DenseTracker:
         ms = C.c_float()
         self.ctx.check(self.ctx._lib.dvo_hip_time_residual_kernel(self.ctx.ptr, n, refs, curs, level, reps, C.byref(ms)))
         return ms.value
+
+    def time_stream_mix(self, references, currents, level, reps=20):
+        """Average duration (ms) of a kernel that only streams the sweep's planes (40 B read + 8 B written per pixel)."""
+        n = len(references)
+        vp = C.c_void_p
+        refs = (vp * n)(*[p.ptr for p in references])
+        curs = (vp * n)(*[p.ptr for p in currents])
+        ms = C.c_float()
+        self.ctx.check(self.ctx._lib.dvo_hip_time_stream_mix(self.ctx.ptr, n, refs, curs, level, reps, C.byref(ms)))
+        return ms.value

@@ -238,6 +238,13 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs,
                                  dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
                                  int level, int reps, float* avg_ms);
 
+/* The yardstick for that number: a kernel that only streams the same planes of the same pairs in pixel order (16 + 16 + 8 B
+ * read, 8 B written per pixel) -- no gather, no arithmetic, no reduction.  What the memory system needs for the sweep's
+ * algorithmic traffic on this part. */
+int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
+                            dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
+                            int level, int reps, float* avg_ms);
+
 /* Tunables (0 = library default).  key: "rows_per_wave" (1,2,4,8,16: tile height of the reduce kernel),
  * "iters_per_sync" (host polling cadence of the batched Gauss-Newton loop), "variant" (schedule of the reduce
  * kernel: 0, 1, 3, 4, 5), "min_workgroups" (tile-height heuristic: smallest launch that
