@@ -175,10 +175,20 @@ def main():
         out = tracker.match_batch_arrays(fs[:B], fs[B:])                # synchronous: returns when the transforms are on the host
         last.update(out)
         if world > 1:
+            # the records of this batch travel (one all-gather, RCCL) while the next batch is aligned
             tw = [_twist(T) for T in out["T"]]
             rec = parallel.pack_records(tw, out["information"], out["loglik"])
-            return parallel.gather_records(rec, n_total, rank, world, device=comm_dev)
+            if pending[0] is not None:
+                gathered[0] = pending[0].result()
+            pending[0] = parallel.gather_records_start(rec, n_total, rank, world, device=comm_dev)
         return None
+
+    pending, gathered = [None], [None]
+
+    def drain():
+        if pending[0] is not None:
+            gathered[0] = pending[0].result()
+            pending[0] = None
 
     def barrier():
         torch.cuda.synchronize()
@@ -189,10 +199,12 @@ def main():
         build(0)                                                        # prime the pipeline: step k aligns set k % 2 and builds the other
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                                                             # the last batch's records have arrived on every rank
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

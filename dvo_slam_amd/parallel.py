@@ -39,12 +39,26 @@ def unpack_records(rec):
     return twists, infos, rec[:, 27].copy(), rec[:, 28].copy()
 
 
-def gather_records(local_records, n_pairs, rank, world_size, device=None):
-    """All-gather the per-rank record blocks and restore global pair order.  Needs an initialised
-    torch.distributed process group when world_size > 1 (backend "nccl" = RCCL on the GPUs, "gloo" in CPU tests).
-    Ranks may own different numbers of pairs (n_pairs need not divide by world_size): blocks are padded."""
-    if world_size == 1:
-        return np.asarray(local_records, np.float64).reshape(-1, RECORD)
+class PendingGather:
+    """An all-gather in flight (gather_records_start); result() waits for it and restores global pair order."""
+
+    def __init__(self, n_pairs, world_size, work, out, keep):
+        self.n_pairs, self.world_size, self.work, self.out, self.keep = n_pairs, world_size, work, out, keep
+
+    def result(self):
+        if self.work is not None:
+            self.work.wait()
+        full = np.zeros((self.n_pairs, RECORD), np.float64)
+        for r in range(self.world_size):
+            idx = shard_indices(self.n_pairs, r, self.world_size)
+            full[idx] = self.out[r][: len(idx)].cpu().numpy()
+        return full
+
+
+def gather_records_start(local_records, n_pairs, rank, world_size, device=None):
+    """Start the all-gather of the per-rank record blocks (asynchronous: the collective of batch k travels while batch k+1
+    is being aligned).  Needs an initialised torch.distributed process group (backend "nccl" = RCCL on the GPUs, "gloo" in
+    CPU tests).  Ranks may own different numbers of pairs (n_pairs need not divide by world_size): blocks are padded."""
     import torch
     import torch.distributed as dist
     per_rank = (n_pairs + world_size - 1) // world_size
@@ -52,9 +66,12 @@ def gather_records(local_records, n_pairs, rank, world_size, device=None):
     loc = torch.from_numpy(np.ascontiguousarray(local_records, dtype=np.float64).reshape(-1, RECORD))
     buf[: loc.shape[0]] = loc.to(buf.device)
     out = [torch.empty_like(buf) for _ in range(world_size)]
-    dist.all_gather(out, buf)
-    full = np.zeros((n_pairs, RECORD), np.float64)
-    for r in range(world_size):
-        idx = shard_indices(n_pairs, r, world_size)
-        full[idx] = out[r][: len(idx)].cpu().numpy()
-    return full
+    work = dist.all_gather(out, buf, async_op=True)
+    return PendingGather(n_pairs, world_size, work, out, (buf, loc))
+
+
+def gather_records(local_records, n_pairs, rank, world_size, device=None):
+    """All-gather the per-rank record blocks and restore global pair order (blocking)."""
+    if world_size == 1:
+        return np.asarray(local_records, np.float64).reshape(-1, RECORD)
+    return gather_records_start(local_records, n_pairs, rank, world_size, device).result()

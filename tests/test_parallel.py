@@ -32,6 +32,10 @@ def _worker(rank, world, port, n_pairs, q):
     info = np.array([np.eye(6) * (i + 1) for i in idx]).reshape(-1, 6, 6)
     rec = par.pack_records(tw, info, [float(i) for i in idx], [rank] * len(idx))
     full = par.gather_records(rec, n_pairs, rank, world)
+    # the pipelined form bench.py uses: the gather of batch k is collected after batch k+1 has been started
+    first = par.gather_records_start(rec, n_pairs, rank, world)
+    second = par.gather_records_start(rec * 2.0, n_pairs, rank, world)
+    assert np.array_equal(first.result(), full) and np.array_equal(second.result(), full * 2.0)
     dist.barrier()
     q.put((rank, full))
     dist.destroy_process_group()
