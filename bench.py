@@ -154,6 +154,11 @@ def main():
     sets = [[cam.create_raw_device(grey_ptrs[i], depth_ptrs[i]) for i in range(2 * B)] for _ in range(n_sets)]
     frames = sets[0]
     refs, curs = frames[:B], frames[B:]
+    # handle / address arrays of the streaming loop are built once (a C++ caller has them as plain arrays anyway)
+    ref_sets = [d.FrameSet(fs[:B]) for fs in sets]
+    cur_sets = [d.FrameSet(fs[B:]) for fs in sets]
+    g_ref, z_ref = d.device_pointer_array(grey_ptrs[:B]), d.device_pointer_array(depth_ptrs[:B])
+    g_cur, z_cur = d.device_pointer_array(grey_ptrs[B:]), d.device_pointer_array(depth_ptrs[B:])
     cfg_kwargs = dict(first_level=3, last_level=0, max_iterations=100, precision=5e-7, mu=0.0)
     cfg = d.Config(FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0.0)
     tracker = d.DenseTracker(cfg, ctx)
@@ -163,16 +168,14 @@ def main():
 
     def build(k):
         # ingest + pyramids + the planes of the role each frame plays, from HBM-resident raw planes, on the build stream (asynchronous)
-        fs = sets[k]
-        d.update_raw_device_batch(fs[:B], grey_ptrs[:B], depth_ptrs[:B], role="reference", config=cfg)
-        d.update_raw_device_batch(fs[B:], grey_ptrs[B:], depth_ptrs[B:], role="current", config=cfg)
+        d.update_raw_device_batch(ref_sets[k], g_ref, z_ref, role="reference", config=cfg)
+        d.update_raw_device_batch(cur_sets[k], g_cur, z_cur, role="current", config=cfg)
 
     def step():
         k = counter[0] % n_sets
         counter[0] += 1
         build((k + 1) % n_sets)                                         # next batch (with one set: this batch, built right before its match)
-        fs = sets[k]
-        out = tracker.match_batch_arrays(fs[:B], fs[B:])                # synchronous: returns when the transforms are on the host
+        out = tracker.match_batch_arrays(ref_sets[k], cur_sets[k])      # synchronous: returns when the transforms are on the host
         last.update(out)
         if world > 1:
             # the records of this batch travel (one all-gather, RCCL) while the next batch is aligned
@@ -253,13 +256,13 @@ def main():
             pinned.depth[i][:] = pairs_np["depth_ref"][i]
             pinned.depth[B + i][:] = pairs_np["depth_cur"][i]
 
-        def host_build(k):
+        def host_build(k):   # this leg is bound by the PCIe link (4.3 ms per step), not by the host: plain lists will do
             d.update_raw_host_batch(sets[k][:B], pinned.grey[:B], pinned.depth[:B], role="reference", config=cfg)
             d.update_raw_host_batch(sets[k][B:], pinned.grey[B:], pinned.depth[B:], role="current", config=cfg)
 
         def host_step(j):
             host_build((j + 1) % n_sets)
-            out_h = tracker.match_batch_arrays(sets[j % n_sets][:B], sets[j % n_sets][B:])
+            out_h = tracker.match_batch_arrays(ref_sets[j % n_sets], cur_sets[j % n_sets])
             return out_h
 
         if n_sets > 1:

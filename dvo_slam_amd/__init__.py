@@ -6,4 +6,4 @@ this package is the thin Python mirror of the reference's class API used by the 
 from ._lib import DvoHipError, build, lib, LIB_PATH  # noqa: F401
 from .tracker import (Config, Context, DenseTracker, IterationStats, LevelStats, PointSelection, Result,  # noqa: F401
                       RgbdCameraPyramid, RgbdImage, RgbdImagePyramid, Stats, TERMINATION, default_context,
-                      update_raw_device_batch, prepare_roles_batch, update_raw_host_batch, upload_wait, PinnedRawPlanes)
+                      update_raw_device_batch, prepare_roles_batch, update_raw_host_batch, upload_wait, PinnedRawPlanes, FrameSet, device_pointer_array)

@@ -82,12 +82,69 @@ struct dvo_hip_frame {
   float depth_scale = 0.0f;
 };
 
+// Small host -> device transfers (pointer tables, initial guesses) go through slots of pinned memory.  From pageable memory
+// hipMemcpyAsync does not return before the stream has reached the copy: a table upload queued behind a 300-us build kernel
+// held the host, and with it the alignment it was about to enqueue on the other stream, for as long (kernel trace: the
+// match of a step started 250 us late).  A slot is reused only after the copy that read it has completed (one event per slot).
+struct PinnedRing {
+  static const int kSlots = 48;
+  char* base = nullptr;
+  size_t slot_bytes = 0;
+  hipEvent_t done[kSlots] = {};
+  bool in_flight[kSlots] = {};
+  unsigned next = 0;
+
+  hipError_t upload(hipStream_t stream, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes > slot_bytes) {                      // grow: wait for every copy in flight, then one new block
+      hipError_t e = drain();
+      if (e != hipSuccess) return e;
+      if (base) (void)hipHostFree(base);
+      base = nullptr;
+      slot_bytes = 0;
+      size_t want = 64 * 1024;
+      while (want < bytes) want *= 2;
+      e = hipHostMalloc(reinterpret_cast<void**>(&base), want * kSlots, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      slot_bytes = want;
+    }
+    const unsigned k = next++ % kSlots;
+    hipError_t e = hipSuccess;
+    if (!done[k]) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+    if (e == hipSuccess && in_flight[k]) e = hipEventSynchronize(done[k]);
+    if (e != hipSuccess) return e;
+    std::memcpy(base + slot_bytes * k, src, bytes);
+    e = hipMemcpyAsync(dst, base + slot_bytes * k, bytes, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipEventRecord(done[k], stream);
+    in_flight[k] = e == hipSuccess;
+    return e;
+  }
+  hipError_t drain() {
+    for (int k = 0; k < kSlots; ++k)
+      if (in_flight[k]) {
+        const hipError_t e = hipEventSynchronize(done[k]);
+        if (e != hipSuccess) return e;
+        in_flight[k] = false;
+      }
+    return hipSuccess;
+  }
+  void release() {
+    (void)drain();
+    for (hipEvent_t& ev : done)
+      if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    if (base) (void)hipHostFree(base);
+    base = nullptr;
+    slot_bytes = 0;
+  }
+};
+
 // The batch workspace: one HIP stream, device scratch and the pinned poll words of the Gauss-Newton loop.
 // (Splitting a batch into concurrently iterating pair groups on several streams was measured and dropped: the coarse
 // levels are bound by the host's launch rate, which more streams only divide -- profiles/r01_d_groups.txt.)
 struct Workspace {
   hipStream_t stream = nullptr;
   DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters;
+  PinnedRing* tables = nullptr;  // the context's ring for small uploads
   int* host_status = nullptr;    // pinned: one word per Gauss-Newton step of a batch, written by the device (k_solver_step)
   size_t host_status_words = 0;
   std::string err;
@@ -107,6 +164,7 @@ struct dvo_hip_context {
   std::vector<CameraGeom*> cameras;
   Workspace ws[1];
   DevBuf misc, build_tbl, role_tbl_cur, role_tbl_ref, prep_tbl_cur, prep_tbl_ref;
+  PinnedRing tables;
   // Frame construction (ingest, pyramid, eagerly prepared role planes) runs on its own stream so that the next batch of
   // frames can be built while the current batch is being aligned: the build is bandwidth-bound, the coarse pyramid levels
   // of an alignment are latency-bound, and the two overlap.  Every build call takes a ticket and records an event; an
@@ -407,7 +465,7 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
   }
   DVO_HIP_TRY(ctx, ctx->build_tbl.reserve(size_t(n) * sizeof(FrameBuildPtrs)));
   hipStream_t bs = ctx->build_stream;
-  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->build_tbl.p, host.data(), size_t(n) * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, bs));
+  DVO_HIP_TRY(ctx, ctx->tables.upload(bs, ctx->build_tbl.p, host.data(), size_t(n) * sizeof(FrameBuildPtrs)));
   const FrameBuildPtrs* tbl = ctx->build_tbl.as<FrameBuildPtrs>();
   int built = 1;                                       // float ingest: level 0 is already in place
   if (grey) {
@@ -467,7 +525,7 @@ int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int 
       // each level has its own slice of the table so that a copy never waits for the previous level's kernel
       DVO_HIP_TRY(ctx, table.reserve(slice * (kMaxLevels + 1)));
       FrameBuildPtrs* tbl = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * l);
-      DVO_HIP_TRY(ctx, hipMemcpyAsync(tbl, host.data(), host.size() * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, stream));
+      DVO_HIP_TRY(ctx, ctx->tables.upload(stream, tbl, host.data(), host.size() * sizeof(FrameBuildPtrs)));
       if (role == 0) launch_derive_current(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], cap);
       else launch_derive_reference(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], ithr, dthr, cap);
       launched = true;
@@ -475,7 +533,7 @@ int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int 
     if (!from_raw.empty()) {
       DVO_HIP_TRY(ctx, table.reserve(slice * (kMaxLevels + 1)));
       FrameBuildPtrs* tbl = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * kMaxLevels);
-      DVO_HIP_TRY(ctx, hipMemcpyAsync(tbl, from_raw.data(), from_raw.size() * sizeof(FrameBuildPtrs), hipMemcpyHostToDevice, stream));
+      DVO_HIP_TRY(ctx, ctx->tables.upload(stream, tbl, from_raw.data(), from_raw.size() * sizeof(FrameBuildPtrs)));
       launch_build_from_raw(stream, tbl, int(from_raw.size()), raw_scale, cam->w[0], cam->h[0], /*levels=*/1, role, cam->w[0] % 4 == 0, ithr, dthr, cap);
       launched = true;
     }
@@ -597,8 +655,7 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
       p.curB = curs[i]->lv[l].B;
       p.n_selected = refs[i]->sel_count + l;
     }
-  // pageable source: the runtime stages the bytes before the call returns, so `host` may go out of scope
-  DVO_WS_TRY(w, hipMemcpyAsync(w.pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs), hipMemcpyHostToDevice, w.stream));
+  DVO_WS_TRY(w, w.tables->upload(w.stream, w.pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs)));
   bp.pair_ptrs = w.pair_ptrs.as<PairPtrs>();
   return DVO_HIP_OK;
 }
@@ -642,7 +699,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   // initial guesses (Result.Transformation is in/out, dense_tracking.cpp:137-147)
   std::vector<double> tinit(size_t(n) * 16);
   for (int i = 0; i < n; ++i) std::memcpy(&tinit[size_t(i) * 16], results[i].transformation, 16 * sizeof(double));
-  DVO_WS_TRY(w, hipMemcpyAsync(w.t_init.p, tinit.data(), tinit.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  DVO_WS_TRY(w, w.tables->upload(s, w.t_init.p, tinit.data(), tinit.size() * sizeof(double)));
   // per-step tallies (device) and status words (pinned host memory the device writes, see publish_step)
   const size_t n_steps = size_t(bp.cap_iters) + 8;
   if (w.host_status_words < n_steps) {
@@ -789,6 +846,7 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
     return DVO_HIP_ERR_HIP;
   }
   ctx->stream = ctx->ws[0].stream;
+  ctx->ws[0].tables = &ctx->tables;
   int prio_least = 0, prio_greatest = 0;
   e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->build_stream, hipStreamNonBlocking, prio_least);
@@ -817,6 +875,7 @@ void dvo_hip_context_destroy(dvo_hip_context* ctx) {
   if (ctx->build_stream) (void)hipStreamDestroy(ctx->build_stream);
   for (DevBuf* b : {&ctx->misc, &ctx->build_tbl, &ctx->role_tbl_cur, &ctx->role_tbl_ref, &ctx->prep_tbl_cur, &ctx->prep_tbl_ref}) b->release();
   for (DevBuf& b : ctx->upload_buf) b.release();
+  ctx->tables.release();
   for (CameraGeom* c : ctx->cameras) {
     c->tables.release();
     delete c;

@@ -294,19 +294,52 @@ class RgbdCameraPyramid:
 _ROLES = {"current": 0, "reference": 1}
 
 
+class FrameSet:
+    """A fixed list of pyramids with its ctypes handle array built once: a streaming caller that re-ingests and aligns the
+    same frame objects batch after batch does not rebuild 128-element pointer arrays on every call (the batch entry points
+    accept a FrameSet wherever they accept a list of pyramids)."""
+
+    def __init__(self, pyramids):
+        self.pyramids = list(pyramids)
+        self.n = len(self.pyramids)
+        self.ctx = self.pyramids[0].ctx
+        self.handles = (C.c_void_p * self.n)(*[p.ptr for p in self.pyramids])
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        return iter(self.pyramids)
+
+    def __getitem__(self, i):
+        return self.pyramids[i]
+
+
+def _handles(frames):
+    if isinstance(frames, FrameSet):
+        return frames.handles
+    return (C.c_void_p * len(frames))(*[p.ptr for p in frames])
+
+
+def device_pointer_array(ptrs):
+    """ctypes array of device addresses (built once by callers that stream from fixed buffers)"""
+    return (C.c_void_p * len(ptrs))(*[C.c_void_p(int(x)) for x in ptrs])
+
+
+def _pointer_array(ptrs):
+    return ptrs if isinstance(ptrs, C.Array) else device_pointer_array(ptrs)
+
+
 def update_raw_device_batch(pyramids, grey_dev_ptrs, depth_dev_ptrs, depth_scale=1.0 / 5000.0, role=None, config=None):
     """Re-ingest raw planes (device pointers) into n existing pyramids of one camera, batched.  With role ("current" /
     "reference") and config: ingest and prepare_roles_batch in one pass over the raw planes (dvo_hip_frames_update_raw_device_as)."""
     n = len(pyramids)
     ctx = pyramids[0].ctx
-    vp = C.c_void_p
-    fr = (vp * n)(*[p.ptr for p in pyramids])
-    g = (vp * n)(*[vp(int(x)) for x in grey_dev_ptrs])
-    z = (vp * n)(*[vp(int(x)) for x in depth_dev_ptrs])
+    fr, g, z = _handles(pyramids), _pointer_array(grey_dev_ptrs), _pointer_array(depth_dev_ptrs)
     if role is None:
         ctx.check(ctx._lib.dvo_hip_frames_update_raw_device(ctx.ptr, n, fr, g, z, depth_scale))
     else:
-        ccfg = config.to_c()
+        ccfg = config if isinstance(config, _lib.Config) else config.to_c()
         ctx.check(ctx._lib.dvo_hip_frames_update_raw_device_as(ctx.ptr, n, fr, g, z, depth_scale, _ROLES[role], C.byref(ccfg)))
 
 
@@ -339,15 +372,18 @@ def update_raw_host_batch(pyramids, grey_host, depth_host, depth_scale=1.0 / 500
     n = len(pyramids)
     ctx = pyramids[0].ctx
     vp = C.c_void_p
-    for g, z in zip(grey_host, depth_host):
-        assert g.dtype == np.uint8 and z.dtype == np.uint16 and g.flags.c_contiguous and z.flags.c_contiguous
-    fr = (vp * n)(*[p.ptr for p in pyramids])
-    g = (vp * n)(*[vp(a.ctypes.data) for a in grey_host])
-    z = (vp * n)(*[vp(a.ctypes.data) for a in depth_host])
+    fr = _handles(pyramids)
+    if isinstance(grey_host, C.Array):          # addresses prepared once by the caller (device_pointer_array of host addresses)
+        g, z = grey_host, depth_host
+    else:
+        for a, b in zip(grey_host, depth_host):
+            assert a.dtype == np.uint8 and b.dtype == np.uint16 and a.flags.c_contiguous and b.flags.c_contiguous
+        g = (vp * n)(*[vp(a.ctypes.data) for a in grey_host])
+        z = (vp * n)(*[vp(a.ctypes.data) for a in depth_host])
     if role is None:
         ctx.check(ctx._lib.dvo_hip_frames_update_raw(ctx.ptr, n, fr, g, z, depth_scale))
     else:
-        ccfg = config.to_c()
+        ccfg = config if isinstance(config, _lib.Config) else config.to_c()
         ctx.check(ctx._lib.dvo_hip_frames_update_raw_as(ctx.ptr, n, fr, g, z, depth_scale, _ROLES[role], C.byref(ccfg)))
 
 
@@ -361,8 +397,7 @@ def prepare_roles_batch(pyramids, role, config):
     context's build stream, concurrently with a match started afterwards on other frames."""
     n = len(pyramids)
     ctx = pyramids[0].ctx
-    vp = C.c_void_p
-    fr = (vp * n)(*[p.ptr for p in pyramids])
+    fr = _handles(pyramids)
     ccfg = config.to_c()
     ctx.check(ctx._lib.dvo_hip_frames_prepare(ctx.ptr, n, fr, _ROLES[role], C.byref(ccfg)))
 
@@ -505,9 +540,10 @@ class DenseTracker:
         n_iterations [n]).  T_init: optional [n,4,4] initial guesses (used when UseInitialEstimate)."""
         n = len(references)
         cfg = self.cfg
-        for r, c in zip(references, currents):
-            r.build(cfg.getNumLevels())
-            c.build(cfg.getNumLevels())
+        if not (isinstance(references, FrameSet) and isinstance(currents, FrameSet)):   # a FrameSet's pyramids are final
+            for r, c in zip(references, currents):
+                r.build(cfg.getNumLevels())
+                c.build(cfg.getNumLevels())
         cres = (_lib.Result * n)()
         view = np.frombuffer(cres, dtype=_RESULT_DTYPE)
         if cfg.UseInitialEstimate:
@@ -515,9 +551,7 @@ class DenseTracker:
             view["transformation"][:] = np.asarray(T_init, dtype=np.float64).reshape(n, 16)
         else:
             view["transformation"][:] = np.eye(4).reshape(16)
-        vp = C.c_void_p
-        refs = (vp * n)(*[p.ptr for p in references])
-        curs = (vp * n)(*[p.ptr for p in currents])
+        refs, curs = _handles(references), _handles(currents)
         ccfg = cfg.to_c()
         self.ctx.check(self.ctx._lib.dvo_hip_match_batch(self.ctx.ptr, n, refs, curs, C.byref(ccfg), cres, None, 0, None, 0))
         return dict(T=view["transformation"].reshape(n, 4, 4).copy(), information=view["information"].reshape(n, 6, 6).copy(),
