@@ -165,6 +165,9 @@ struct dvo_hip_context {
   Workspace ws[1];
   DevBuf misc, build_tbl, role_tbl_cur, role_tbl_ref, prep_tbl_cur, prep_tbl_ref;
   PinnedRing tables;
+  // build_tbl holds, in build-stream order, the table of exactly these frames (frames_build): the per-level launches of an
+  // eager prepare of the same list reuse it instead of uploading the same bytes again
+  std::vector<dvo_hip_frame*> build_tbl_frames;
   // Frame construction (ingest, pyramid, eagerly prepared role planes) runs on its own stream so that the next batch of
   // frames can be built while the current batch is being aligned: the build is bandwidth-bound, the coarse pyramid levels
   // of an alignment are latency-bound, and the two overlap.  Every build call takes a ticket and records an event; an
@@ -467,6 +470,7 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
   hipStream_t bs = ctx->build_stream;
   DVO_HIP_TRY(ctx, ctx->tables.upload(bs, ctx->build_tbl.p, host.data(), size_t(n) * sizeof(FrameBuildPtrs)));
   const FrameBuildPtrs* tbl = ctx->build_tbl.as<FrameBuildPtrs>();
+  ctx->build_tbl_frames.assign(frames, frames + n);
   int built = 1;                                       // float ingest: level 0 is already in place
   if (grey) {
     launch_build_from_raw(bs, tbl, n, depth_scale, cam->w[0], cam->h[0], levels, role, wide, ithr, dthr, ctx->opt_build_workgroups);
@@ -522,10 +526,17 @@ int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int 
     }
     const int cap = eager ? ctx->opt_build_workgroups : 0;   // planes needed right now are built at full width
     if (!host.empty()) {
-      // each level has its own slice of the table so that a copy never waits for the previous level's kernel
-      DVO_HIP_TRY(ctx, table.reserve(slice * (kMaxLevels + 1)));
-      FrameBuildPtrs* tbl = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * l);
-      DVO_HIP_TRY(ctx, ctx->tables.upload(stream, tbl, host.data(), host.size() * sizeof(FrameBuildPtrs)));
+      const FrameBuildPtrs* tbl;
+      if (eager && int(host.size()) == n && ctx->build_tbl_frames.size() == size_t(n) &&
+          std::equal(frames, frames + n, ctx->build_tbl_frames.begin())) {
+        tbl = ctx->build_tbl.as<FrameBuildPtrs>();       // the ingest of these very frames left their table on this stream
+      } else {
+        // each level has its own slice of the table so that a copy never waits for the previous level's kernel
+        DVO_HIP_TRY(ctx, table.reserve(slice * (kMaxLevels + 1)));
+        FrameBuildPtrs* up = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * l);
+        DVO_HIP_TRY(ctx, ctx->tables.upload(stream, up, host.data(), host.size() * sizeof(FrameBuildPtrs)));
+        tbl = up;
+      }
       if (role == 0) launch_derive_current(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], cap);
       else launch_derive_reference(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], ithr, dthr, cap);
       launched = true;
@@ -1155,6 +1166,7 @@ void dvo_hip_frame_destroy(dvo_hip_context* ctx, dvo_hip_frame* frame) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
     if (ctx->build_stream) (void)hipStreamSynchronize(ctx->build_stream);
+    ctx->build_tbl_frames.clear();   // a later frame may be given the same address
   }
   frame->pool.release();
   delete frame;
