@@ -62,7 +62,9 @@ def test_pyramid_planes_bit_exact(gpu_ctx, w, h, levels):
     assert sel.select(0) == oref.select(0, 5.0, 0.02)[0]
 
 
-@pytest.mark.parametrize("w,h,level", [(640, 480, 0), (640, 480, 1), (640, 480, 3), (160, 120, 0), (100, 76, 1)])
+@pytest.mark.parametrize("w,h,level", [(640, 480, 0), (640, 480, 1), (640, 480, 3), (160, 120, 0), (100, 76, 1),
+                                       # odd and tiny sizes, widths around the 64-pixel tile, a tall image: ragged tiles / segments
+                                       (131, 97, 0), (131, 97, 2), (65, 49, 0), (63, 130, 0), (258, 194, 1), (36, 20, 0), (1281, 13, 0)])
 def test_single_linearisation_against_oracle(gpu_ctx, w, h, level):
     pair = cm.synth(23, w, h)
     levels = level + 1
@@ -78,7 +80,8 @@ def test_single_linearisation_against_oracle(gpu_ctx, w, h, level):
         assert g["n"] == o["n"] and g["n_selected"] == o["n_selected"]
         assert np.array_equal(np.isnan(g["residuals"]), np.isnan(o["residuals"]))
         assert np.array_equal(np.nan_to_num(g["residuals"]), np.nan_to_num(o["residuals"]))
-        assert np.allclose(g["P"], o["P"], rtol=1e-5)
+        # sums accumulated in another order: relative to the matrix, not to a small off-diagonal element that is a cancellation
+        assert np.abs(g["P"] - o["P"]).max() <= 1e-5 * np.abs(o["P"]).max()
         assert abs(g["neg_ll"] - o["neg_ll"]) <= 1e-6 * abs(o["neg_ll"])
         assert np.abs(g["A"] - o["A"]).max() <= 1e-5 * np.abs(o["A"]).max()
         assert np.abs(g["b"] - o["b"]).max() <= 1e-5 * np.abs(o["b"]).max()
@@ -86,7 +89,7 @@ def test_single_linearisation_against_oracle(gpu_ctx, w, h, level):
         o2 = po.level_iteration(oref, ocur, level, T34, P_prev=o["P"], first=False, mode=po.MATH)
         g2 = trk.level_iteration(gref, gcur, level, T34, P_prev=o["P"], first=False)
         assert g2["n"] == o2["n"]
-        assert np.allclose(g2["P"], o2["P"], rtol=1e-5)
+        assert np.abs(g2["P"] - o2["P"]).max() <= 1e-5 * np.abs(o2["P"]).max()
         assert abs(g2["neg_ll"] - o2["neg_ll"]) <= 1e-6 * abs(o2["neg_ll"])
         assert np.abs(g2["A"] - o2["A"]).max() <= 1e-5 * np.abs(o2["A"]).max()
         assert np.abs(g2["b"] - o2["b"]).max() <= 1e-5 * np.abs(o2["b"]).max()
@@ -129,6 +132,8 @@ def run_gpu_match(ctx, gref, gcur, cfg, T_init=None):
     (6, 640, 480, 3, 1, 0.0, False, 5e-7),        # reference defaults
     (7, 160, 120, 2, 0, 0.0, False, 5e-7),
     (4321, 1280, 960, 4, 0, 0.0, False, 1e-4),    # BASELINE config 5: 1280x960, 5 levels
+    (9, 131, 97, 2, 0, 0.0, False, 5e-7),         # odd sizes: every level has ragged tiles
+    (10, 258, 194, 3, 0, 0.05, True, 1e-4),
 ])
 def test_full_match_against_oracle(gpu_ctx, seed, w, h, first, last, mu, init, precision):
     pair = cm.synth(seed, w, h)
@@ -156,10 +161,10 @@ def test_full_match_against_oracle(gpu_ctx, seed, w, h, first, last, mu, init, p
     # and against the quirk-faithful restatement of the SSE path, and the ground truth of the synthetic pair
     q = po.match(oref, ocur, cm.oracle_config_from(cfg, po.REF_SSE), T0)
     assert cm.twist_matrix_error(g["T"], q["T"]) < 5e-5
-    assert np.abs(po.se3_log(g["T"]) - pair["xi_true"]).max() < 1e-4
+    assert np.abs(po.se3_log(g["T"]) - pair["xi_true"]).max() < (1e-4 if w >= 160 else 5e-4)   # the estimator's accuracy, by image size
     # ... and against the REFERENCE ITSELF: its own DenseTracker::match(), compiled from /root/reference into oracle/_ref (the built
     # library travels to the GPU box), on the same frames.  REF_SSE reproduces it bit for bit; the GPU within the quirk distance.
-    if po.ref_lib() is not None:
+    if po.ref_lib() is not None and w % (4 << first) == 0:   # the reference's SSE derivative needs widths that are multiples of 4
         r = po.ref_match(pair["grey_ref"].astype(np.float32), po.convert_raw_depth(pair["depth_ref"]),
                          pair["grey_cur"].astype(np.float32), po.convert_raw_depth(pair["depth_cur"]), pair["K"],
                          cm.oracle_config_from(cfg, po.REF_SSE), T0)
