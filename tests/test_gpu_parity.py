@@ -484,3 +484,59 @@ def test_role_aware_ingest_is_bit_identical(gpu_ctx, w, h, levels):
     d.update_raw_host_batch(R, gr, zr, role="reference", config=coarse)
     d.update_raw_host_batch(Cu, gc, zc, role="current", config=coarse)
     assert raw(trk.match_batch_arrays(R, Cu)) == forward
+
+
+@pytest.mark.gpu
+def test_large_ragged_batch_equals_its_pairs(gpu_ctx):
+    """603 pairs in one batch (frames shared between pairs, a batch size that divides nothing).  With the tile height pinned
+    (option rows_per_wave) a pair's record is bit-identical whatever else is in the launch: a batch of 603, of 77 in another
+    order, of one.  With the default heuristic the tile height of a level follows the batch size, the per-tile partial sums group
+    differently, and the records agree to rounding."""
+    n_distinct, n = 9, 603
+    w, h = 320, 240
+    cfg = d.Config(FirstLevel=2, LastLevel=0)
+    trk = d.DenseTracker(cfg, gpu_ctx)
+    cam = d.RgbdCameraPyramid(w, h, po.FR1_K * 0.5, gpu_ctx)
+    cam.build(3)
+    b = datagen.synth_batch(900, n_distinct, w, h)
+    refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n_distinct)]
+    curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n_distinct)]
+    keys = ("T", "information", "loglik", "n_iterations", "entropy", "constraint_ratio")
+    # pair j of the big batch = (refs[j % 9], curs[(j * 4) % 9]): also pairs that do not belong together (they just have to agree)
+    pick_r = [j % n_distinct for j in range(n)]
+    pick_c = [(j * 4) % n_distinct for j in range(n)]
+    m = 77
+    order = [(5 * j + 3) % n for j in range(m)]
+
+    def run_all():
+        big = trk.match_batch_arrays([refs[i] for i in pick_r], [curs[i] for i in pick_c])
+        other = trk.match_batch_arrays([refs[pick_r[j]] for j in order], [curs[pick_c[j]] for j in order])
+        singles = [trk.match_batch_arrays([refs[pick_r[j]]], [curs[pick_c[j]]]) for j in order[:6]]
+        return big, other, singles
+    try:
+        gpu_ctx.set_option("rows_per_wave", 4)
+        big, other, singles = run_all()
+    finally:
+        gpu_ctx.set_option("rows_per_wave", 0)
+    for slot, j in enumerate(order):
+        for k in keys:
+            assert np.array_equal(np.asarray(big[k][j]), np.asarray(other[k][slot]), equal_nan=True), (j, k)
+    for slot, j in enumerate(order[:6]):
+        for k in keys:
+            assert np.array_equal(np.asarray(big[k][j]), np.asarray(singles[slot][k][0]), equal_nan=True), (j, k)
+    first_seen = {}
+    for j in range(n):          # equal pairs inside the batch got equal records
+        key = (pick_r[j], pick_c[j])
+        if key in first_seen:
+            for k in keys:
+                assert np.array_equal(np.asarray(big[k][j]), np.asarray(big[k][first_seen[key]]), equal_nan=True)
+        else:
+            first_seen[key] = j
+    # default heuristic: the same answers to the precision of the stopping rule (a rounding difference may cost or save an iteration)
+    big2, other2, singles2 = run_all()
+    for slot, j in enumerate(order):
+        assert np.abs(po.se3_log(np.linalg.inv(big2["T"][j]) @ other2["T"][slot])).max() < 5e-6
+        assert abs(int(big2["n_iterations"][j]) - int(other2["n_iterations"][slot])) <= 2
+    for slot, j in enumerate(order[:6]):
+        assert np.abs(po.se3_log(np.linalg.inv(big2["T"][j]) @ singles2[slot]["T"][0])).max() < 5e-6
+        assert np.abs(po.se3_log(np.linalg.inv(big2["T"][j]) @ big["T"][j])).max() < 5e-6
