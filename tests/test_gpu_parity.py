@@ -540,3 +540,42 @@ def test_large_ragged_batch_equals_its_pairs(gpu_ctx):
     for slot, j in enumerate(order[:6]):
         assert np.abs(po.se3_log(np.linalg.inv(big2["T"][j]) @ singles2[slot]["T"][0])).max() < 5e-6
         assert np.abs(po.se3_log(np.linalg.inv(big2["T"][j]) @ big["T"][j])).max() < 5e-6
+
+
+@pytest.mark.gpu
+def test_one_context_per_host_thread(gpu_ctx):
+    """The threading model of the boundary (one context per host thread, like one DenseTracker per TBB worker in
+    dvo_slam/src/keyframe_graph.cpp:576-593): four threads align their own batches at the same time on one GPU, each through
+    its own context, and get exactly what a single context gets alone."""
+    import threading
+    w, h, n = 320, 240, 12
+    cfg = d.Config(FirstLevel=2, LastLevel=0)
+    K = po.FR1_K * 0.5
+    batches = [datagen.synth_batch(1000 + t, n, w, h) for t in range(4)]
+
+    def run(ctx, b, reps):
+        cam = d.RgbdCameraPyramid(w, h, K, ctx)
+        cam.build(3)
+        trk = d.DenseTracker(cfg, ctx)
+        out = None
+        for _ in range(reps):
+            refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)]
+            curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)]
+            out = trk.match_batch_arrays(refs, curs)
+        return b"".join(np.ascontiguousarray(out[k]).tobytes() for k in ("T", "information", "loglik", "n_iterations"))
+    alone = [run(gpu_ctx, b, 1) for b in batches]
+    assert len(set(alone)) == 4
+    got, errors = [None] * 4, []
+
+    def worker(t):
+        try:
+            got[t] = run(d.Context(0), batches[t], 5)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert got == alone
