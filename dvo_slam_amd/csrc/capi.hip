@@ -160,6 +160,7 @@ struct dvo_hip_context {
   int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
+  int opt_fused_ll_pixels = 0;     // largest level (pixels) whose log-likelihood sweep runs inside the solver workgroup (0 = by batch size)
   int opt_variant = 5;             // schedule of the reduce kernel: 5 = Gram accumulation on the matrix cores (default)
   std::vector<CameraGeom*> cameras;
   Workspace ws[1];
@@ -273,7 +274,8 @@ int wait_for_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames) {
 }
 
 const int kLlBlocksPerPair = 32;
-const int kFusedLoglikMaxPixels = 160 * 120;
+const int kFusedLoglikMaxPixels = 160 * 120;      // any batch
+const int kFusedLoglikMaxPixelsBatch = 320 * 240;  // batches that fill the chip with one solver workgroup per pair
 
 // RgbdCameraPyramid::build (rgbd_image.cpp:283-296) + RgbdCamera ctor template (:186-204)
 int get_camera(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, const CameraGeom** out) {
@@ -740,7 +742,10 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     const PairPtrs* pp = bp.pair_ptrs + size_t(level) * n;
     launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels);
     // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
-    const bool fused_ll = g.w * g.h <= kFusedLoglikMaxPixels;
+    // (measured, scripts/ab_match.py fused_ll_pixels: 128 pairs 2.152 -> 2.117 ms with level 1 fused; 16 pairs 0.756 -> 0.799, one
+    // pair 0.524 -> 0.547: a lone workgroup per pair is slower than 32 blocks when the chip is empty)
+    const int fuse_opt = ctx->opt_fused_ll_pixels;
+    const bool fused_ll = g.w * g.h <= (fuse_opt > 0 ? fuse_opt : (n >= 64 ? kFusedLoglikMaxPixelsBatch : kFusedLoglikMaxPixels));
     // Chunks of `per_sync` iterations are enqueued ONE AHEAD of the poll: while the host waits for the status word of
     // chunk k, chunk k+1 is already queued, so the GPU never idles for a host round trip.  Iterations enqueued past the
     // end of the level are no-ops (workgroups exit on !active).
@@ -929,6 +934,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "condition_number") == 0) {
     if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "condition_number must be 0 or 1");
     ctx->opt_condition_number = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "fused_ll_pixels") == 0) {
+    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "fused_ll_pixels must be >= 0");
+    ctx->opt_fused_ll_pixels = value;
     return DVO_HIP_OK;
   }
   return fail(ctx, DVO_HIP_ERR_INVALID, "unknown option");

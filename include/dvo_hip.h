@@ -248,7 +248,9 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
 /* Tunables (0 = library default).  key: "rows_per_wave" (1,2,4,8,16: tile height of the reduce kernel),
  * "iters_per_sync" (host polling cadence of the batched Gauss-Newton loop), "variant" (schedule of the reduce
  * kernel: 0, 1, 3, 4, 5), "min_workgroups" (tile-height heuristic: smallest launch that
- * counts as filling the chip; 0 = built-in table), "condition_number" (1: results carry the condition number of the information
+ * counts as filling the chip; 0 = built-in table), "fused_ll_pixels" (largest level, in pixels, whose log-likelihood sweep runs inside the solver
+ * workgroup instead of a launch of its own; 0 = 160x120, and 320x240 for batches of 64 pairs and more),
+ * "condition_number" (1: results carry the condition number of the information
  * matrix, ~20 us of extra serial work per batch; default 0). */
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 
