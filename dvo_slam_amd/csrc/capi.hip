@@ -82,10 +82,11 @@ struct dvo_hip_frame {
   float depth_scale = 0.0f;
 };
 
-// Small host -> device transfers (pointer tables, initial guesses) go through slots of pinned memory.  From pageable memory
-// hipMemcpyAsync does not return before the stream has reached the copy: a table upload queued behind a 300-us build kernel
-// held the host, and with it the alignment it was about to enqueue on the other stream, for as long (kernel trace: the
-// match of a step started 250 us late).  A slot is reused only after the copy that read it has completed (one event per slot).
+// Small host -> device transfers (pointer tables, initial guesses) go through slots of pinned memory: from a pageable
+// source the runtime stages the bytes itself and may hold the calling thread while it does; from a pinned slot the upload is a
+// plain asynchronous copy and the host goes on enqueueing.  (No measurable difference in the benchmark loop, whose host side
+// is dominated by the caller; kept because it takes a host-side wait out of the enqueue path.)  A slot is reused only after
+// the copy that read it has completed (one event per slot).
 struct PinnedRing {
   static const int kSlots = 48;
   char* base = nullptr;
