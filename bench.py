@@ -166,19 +166,25 @@ def main():
 
     counter = [0]
 
+    # The streaming loop is one foreign call per step (dvo_slam_amd/apps/stream_pipeline.cpp, a C function on the C-ABI): ingest +
+    # pyramids + the planes of the role each frame plays for the NEXT batch, from HBM-resident raw planes on the build stream
+    # (asynchronous), then the alignment of the current batch (synchronous: returns when the transforms are on the host).
+    from dvo_slam_amd.stream import StreamPipeline
+    pipe = StreamPipeline(ctx, cfg, ref_sets, cur_sets, grey_ptrs[:B], depth_ptrs[:B], grey_ptrs[B:], depth_ptrs[B:])
+
     def build(k):
-        # ingest + pyramids + the planes of the role each frame plays, from HBM-resident raw planes, on the build stream (asynchronous)
-        d.update_raw_device_batch(ref_sets[k], g_ref, z_ref, role="reference", config=cfg)
-        d.update_raw_device_batch(cur_sets[k], g_cur, z_cur, role="current", config=cfg)
+        pipe.step(now=None, nxt=k)
 
     def step():
         k = counter[0] % n_sets
         counter[0] += 1
-        build((k + 1) % n_sets)                                         # next batch (with one set: this batch, built right before its match)
-        out = tracker.match_batch_arrays(ref_sets[k], cur_sets[k])      # synchronous: returns when the transforms are on the host
-        last.update(out)
+        res = pipe.step(now=k, nxt=(k + 1) % n_sets)                    # next batch (with one set: this batch, built right before its match)
+        last["T"] = res["transformation"].reshape(B, 4, 4)
+        last["information"] = res["information"].reshape(B, 6, 6)
+        last["loglik"] = res["loglik"]
         if world > 1:
             # the records of this batch travel (one all-gather, RCCL) while the next batch is aligned
+            out = last
             tw = [_twist(T) for T in out["T"]]
             rec = parallel.pack_records(tw, out["information"], out["loglik"])
             if pending[0] is not None:

@@ -1,0 +1,33 @@
+// stream_pipeline.cpp -- the steady state of a streaming consumer of the C-ABI, as one C function: re-ingest the next batch of
+// raw planes in the roles its frames will play (build stream), then align the current batch (main stream).  This is the loop
+// bench.py times; it is written against include/dvo_hip.h only (no access to the library's internals) and lives in its own
+// shared object so that the benchmark harness pays one foreign call per step instead of a dozen plus array marshalling.
+//
+// Reference call pattern it stands for: dvo_benchmark/src/benchmark_slam.cpp:327-383 (load pair -> create pyramid -> track),
+// with the proposals of dvo_slam/src/keyframe_graph.cpp:576-593 as the source of independent pairs.
+#include <cstring>
+
+#include "dvo_hip.h"
+
+extern "C" {
+
+// One step on frame sets `next` (to be re-ingested: n reference frames from (grey_ref, raw_ref), n current frames from
+// (grey_cur, raw_cur), device pointers) and `now` (to be aligned: results[n], identity initial guess).
+int dvo_stream_step(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next_refs, dvo_hip_frame* const* next_curs,
+                    const void* const* grey_ref, const void* const* raw_ref, const void* const* grey_cur, const void* const* raw_cur,
+                    float depth_scale, dvo_hip_frame* const* now_refs, dvo_hip_frame* const* now_curs, const dvo_hip_config* cfg,
+                    dvo_hip_result* results) {
+  int rc = DVO_HIP_OK;
+  if (next_refs) {
+    rc = dvo_hip_frames_update_raw_device_as(ctx, n, next_refs, grey_ref, raw_ref, depth_scale, DVO_HIP_ROLE_REFERENCE, cfg);
+    if (rc != DVO_HIP_OK) return rc;
+    rc = dvo_hip_frames_update_raw_device_as(ctx, n, next_curs, grey_cur, raw_cur, depth_scale, DVO_HIP_ROLE_CURRENT, cfg);
+    if (rc != DVO_HIP_OK) return rc;
+  }
+  if (!now_refs) return rc;
+  static const double identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, identity, sizeof(identity));   // Result is in/out
+  return dvo_hip_match_batch(ctx, n, now_refs, now_curs, cfg, results, nullptr, 0, nullptr, 0);
+}
+
+}  // extern "C"

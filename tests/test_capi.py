@@ -86,3 +86,19 @@ def test_cpp_facade_compiles_against_the_reference_api():
     d.build()
     exe = build_facade_example()
     assert os.path.exists(exe)
+
+
+def test_stream_pipeline_object_builds_and_binds_only_the_c_abi():
+    """dvo_slam_amd/apps/stream_pipeline.cpp (the benchmark's streaming loop as a C function) is a consumer of include/dvo_hip.h:
+    it builds with the host compiler, exports dvo_stream_step and has no undefined symbol outside the C-ABI and libc."""
+    import subprocess
+    d.build()
+    path = os.path.join(os.path.dirname(d.LIB_PATH), "libdvo_stream.so")
+    assert os.path.exists(path)
+    syms = subprocess.check_output(["nm", "-D", path], text=True).splitlines()
+    defined = [l.split()[-1] for l in syms if " T " in l]
+    undefined = [l.split()[-1] for l in syms if l.strip().startswith("U ")]
+    assert "dvo_stream_step" in defined
+    ours = [u for u in undefined if u.startswith("dvo_hip_")]
+    assert sorted(ours) == ["dvo_hip_frames_update_raw_device_as", "dvo_hip_match_batch"]
+    assert all(u.startswith("dvo_hip_") or "GLIBC" in u or u.startswith(("mem", "__")) for u in undefined), undefined
