@@ -65,5 +65,11 @@ int main() {
     std::printf("blocks %6d: read %.0f GB/s, copy %.0f GB/s (read + write), sweep mix %.0f GB/s (48 B per element, %.3f ms for %zu elements)\n",
                 blocks, big * 16 / r / 1e6, 2.0 * big * 16 / cp / 1e6, n * 48.0 / mx / 1e6, mx, n);
   }
+  // the same mix on footprints that fit the 256 MB Infinity Cache: what a sub-batch of pairs swept repeatedly would see
+  for (int pairs : {2, 4, 8, 16, 32, 64}) {
+    const size_t m = size_t(pairs) * 640 * 480;
+    const double mx = time_ms([&] { k_mix<<<8192, 256>>>(a, b, c, o, m); }, 40);
+    std::printf("sweep mix on %2d pairs (%4.0f MB footprint, repeated): %.0f GB/s, %.4f ms\n", pairs, m * 48.0 / 1e6, m * 48.0 / mx / 1e6, mx);
+  }
   return 0;
 }
