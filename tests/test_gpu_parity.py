@@ -479,6 +479,20 @@ def test_role_aware_ingest_is_bit_identical(gpu_ctx, w, h, levels):
     n_tight = count(R[1], 0, 8.0, 0.02)
     assert 0 < n_tight < count(refs[1], 0) and n_tight == count(refs[1], 0, 8.0, 0.02)
     assert raw(trk.match_batch_arrays(R, Cu)) == forward
+    # argument errors of the C-ABI entry point: unknown role, more levels than the frames have, a null plane
+    import ctypes as C
+    vp = C.c_void_p
+    L, fr = gpu_ctx._lib, (vp * n)(*[f.ptr for f in R])
+    g = (vp * n)(*[vp(a.ctypes.data) for a in gr])
+    z = (vp * n)(*[vp(a.ctypes.data) for a in zr])
+    ok_cfg, deep = cfg.to_c(), d.Config(FirstLevel=levels + 1, LastLevel=0).to_c()
+    assert L.dvo_hip_frames_update_raw_as(gpu_ctx.ptr, n, fr, g, z, 0.0002, 7, C.byref(ok_cfg)) == d._lib.ERR_INVALID
+    assert L.dvo_hip_frames_update_raw_as(gpu_ctx.ptr, n, fr, g, z, 0.0002, 1, C.byref(deep)) == d._lib.ERR_INVALID
+    assert L.dvo_hip_frames_update_raw_as(gpu_ctx.ptr, n, fr, g, z, 0.0002, 1, None) == d._lib.ERR_INVALID
+    g_bad = (vp * n)(*([vp(a.ctypes.data) for a in gr[:-1]] + [vp(None)]))
+    assert L.dvo_hip_frames_update_raw_as(gpu_ctx.ptr, n, fr, g_bad, z, 0.0002, 1, C.byref(ok_cfg)) == d._lib.ERR_INVALID
+    assert L.dvo_hip_frames_update_raw_device_as(gpu_ctx.ptr, n, fr, g_bad, z, 0.0002, 0, C.byref(ok_cfg)) == d._lib.ERR_INVALID
+    assert raw(trk.match_batch_arrays(R, Cu)) == forward               # a rejected call leaves the frames untouched
     # a configuration that does not use level 0: nothing of level 0 is built at ingest, the match of the full pyramid still agrees
     coarse = d.Config(FirstLevel=levels - 1, LastLevel=1)
     d.update_raw_host_batch(R, gr, zr, role="reference", config=coarse)
