@@ -280,3 +280,94 @@ def test_tracking_front_end_restatement_is_the_references(max_distance, what, ca
     assert np.array_equal(maps, completed)
     # pose composition and the inverse of the keyframe estimate run through the Eigen stand-in there and numpy here
     assert max(np.abs(p - q).max() for p, (q, _) in zip(poses, want)) < 1e-12
+
+
+# ---- randomised pins (hypothesis): sizes, point counts, precisions and transforms nobody picked by hand ----------------------
+from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+
+_rand = dict(max_examples=150, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+
+
+@settings(**_rand)
+@given(n=st.integers(1, 3000), seed=st.integers(0, 2**31 - 1), s0=st.floats(1e-3, 0.5), s1=st.floats(1e-3, 0.5),
+       p00=st.floats(10.0, 1e5), p11=st.floats(10.0, 1e5), rho=st.floats(-0.9, 0.9), outliers=st.integers(0, 40))
+def test_random_weights_scale_loglik_are_the_references(n, seed, s0, s1, p00, p11, rho, outliers):
+    rng = np.random.default_rng(seed)
+    res = np.ascontiguousarray(rng.normal(size=(n, 2)) * [s0, s1], np.float32)
+    if outliers:
+        res[rng.integers(0, n, outliers)] *= 50.0
+    p01 = rho * np.sqrt(p00 * p11)
+    P = f32(p00, p01, p01, p11)
+    zero = f32(0, 0)
+    w_ref, w_ora = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    ref.ref_compute_weights(1, n, fp(res), fp(zero), fp(P), fp(w_ref))
+    po.lib().oracle_pass_weights(po.REF_SSE, n, fp(res), fp(P), fp(w_ora))
+    assert w_ref.tobytes() == w_ora.tobytes()
+    S, Cc = np.zeros(4, np.float32), np.zeros(4, np.float32)
+    ref.ref_compute_scale(1, n, fp(res), fp(w_ref), fp(zero), fp(S))
+    po.lib().oracle_pass_scale(po.REF_SSE, n, fp(res), fp(w_ref), fp(Cc))
+    assert S[[0, 1, 3, 2]].tobytes() == Cc.tobytes()
+    ll_ref = ref.ref_loglik(n, fp(res), fp(w_ref), fp(zero), fp(P))
+    ll_ora = po.lib().oracle_pass_loglik(po.REF_SSE, n, fp(res), fp(P))
+    assert np.float32(ll_ora).tobytes() == np.float32(ll_ref).tobytes()
+
+
+@settings(**_rand)
+@given(n=st.integers(1, 2000), seed=st.integers(0, 2**31 - 1), a00=st.floats(0.01, 1e4), a11=st.floats(0.01, 1e4), rho=st.floats(-0.95, 0.95))
+def test_random_normal_equation_accumulation_is_the_references(n, seed, a00, a11, rho):
+    rng = np.random.default_rng(seed)
+    J = np.ascontiguousarray(rng.normal(size=(n, 12)) * rng.uniform(0.01, 100.0, size=(1, 12)), np.float32)
+    a01 = rho * np.sqrt(a00 * a11)
+    alpha = f32(a00, a01, a01, a11)
+    A_ref, A_ora = np.zeros(36, np.float32), np.zeros(36, np.float64)
+    ref.ref_rank_update_2x6(n, fp(J), fp(alpha), fp(A_ref))
+    po.lib().oracle_rank_update_2x6(fp(J), n, fp(alpha), po.REF_SSE, A_ora.ctypes.data_as(C.POINTER(C.c_double)))
+    assert A_ora.astype(np.float32).tobytes() == A_ref.tobytes()
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
+@given(seed=st.integers(0, 10_000), wq=st.integers(6, 40), hq=st.integers(5, 30), level=st.integers(0, 1),
+       xi=st.lists(st.floats(-0.08, 0.08), min_size=6, max_size=6), drop=st.integers(0, 3))
+def test_random_residual_pass_is_the_references(seed, wq, hq, level, xi, drop):
+    """random image sizes (multiples of 8 so that both levels keep the SSE derivative's multiple-of-4 widths), transforms and
+    point counts"""
+    w, h = 8 * wq, 8 * hq
+    pair = cm.synth(seed, w, h)
+    oref, ocur = cm.oracle_pyramids(pair, 2)
+    _, pts, K, lw, lh = level_arrays(oref, level)
+    accel, _, _, _, _ = level_arrays(ocur, level)
+    p = pts[:max(1, len(pts) - drop)]
+    T34 = po.se3_exp(np.array(xi))[:3]
+    n_r, pr, rr = run_residuals("ref", p, accel, lw, lh, K, T34)
+    n_o, po_, ro = run_residuals("oracle", p, accel, lw, lh, K, T34)
+    assert n_r == n_o
+    assert pr.tobytes() == po_.tobytes() and rr.tobytes() == ro.tobytes()
+
+
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
+@given(seed=st.integers(0, 10_000), wq=st.integers(3, 10), hq=st.integers(3, 8), first=st.integers(0, 2), span=st.integers(0, 2),
+       max_iter=st.integers(1, 30), precision=st.sampled_from([0.0, 5e-7, 1e-4, 1e-2]), mu=st.sampled_from([0.0, 0.05, 1.0]),
+       init=st.booleans(), scale=st.floats(0.2, 3.0))
+def test_random_whole_matches_follow_the_reference_driver(seed, wq, hq, first, span, max_iter, precision, mu, init, scale):
+    """random sizes, level ranges, iteration caps, precisions, priors and initial guesses (also poor ones): every record of every
+    iteration of DenseTracker::match() coincides with the oracle's REF_SSE restatement."""
+    last = max(0, first - span)
+    w, h = 32 * wq, 32 * hq                       # every level keeps a multiple-of-4 width down to level 2
+    pair = cm.synth(seed, w, h)
+    planes = [pair["grey_ref"].astype(np.float32), po.convert_raw_depth(pair["depth_ref"]),
+              pair["grey_cur"].astype(np.float32), po.convert_raw_depth(pair["depth_cur"])]
+    cfg = po.make_config(first, last, max_iter, precision, mu, init, mode=po.REF_SSE)
+    T0 = po.se3_exp(scale * pair["xi_true"]) if init else None
+    r = po.ref_match(*planes, pair["K"], cfg, T0)
+    o = po.match(po.Pyramid(planes[0], planes[1], pair["K"], first + 1), po.Pyramid(planes[2], planes[3], pair["K"], first + 1), cfg, T0)
+    assert [(L["id"], L["valid_pixels"], L["termination"], len(L["iterations"])) for L in r["levels"]] == \
+           [(L["id"], L["valid_pixels"], L["termination"], len(L["iterations"])) for L in o["levels"]]
+    for Lr, Lo in zip(r["levels"], o["levels"]):
+        for ir, io in zip(Lr["iterations"], Lo["iterations"]):
+            assert (ir["id"], ir["n"]) == (io["id"], io["n"])
+            for key in ("neg_ll", "prior_ll", "precision", "x", "A"):
+                a, b = np.asarray(ir[key], float), np.asarray(io[key], float)
+                if np.isnan(b).all():
+                    continue
+                assert np.array_equal(a, b), (key, Lr["id"], ir["id"])
+    assert np.array_equal(r["T"], o["T"], equal_nan=True) and (r["loglik"] == o["loglik"] or (np.isnan(r["loglik"]) and np.isnan(o["loglik"])))
