@@ -140,3 +140,27 @@ def test_state_machine_edge_cases():
     o = po.match(ref, cur, cm.oracle_config_from(cfg, po.MATH))
     cm.compare_runs(e, o)
     assert all(len(L["iterations"]) <= 3 for L in e["levels"])
+
+
+from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 10_000), w=st.integers(24, 200), h=st.integers(20, 150), level=st.integers(0, 1), form=st.integers(0, 1),
+       xi=st.lists(st.floats(-0.06, 0.06), min_size=6, max_size=6))
+def test_random_sizes_and_transforms_bit_exact_against_oracle(seed, w, h, level, form, xi, schedule):
+    """any image size (odd ones too), any small transform, both forms of the device stages: valid count and residuals equal the
+    oracle's MATH mode bit for bit, sums to accumulation-order tolerance"""
+    schedule(form)
+    pair = cm.synth(seed, w, h)
+    ref, cur = cm.oracle_pyramids(pair, level + 1)
+    ep = cm.EmulPair(ref, cur, level + 1)
+    T34 = po.se3_exp(np.array(xi))[:3]
+    o = po.level_iteration(ref, cur, level, T34, first=True, mode=po.MATH, want_residuals=True)
+    e = ep.level_iteration(level, T34, first=True)
+    assert e["n"] == o["n"] and e["n_selected"] == o["n_selected"]
+    assert np.array_equal(np.isnan(e["residuals"]), np.isnan(o["residuals"]))
+    assert np.array_equal(np.nan_to_num(e["residuals"]), np.nan_to_num(o["residuals"]))
+    if o["n"] >= 6:
+        assert np.abs(e["A"] - o["A"]).max() <= 2e-6 * np.abs(o["A"]).max()
+        assert np.abs(e["b"] - o["b"]).max() <= 2e-6 * max(np.abs(o["b"]).max(), 1e-3 * np.abs(o["A"]).max())
