@@ -593,3 +593,32 @@ def test_one_context_per_host_thread(gpu_ctx):
         t.join()
     assert not errors, errors
     assert got == alone
+
+
+@pytest.mark.gpu
+def test_random_sizes_and_transforms_bit_exact(gpu_ctx):
+    """twenty random image sizes (odd ones, tiny ones, wide and tall ones), levels and small transforms, first and later passes:
+    valid count and residuals of the device sweep equal the oracle's MATH mode bit for bit."""
+    rng = np.random.default_rng(2024)
+    for case in range(20):
+        w, h = int(rng.integers(24, 420)), int(rng.integers(20, 320))
+        level = int(rng.integers(0, 2))
+        if (w >> level) < 8 or (h >> level) < 8:
+            level = 0
+        pair = cm.synth(int(rng.integers(0, 10_000)), w, h)
+        oref, ocur = cm.oracle_pyramids(pair, level + 1)
+        gref, gcur = gpu_pyramids(gpu_ctx, pair, level + 1)
+        trk = d.DenseTracker(d.Config(FirstLevel=level, LastLevel=level), gpu_ctx)
+        T34 = po.se3_exp(rng.uniform(-0.05, 0.05, 6))[:3]
+        o = po.level_iteration(oref, ocur, level, T34, first=True, mode=po.MATH, want_residuals=True)
+        g = trk.level_iteration(gref, gcur, level, T34, first=True, want_residuals=True)
+        assert g["n"] == o["n"] and g["n_selected"] == o["n_selected"], (case, w, h, level)
+        assert np.array_equal(np.isnan(g["residuals"]), np.isnan(o["residuals"])), (case, w, h, level)
+        assert np.array_equal(np.nan_to_num(g["residuals"]), np.nan_to_num(o["residuals"])), (case, w, h, level)
+        if o["n"] >= 6:
+            assert np.abs(g["A"] - o["A"]).max() <= 1e-5 * np.abs(o["A"]).max()
+            o2 = po.level_iteration(oref, ocur, level, T34, P_prev=o["P"], first=False, mode=po.MATH)
+            g2 = trk.level_iteration(gref, gcur, level, T34, P_prev=o["P"], first=False)
+            assert g2["n"] == o2["n"]
+            assert abs(g2["neg_ll"] - o2["neg_ll"]) <= 1e-6 * abs(o2["neg_ll"])
+            assert np.abs(g2["A"] - o2["A"]).max() <= 1e-5 * np.abs(o2["A"]).max()
