@@ -622,3 +622,34 @@ def test_random_sizes_and_transforms_bit_exact(gpu_ctx):
             assert g2["n"] == o2["n"]
             assert abs(g2["neg_ll"] - o2["neg_ll"]) <= 1e-6 * abs(o2["neg_ll"])
             assert np.abs(g2["A"] - o2["A"]).max() <= 1e-5 * np.abs(o2["A"]).max()
+
+
+@pytest.mark.gpu
+def test_random_whole_matches_against_oracle(gpu_ctx):
+    """twelve random sizes / level ranges / iteration caps / precisions / priors / initial guesses: every iteration record of
+    the common prefix and the final transform agree with the oracle's MATH mode (see common.compare_runs for what may differ:
+    a stopping decision at the float noise floor)."""
+    rng = np.random.default_rng(777)
+    for case in range(12):
+        first = int(rng.integers(1, 4))
+        last = int(rng.integers(0, first + 1))
+        w = int(rng.integers(16, 60)) * (1 << first) + int(rng.integers(0, 1 << first))
+        h = int(rng.integers(12, 44)) * (1 << first) + int(rng.integers(0, 1 << first))
+        init = bool(rng.integers(0, 2))
+        mu = float(rng.choice([0.0, 0.05, 0.5]))
+        precision = float(rng.choice([5e-7, 1e-5, 1e-4]))
+        max_iter = int(rng.integers(3, 60))
+        pair = cm.synth(int(rng.integers(0, 10_000)), w, h)
+        oref, ocur = cm.oracle_pyramids(pair, first + 1)
+        gref, gcur = gpu_pyramids(gpu_ctx, pair, first + 1)
+        cfg = d.Config(FirstLevel=first, LastLevel=last, Mu=mu, UseInitialEstimate=init, Precision=precision, MaxIterationsPerLevel=max_iter)
+        T0 = po.se3_exp(float(rng.uniform(0.2, 1.5)) * pair["xi_true"]) if init else None
+        g = run_gpu_match(gpu_ctx, gref, gcur, cfg, T0)
+        o = po.match(oref, ocur, cm.oracle_config_from(cfg, po.MATH), T0)
+        s = cm.compare_runs(g, o)
+        what = (case, w, h, first, last, init, mu, precision, max_iter, s)
+        assert s["n_mismatch"] == 0 and s["max_x_err"] < 5e-5, what
+        assert s["max_iter_count_diff"] <= 2, what
+        assert s["T_err"] < max(2e-5, 30 * precision), what
+        if s["structure_mismatch"] == 0:
+            assert np.abs(g["information"] - o["information"]).max() <= 2e-3 * np.abs(o["information"]).max(), what
