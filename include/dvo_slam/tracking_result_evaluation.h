@@ -12,54 +12,56 @@
 
 namespace dvo_slam {
 
+// Base: keeps the first value and the running mean of the values added since; ratios of a new result against either.
 class TrackingResultEvaluation {
  public:
+  using Result = dvo::DenseTracker::Result;
   typedef std::shared_ptr<TrackingResultEvaluation> Ptr;
   typedef std::shared_ptr<const TrackingResultEvaluation> ConstPtr;
   virtual ~TrackingResultEvaluation() {}
 
-  virtual void add(const dvo::DenseTracker::Result& r) {
+  virtual void add(const Result& r) {
     sum_ += value(r);
     count_ += 1.0;
   }
-  virtual double ratioWithFirst(const dvo::DenseTracker::Result& r) const { return value(r) / first_; }
-  virtual double ratioWithAverage(const dvo::DenseTracker::Result& r) const { return value(r) / sum_ * count_; }
+  virtual double ratioWithFirst(const Result& r) const { return value(r) / first_; }
+  virtual double ratioWithAverage(const Result& r) const { return value(r) / sum_ * count_; }
 
  protected:
   explicit TrackingResultEvaluation(double first) : first_(first), sum_(first), count_(1.0) {}
-  virtual double value(const dvo::DenseTracker::Result& r) const = 0;
+  virtual double value(const Result& r) const = 0;
 
  private:
   double first_, sum_, count_;
 };
 
-class LogLikelihoodTrackingResultEvaluation : public TrackingResultEvaluation {
- public:
-  explicit LogLikelihoodTrackingResultEvaluation(const dvo::DenseTracker::Result& r) : TrackingResultEvaluation(measure(r)) {}
-  virtual double value(const dvo::DenseTracker::Result& r) const { return measure(r); }
+namespace detail {
 
- private:
-  static double measure(const dvo::DenseTracker::Result& r) { return -r.LogLikelihood; }
+// one concrete evaluation per scalar measure of a result
+template <typename Measure>
+class MeasuredEvaluation : public TrackingResultEvaluation {
+ public:
+  explicit MeasuredEvaluation(const Result& first) : TrackingResultEvaluation(Measure::of(first)) {}
+  double value(const Result& r) const override { return Measure::of(r); }
 };
 
-class NormalizedLogLikelihoodTrackingResultEvaluation : public TrackingResultEvaluation {
- public:
-  explicit NormalizedLogLikelihoodTrackingResultEvaluation(const dvo::DenseTracker::Result& r) : TrackingResultEvaluation(measure(r)) {}
-  virtual double value(const dvo::DenseTracker::Result& r) const { return measure(r); }
-
- private:
-  static double measure(const dvo::DenseTracker::Result& r) {
+struct NegativeLogLikelihood {          // tracking_result_evaluation.cpp:54-57
+  static double of(const dvo::DenseTracker::Result& r) { return -r.LogLikelihood; }
+};
+struct NegativeLogLikelihoodPerConstraint {   // :59-62
+  static double of(const dvo::DenseTracker::Result& r) {
     return -r.LogLikelihood / double(r.Statistics.Levels.back().Iterations.back().ValidConstraints);
   }
 };
-
-class EntropyRatioTrackingResultEvaluation : public TrackingResultEvaluation {
- public:
-  explicit EntropyRatioTrackingResultEvaluation(const dvo::DenseTracker::Result& r) : TrackingResultEvaluation(measure(r)) {}
-  virtual double value(const dvo::DenseTracker::Result& r) const { return measure(r); }
-
- private:
-  static double measure(const dvo::DenseTracker::Result& r) { return std::log(dvo::compat::determinant6(r.Information)); }
+struct InformationEntropy {             // :49-52
+  static double of(const dvo::DenseTracker::Result& r) { return std::log(dvo::compat::determinant6(r.Information)); }
 };
+
+}  // namespace detail
+
+// the reference's three evaluations, by name
+typedef detail::MeasuredEvaluation<detail::NegativeLogLikelihood> LogLikelihoodTrackingResultEvaluation;
+typedef detail::MeasuredEvaluation<detail::NegativeLogLikelihoodPerConstraint> NormalizedLogLikelihoodTrackingResultEvaluation;
+typedef detail::MeasuredEvaluation<detail::InformationEntropy> EntropyRatioTrackingResultEvaluation;
 
 }  // namespace dvo_slam
