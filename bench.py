@@ -234,7 +234,8 @@ def main():
     algo_bytes = ALGO_BYTES_PER_PIXEL * W * H * B
     achieved = algo_bytes / (k_ms[0] * 1e-3) / 1e9
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                    traffic=_pmc_traffic(B), kernel="dvo_hip::k_residual_reduce_mfma<RPW, true> (pyramid level 0, %d pairs per launch)" % B,
+                    traffic=_pmc_traffic(B), kernel="dvo_hip::k_residual_reduce_mfma<%d, true, false> (pyramid level 0, %d pairs per launch)" % (
+                        args.rows_per_wave or _rows_per_wave(B), B),
                     kernel_ms=round(k_ms[0], 4), algorithmic_bytes_per_launch=algo_bytes,
                     bare_stream_ms=round(stream_ms, 4), bare_stream_frac=round(algo_bytes / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     bare_stream_note="a kernel that only reads the same planes in pixel order and writes the 8-B pair (no gather, "
@@ -323,6 +324,16 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def _rows_per_wave(pairs):
+    """the tile height the library picks for the 640x480 level of a batch (capi.hip::pick_rows_per_wave), to name the kernel
+    instantiation the way rocprofv3 lists it"""
+    enough = 512 if pairs <= 8 else 1024 if pairs < 64 else 2048
+    for r in (8, 4, 2, 1):
+        if (W // 64) * -(-H // (4 * r)) * pairs >= enough:
+            return r
+    return 1
 
 
 def _pmc_traffic(pairs):
