@@ -132,8 +132,9 @@ __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const Pair
   if (!states[pair].active) return;
   __shared__ double sh[16];
   __shared__ double sums[4];
+  __shared__ float stage[kScaleStageFloats];
   float C[3], P[4];
-  reduce_partials_scale(partials, pair, g.tiles_x * g.tiles_y, sh, sums);
+  reduce_partials_scale(partials, pair, g.tiles_x * g.tiles_y, stage, sh, sums);
   const int n = scale_from_sums(sums, C, P);
   double total = 0.0;
   if (n >= 6) total = loglik_partial<4>(scratch + size_t(pair) * g.w * g.h, g.w * g.h, P, blockIdx.x, blocks_per_pair);

@@ -54,26 +54,45 @@ __device__ inline void reduce_partials(const float* __restrict__ partials, int p
   __syncthreads();
 }
 
-// The same reduction restricted to the four scale accumulators (n, S00, S01, S11), for kernels that only need P:
-// lane k < 4 of wavefront w adds tiles w, w+4, ... in the same order as reduce_partials, so the result is
-// bit-identical to sums[0..3] of the full reduction while reading 16 B instead of 352 B per tile.
-__device__ inline void reduce_partials_scale(const float* __restrict__ partials, int pair, int tiles, double* sh, double* sums) {
+// The same reduction restricted to the four scale accumulators (n, S00, S01, S11), for kernels that only need P.  The
+// additions happen in the same order as in reduce_partials (wavefront w adds tiles w, w+4, ...; then (0+1)+(2+3)), so the
+// result is bit-identical to sums[0..3] of the full reduction while reading 16 B instead of 352 B per tile.  All 64 lanes of
+// a wavefront fetch (lane l: component l&3 of the wavefront's rows l>>2, l>>2 + 16, ...), up to kScaleRowsPerRound rows per
+// round trip, into LDS; lanes 0..3 then add their component in row order.  (With only the four adding lanes fetching, a lone
+// pair's 600 finest-level tiles cost five dependent round trips: 10 of the log-likelihood kernel's 17 us.)
+constexpr int kScaleLoadsInFlight = 16;
+constexpr int kScaleRowsPerRound = 16 * kScaleLoadsInFlight;      // per wavefront
+constexpr int kScaleStageFloats = kWavesPerBlock * kScaleRowsPerRound * 4;
+
+// stage: kScaleStageFloats floats of LDS; sh: 16 doubles; sums: 4 doubles, valid for all threads after the call
+__device__ inline void reduce_partials_scale(const float* __restrict__ partials, int pair, int tiles, float* stage, double* sh, double* sums) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane < 4) {
-    const float* base = partials + size_t(pair) * tiles * kAccStride;
-    double a0 = 0.0;
-    for (int t0 = wave; t0 < tiles; t0 += kReduceInFlight * kWavesPerBlock) {
-      float v0[kReduceInFlight];
+  const float* base = partials + size_t(pair) * tiles * kAccStride;
+  const int my_rows = tiles > wave ? (tiles - wave + kWavesPerBlock - 1) / kWavesPerBlock : 0;   // tiles wave, wave + 4, ...
+  float* mine = stage + wave * kScaleRowsPerRound * 4;
+  double a0 = 0.0;
+  for (int r0 = 0; r0 < my_rows; r0 += kScaleRowsPerRound) {
+    float v[kScaleLoadsInFlight];
 #pragma unroll
-      for (int j = 0; j < kReduceInFlight; ++j) {
-        const int t = t0 + j * kWavesPerBlock;
-        v0[j] = base[size_t(t < tiles ? t : tiles - 1) * kAccStride + lane];
-      }
-#pragma unroll
-      for (int j = 0; j < kReduceInFlight; ++j) a0 += (t0 + j * kWavesPerBlock < tiles) ? double(v0[j]) : 0.0;
+    for (int j = 0; j < kScaleLoadsInFlight; ++j) {
+      const int r = r0 + j * 16 + (lane >> 2);
+      const int t = wave + (r < my_rows ? r : my_rows - 1) * kWavesPerBlock;
+      v[j] = base[size_t(t) * kAccStride + (lane & 3)];
     }
-    sh[wave * 4 + lane] = a0;
+#pragma unroll
+    for (int j = 0; j < kScaleLoadsInFlight; ++j) mine[(j * 16 + (lane >> 2)) * 4 + (lane & 3)] = v[j];
+    // the slab is private to the wavefront: LDS executes its operations in order, only the compiler must not reorder
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 4) {
+      const int count = min(kScaleRowsPerRound, my_rows - r0);
+      for (int r = 0; r < count; ++r) a0 += double(mine[r * 4 + lane]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+  if (lane < 4) sh[wave * 4 + lane] = a0;
   __syncthreads();
   if (threadIdx.x < 4) {
     const int k = threadIdx.x;
