@@ -532,12 +532,19 @@ def test_large_ragged_batch_equals_its_pairs(gpu_ctx):
         big, other, singles = run_all()
     finally:
         gpu_ctx.set_option("rows_per_wave", 0)
+    def same(a, b, k, what):
+        # the log-likelihood sweep groups its partial sums by batch-size class (inside the solver workgroup for full batches,
+        # more loads in flight for small ones): that one number may differ in its last bits
+        if k == "loglik":
+            assert abs(float(a) - float(b)) <= 1e-12 * abs(float(b)), what
+        else:
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True), what
     for slot, j in enumerate(order):
         for k in keys:
-            assert np.array_equal(np.asarray(big[k][j]), np.asarray(other[k][slot]), equal_nan=True), (j, k)
+            same(big[k][j], other[k][slot], k, (j, k))
     for slot, j in enumerate(order[:6]):
         for k in keys:
-            assert np.array_equal(np.asarray(big[k][j]), np.asarray(singles[slot][k][0]), equal_nan=True), (j, k)
+            same(big[k][j], singles[slot][k][0], k, (j, k))
     first_seen = {}
     for j in range(n):          # equal pairs inside the batch got equal records
         key = (pick_r[j], pick_c[j])
