@@ -733,15 +733,13 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   float2* scratch = w.scratch.as<float2>();
   double* ll_partials = w.ll_partials.as<double>();
   unsigned long long* tallies = w.counters.as<unsigned long long>();
-  launch_init_pairs(s, states, n, bp.prm, w.t_init.as<double>());
-
   const int per_level = cfg->max_iterations_per_level;
   const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 1;
   int step = 0;
   for (int level = cfg->first_level; level >= cfg->last_level; --level) {
     const LevelGeom& g = bp.geom[level];
     const PairPtrs* pp = bp.pair_ptrs + size_t(level) * n;
-    launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels);
+    launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);
     // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
     // (measured, scripts/ab_match.py fused_ll_pixels: 128 pairs 2.152 -> 2.117 ms with level 1 fused; 16 pairs 0.756 -> 0.799, one
     // pair 0.524 -> 0.547: a lone workgroup per pair is slower than 32 blocks when the chip is empty)

@@ -17,10 +17,12 @@ __global__ void k_init_pairs(PairState* states, int n_pairs, SolverParams prm, c
   gn_init_pair(states[p], prm, T_init + size_t(p) * 16);
 }
 
+// T_init != null: the first level of a match -- the pair is initialised here as well (one launch less per match)
 __global__ void k_level_begin(PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
-                              const PairPtrs* __restrict__ pairs, dvo_hip_level_stats* levels) {
+                              const PairPtrs* __restrict__ pairs, dvo_hip_level_stats* levels, const double* __restrict__ T_init) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
+  if (T_init) gn_init_pair(states[p], prm, T_init + size_t(p) * 16);
   gn_level_begin(states[p], prm, g, level, *pairs[p].n_selected, levels + size_t(p) * prm.cap_levels);
 }
 
@@ -159,8 +161,8 @@ void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverPara
 }
 
 void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
-                        const PairPtrs* pairs, dvo_hip_level_stats* levels) {
-  k_level_begin<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, g, level, pairs, levels);
+                        const PairPtrs* pairs, dvo_hip_level_stats* levels, const double* T_init_or_null) {
+  k_level_begin<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, g, level, pairs, levels, T_init_or_null);
 }
 
 void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
