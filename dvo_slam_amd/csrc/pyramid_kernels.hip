@@ -118,16 +118,18 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
     }
     __syncthreads();
     // ---- level 0 in the frame's role ----
-    const int x1 = bx * 32 + tx, y1 = by * 8 + ty;              // level-1 pixel = level-0 quad
+    // wavefront w writes rows w, w + 4, ... of the tile, lane = column: every store instruction covers 64 consecutive pixels
+    // (1 KiB of A or R, 512 B of B) instead of every other pixel of two rows
+    const int x1 = bx * 32 + tx, y1 = by * 8 + ty;              // level-1 pixel = level-0 quad (pyramid part below)
     int count = 0;
+    if (ROLE >= 0) {
+      const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int x = 2 * x1 + dx, y = 2 * y1 + dy;
-        const int r = 2 * ty + dy + 1, c = 2 * tx + dx + 1;
+      for (int k = 0; k < kB0H / 4; ++k) {
+        const int x = x0 + lx, y = y0 + ly + 4 * k;
+        const int r = ly + 4 * k + 1, c = lx + 1;
         bool ok = false;
-        if (ROLE >= 0 && x < w0 && y < h0) {
+        if (x < w0 && y < h0) {
           const float i0 = sI[r][c], z0 = sZ[r][c];
           const float idx = (sI[r][c + 1] - sI[r][c - 1]) * 0.5f, idy = (sI[r + 1][c] - sI[r - 1][c]) * 0.5f;
           const float zdx = (sZ[r][c + 1] - sZ[r][c - 1]) * 0.5f, zdy = (sZ[r + 1][c] - sZ[r - 1][c]) * 0.5f;
