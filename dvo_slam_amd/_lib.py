@@ -124,8 +124,8 @@ def lib():
                                       C.POINTER(LevelStats), C.c_int, C.POINTER(IterationStats), C.c_int]
     L.dvo_hip_level_iteration.argtypes = [vp, vp, vp, C.c_int, C.c_float, C.c_float, fp, fp, C.c_int,
                                           C.POINTER(IterationOut), fp]
-    L.dvo_hip_time_residual_kernel.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, fp]
-    L.dvo_hip_time_stream_mix.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, fp]
+    L.dvo_hip_time_residual_kernel.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, fp]
+    L.dvo_hip_time_stream_mix.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, fp]
     L.dvo_hip_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.dvo_hip_version.restype = C.c_char_p
     _lib = L

@@ -88,7 +88,7 @@ __device__ __forceinline__ double wave_sum_double(double v) {
 // sum over a range of stored residual pairs of log(1 + 0.2 r^T P r) (dense_tracking_impl.cpp:413-422), two pixels per
 // 16-B load.  The reference multiplies 50 terms between logs; here a lane multiplies ALL its terms and takes ONE log:
 // after every eight factors the running product is renormalised with frexp (two instructions) and the exponent is
-// summed separately, so the product can neither overflow nor lose precision.  `first_chunk`/`chunk_stride` in units
+// summed separately, so the product can neither overflow (eight factors of up to 1e38 stay inside float64) nor lose precision.  `first_chunk`/`chunk_stride` in units
 // of LOADS x blockDim pixel pairs; LOADS = 16-B loads in flight per lane between renormalisations (frexp only rescales by
 // a power of two, so the value does not depend on LOADS -- only the latency hiding does).
 template <int LOADS>
@@ -111,10 +111,12 @@ __device__ __forceinline__ double loglik_partial(const float2* __restrict__ res,
     for (int k = 0; k < LOADS; ++k) {
       if (rr[k].x == rr[k].x) prod *= 1.0 + 0.2 * double(mahalanobis(rr[k].x, rr[k].y, P));
       if (rr[k].z == rr[k].z) prod *= 1.0 + 0.2 * double(mahalanobis(rr[k].z, rr[k].w, P));
+      if ((k & 3) == 3 || k == LOADS - 1) {                  // eight factors at most between renormalisations: with a near-
+        int e;                                                // singular scale (noise-free input) one factor can reach 1e13
+        prod = frexp(prod, &e);
+        exponent += e;
+      }
     }
-    int e;
-    prod = frexp(prod, &e);
-    exponent += e;
   }
   if ((npx & 1) && first_chunk == 0 && threadIdx.x == 0) {   // odd pixel count: last pixel
     const float2 rr = res[npx - 1];

@@ -10,22 +10,19 @@
 // k_loglik           pass 4 (dense_tracking_impl.cpp:406-425): needs the precision P that is only known
 //                    after the whole of pass 3, hence a second, light sweep over the 8-B residual pairs.
 //
-// Memory-bound per-pixel work (about 6 flop/B), so no MFMA: the design goals are coalesced 16-B
-// streaming of the reference plane, 16-B/8-B gathers of the current planes that stay in L1/L2 thanks
-// to 2-D tiles, XCD-aware tile->workgroup mapping, and a deterministic (atomic-free, fixed-order)
-// wavefront-DPP -> LDS -> per-workgroup-partial reduction.
+// This file holds the all-VALU schedule the north star sketches ("variant 0": coalesced 16-B streaming of the reference
+// plane, 16-B/8-B gathers of the current planes that stay in L1/L2 thanks to 2-D tiles, XCD-aware tile->workgroup
+// mapping, and a deterministic (atomic-free, fixed-order) wavefront-DPP -> LDS -> per-workgroup-partial reduction of the
+// 85 accumulators), which stores the residual pairs and leaves the log-likelihood to k_loglik.  The default schedule
+// (align_mfma.hip) produces the same outputs 1.3x faster and evaluates the log-likelihood in the same launch; variant 0 is
+// kept as the independent second implementation the parity tests compare it with.
 #include "align_common.h"
 
 namespace dvo_hip {
 
 // FINEST only tags the instantiation that sweeps pyramid level 0 with a distinct symbol, so that a rocprofv3
-// kernel trace reports the finest-level launches (the roofline kernel) separately from the coarser ones.
-// VARIANT selects the schedule of the row loop (same arithmetic, same results):
-//   0  one row at a time (lowest register count)
-//   1  software pipeline: the reference row k+2 and the eight taps of row k+1 are in flight while row k is
-//      blended and accumulated, so each wavefront overlaps its own HBM/L2 latency with its ~1000 cycles of VALU
-//      work instead of relying on the 2-3 co-resident wavefronts the 85 accumulators leave room for
-template <int RPW, bool FINEST, int VARIANT>
+// kernel trace reports the finest-level launches separately from the coarser ones.
+template <int RPW, bool FINEST>
 __global__ __launch_bounds__(kBlock) void k_residual_reduce(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd) {
@@ -83,31 +80,13 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce(
     accumulate_pixel(acc, o, w);
   };
 
-  if constexpr (VARIANT >= 1) {
-    float4 ref_cur = load_ref(0);
-    float4 ref_next = load_ref(1);
-    PixelProj p_cur = pixel_project(g, KT, ref_cur, col_ok ? u_r : 0, min(row0, g.h - 1));
-    PixelTaps t_cur;
-    if (p_cur.ok) pixel_fetch(g, curA, curB, p_cur, t_cur);
 #pragma unroll 1
-    for (int k = 0; k < RPW; ++k) {
-      const float4 ref_next2 = load_ref(k + 2);                      // stage 1 of row k+2
-      const PixelProj p_next = pixel_project(g, KT, ref_next, col_ok ? u_r : 0, min(row0 + k + 1, g.h - 1));
-      PixelTaps t_next;
-      if (p_next.ok) pixel_fetch(g, curA, curB, p_next, t_next);     // stage 2 of row k+1: eight gathers in flight
-      finish_row(k, ref_cur, p_cur, t_cur);                          // stage 3 of row k
-      ref_cur = ref_next; ref_next = ref_next2;
-      p_cur = p_next; t_cur = t_next;
-    }
-  } else {
-#pragma unroll 1
-    for (int k = 0; k < RPW; ++k) {
-      const float4 ref = load_ref(k);
-      const PixelProj p = pixel_project(g, KT, ref, col_ok ? u_r : 0, min(row0 + k, g.h - 1));
-      PixelTaps t;
-      if (p.ok) pixel_fetch(g, curA, curB, p, t);
-      finish_row(k, ref, p, t);
-    }
+  for (int k = 0; k < RPW; ++k) {
+    const float4 ref = load_ref(k);
+    const PixelProj p = pixel_project(g, KT, ref, col_ok ? u_r : 0, min(row0 + k, g.h - 1));
+    PixelTaps t;
+    if (p.ok) pixel_fetch(g, curA, curB, p, t);
+    finish_row(k, ref, p, t);
   }
 
   // stage 1: DPP reduction inside each wavefront; stage 2: the four wave results through LDS;
@@ -129,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce(
 template <int LOADS>
 __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const PairState* __restrict__ states, int n_pairs,
                                                    const float* __restrict__ partials, const float2* __restrict__ scratch,
-                                                   double* __restrict__ ll_partials, int blocks_per_pair) {
+                                                   double* __restrict__ ll_partials, int ll_stride, int blocks_per_pair) {
   const int pair = blockIdx.y;
   if (!states[pair].active) return;
   __shared__ double sh[16];
@@ -145,67 +124,71 @@ __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const Pair
   __syncthreads();
   if (lane == 0) sh[wave] = total;
   __syncthreads();
-  if (threadIdx.x == 0) ll_partials[size_t(pair) * blocks_per_pair + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if (threadIdx.x == 0) ll_partials[size_t(pair) * ll_stride + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-template <int RPW, int VARIANT>
+template <int RPW>
 static void launch_rr(hipStream_t s, bool finest, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                       float* partials, float2* scratch) {
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   if (finest)
-    k_residual_reduce<RPW, true, VARIANT><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+    k_residual_reduce<RPW, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
   else
-    k_residual_reduce<RPW, false, VARIANT><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+    k_residual_reduce<RPW, false><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
 }
 
-template <int VARIANT>
-static void launch_rr_v(hipStream_t s, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
-                        const PairState* states, int n_pairs, float* partials, float2* scratch) {
-  switch (rows_per_wave) {
-    case 1: launch_rr<1, VARIANT>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 2: launch_rr<2, VARIANT>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 4: launch_rr<4, VARIANT>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 16: launch_rr<16, VARIANT>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    default: launch_rr<8, VARIANT>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+void launch_residual_reduce(hipStream_t s, int variant, int ll_mode, int rows_per_wave, bool finest, const LevelGeom& g,
+                            const PairPtrs* pairs, const PairState* states, int n_pairs, float* partials, PairSync* sync,
+                            double* ll_partials, int ll_stride, float2* scratch, unsigned* error_word) {
+  if (variant == 5) {
+    launch_residual_reduce_mfma(s, ll_mode, rows_per_wave, finest, g, pairs, states, n_pairs, partials, sync, ll_partials, ll_stride,
+                                scratch, error_word);
+    return;
   }
-}
-
-void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
-                            const PairState* states, int n_pairs, float* partials, float2* scratch) {
-  switch (variant) {
-    case 5: launch_residual_reduce_mfma(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 3: launch_residual_reduce_split(s, false, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 4: launch_residual_reduce_split(s, true, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 1: launch_rr_v<1>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    default: launch_rr_v<0>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch); break;
+  // variant 0: always the second-sweep form (the caller allocates `scratch` and runs launch_loglik)
+  switch (rows_per_wave) {
+    case 1: launch_rr<1>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 2: launch_rr<2>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 4: launch_rr<4>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    default: launch_rr<8>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
   }
 }
 
 // The sweep's bytes without the sweep: every pixel's reference quad, current-frame quad and gradient pair are read in
 // pixel order and an 8-byte pair is written where the sweep writes its residuals.  No gather, no arithmetic, no reduction:
 // the time of this kernel is what the memory system needs for the sweep's algorithmic traffic (dvo_hip_time_stream_mix).
-__global__ __launch_bounds__(kBlock) void k_stream_mix(const PairPtrs* __restrict__ pairs, int n_px, float2* __restrict__ scratch) {
+// WRITE = false: the read side alone (what the default sweep moves since it keeps the residual pairs in registers).
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_stream_mix(const PairPtrs* __restrict__ pairs, int n_px, float2* __restrict__ scratch, float* __restrict__ sink) {
   const PairPtrs pp = pairs[blockIdx.y];
   float2* out = scratch + size_t(blockIdx.y) * n_px;
+  float fold = 0.0f;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_px; i += gridDim.x * kBlock) {
     const float4 r = pp.refR[i], a = pp.curA[i];
     const float2 b = pp.curB[i];
-    out[i] = make_float2(r.x + a.y + b.x, r.w + a.z + b.y);
+    if constexpr (WRITE) out[i] = make_float2(r.x + a.y + b.x, r.w + a.z + b.y);
+    else fold += (r.x + a.y + b.x) + (r.w + a.z + b.y) + (r.y + r.z) + (a.x + a.w);
+  }
+  if constexpr (!WRITE) {
+    // keep the loads alive with one store per workgroup
+    for (int off = 32; off > 0; off >>= 1) fold += __shfl_down(fold, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sink[blockIdx.y * gridDim.x + blockIdx.x], fold);
   }
 }
 
-void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch) {
+void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch, float* sink) {
   const int per_pair = (n_px + kBlock * 8 - 1) / (kBlock * 8);
-  k_stream_mix<<<dim3(per_pair, n_pairs), dim3(kBlock), 0, s>>>(pairs, n_px, scratch);
+  if (scratch) k_stream_mix<true><<<dim3(per_pair, n_pairs), dim3(kBlock), 0, s>>>(pairs, n_px, scratch, sink);
+  else k_stream_mix<false><<<dim3(per_pair, n_pairs), dim3(kBlock), 0, s>>>(pairs, n_px, scratch, sink);
 }
 
 void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,
-                   const float2* scratch, double* ll_partials, int blocks_per_pair) {
+                   const float2* scratch, double* ll_partials, int ll_stride, int blocks_per_pair) {
   // few pairs: the sweep is a handful of dependent round trips per lane, more loads in flight shorten it (one pair 0.52 -> 0.50 ms);
   // a full batch is bandwidth-bound and runs 6 % slower with the larger chunks
-  if (n_pairs <= 16) k_loglik<8><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, blocks_per_pair);
-  else k_loglik<4><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, blocks_per_pair);
+  if (n_pairs <= 16) k_loglik<8><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, ll_stride, blocks_per_pair);
+  else k_loglik<4><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, ll_stride, blocks_per_pair);
 }
 
 }  // namespace dvo_hip

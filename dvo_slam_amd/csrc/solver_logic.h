@@ -144,7 +144,9 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   const double d = double(n) - 3.0;
   scale_to_precision(sums[kAccS] / d, sums[kAccS + 1] / d, sums[kAccS + 2] / d, C, P);   // :295
   const double det = double(P[0]) * double(P[3]) - double(P[1]) * double(P[2]);
-  const double ll = 0.5 * double(n) * log(det) - 3.5 * ll_sum;                           // :297, impl:424
+  // the reference's log-likelihood is a float (computeCompleteDataLogLikelihood returns float into `float ll`, :297,
+  // impl:406-425): the rounding decides `Error < LastError` at the noise floor, so it is part of the algorithm
+  const double ll = double(float(0.5 * double(n) * log(det) - 3.5 * ll_sum));
   rec.tdist_loglik = -ll;
   for (int i = 0; i < 4; ++i) rec.tdist_precision[i] = double(P[i]);
   double li[6] = {0, 0, 0, 0, 0, 0};

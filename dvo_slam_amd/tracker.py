@@ -575,22 +575,23 @@ class DenseTracker:
             d["residuals"] = res
         return d
 
-    def time_residual_kernel(self, references, currents, level, reps=20):
-        """Average duration (ms) of one launch of the fused residual/Jacobian/reduce kernel (HIP events)."""
+    def time_residual_kernel(self, references, currents, level, reps=20, warm_iterations=3):
+        """Average duration (ms) of one launch of the fused residual/Jacobian/reduce/log-likelihood kernel (HIP events), after
+        `warm_iterations` Gauss-Newton steps on that level (converged transform, t-distribution weights on; 0 = identity)."""
         n = len(references)
         vp = C.c_void_p
         refs = (vp * n)(*[p.ptr for p in references])
         curs = (vp * n)(*[p.ptr for p in currents])
         ms = C.c_float()
-        self.ctx.check(self.ctx._lib.dvo_hip_time_residual_kernel(self.ctx.ptr, n, refs, curs, level, reps, C.byref(ms)))
+        self.ctx.check(self.ctx._lib.dvo_hip_time_residual_kernel(self.ctx.ptr, n, refs, curs, level, warm_iterations, reps, C.byref(ms)))
         return ms.value
 
-    def time_stream_mix(self, references, currents, level, reps=20):
-        """Average duration (ms) of a kernel that only streams the sweep's planes (40 B read + 8 B written per pixel)."""
+    def time_stream_mix(self, references, currents, level, reps=20, with_write=False):
+        """Average duration (ms) of a kernel that only streams the sweep's planes (40 B read per pixel; with_write: + 8 B written)."""
         n = len(references)
         vp = C.c_void_p
         refs = (vp * n)(*[p.ptr for p in references])
         curs = (vp * n)(*[p.ptr for p in currents])
         ms = C.c_float()
-        self.ctx.check(self.ctx._lib.dvo_hip_time_stream_mix(self.ctx.ptr, n, refs, curs, level, reps, C.byref(ms)))
+        self.ctx.check(self.ctx._lib.dvo_hip_time_stream_mix(self.ctx.ptr, n, refs, curs, level, int(with_write), reps, C.byref(ms)))
         return ms.value

@@ -406,7 +406,7 @@ static double loglik_pass(const float* res, int n, const float P[4], int mode) {
   double sum = 0.0;
   for (int i = 0; i < n; ++i) sum += std::log1p(0.2 * double(mahalanobis(res + 2 * i, P)));
   const double det = double(P[0]) * P[3] - double(P[1]) * P[2];
-  return 0.5 * n * std::log(det) - 3.5 * sum;
+  return float(0.5 * n * std::log(det) - 3.5 * sum);   // a float in the reference (:297): the rounding is not a quirk
 }
 
 // dense_tracking.cpp:448-476 and :333-340
