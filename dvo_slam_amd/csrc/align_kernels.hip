@@ -14,8 +14,8 @@
 // plane, 16-B/8-B gathers of the current planes that stay in L1/L2 thanks to 2-D tiles, XCD-aware tile->workgroup
 // mapping, and a deterministic (atomic-free, fixed-order) wavefront-DPP -> LDS -> per-workgroup-partial reduction of the
 // 85 accumulators), which stores the residual pairs and leaves the log-likelihood to k_loglik.  The default schedule
-// (align_mfma.hip) produces the same outputs 1.3x faster and evaluates the log-likelihood in the same launch; variant 0 is
-// kept as the independent second implementation the parity tests compare it with.
+// (align_mfma.hip) produces the same outputs 1.3x faster; variant 0 is kept as the independent second implementation the
+// parity tests compare it with.
 #include "align_common.h"
 
 namespace dvo_hip {
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce(
 template <int LOADS>
 __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const PairState* __restrict__ states, int n_pairs,
                                                    const float* __restrict__ partials, const float2* __restrict__ scratch,
-                                                   double* __restrict__ ll_partials, int ll_stride, int blocks_per_pair) {
+                                                   double* __restrict__ ll_partials, int blocks_per_pair) {
   const int pair = blockIdx.y;
   if (!states[pair].active) return;
   __shared__ double sh[16];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const Pair
   __syncthreads();
   if (lane == 0) sh[wave] = total;
   __syncthreads();
-  if (threadIdx.x == 0) ll_partials[size_t(pair) * ll_stride + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if (threadIdx.x == 0) ll_partials[size_t(pair) * blocks_per_pair + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 template <int RPW>
@@ -138,19 +138,17 @@ static void launch_rr(hipStream_t s, bool finest, const LevelGeom& g, const Pair
     k_residual_reduce<RPW, false><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
 }
 
-void launch_residual_reduce(hipStream_t s, int variant, int ll_mode, int rows_per_wave, bool finest, const LevelGeom& g,
-                            const PairPtrs* pairs, const PairState* states, int n_pairs, float* partials, PairSync* sync,
-                            double* ll_partials, int ll_stride, float2* scratch, unsigned* error_word) {
+void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
+                            const PairState* states, int n_pairs, float* partials, float2* scratch) {
   if (variant == 5) {
-    launch_residual_reduce_mfma(s, ll_mode, rows_per_wave, finest, g, pairs, states, n_pairs, partials, sync, ll_partials, ll_stride,
-                                scratch, error_word);
+    launch_residual_reduce_mfma(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch);
     return;
   }
-  // variant 0: always the second-sweep form (the caller allocates `scratch` and runs launch_loglik)
   switch (rows_per_wave) {
     case 1: launch_rr<1>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
     case 2: launch_rr<2>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
     case 4: launch_rr<4>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 16: launch_rr<16>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
     default: launch_rr<8>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
   }
 }
@@ -184,11 +182,11 @@ void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_
 }
 
 void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,
-                   const float2* scratch, double* ll_partials, int ll_stride, int blocks_per_pair) {
+                   const float2* scratch, double* ll_partials, int blocks_per_pair) {
   // few pairs: the sweep is a handful of dependent round trips per lane, more loads in flight shorten it (one pair 0.52 -> 0.50 ms);
   // a full batch is bandwidth-bound and runs 6 % slower with the larger chunks
-  if (n_pairs <= 16) k_loglik<8><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, ll_stride, blocks_per_pair);
-  else k_loglik<4><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, ll_stride, blocks_per_pair);
+  if (n_pairs <= 16) k_loglik<8><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, blocks_per_pair);
+  else k_loglik<4><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, blocks_per_pair);
 }
 
 }  // namespace dvo_hip

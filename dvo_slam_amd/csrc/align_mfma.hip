@@ -1,114 +1,38 @@
-// align_mfma.hip -- the fused residual / Jacobian / reduce / log-likelihood sweep (the default schedule, "variant 5").
+// align_mfma.hip -- the fused residual / Jacobian / reduce sweep with the normal-equation accumulation on the
+// matrix cores (schedule variant 5 of k_residual_reduce; same per-pixel arithmetic, same outputs).
 //
-// One launch does the reference's passes 1-5 (dense_tracking.cpp:271-343) for every pair of a batch:
+// Why a matrix instruction in a "memory-bound per-pixel" kernel: measured on MI355X (profiles/r01_*), the
+// all-VALU schedule is NOT memory-bound.  Its 85 per-lane accumulators cost ~125 FMAs per pixel plus a
+// 600-instruction DPP reduction per wavefront, SQ_ACTIVE_INST_VALU shows the vector ALUs 78 % busy, and the
+// kernel stops at 0.50 ms per 128-pair finest-level launch (39 % of the HBM roofline) with 150 VGPRs = 3
+// wavefronts per SIMD.  The accumulation itself is a rank-k update  G += V^T V  of the 16x16 Gram matrix of the
+// per-pixel vectors  v = sqrt(w) * [J0(6), J1(6), r0, r1, 0, 0]  (least_squares.cpp:58-64 contracts exactly this
+// with the 2x2 precision) -- matrix math, four pixels (k = 4) per v_mfma_f32_16x16x4_f32.  That instruction is an
+// exact f32 fmaf chain (no reduced precision), runs on the otherwise idle matrix pipe, keeps the whole Gram
+// matrix in 4 accumulator registers per lane instead of 85, and leaves NO cross-lane reduction to do: the sum
+// over the 64 pixels of a row happens inside the 16 MFMAs.  The per-pixel part (warp, bilinear taps, residual,
+// weights, Jacobian: dense_tracking_impl.cpp:148-281, dense_tracking.cpp:448-476) is unchanged VALU code.
 //
-//   per pixel   warp, bilinear taps, residual, validity tests, t-distribution weight, 2x6 Jacobian  (VALU code,
-//               dense_tracking_impl.cpp:148-281, dense_tracking.cpp:448-476)
-//   per tile    n, sum w r r^T and the P-independent Gram sums of J^T W J / J^T W r, accumulated on the matrix cores
-//   per pair    the 2x2 precision P = (sum w r r^T / (n - 3))^-1 is only known when ALL tiles of the pair are through
-//               (dense_tracking.cpp:295).  The last tile workgroup of a pair to arrive reduces the pair's scale sums in
-//               the fixed tile order and publishes P; every tile workgroup of the pair then evaluates its share of the
-//               log-likelihood sum  sum log(1 + 0.2 r^T P r)  (dense_tracking_impl.cpp:406-425) from the residual pairs
-//               it STILL HOLDS IN REGISTERS.
-//
-// Round 1 wrote the residual pair of every pixel to HBM (8 B per pixel on top of the 40 B read: 1.24x the algorithmic
-// traffic, and a read/write mix this part streams at 4.8 instead of 6.3 TB/s) and swept it again in a second kernel once P
-// was known.  Both the write and the second launch are gone.
-//
-// Why a matrix instruction in a "memory-bound per-pixel" kernel: measured on MI355X (profiles/r01_*), the all-VALU schedule
-// is NOT memory-bound.  Its 85 per-lane accumulators cost ~125 FMAs per pixel plus a 600-instruction DPP reduction per
-// wavefront and 150 VGPRs (3 wavefronts per SIMD).  The accumulation itself is a rank-k update  G += V^T V  of the 16x16
-// Gram matrix of the per-pixel vectors  v = sqrt(w) * [J0(6), J1(6), r0, r1, 0, 0]  (least_squares.cpp:58-64 contracts
-// exactly this with the 2x2 precision) -- matrix math, four pixels (k = 4) per v_mfma_f32_16x16x4_f32.  That instruction is
-// an exact f32 fmaf chain (no reduced precision), runs on the otherwise idle matrix pipe, keeps the whole Gram matrix in 4
-// accumulator registers per lane instead of 85, and leaves NO cross-lane reduction to do.
-//
-// Data movement per pixel row of a wavefront: each lane (= pixel) writes its 16-vector to LDS as four conflict-free
-// ds_write_b128; the MFMA operand for pixel group g (lane l <- component l&15 of pixel 4g + l>>4) is one conflict-free
-// ds_read_b32 at a constant offset.  A == B (the sqrt(w)-scaled vector on both sides).  The LDS slab is private to the
-// wavefront, so the row loop contains no barrier.
-//
-// The per-pair hand-off (MI355X: 8 XCDs with private L2s, per-CU L1s that other CUs' stores never refresh) follows the
-// write-through recipe of the CDNA4 guide: every shared word is stored and loaded with agent-scope (sc1) accesses, the
-// storing wavefront drains its stores (s_waitcnt vmcnt(0)) before the arrival ticket / the flag is touched, ONE lane polls
-// ONE word with s_sleep in between, every spin is bounded and reports through a sticky error word.  A pair's tiles are
-// dealt to consecutive workgroups of one XCD (150 at the finest level of a 640x480 pair, 192+ resident per XCD), so the
-// waiting workgroups of a pair never keep its remaining tiles from being dispatched; should a dispatcher ever violate that,
-// the bounded spin turns the hang into an error code, never into a wrong number.
-#include <cstdlib>
-
+// Data movement per pixel row of a wavefront: each lane (= pixel) writes its 16-vector to LDS as four
+// conflict-free ds_write_b128; the MFMA operand for pixel group g (lane l <- component l&15 of pixel 4g + l>>4)
+// is one conflict-free ds_read_b32 at a constant offset.  A == B (the sqrt(w)-scaled vector on both sides).
+// The LDS slab is private to the wavefront, so the row loop contains no barrier.
 #include "align_common.h"
 
 namespace dvo_hip {
 
 typedef float __attribute__((ext_vector_type(4))) f32x4;
-typedef __attribute__((address_space(1))) unsigned* GlobalU32;
 
 constexpr int kQuadStride = 264;                 // floats per component quad: 64 pixels x 4 + 8 skew (bank-conflict-free reads)
 constexpr int kSlabFloats = 4 * kQuadStride;     // per-wavefront LDS slab (4224 B)
-static_assert(kWavesPerBlock * kSlabFloats >= kScaleStageFloats, "the last arriver stages the pair's scale sums in the slabs");
-
-constexpr unsigned kSpinLimit = 1u << 22;        // polls (~1 us each) before a waiting workgroup gives up
-
-__device__ __forceinline__ unsigned load_agent(const unsigned* p) {
-  return __hip_atomic_load((GlobalU32)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void store_agent(unsigned* p, unsigned v) {
-  __hip_atomic_store((GlobalU32)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// reduce_partials_scale (reduce_scale.h) over rows that other workgroups of THIS launch have just written: the same
-// additions in the same order (hence the same n, S and P the solver kernel derives a launch later from the same rows), the
-// loads agent-scope so that they are served from behind the per-XCD L2s.
-__device__ inline void reduce_partials_scale_coherent(const float* partials, int pair, int tiles, float* stage, double* sh, double* sums) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned* base = reinterpret_cast<const unsigned*>(partials + size_t(pair) * tiles * kAccStride);
-  const int my_rows = tiles > wave ? (tiles - wave + kWavesPerBlock - 1) / kWavesPerBlock : 0;
-  float* mine = stage + wave * kScaleRowsPerRound * 4;
-  double a0 = 0.0;
-  for (int r0 = 0; r0 < my_rows; r0 += kScaleRowsPerRound) {
-    unsigned v[kScaleLoadsInFlight];
-#pragma unroll
-    for (int j = 0; j < kScaleLoadsInFlight; ++j) {
-      const int r = r0 + j * 16 + (lane >> 2);
-      const int t = wave + (r < my_rows ? r : my_rows - 1) * kWavesPerBlock;
-      v[j] = load_agent(base + size_t(t) * kAccStride + (lane & 3));
-    }
-#pragma unroll
-    for (int j = 0; j < kScaleLoadsInFlight; ++j) mine[(j * 16 + (lane >> 2)) * 4 + (lane & 3)] = __uint_as_float(v[j]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < 4) {
-      const int count = min(kScaleRowsPerRound, my_rows - r0);
-      for (int r = 0; r < count; ++r) a0 += double(mine[r * 4 + lane]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (lane < 4) sh[wave * 4 + lane] = a0;
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    const int k = threadIdx.x;
-    sums[k] = (sh[k] + sh[4 + k]) + (sh[8 + k] + sh[12 + k]);
-  }
-  __syncthreads();
-}
 
 // LINEAR: the level is walked as one row of w*h pixels in 64-pixel segments (LevelGeom::linear) -- same per-pixel arithmetic,
 // the pixel coordinates come from a division instead of the tile position.
-// MODE 0: the log-likelihood sums are evaluated in this launch (hand-off of P, residual pairs in registers); nothing but the
-//         partial rows and one float64 per tile is written.
-// MODE 1: as 0, and the residual pairs are ALSO left in `scratch` (parity entry point / error image; never on the match path).
-// MODE 2: no hand-off: the residual pairs go to `scratch` and k_loglik sweeps them a second time.  For levels with more tiles
-//         per pair than are resident at a time (the hand-off needs every tile of a pair in flight together).
-template <int RPW, bool FINEST, bool LINEAR, int MODE>
+template <int RPW, bool FINEST, bool LINEAR>
 __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
-    float* partials, PairSync* sync, double* __restrict__ ll_partials, int ll_stride, float2* __restrict__ scratch,
-    unsigned* error_word, int blocks_per_xcd, int exp_skip) {
-  // XCD-aware (pair, tile) -> workgroup mapping: workgroup b runs on XCD b % 8 (observed dispatch order; speed only), every XCD
-  // gets one contiguous run of (pair, tile) items so that a pair's planes flow through a single L2
+    float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd) {
+  // XCD-aware (pair, tile) -> workgroup mapping, see k_residual_reduce
   const int tiles = g.tiles_x * g.tiles_y;
   const int total = tiles * n_pairs;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -147,6 +71,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   // wavefront w sweeps rows w, w+4, w+8, ... of the tile: the four waves work on ADJACENT rows at the same time, so the
   // lower tap row of one wave is the upper tap row of the next and is served by the CU's L1 instead of a second L2 request
   const int row0 = (tile / g.tiles_x) * (kWavesPerBlock * RPW) + wave;
+  const size_t pix_base = size_t(pair) * size_t(g.w) * g.h;
   const float nanv = __builtin_nanf("");
   const bool col_ok = LINEAR || u_r < g.w;
   const int n_px = g.w * g.h;
@@ -157,11 +82,6 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
 
   __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kSlabFloats];
   __shared__ int counts[kWavesPerBlock];
-  __shared__ double sh[16];
-  __shared__ double sums[4];
-  __shared__ float sh_P[4];
-  __shared__ unsigned sh_word;
-  __shared__ int sh_n;
   float* my = slab[wave];
   // write side: component quad q of pixel `lane` at my[q*kQuadStride + lane*4 .. +3]
   f32x4* wr = reinterpret_cast<f32x4*>(my + lane * 4);
@@ -170,19 +90,22 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
 
   f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   int n_valid = 0;
-  float hr0[RPW], hr1[RPW];                                   // this lane's residual pairs (NaN = no constraint), kept for the log-likelihood
 
   // The row is straight-line code with two divergent regions (tap fetch; constraint / no constraint): no nested early exits
-  // and no per-exit default values (pixel_math.h, the *_flat stages).  The reference row of iteration k+1 is requested before
-  // row k is processed: one of the two dependent memory round trips of a row (reference pixel -> projected tap addresses) is
-  // off the critical path.  The rows are unrolled (the residual pairs live in registers, which cannot be indexed at run time).
+  // and no per-exit default values (pixel_math.h, the *_flat stages); the reference rows alternate between two register quads
+  // (rows are processed in pairs) instead of being copied.  The reference row of iteration k+1 is requested before row k is
+  // processed: one of the two dependent memory round trips of a row (reference pixel -> projected tap addresses) is off the
+  // critical path.  (Measured and dropped: reading all sixteen matrix operands of a row behind a scheduling barrier before
+  // the first matrix instruction, +15 %; one residual store per branch instead of a select, no gain; tap fetches of lanes
+  // without a usable projection redirected to tap 0 instead of branched around, no gain; the three stages of a row software-
+  // pipelined over rows (taps of row k+1 in flight during the second half of row k): 104 registers, 4 waves per SIMD, +10 %.)
   const float P00 = Pp[0], P11 = Pp[3];
   const int u_c = LINEAR ? lane : min(u_r, g.w - 1);
   auto load_ref = [&](int v_r) {                              // clamped: rows / segments past the end are masked by in_image
     const int idx = LINEAR ? min(v_r * kTileW + lane, n_px - 1) : min(v_r, g.h - 1) * g.w + u_c;
     return refR[idx];                                         // tiled: 64 lanes x 16 B = 1 KiB contiguous per wave
   };
-  auto sweep_row = [&](int v_r, const float4 ref, float& keep0, float& keep1) __attribute__((always_inline)) {
+  auto sweep_row = [&](int v_r, const float4 ref) __attribute__((always_inline)) {
     bool in_image;
     size_t pix;                                               // index of this lane's pixel in the level
     float tx_p, ty_p, cx;
@@ -207,31 +130,11 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     }
     const PixelProj p = pixel_project_flat(g, KT, in_image ? ref.x : nanv, tx_p, ty_p);
     PixelTaps t;
-    if (exp_skip & 4) {                                       // EXPERIMENT
-      t.A00 = t.A10 = t.A01 = t.A11 = ref;
-      t.B00 = t.B10 = t.B01 = t.B11 = make_float2(ref.z, ref.w);
-    } else
     if (p.ok) pixel_fetch(g, curA, curB, p, t);               // lanes without a usable projection are masked out of `valid`
     PixelTerms o;
     const bool valid = pixel_finish_flat(g, ref, p, t, o) && p.ok;
     n_valid += __popcll(__ballot(valid));                     // exact count on the scalar unit
-    if constexpr (MODE != 2) {
-      keep0 = valid ? o.r0 : nanv;
-      keep1 = o.r1;
-    }
-    if constexpr (MODE == 1 || MODE == 2) {
-      if (in_image && !(exp_skip & 16)) scratch[size_t(pair) * size_t(n_px) + pix] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);
-    }
-    if (exp_skip & 2) {                                       // EXPERIMENT: no accumulation at all
-      acc0[0] += o.r0 + o.gix + o.giy + o.gzx + o.gzy;
-      return;
-    }
-    if (valid && (exp_skip & 8)) {                            // EXPERIMENT: no weights / Jacobian arithmetic
-      wr[0] = f32x4{o.gix, o.giy, o.gzx, o.gzy};
-      wr[kQuadStride / 4] = f32x4{o.r0, o.r1, o.X, o.Y};
-      wr[2 * (kQuadStride / 4)] = f32x4{o.Z, o.r1, o.X, o.Y};
-      wr[3 * (kQuadStride / 4)] = f32x4{o.r0, o.r1, 0.0f, 0.0f};
-    } else
+    if (in_image) scratch[pix_base + pix] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);   // one full-width store
     if (valid) {
       // t-distribution weight with the PREVIOUS pass' precision (Q11); first pass on a level: w = 1.  sqrt(w) is folded into
       // the four gradient factors of the Jacobian rows.
@@ -256,7 +159,6 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (!(exp_skip & 1))
 #pragma unroll
     for (int grp = 0; grp < 16; grp += 2) {                   // 4 pixels per MFMA, two independent accumulator chains
       const float a0 = rd[grp * 16], a1 = rd[grp * 16 + 16];
@@ -266,14 +168,16 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
-  float4 ref_cur = load_ref(row0);
-#pragma unroll
-  for (int k = 0; k < RPW; ++k) {
+  float4 ref_a = load_ref(row0), ref_b = ref_a;
+#pragma unroll 1
+  for (int k = 0; k < RPW; k += 2) {
     const int v_r = row0 + k * kWavesPerBlock;                // scalar: image row (tiled) or segment (linear)
-    float4 ref_next = ref_cur;
-    if (k + 1 < RPW) ref_next = load_ref(v_r + kWavesPerBlock);
-    sweep_row(v_r, ref_cur, hr0[k], hr1[k]);
-    ref_cur = ref_next;
+    if (k + 1 < RPW) ref_b = load_ref(v_r + kWavesPerBlock);
+    sweep_row(v_r, ref_a);
+    if (k + 1 < RPW) {
+      if (k + 2 < RPW) ref_a = load_ref(v_r + 2 * kWavesPerBlock);
+      sweep_row(v_r + kWavesPerBlock, ref_b);
+    }
   }
 
   // lane l, register i holds G[row (l>>4)*4 + i][col l&15] of this wavefront's rows
@@ -306,138 +210,33 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     } else if (k < kAccB01) v = G(k - kAccB00, 12);
     else if (k < kAccB11) v = G(k - kAccB01, 13) + G(6 + (k - kAccB01), 12);
     else v = G(6 + (k - kAccB11), 13);
-    float* row = partials + (size_t(pair) * tiles + tile) * kAccStride;
-    // the four scale sums are read by another workgroup of this launch (the pair's last arriver): write-through stores
-    if (MODE != 2 && k < 4) store_agent(reinterpret_cast<unsigned*>(row + k), __float_as_uint(v));
-    else row[k] = v;
+    partials[(size_t(pair) * tiles + tile) * kAccStride + k] = v;
   }
-  if constexpr (MODE == 2) return;
-  if constexpr (MODE == 3) {                                  // EXPERIMENT (timing only): the log-likelihood arithmetic without the hand-off
-    double prod = 1.0;
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const double f = 1.0 + 0.2 * double(mahalanobis(hr0[r], hr1[r], Pp));
-      prod *= hr0[r] == hr0[r] ? f : 1.0;
-    }
-    double t = wave_sum_double(log(prod));
-    if (lane == 0) sh[wave] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) ll_partials[size_t(pair) * ll_stride + tile] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-    return;
-  }
-
-  // ---- per-pair hand-off: arrive, (last arriver: publish P), wait for P ----------------------------------------------------
-  PairSync* sy = sync + pair;
-  if (wave == 0) {                                            // wavefront 0 holds the four write-through stores
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) sh_word = __hip_atomic_fetch_add((GlobalU32)&sy->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  const unsigned ticket = sh_word;
-  const unsigned gen = ticket / unsigned(tiles) + 1u;         // the generation (= sweep of this level) this arrival belongs to
-  const bool last = ticket % unsigned(tiles) == unsigned(tiles) - 1u;
-  if (last) {                                                 // workgroup-uniform
-    reduce_partials_scale_coherent(partials, pair, tiles, &slab[0][0], sh, sums);
-    if (threadIdx.x == 0) {
-      float C[3], P[4];
-      const int n = scale_from_sums(sums, C, P);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        sh_P[i] = P[i];
-        store_agent(reinterpret_cast<unsigned*>(&sy->P[i]), __float_as_uint(P[i]));
-      }
-      sh_n = n;
-      store_agent(reinterpret_cast<unsigned*>(&sy->n), unsigned(n));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the payload has left before the flag is stored
-      store_agent(&sy->flag, gen);
-    }
-  } else if (threadIdx.x == 0) {
-    unsigned spins = 0;
-    bool ok = true;
-    while (load_agent(&sy->flag) < gen) {                     // ONE lane polls ONE word
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > kSpinLimit) { ok = false; break; }
-    }
-    asm volatile("" ::: "memory");
-    if (ok) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sh_P[i] = __uint_as_float(load_agent(reinterpret_cast<const unsigned*>(&sy->P[i])));
-      sh_n = int(load_agent(reinterpret_cast<const unsigned*>(&sy->n)));
-    } else {                                                  // never a wrong number: NaN precision + sticky error word
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sh_P[i] = nanv;
-      sh_n = 6;
-      __hip_atomic_fetch_or((GlobalU32)error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
-
-  // ---- this tile's share of sum log(1 + 0.2 r^T P r)  (dense_tracking_impl.cpp:413-422) ------------------------------------
-  // A lane multiplies the factors of its RPW pixels in float64 (renormalised with frexp every eight factors, so the product
-  // can neither overflow nor lose precision) and takes ONE log; wavefront sums by shuffle, then (w0 + w1) + (w2 + w3).
-  float P[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) P[i] = sh_P[i];
-  double t = 0.0;
-  if (sh_n >= 6) {
-    double prod = 1.0;
-    int exponent = 0;
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const double f = 1.0 + 0.2 * double(mahalanobis(hr0[r], hr1[r], P));
-      prod *= hr0[r] == hr0[r] ? f : 1.0;
-      if ((r & 7) == 7 && r + 1 < RPW) {
-        int e;
-        prod = frexp(prod, &e);
-        exponent += e;
-      }
-    }
-    t = log(prod) + double(exponent) * 0.6931471805599453094;
-  }
-  t = wave_sum_double(t);
-  if (lane == 0) sh[wave] = t;
-  __syncthreads();
-  if (threadIdx.x == 0) ll_partials[size_t(pair) * ll_stride + tile] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 template <int RPW>
-static void launch_m(hipStream_t s, int ll_mode, bool finest, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
-                     float* partials, PairSync* sync, double* ll_partials, int ll_stride, float2* scratch, unsigned* error_word) {
+static void launch_m(hipStream_t s, bool finest, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
+                     float* partials, float2* scratch) {
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(kBlock);
-  static const int exp_lds = getenv("DVO_EXP_LDS") ? atoi(getenv("DVO_EXP_LDS")) : 0;      // EXPERIMENT: occupancy limiter
-  static const int exp_mode3 = getenv("DVO_EXP_MODE3") ? atoi(getenv("DVO_EXP_MODE3")) : 0;
-  static const int exp_skip = getenv("DVO_EXP_SKIP") ? atoi(getenv("DVO_EXP_SKIP")) : 0;
-#define DVO_LAUNCH_M(FIN, LIN, MODE) \
-  k_residual_reduce_mfma<RPW, FIN, LIN, MODE><<<grid, block, exp_lds, s>>>(g, pairs, states, n_pairs, partials, sync, ll_partials, ll_stride, scratch, error_word, per_xcd, exp_skip)
-  if (exp_mode3 && finest && !g.linear) {
-    DVO_LAUNCH_M(true, false, 3);
-  } else if (ll_mode == kLlSecondSweep) {
-    if (g.linear) DVO_LAUNCH_M(false, true, 2);
-    else if (finest) DVO_LAUNCH_M(true, false, 2);
-    else DVO_LAUNCH_M(false, false, 2);
-  } else if (scratch) {                                       // parity / error-image entry points only
-    if (g.linear) DVO_LAUNCH_M(false, true, 1);
-    else DVO_LAUNCH_M(false, false, 1);
-  } else if (g.linear) {
-    if (finest) DVO_LAUNCH_M(true, true, 0);
-    else DVO_LAUNCH_M(false, true, 0);
+  if (g.linear) {
+    if (finest) k_residual_reduce_mfma<RPW, true, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+    else k_residual_reduce_mfma<RPW, false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
   } else {
-    if (finest) DVO_LAUNCH_M(true, false, 0);
-    else DVO_LAUNCH_M(false, false, 0);
+    if (finest) k_residual_reduce_mfma<RPW, true, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+    else k_residual_reduce_mfma<RPW, false, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
   }
-#undef DVO_LAUNCH_M
 }
 
-void launch_residual_reduce_mfma(hipStream_t s, int ll_mode, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
-                                 const PairState* states, int n_pairs, float* partials, PairSync* sync, double* ll_partials,
-                                 int ll_stride, float2* scratch, unsigned* error_word) {
+void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
+                                 const PairState* states, int n_pairs, float* partials, float2* scratch) {
   switch (rows_per_wave) {
-    case 1: launch_m<1>(s, ll_mode, finest, g, pairs, states, n_pairs, partials, sync, ll_partials, ll_stride, scratch, error_word); break;
-    case 2: launch_m<2>(s, ll_mode, finest, g, pairs, states, n_pairs, partials, sync, ll_partials, ll_stride, scratch, error_word); break;
-    case 4: launch_m<4>(s, ll_mode, finest, g, pairs, states, n_pairs, partials, sync, ll_partials, ll_stride, scratch, error_word); break;
-    default: launch_m<8>(s, ll_mode, finest, g, pairs, states, n_pairs, partials, sync, ll_partials, ll_stride, scratch, error_word); break;
+    case 1: launch_m<1>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 2: launch_m<2>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 4: launch_m<4>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    case 16: launch_m<16>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
+    default: launch_m<8>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
   }
 }
 

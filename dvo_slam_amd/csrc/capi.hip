@@ -145,7 +145,6 @@ struct PinnedRing {
 struct Workspace {
   hipStream_t stream = nullptr;
   DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters;
-  DevBuf sync;                   // PairSync[n] + one sticky error word (hand-off time-outs of the sweep kernel)
   PinnedRing* tables = nullptr;  // the context's ring for small uploads
   int* host_status = nullptr;    // pinned: one word per Gauss-Newton step of a batch, written by the device (k_solver_step)
   size_t host_status_words = 0;
@@ -162,7 +161,7 @@ struct dvo_hip_context {
   int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
-  int opt_inkernel_ll = 1;         // 0: always store the residual pairs and sweep them a second time (the round-1 schedule; A/B tests)
+  int opt_fused_ll_pixels = 0;     // largest level (pixels) whose log-likelihood sweep runs inside the solver workgroup (0 = by batch size)
   int opt_variant = 5;             // schedule of the reduce kernel: 5 = Gram accumulation on the matrix cores (default)
   std::vector<CameraGeom*> cameras;
   Workspace ws[1];
@@ -231,7 +230,7 @@ void workspace_destroy(Workspace& w) {
   if (!w.created) return;
   (void)hipStreamSynchronize(w.stream);
   for (DevBuf* b : {&w.states, &w.pair_ptrs, &w.partials, &w.scratch, &w.ll_partials, &w.lvl_stats, &w.it_stats, &w.results,
-                    &w.t_init, &w.counters, &w.sync})
+                    &w.t_init, &w.counters})
     b->release();
   if (w.host_status) (void)hipHostFree(w.host_status);
   w.host_status = nullptr;
@@ -275,11 +274,9 @@ int wait_for_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames) {
   return wait_for_ticket(ctx, need, /*upload=*/false);
 }
 
-const int kLlBlocksPerPair = 32;   // partial sums per pair of the second log-likelihood sweep
-// The in-kernel hand-off of the precision needs all tile workgroups of a pair in flight together.  A pair's tiles are dealt to
-// consecutive workgroups of ONE XCD (or, for a small batch, to one run on each XCD): 32 CUs x 6 workgroups (80 registers) are
-// resident there.  Levels with more tiles per pair and XCD than this bound fall back to the second sweep.
-const int kResidentTilesPerXcd = 160;
+const int kLlBlocksPerPair = 32;
+const int kFusedLoglikMaxPixels = 160 * 120;      // any batch
+const int kFusedLoglikMaxPixelsBatch = 320 * 240;  // batches that fill the chip with one solver workgroup per pair
 
 // RgbdCameraPyramid::build (rgbd_image.cpp:283-296) + RgbdCamera ctor template (:186-204)
 int get_camera(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, const CameraGeom** out) {
@@ -361,14 +358,6 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   return g;
 }
 
-// How many tile workgroups of one pair one XCD has to hold at a time: the (pair, tile) items are dealt to the XCDs in eight
-// contiguous runs, so a pair lies inside one run (large batch) or is cut into at most `runs` pieces (small batch).
-int tiles_in_flight(int tiles_per_pair, int n_pairs) {
-  const long total = long(tiles_per_pair) * n_pairs;
-  const long per_xcd = (total + 7) / 8;
-  return int(std::min<long>(tiles_per_pair, per_xcd));
-}
-
 // rows of 64 pixels each wavefront sweeps: large tiles amortise the 85-value wave reduction, small tiles
 // keep all 256 CUs busy when the batch is small
 int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_pairs) {
@@ -377,21 +366,12 @@ int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int le
   // The tallest tile that still yields this many workgroups.  Fewer, taller tiles also mean fewer partial rows for the
   // bookkeeping kernel, which matters most when there are few pairs (whole-match timings: profiles/r01_f_tile_heuristic.txt).
   const size_t enough = ctx->opt_min_workgroups > 0 ? size_t(ctx->opt_min_workgroups) : (n_pairs <= 8 ? 512 : n_pairs < 64 ? 1024 : 2048);
-  int pick = 1;
   for (int r : candidates) {
     int tx, ty;
     level_tiles(cam->w[level], cam->h[level], r, level_is_linear(ctx, cam->w[level]), &tx, &ty);
-    if (size_t(tx) * ty * n_pairs >= enough) { pick = r; break; }
+    if (size_t(tx) * ty * n_pairs >= enough) return r;
   }
-  // the in-kernel hand-off wants a pair's tiles resident together (tiles_in_flight): prefer a taller tile that allows it
-  if (ctx->opt_variant == 5 && ctx->opt_inkernel_ll)
-    for (int r : {pick, 8, 4, 2}) {
-      if (r < pick) continue;
-      int tx, ty;
-      level_tiles(cam->w[level], cam->h[level], r, level_is_linear(ctx, cam->w[level]), &tx, &ty);
-      if (tiles_in_flight(tx * ty, n_pairs) <= kResidentTilesPerXcd) return r;
-    }
-  return pick;
+  return 1;
 }
 
 // device layout of a frame: [raw staging][per level: I Z A B R][sel counts]
@@ -612,9 +592,6 @@ struct BatchPlan {
   const CameraGeom* cam = nullptr;
   std::vector<int> rpw;          // per absolute level
   std::vector<LevelGeom> geom;   // per absolute level
-  std::vector<int> ll_mode;      // per absolute level: kLlInKernel / kLlSecondSweep
-  int ll_stride = 0;             // log-likelihood partial sums per pair (capacity)
-  bool need_scratch = false;     // some level stores its residual pairs
   PairPtrs* pair_ptrs = nullptr; // device [levels][n]
 };
 
@@ -654,19 +631,9 @@ void make_plan(const dvo_hip_context* ctx, const CameraGeom* cam, const dvo_hip_
   bp.prm.want_condition_number = ctx->opt_condition_number;
   bp.rpw.assign(need_levels, 1);
   bp.geom.resize(need_levels);
-  bp.ll_mode.assign(need_levels, kLlSecondSweep);
-  bp.ll_stride = kLlBlocksPerPair;
-  bp.need_scratch = false;
   for (int l = cfg->last_level; l <= cfg->first_level; ++l) {
     bp.rpw[l] = pick_rows_per_wave(ctx, cam, l, n);
     bp.geom[l] = make_geom(ctx, cam, l, bp.rpw[l]);
-    const int tiles = bp.geom[l].tiles_x * bp.geom[l].tiles_y;
-    if (ctx->opt_variant == 5 && ctx->opt_inkernel_ll && tiles_in_flight(tiles, n) <= kResidentTilesPerXcd) {
-      bp.ll_mode[l] = kLlInKernel;
-      bp.ll_stride = std::max(bp.ll_stride, tiles);
-    } else {
-      bp.need_scratch = true;
-    }
   }
 }
 
@@ -683,8 +650,7 @@ int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, 
 }
 
 // Device scratch for n pairs + the per-level pointer tables
-int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, BatchPlan& bp,
-                    bool want_residuals = false) {
+int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, BatchPlan& bp) {
   const int n = bp.n, need_levels = cfg->first_level + 1;
   size_t max_tiles = 1;
   for (int l = cfg->last_level; l <= cfg->first_level; ++l) max_tiles = std::max(max_tiles, size_t(bp.geom[l].tiles_x) * bp.geom[l].tiles_y);
@@ -692,10 +658,8 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
   DVO_WS_TRY(w, w.states.reserve(size_t(n) * sizeof(PairState)));
   DVO_WS_TRY(w, w.pair_ptrs.reserve(size_t(n) * need_levels * sizeof(PairPtrs)));
   DVO_WS_TRY(w, w.partials.reserve(size_t(n) * max_tiles * kAccStride * sizeof(float)));
-  if (bp.need_scratch || want_residuals) DVO_WS_TRY(w, w.scratch.reserve(size_t(n) * npx * sizeof(float2)));
-  DVO_WS_TRY(w, w.ll_partials.reserve(size_t(n) * bp.ll_stride * sizeof(double)));
-  DVO_WS_TRY(w, w.sync.reserve((size_t(n) + 1) * sizeof(PairSync)));
-  DVO_WS_TRY(w, hipMemsetAsync(w.sync.p, 0, (size_t(n) + 1) * sizeof(PairSync), w.stream));   // tickets, flags and the error word
+  DVO_WS_TRY(w, w.scratch.reserve(size_t(n) * npx * sizeof(float2)));
+  DVO_WS_TRY(w, w.ll_partials.reserve(size_t(n) * kLlBlocksPerPair * sizeof(double)));
   DVO_WS_TRY(w, w.lvl_stats.reserve(size_t(n) * bp.cap_levels * sizeof(dvo_hip_level_stats)));
   DVO_WS_TRY(w, w.it_stats.reserve(size_t(n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats)));
   DVO_WS_TRY(w, w.results.reserve(size_t(n) * sizeof(dvo_hip_result)));
@@ -784,8 +748,6 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   float* partials = w.partials.as<float>();
   float2* scratch = w.scratch.as<float2>();
   double* ll_partials = w.ll_partials.as<double>();
-  PairSync* sync = w.sync.as<PairSync>();
-  unsigned* error_word = reinterpret_cast<unsigned*>(sync + n);
   unsigned long long* tallies = w.counters.as<unsigned long long>();
   const int per_level = cfg->max_iterations_per_level;
   const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 1;
@@ -793,21 +755,21 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   for (int level = cfg->first_level; level >= cfg->last_level; --level) {
     const LevelGeom& g = bp.geom[level];
     const PairPtrs* pp = bp.pair_ptrs + size_t(level) * n;
-    launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, sync, level == cfg->first_level ? w.t_init.as<double>() : nullptr);
-    // One iteration = sweep (+ log-likelihood in the same launch) and solver step: two launches.  Levels whose pairs have more
-    // tiles than are resident at a time store the residual pairs and sweep them once more (three launches).
-    const int ll_mode = bp.ll_mode[level];
-    const int ll_count = ll_mode == kLlInKernel ? g.tiles_x * g.tiles_y : kLlBlocksPerPair;
+    launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);
+    // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
+    // (measured, scripts/ab_match.py fused_ll_pixels: 128 pairs 2.152 -> 2.117 ms with level 1 fused; 16 pairs 0.756 -> 0.799, one
+    // pair 0.524 -> 0.547: a lone workgroup per pair is slower than 32 blocks when the chip is empty)
+    const int fuse_opt = ctx->opt_fused_ll_pixels;
+    const bool fused_ll = g.w * g.h <= (fuse_opt > 0 ? fuse_opt : (n >= 64 ? kFusedLoglikMaxPixelsBatch : kFusedLoglikMaxPixels));
     // Chunks of `per_sync` iterations are enqueued ONE AHEAD of the poll: while the host waits for the status word of
     // chunk k, chunk k+1 is already queued, so the GPU never idles for a host round trip.  Iterations enqueued past the
     // end of the level are no-ops (workgroups exit on !active).
     auto enqueue_chunk = [&](int count) {
       for (int c = 0; c < count; ++c, ++step) {
-        launch_residual_reduce(s, ctx->opt_variant, ll_mode, bp.rpw[level], level == 0, g, pp, states, n, partials, sync, ll_partials,
-                               bp.ll_stride, ll_mode == kLlSecondSweep ? scratch : nullptr, error_word);
-        if (ll_mode == kLlSecondSweep) launch_loglik(s, g, states, n, partials, scratch, ll_partials, bp.ll_stride, kLlBlocksPerPair);
-        launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, bp.ll_stride, ll_count, d_levels, d_iters, tallies + step,
-                           w.host_status + step);
+        launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch);
+        if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, kLlBlocksPerPair);
+        launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, kLlBlocksPerPair, fused_ll ? scratch : nullptr, d_levels, d_iters,
+                           tallies + step, w.host_status + step);
       }
     };
     int enqueued = std::min(per_sync, per_level);
@@ -839,14 +801,8 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     hi.resize(size_t(n) * bp.cap_iters);
     DVO_WS_TRY(w, hipMemcpyAsync(hi.data(), d_iters, hi.size() * sizeof(dvo_hip_iteration_stats), hipMemcpyDeviceToHost, s));
   }
-  unsigned handoff_error = 0;
-  DVO_WS_TRY(w, hipMemcpyAsync(&handoff_error, error_word, sizeof(unsigned), hipMemcpyDeviceToHost, s));
   DVO_WS_TRY(w, hipStreamSynchronize(s));
   DVO_WS_TRY(w, hipGetLastError());
-  if (handoff_error) {
-    w.err = "match: a tile workgroup timed out waiting for its pair's precision (in-kernel hand-off); results are NaN";
-    return DVO_HIP_ERR_HIP;
-  }
   bool truncated = false;
   for (int i = 0; i < n; ++i) {
     if (!hl.empty()) {
@@ -868,15 +824,14 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
 }
 
 // preparation for the parity / measurement entry points
-int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg, BatchPlan& bp,
-                   bool want_residuals = false) {
+int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg, BatchPlan& bp) {
   int rc = validate_batch(ctx, n, refs, curs, cfg);
   if (rc != DVO_HIP_OK) return rc;
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   rc = ensure_batch_roles(ctx, n, refs, curs, cfg);
   if (rc != DVO_HIP_OK) return rc;
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
-  rc = prepare_buffers(ctx->ws[0], cfg, refs, curs, bp, want_residuals);
+  rc = prepare_buffers(ctx->ws[0], cfg, refs, curs, bp);
   if (rc == DVO_HIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = DVO_HIP_ERR_HIP;
   if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
   return rc;
@@ -966,8 +921,8 @@ void* dvo_hip_context_stream(dvo_hip_context* ctx) { return ctx ? static_cast<vo
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (!ctx || !key) return DVO_HIP_ERR_INVALID;
   if (std::strcmp(key, "rows_per_wave") == 0) {
-    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
-      return fail(ctx, DVO_HIP_ERR_INVALID, "rows_per_wave must be 0,1,2,4,8");
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
+      return fail(ctx, DVO_HIP_ERR_INVALID, "rows_per_wave must be 0,1,2,4,8,16");
     ctx->opt_rows_per_wave = value;
     return DVO_HIP_OK;
   }
@@ -996,9 +951,9 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     ctx->opt_condition_number = value;
     return DVO_HIP_OK;
   }
-  if (std::strcmp(key, "inkernel_ll") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "inkernel_ll must be 0 or 1");
-    ctx->opt_inkernel_ll = value;
+  if (std::strcmp(key, "fused_ll_pixels") == 0) {
+    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "fused_ll_pixels must be >= 0");
+    ctx->opt_fused_ll_pixels = value;
     return DVO_HIP_OK;
   }
   return fail(ctx, DVO_HIP_ERR_INVALID, "unknown option");
@@ -1337,15 +1292,11 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
   dvo_hip_frame* r[1] = {reference};
   dvo_hip_frame* c[1] = {current};
   BatchPlan bp;
-  int rc = prepare_single(ctx, 1, r, c, &cfg, bp, /*want_residuals=*/true);
+  int rc = prepare_single(ctx, 1, r, c, &cfg, bp);
   if (rc != DVO_HIP_OK) return rc;
   hipStream_t s = ctx->stream;
   const LevelGeom& g = bp.geom[level];
   const size_t npx = size_t(g.w) * g.h;
-  Workspace& w = ctx->ws[0];
-  PairSync* sync = w.sync.as<PairSync>();
-  const int ll_mode = bp.ll_mode[level];
-  const int ll_count = ll_mode == kLlInKernel ? g.tiles_x * g.tiles_y : kLlBlocksPerPair;
   DVO_HIP_TRY(ctx, ctx->misc.reserve(256 + sizeof(dvo_hip_iteration_out)));
   float* d_T = ctx->misc.as<float>();
   float* d_P = d_T + 12;
@@ -1356,15 +1307,12 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
   DVO_HIP_TRY(ctx, hipMemsetAsync(states, 0, sizeof(PairState), s));
   launch_set_fixed_state(s, states, g, d_T, d_P, first_iteration_on_level ? 1 : 0);
   const PairPtrs* pp = bp.pair_ptrs + size_t(level);
-  // (prepare_buffers zeroed the hand-off words; the residual pairs are always stored here: this is the parity entry point)
-  launch_residual_reduce(s, ctx->opt_variant, ll_mode, bp.rpw[level], level == 0, g, pp, states, 1, w.partials.as<float>(), sync,
-                         w.ll_partials.as<double>(), bp.ll_stride, w.scratch.as<float2>(), reinterpret_cast<unsigned*>(sync + 1));
-  if (ll_mode == kLlSecondSweep)
-    launch_loglik(s, g, states, 1, w.partials.as<float>(), w.scratch.as<float2>(), w.ll_partials.as<double>(), bp.ll_stride, kLlBlocksPerPair);
+  launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>());
+  launch_loglik(s, g, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>(), ctx->ws[0].ll_partials.as<double>(), kLlBlocksPerPair);
   int n_sel = 0;
   DVO_HIP_TRY(ctx, hipMemcpyAsync(&n_sel, reference->sel_count + level, sizeof(int), hipMemcpyDeviceToHost, s));
   DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
-  launch_single_shot_out(s, g, w.partials.as<float>(), w.ll_partials.as<double>(), ll_count, n_sel, d_out);
+  launch_single_shot_out(s, g, ctx->ws[0].partials.as<float>(), ctx->ws[0].ll_partials.as<double>(), kLlBlocksPerPair, n_sel, d_out);
   DVO_HIP_TRY(ctx, hipMemcpyAsync(out, d_out, sizeof(dvo_hip_iteration_out), hipMemcpyDeviceToHost, s));
   if (residuals_or_null) DVO_HIP_TRY(ctx, hipMemcpyAsync(residuals_or_null, ctx->ws[0].scratch.p, npx * sizeof(float2), hipMemcpyDeviceToHost, s));
   DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -1384,35 +1332,29 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs, dvo_hip_fram
   BatchPlan bp;
   int rc = prepare_single(ctx, n_pairs, references, currents, &cfg, bp);
   if (rc != DVO_HIP_OK) return rc;
-  rc = ensure_host_status(ctx->ws[0], 8);
-  if (rc != DVO_HIP_OK) { ctx->err = ctx->ws[0].err; return rc; }
+  Workspace& w = ctx->ws[0];
+  rc = ensure_host_status(w, 8);
+  if (rc != DVO_HIP_OK) { ctx->err = w.err; return rc; }
   hipStream_t s = ctx->stream;
   const LevelGeom& g = bp.geom[level];
   const PairPtrs* pp = bp.pair_ptrs + size_t(level) * bp.n;
   std::vector<double> tinit(size_t(bp.n) * 16, 0.0);
   for (int i = 0; i < bp.n; ++i)
     for (int k = 0; k < 4; ++k) tinit[size_t(i) * 16 + k * 5] = 1.0;
-  DVO_HIP_TRY(ctx, hipMemcpyAsync(ctx->ws[0].t_init.p, tinit.data(), tinit.size() * sizeof(double), hipMemcpyHostToDevice, s));
-  PairState* states = ctx->ws[0].states.as<PairState>();
-  launch_init_pairs(s, states, bp.n, bp.prm, ctx->ws[0].t_init.as<double>());
-  Workspace& w = ctx->ws[0];
-  PairSync* sync = w.sync.as<PairSync>();
-  unsigned* error_word = reinterpret_cast<unsigned*>(sync + bp.n);
-  launch_level_begin(s, states, bp.n, bp.prm, g, level, pp, w.lvl_stats.as<dvo_hip_level_stats>(), sync);
-  const int ll_mode = bp.ll_mode[level];
-  const int ll_count = ll_mode == kLlInKernel ? g.tiles_x * g.tiles_y : kLlBlocksPerPair;
-  float2* scratch = ll_mode == kLlSecondSweep ? w.scratch.as<float2>() : nullptr;
+  DVO_HIP_TRY(ctx, hipMemcpyAsync(w.t_init.p, tinit.data(), tinit.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  PairState* states = w.states.as<PairState>();
+  launch_init_pairs(s, states, bp.n, bp.prm, w.t_init.as<double>());
+  launch_level_begin(s, states, bp.n, bp.prm, g, level, pp, w.lvl_stats.as<dvo_hip_level_stats>());
   auto sweep = [&]() {
-    launch_residual_reduce(s, ctx->opt_variant, ll_mode, bp.rpw[level], level == 0, g, pp, states, bp.n, w.partials.as<float>(), sync,
-                           w.ll_partials.as<double>(), bp.ll_stride, scratch, error_word);
+    launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, bp.n, w.partials.as<float>(), w.scratch.as<float2>());
   };
   // `warm_iterations` Gauss-Newton steps first: the timed sweeps then run where the sweeps of a match run -- at the transform
   // the solver moved to, with the t-distribution weights on (first = 0) -- instead of at the identity with unit weights
   for (int it = 0; it < warm_iterations; ++it) {
     sweep();
-    if (ll_mode == kLlSecondSweep) launch_loglik(s, g, states, bp.n, w.partials.as<float>(), scratch, w.ll_partials.as<double>(), bp.ll_stride, kLlBlocksPerPair);
+    launch_loglik(s, g, states, bp.n, w.partials.as<float>(), w.scratch.as<float2>(), w.ll_partials.as<double>(), kLlBlocksPerPair);
     DVO_HIP_TRY(ctx, hipMemsetAsync(w.counters.p, 0, sizeof(unsigned long long), s));
-    launch_solver_step(s, states, bp.n, bp.prm, g, w.partials.as<float>(), w.ll_partials.as<double>(), bp.ll_stride, ll_count,
+    launch_solver_step(s, states, bp.n, bp.prm, g, w.partials.as<float>(), w.ll_partials.as<double>(), kLlBlocksPerPair, nullptr,
                        w.lvl_stats.as<dvo_hip_level_stats>(), w.it_stats.as<dvo_hip_iteration_stats>(), w.counters.as<unsigned long long>(),
                        w.host_status);
   }
@@ -1444,7 +1386,7 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* co
   cfg.last_level = level;
   cfg.max_iterations_per_level = 1;
   BatchPlan bp;
-  int rc = prepare_single(ctx, n_pairs, references, currents, &cfg, bp, /*want_residuals=*/with_write != 0);
+  int rc = prepare_single(ctx, n_pairs, references, currents, &cfg, bp);
   if (rc != DVO_HIP_OK) return rc;
   hipStream_t s = ctx->stream;
   const LevelGeom& g = bp.geom[level];

@@ -84,18 +84,6 @@ struct PairState {
   int pad;
 };
 
-// Per-pair hand-off words of the sweep kernel (align_mfma.hip): the tile workgroups of a pair arrive on `ticket`; the last one
-// of a sweep publishes the pass' precision and then `flag` = the sweep's generation.  Every access is agent-scope (sc1).
-// Zeroed when a pair enters a level (k_level_begin); one 64-byte line per pair.
-struct PairSync {
-  unsigned ticket;                    // arrivals on this level so far (generation g covers tickets (g-1)*tiles .. g*tiles - 1)
-  unsigned flag;                      // newest generation whose precision is published
-  float P[4];                         // precision of that generation, row-major 2x2
-  int n;                              // its valid-constraint count
-  unsigned pad[9];
-};
-static_assert(sizeof(PairSync) == 64, "one cache line per pair");
-
 // a step's word in the pinned status array: kStepDoneFlag | number of pairs still active on the level
 constexpr int kStepDoneFlag = 0x40000000;
 

@@ -21,31 +21,23 @@ void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, 
 void launch_unpack_plane(hipStream_t s, const float4* A, const float2* B, int n, int plane, float* out);
 
 // align_kernels.hip / align_mfma.hip
-// One sweep of a level for every active pair of the batch.  variant 5 (default): Gram accumulation on the matrix cores; variant 0:
-// the all-VALU schedule with the DPP + LDS two-stage reduction (same outputs).
-// ll_mode: kLlInKernel -- the sweep also evaluates the log-likelihood sums (per-pair hand-off of the precision inside the launch,
-// residual pairs held in registers; variant 5 only) and leaves one partial per tile in ll_partials; scratch may be null, or
-// non-null to ALSO get the residual pairs (parity entry point).  kLlSecondSweep -- the sweep stores the residual pairs in
-// `scratch` and launch_loglik sweeps them once more (variant 0; levels whose tile count exceeds what is resident at a time).
-constexpr int kLlInKernel = 0, kLlSecondSweep = 1;
-void launch_residual_reduce(hipStream_t s, int variant, int ll_mode, int rows_per_wave, bool finest_level, const LevelGeom& g,
-                            const PairPtrs* pairs, const PairState* states, int n_pairs, float* partials, PairSync* sync,
-                            double* ll_partials, int ll_stride, float2* scratch, unsigned* error_word);
-void launch_residual_reduce_mfma(hipStream_t s, int ll_mode, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
-                                 const PairState* states, int n_pairs, float* partials, PairSync* sync, double* ll_partials,
-                                 int ll_stride, float2* scratch, unsigned* error_word);
+// variant 5 (default): Gram accumulation on the matrix cores (align_mfma.hip); variant 0: the all-VALU schedule with the DPP + LDS
+// two-stage reduction (align_kernels.hip).  Same outputs.
+void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
+                            const PairState* states, int n_pairs, float* partials, float2* scratch);
+void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
+                                 const PairState* states, int n_pairs, float* partials, float2* scratch);
 // scratch == null: read-only (one float per workgroup goes to `sink`, which must hold a float per (8 * 256)-pixel block)
 void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch, float* sink);
-// second sweep over the stored residual pairs: blocks_per_pair partial sums per pair at ll_partials[pair * ll_stride + b]
 void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,
-                   const float2* scratch, double* ll_partials, int ll_stride, int blocks_per_pair);
+                   const float2* scratch, double* ll_partials, int blocks_per_pair);
 
 // solver_kernels.hip
 void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, const double* T_init);
 void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
-                        const PairPtrs* pairs, dvo_hip_level_stats* levels, PairSync* sync, const double* T_init_or_null = nullptr);
+                        const PairPtrs* pairs, dvo_hip_level_stats* levels, const double* T_init_or_null = nullptr);
 void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
-                        const float* partials, const double* ll_partials, int ll_stride, int ll_count,
+                        const float* partials, const double* ll_partials, int ll_blocks_per_pair, const float2* scratch_for_fused_ll,
                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, unsigned long long* step_tally,
                         int* host_status);
 void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverParams prm,
@@ -54,7 +46,7 @@ void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverPa
 // measurement: every pair back on its level with the weights on (after warm-up iterations)
 void launch_force_active(hipStream_t s, PairState* states, int n_pairs);
 void launch_set_fixed_state(hipStream_t s, PairState* states, LevelGeom g, const float* T34_dev, const float* Pprev_dev, int first);
-void launch_single_shot_out(hipStream_t s, LevelGeom g, const float* partials, const double* ll_partials, int ll_count,
+void launch_single_shot_out(hipStream_t s, LevelGeom g, const float* partials, const double* ll_partials, int ll_blocks_per_pair,
                             int n_selected, dvo_hip_iteration_out* out_dev);
 
 }  // namespace dvo_hip

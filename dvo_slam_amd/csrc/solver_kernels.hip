@@ -19,12 +19,9 @@ __global__ void k_init_pairs(PairState* states, int n_pairs, SolverParams prm, c
 
 // T_init != null: the first level of a match -- the pair is initialised here as well (one launch less per match)
 __global__ void k_level_begin(PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
-                              const PairPtrs* __restrict__ pairs, dvo_hip_level_stats* levels, PairSync* sync,
-                              const double* __restrict__ T_init) {
+                              const PairPtrs* __restrict__ pairs, dvo_hip_level_stats* levels, const double* __restrict__ T_init) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
-  sync[p].ticket = 0;                 // the sweeps of this level count their arrivals from zero (align_mfma.hip)
-  sync[p].flag = 0;
   if (T_init) gn_init_pair(states[p], prm, T_init + size_t(p) * 16);
   gn_level_begin(states[p], prm, g, level, *pairs[p].n_selected, levels + size_t(p) * prm.cap_levels);
 }
@@ -51,7 +48,8 @@ __device__ __forceinline__ void publish_step(unsigned long long* step_tally, int
 
 __global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
                                                         const float* __restrict__ partials,
-                                                        const double* __restrict__ ll_partials, int ll_stride, int ll_count,
+                                                        const double* __restrict__ ll_partials, int ll_blocks_per_pair,
+                                                        const float2* __restrict__ scratch_for_fused_ll,
                                                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters,
                                                         unsigned long long* step_tally, int* host_status) {
   const int pair = blockIdx.x;
@@ -76,18 +74,24 @@ __global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n
   const bool have_level = level_slot >= 0 && level_slot < prm.cap_levels;
   if (have_level) coop_copy(&lvl, lvl_global);
   reduce_partials(partials, pair, g.tiles_x * g.tiles_y, sh, sums);   // same routine, same order as k_loglik: identical n, S, P
-  // the log-likelihood partial sums of the sweep (one per tile, or one per block of the second sweep), added in a fixed order:
-  // thread i takes entries i, i + 256, ...; wavefront sums by shuffle; then (w0 + w1) + (w2 + w3)
-  {
-    const double* p = ll_partials + size_t(pair) * ll_stride;
+  if (scratch_for_fused_ll) {
+    // coarse levels: the log-likelihood sweep is small enough for this workgroup, which saves a launch per iteration
+    float C[3], P[4];
+    const int n = scale_from_sums(sums, C, P);
     double t = 0.0;
-    for (int b = threadIdx.x; b < ll_count; b += kBlock) t += p[b];
+    if (n >= 6) t = loglik_partial<16>(scratch_for_fused_ll + size_t(pair) * g.w * g.h, g.w * g.h, P, 0, 1);
     t = wave_sum_double(t);
     if ((threadIdx.x & 63) == 0) ll_waves[threadIdx.x >> 6] = t;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const double ll_sum = (ll_waves[0] + ll_waves[1]) + (ll_waves[2] + ll_waves[3]);
+    double ll_sum = 0.0;
+    if (scratch_for_fused_ll) {
+      ll_sum = (ll_waves[0] + ll_waves[1]) + (ll_waves[2] + ll_waves[3]);
+    } else {
+      const double* p = ll_partials + size_t(pair) * ll_blocks_per_pair;
+      for (int b = 0; b < ll_blocks_per_pair; ++b) ll_sum += p[b];
+    }
     rec_index = st.n_iters_total;
     // gn_step addresses levels[n_levels - 1] and iters[n_iters_total]: hand it pointers biased so that those land in LDS
     SolverParams local = prm;
@@ -122,29 +126,22 @@ __global__ void k_set_fixed_state(PairState* states, LevelGeom g, const float* _
 }
 
 __global__ __launch_bounds__(kBlock) void k_single_shot_out(LevelGeom g, const float* __restrict__ partials,
-                                                            const double* __restrict__ ll_partials, int ll_count,
+                                                            const double* __restrict__ ll_partials, int ll_blocks_per_pair,
                                                             int n_selected, dvo_hip_iteration_out* out) {
   __shared__ double sh[kWavesPerBlock * kAccStride];
   __shared__ double sums[kAccStride];
-  __shared__ double ll_waves[kWavesPerBlock];
   float C[3], P[4];
   reduce_partials(partials, 0, g.tiles_x * g.tiles_y, sh, sums);
   const int n = scale_from_sums(sums, C, P);
   const int tid = threadIdx.x;
-  {
-    double t = 0.0;                                          // same order as k_solver_step
-    for (int b = tid; b < ll_count; b += kBlock) t += ll_partials[b];
-    t = wave_sum_double(t);
-    if ((tid & 63) == 0) ll_waves[tid >> 6] = t;
-    __syncthreads();
-  }
   if (tid != 0) return;
   out->n = n;
   out->n_selected = n_selected;
   out->sum_w = 0.0;
   for (int i = 0; i < 3; ++i) out->scale_cov[i] = C[i];
   for (int i = 0; i < 4; ++i) out->precision[i] = P[i];
-  const double ll_sum = (ll_waves[0] + ll_waves[1]) + (ll_waves[2] + ll_waves[3]);
+  double ll_sum = 0.0;
+  for (int b = 0; b < ll_blocks_per_pair; ++b) ll_sum += ll_partials[b];
   const double det = double(P[0]) * double(P[3]) - double(P[1]) * double(P[2]);
   out->neg_loglik = -double(float(0.5 * double(n) * log(det) - 3.5 * ll_sum));   // float like the reference's (gn_step)
   const double p00 = double(P[0]), p01 = double(P[1]), p11 = double(P[3]);
@@ -164,15 +161,15 @@ void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverPara
 }
 
 void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
-                        const PairPtrs* pairs, dvo_hip_level_stats* levels, PairSync* sync, const double* T_init_or_null) {
-  k_level_begin<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, g, level, pairs, levels, sync, T_init_or_null);
+                        const PairPtrs* pairs, dvo_hip_level_stats* levels, const double* T_init_or_null) {
+  k_level_begin<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, g, level, pairs, levels, T_init_or_null);
 }
 
 void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
-                        const float* partials, const double* ll_partials, int ll_stride, int ll_count,
+                        const float* partials, const double* ll_partials, int ll_blocks_per_pair, const float2* scratch_for_fused_ll,
                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, unsigned long long* step_tally, int* host_status) {
-  k_solver_step<<<dim3(n_pairs), dim3(kBlock), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_stride, ll_count,
-                                                       levels, iters, step_tally, host_status);
+  k_solver_step<<<dim3(n_pairs), dim3(kBlock), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
+                                                       scratch_for_fused_ll, levels, iters, step_tally, host_status);
 }
 
 void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverParams prm,
@@ -195,9 +192,9 @@ void launch_set_fixed_state(hipStream_t s, PairState* states, LevelGeom g, const
   k_set_fixed_state<<<dim3(1), dim3(64), 0, s>>>(states, g, T34_dev, Pprev_dev, first);
 }
 
-void launch_single_shot_out(hipStream_t s, LevelGeom g, const float* partials, const double* ll_partials, int ll_count,
+void launch_single_shot_out(hipStream_t s, LevelGeom g, const float* partials, const double* ll_partials, int ll_blocks_per_pair,
                             int n_selected, dvo_hip_iteration_out* out_dev) {
-  k_single_shot_out<<<dim3(1), dim3(kBlock), 0, s>>>(g, partials, ll_partials, ll_count, n_selected, out_dev);
+  k_single_shot_out<<<dim3(1), dim3(kBlock), 0, s>>>(g, partials, ll_partials, ll_blocks_per_pair, n_selected, out_dev);
 }
 
 }  // namespace dvo_hip

@@ -231,7 +231,7 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
                             float* residuals_or_null /* w*h*2 floats, NaN where invalid */);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
-/* Launches the dominant kernel (fused warp + residual + weight + Jacobian + reduce + log-likelihood) `reps` times for
+/* Launches the dominant kernel (fused warp + residual + weight + Jacobian + reduce) `reps` times for
  * the given pairs at `level`, bracketed by HIP events on the context stream; returns the average duration of one launch in
  * milliseconds.  `warm_iterations` Gauss-Newton steps are taken on that level first, so that the timed launches run where
  * the sweeps of a match run: at the transform the solver moved to, with the t-distribution weights on.  0 = at the identity
@@ -241,18 +241,18 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs,
                                  int level, int warm_iterations, int reps, float* avg_ms);
 
 /* The yardstick for that number: a kernel that only streams the same planes of the same pairs in pixel order (16 + 16 + 8 B
- * read per pixel; with_write != 0: plus the 8 B per pixel the second-sweep schedule writes) -- no gather, no arithmetic, no
- * reduction.  What the memory system needs for the sweep's algorithmic traffic on this part. */
+ * read per pixel; with_write != 0: plus the 8 B per pixel the sweep writes for the log-likelihood pass) -- no gather, no
+ * arithmetic, no reduction.  What the memory system needs for the sweep's algorithmic traffic on this part. */
 int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
                             dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
                             int level, int with_write, int reps, float* avg_ms);
 
-/* Tunables (0 = library default).  key: "rows_per_wave" (1,2,4,8: tile height of the sweep kernel),
+/* Tunables (0 = library default).  key: "rows_per_wave" (1,2,4,8,16: tile height of the sweep kernel),
  * "iters_per_sync" (host polling cadence of the batched Gauss-Newton loop), "variant" (schedule of the sweep
  * kernel: 5 = Gram accumulation on the matrix cores (default), 0 = all-VALU with the DPP + LDS reduction),
  * "min_workgroups" (tile-height heuristic: smallest launch that counts as filling the chip; 0 = built-in table),
- * "inkernel_ll" (1, default: the sweep evaluates the log-likelihood in the same launch; 0: it stores the residual pairs and
- * a second sweep evaluates it -- the round-1 schedule, kept for A/B tests and for levels too large for the hand-off),
+ * "fused_ll_pixels" (largest level, in pixels, whose log-likelihood sweep runs inside the solver
+ * workgroup instead of a launch of its own; 0 = 160x120, and 320x240 for batches of 64 pairs and more),
  * "condition_number" (1: results carry the condition number of the information
  * matrix, ~20 us of extra serial work per batch; default 0). */
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);

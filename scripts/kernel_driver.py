@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 ctx = d.default_context()
-for k in ("variant", "rows_per_wave", "inkernel_ll"):
+for k in ("variant", "rows_per_wave"):
     if os.environ.get("DVO_" + k.upper()):
         ctx.set_option(k, int(os.environ["DVO_" + k.upper()]))
 b = datagen.synth_batch(0, n, 640, 480)
