@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -153,6 +154,10 @@ struct Workspace {
 };
 
 struct dvo_hip_context {
+  // The reference hands one current pyramid to two trackers on two threads (dvo_slam/src/local_tracker.cpp:180-184) and runs
+  // thread-local validators over shared keyframes (keyframe_graph.cpp:576-593): calls on one context from several host threads
+  // are serialised here (recursive: dvo_hip_match -> dvo_hip_match_batch).  Contexts never share a lock.
+  std::recursive_mutex mutex;
   int device = 0;
   hipStream_t stream = nullptr;    // == ws[0].stream
   std::string err;
@@ -919,6 +924,8 @@ const char* dvo_hip_last_error(const dvo_hip_context* ctx) { return ctx ? ctx->e
 void* dvo_hip_context_stream(dvo_hip_context* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
 
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!ctx || !key) return DVO_HIP_ERR_INVALID;
   if (std::strcmp(key, "rows_per_wave") == 0) {
     if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
@@ -961,6 +968,8 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
 
 int dvo_hip_frame_create_f32(dvo_hip_context* ctx, int width, int height, const float K[4], const float* intensity,
                              const float* depth, int levels, dvo_hip_frame** out) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!ctx || !out || !intensity || !depth || !K) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create_f32: null argument");
   size_t raw_off;
   dvo_hip_frame* f = nullptr;
@@ -985,6 +994,8 @@ int dvo_hip_frame_create_f32(dvo_hip_context* ctx, int width, int height, const 
 
 int dvo_hip_frame_create_raw(dvo_hip_context* ctx, int width, int height, const float K[4], const uint8_t* grey,
                              const uint16_t* raw_depth, float depth_scale, int levels, dvo_hip_frame** out) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!ctx || !out || !grey || !raw_depth || !K) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create_raw: null argument");
   size_t raw_off;
   dvo_hip_frame* f = nullptr;
@@ -1013,6 +1024,8 @@ int dvo_hip_frame_create_raw(dvo_hip_context* ctx, int width, int height, const 
 
 int dvo_hip_frame_create_raw_device(dvo_hip_context* ctx, int width, int height, const float K[4], const void* grey_dev,
                                     const void* raw_depth_dev, float depth_scale, int levels, dvo_hip_frame** out) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!ctx || !out || !grey_dev || !raw_depth_dev || !K) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create_raw_device: null argument");
   size_t raw_off;
   dvo_hip_frame* f = nullptr;
@@ -1078,6 +1091,8 @@ int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip
 
 int dvo_hip_frames_update_raw_device_as(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
                                         const void* const* raw_depth_dev, float depth_scale, int role, const dvo_hip_config* cfg) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   int rc = check_prepare_args(ctx, n_frames, frames, role, cfg, "frames_update_raw_device_as: bad argument");
   if (rc != DVO_HIP_OK) return rc;
   if (!grey_dev || !raw_depth_dev) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device_as: null argument");
@@ -1144,12 +1159,16 @@ int dvo_hip_frames_update_raw(dvo_hip_context* ctx, int n_frames, dvo_hip_frame*
 
 int dvo_hip_frames_update_raw_as(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const uint8_t* const* grey,
                                  const uint16_t* const* raw_depth, float depth_scale, int role, const dvo_hip_config* cfg) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   const int rc = check_prepare_args(ctx, n_frames, frames, role, cfg, "frames_update_raw_as: bad argument");
   if (rc != DVO_HIP_OK) return rc;
   return update_raw_host(ctx, n_frames, frames, grey, raw_depth, depth_scale, role, cfg);
 }
 
 int dvo_hip_upload_wait(dvo_hip_context* ctx) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!ctx) return DVO_HIP_ERR_INVALID;
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   DVO_HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_stream));
@@ -1157,6 +1176,8 @@ int dvo_hip_upload_wait(dvo_hip_context* ctx) {
 }
 
 int dvo_hip_host_alloc(dvo_hip_context* ctx, size_t bytes, void** out) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!ctx || !out || bytes == 0) return fail(ctx, DVO_HIP_ERR_INVALID, "host_alloc: bad argument");
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   DVO_HIP_TRY(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
@@ -1164,12 +1185,16 @@ int dvo_hip_host_alloc(dvo_hip_context* ctx, size_t bytes, void** out) {
 }
 
 void dvo_hip_host_free(dvo_hip_context* ctx, void* p) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!p) return;
   if (ctx) (void)hipSetDevice(ctx->device);
   (void)hipHostFree(p);
 }
 
 int dvo_hip_frames_prepare(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, int role, const dvo_hip_config* cfg) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   const int rc = check_prepare_args(ctx, n_frames, frames, role, cfg, "frames_prepare: bad argument");
   if (rc != DVO_HIP_OK) return rc;
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1185,6 +1210,8 @@ int dvo_hip_frame_update_raw_device(dvo_hip_context* ctx, dvo_hip_frame* frame, 
 }
 
 void dvo_hip_frame_destroy(dvo_hip_context* ctx, dvo_hip_frame* frame) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!frame) return;
   if (ctx) {
     (void)hipSetDevice(ctx->device);
@@ -1206,6 +1233,8 @@ int dvo_hip_frame_info(const dvo_hip_frame* frame, int level, int* width, int* h
 }
 
 int dvo_hip_frame_download_plane(dvo_hip_context* ctx, dvo_hip_frame* frame, int level, int plane, float* out) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!ctx || !frame || !out || level < 0 || level >= frame->levels || plane < 0 || plane > 5)
     return fail(ctx, DVO_HIP_ERR_INVALID, "frame_download_plane: bad argument");
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1224,6 +1253,8 @@ int dvo_hip_frame_download_plane(dvo_hip_context* ctx, dvo_hip_frame* frame, int
 
 int dvo_hip_frame_select(dvo_hip_context* ctx, dvo_hip_frame* frame, int level, float ithr, float dthr, int* n_selected,
                          uint8_t* mask_or_null) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!ctx || !frame || level < 0 || level >= frame->levels) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_select: bad argument");
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t n = size_t(frame->lv[level].w) * frame->lv[level].h;
@@ -1253,6 +1284,8 @@ int dvo_hip_frame_select(dvo_hip_context* ctx, dvo_hip_frame* frame, int level, 
 int dvo_hip_match_batch(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
                         const dvo_hip_config* cfg, dvo_hip_result* results, dvo_hip_level_stats* levels, int cap_levels,
                         dvo_hip_iteration_stats* iters, int cap_iters) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!results) return fail(ctx, DVO_HIP_ERR_INVALID, "match: results is null");
   int rc = validate_batch(ctx, n_pairs, references, currents, cfg);
   if (rc != DVO_HIP_OK) return rc;
@@ -1280,6 +1313,8 @@ int dvo_hip_match(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame*
 int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame* current, int level, float ithr,
                             float dthr, const float T34[12], const float P_prev[4], int first_iteration_on_level,
                             dvo_hip_iteration_out* out, float* residuals_or_null) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!ctx || !reference || !current || !T34 || !P_prev || !out) return fail(ctx, DVO_HIP_ERR_INVALID, "level_iteration: null argument");
   dvo_hip_config cfg;
   std::memset(&cfg, 0, sizeof(cfg));
@@ -1322,6 +1357,8 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
 
 int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
                                  int level, int warm_iterations, int reps, float* avg_ms) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!avg_ms || reps < 1 || warm_iterations < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "time_residual_kernel: bad argument");
   dvo_hip_config cfg;
   std::memset(&cfg, 0, sizeof(cfg));
@@ -1379,6 +1416,8 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs, dvo_hip_fram
 
 int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
                             int level, int with_write, int reps, float* avg_ms) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!avg_ms || reps < 1) return fail(ctx, DVO_HIP_ERR_INVALID, "time_stream_mix: bad argument");
   dvo_hip_config cfg;
   std::memset(&cfg, 0, sizeof(cfg));

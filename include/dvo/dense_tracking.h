@@ -6,7 +6,12 @@
 // argument is in/out (initial guess when UseInitialEstimate), statistics are appended, a tracker is not re-entrant.
 #pragma once
 
+#include <algorithm>
 #include <cassert>
+#include <cmath>
+#include <ostream>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../dvo_hip.h"
@@ -16,10 +21,34 @@
 
 namespace dvo {
 
-// enums kept only so that Config compiles where the reference's callers set them; match() never reads them (Q14)
+// Enumerations of the reference's legacy weighting (dvo_core/include/dvo/core/weight_calculation.h:107-119, 191-203), kept
+// with the same enumerator order (dynamic reconfigure maps integers onto them, dvo_ros/include/dvo_ros/util/configtools.h:70-82)
+// so that Config compiles and prints where the reference's callers set them; match() never reads them.
 namespace core {
-struct InfluenceFunctions { enum enum_t { Tukey, TDistribution, Huber, Unit }; };
-struct ScaleEstimators { enum enum_t { Unit, TDistribution, MAD, NormalDistribution }; };
+struct ScaleEstimators {
+  typedef enum { Unit, NormalDistribution, TDistribution, MAD } enum_t;
+  static const char* str(enum_t type) {
+    switch (type) {
+      case Unit: return "Unit";
+      case NormalDistribution: return "NormalDistribution";
+      case TDistribution: return "TDistribution";
+      case MAD: return "MAD";
+    }
+    return "";
+  }
+};
+struct InfluenceFunctions {
+  typedef enum { Unit, Tukey, TDistribution, Huber } enum_t;
+  static const char* str(enum_t type) {
+    switch (type) {
+      case Unit: return "Unit";
+      case Tukey: return "Tukey";
+      case TDistribution: return "TDistribution";
+      case Huber: return "Huber";
+    }
+    return "";
+  }
+};
 }  // namespace core
 
 class DenseTracker {
@@ -60,6 +89,20 @@ class DenseTracker {
     double PriorLogLikelihood;
     core::Vector6d EstimateIncrement;
     core::Matrix6d EstimateInformation;
+    // dense_tracking_config.cpp:122-135: eigenvalues of the (symmetric) information matrix in ascending order, and
+    // |largest / smallest|.  The device returns the same ratio with every result on request (Result::Keyframe.ConditionNumber).
+    void InformationEigenValues(core::Vector6d& eigenvalues) const {
+      double a[36], ev[6];
+      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) a[i * 6 + j] = EstimateInformation(i, j);
+      dvo::compat::sym6_eigenvalues(a, ev);
+      std::sort(ev, ev + 6);
+      for (int i = 0; i < 6; ++i) eigenvalues(i) = ev[i];
+    }
+    double InformationConditionNumber() const {
+      core::Vector6d ev;
+      InformationEigenValues(ev);
+      return std::abs(ev(5) / ev(0));
+    }
   };
   typedef std::vector<IterationStats> IterationStatsVector;
 
@@ -178,8 +221,10 @@ class DenseTracker {
     dvo_hip_result r;
     dvo::compat::affine_to_rowmajor(result.Transformation, r.transformation);
     dvo_hip_context* ctx = current.device_context();
-    core::dvo_hip_check(ctx, dvo_hip_match(ctx, ref.device_frame(), current.device_frame(), &c, &r, levels_.data(), nl, iters_.data(), cap), "dvo_hip_match");
-    unpack(r, levels_.data(), iters_.data(), result);
+    if (core::dvo_hip_check(ctx, dvo_hip_match(ctx, ref.device_frame(), current.device_frame(), &c, &r, levels_.data(), nl, iters_.data(), cap), "dvo_hip_match"))
+      unpack(r, levels_.data(), iters_.data(), result);
+    else
+      result = Result();   // a failed device call reads as a NaN result, the reference's failure signal (Q16)
     return true;   // dense_tracking.cpp:135, 375
   }
 
@@ -194,30 +239,102 @@ class DenseTracker {
     assert(references.size() == currents.size() && references.size() == results.size());
     const size_t n = references.size();
     if (n == 0) return true;
-    std::vector<dvo_hip_frame*> refs(n), curs(n);
-    std::vector<dvo_hip_result> out(n);
+    const dvo_hip_config c = c_config(selection_predicate_.intensity_threshold, selection_predicate_.depth_threshold);
+    const int nl = cfg.FirstLevel - cfg.LastLevel + 1;
+    const int cap = nl * cfg.MaxIterationsPerLevel;
+    // Pairs are aligned on the device their frames live on (RgbdImagePyramid binds to DeviceContext::current() when it is
+    // created).  Frames spread over several GPUs give one sub-batch per device, run concurrently on one host thread each --
+    // the reference's own model for independent pairs (dvo_slam/src/keyframe_graph.cpp:576-593); no collective is needed
+    // inside a process, the records are concatenated in the callers' order.
+    std::vector<dvo_hip_context*> devices;
+    std::vector<std::vector<size_t> > members;
     for (size_t i = 0; i < n; ++i) {
       references[i]->compute(cfg.getNumLevels());
       currents[i]->compute(cfg.getNumLevels());
-      refs[i] = references[i]->device_frame();
-      curs[i] = currents[i]->device_frame();
+      dvo_hip_context* ctx = currents[i]->device_context();
+      assert(references[i]->device_context() == ctx && "the two frames of a pair must live on the same device");
+      size_t g = 0;
+      while (g < devices.size() && devices[g] != ctx) ++g;
+      if (g == devices.size()) {
+        devices.push_back(ctx);
+        members.push_back(std::vector<size_t>());
+      }
+      members[g].push_back(i);
       if (cfg.UseInitialEstimate) {
         assert(!results[i]->isNaN() && "Provided initialization is NaN!");
       } else {
         results[i]->setIdentity();
       }
-      dvo::compat::affine_to_rowmajor(results[i]->Transformation, out[i].transformation);
     }
-    const dvo_hip_config c = c_config(selection_predicate_.intensity_threshold, selection_predicate_.depth_threshold);
-    const int nl = cfg.FirstLevel - cfg.LastLevel + 1;
-    const int cap = nl * cfg.MaxIterationsPerLevel;
     levels_.resize(n * size_t(nl));
     iters_.resize(n * size_t(cap));
-    dvo_hip_context* ctx = currents[0]->device_context();
-    core::dvo_hip_check(ctx, dvo_hip_match_batch(ctx, int(n), refs.data(), curs.data(), &c, out.data(), levels_.data(), nl, iters_.data(), cap),
-                        "dvo_hip_match_batch");
-    for (size_t i = 0; i < n; ++i) unpack(out[i], &levels_[i * size_t(nl)], &iters_[i * size_t(cap)], *results[i]);
+    std::vector<dvo_hip_result> out(n);
+    std::vector<int> ok(devices.size(), 0);
+    auto run = [&](size_t g) {
+      const std::vector<size_t>& idx = members[g];
+      const size_t m = idx.size();
+      std::vector<dvo_hip_frame*> refs(m), curs(m);
+      std::vector<dvo_hip_result> r(m);
+      std::vector<dvo_hip_level_stats> lv(m * size_t(nl));
+      std::vector<dvo_hip_iteration_stats> it(m * size_t(cap));
+      for (size_t k = 0; k < m; ++k) {
+        refs[k] = references[idx[k]]->device_frame();
+        curs[k] = currents[idx[k]]->device_frame();
+        dvo::compat::affine_to_rowmajor(results[idx[k]]->Transformation, r[k].transformation);
+      }
+      ok[g] = dvo_hip_match_batch(devices[g], int(m), refs.data(), curs.data(), &c, r.data(), lv.data(), nl, it.data(), cap) == DVO_HIP_OK;
+      if (!ok[g]) return;
+      for (size_t k = 0; k < m; ++k) {
+        out[idx[k]] = r[k];
+        std::copy(lv.begin() + k * size_t(nl), lv.begin() + (k + 1) * size_t(nl), levels_.begin() + idx[k] * size_t(nl));
+        std::copy(it.begin() + k * size_t(cap), it.begin() + (k + 1) * size_t(cap), iters_.begin() + idx[k] * size_t(cap));
+      }
+    };
+    if (devices.size() == 1) {
+      run(0);
+    } else {
+      std::vector<std::thread> threads;
+      for (size_t g = 1; g < devices.size(); ++g) threads.emplace_back(run, g);
+      run(0);
+      for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
+    }
+    for (size_t g = 0; g < devices.size(); ++g) {
+      if (!ok[g]) core::dvo_hip_check(devices[g], DVO_HIP_ERR_HIP, "dvo_hip_match_batch");
+      for (size_t k = 0; k < members[g].size(); ++k) {
+        const size_t i = members[g][k];
+        if (ok[g]) unpack(out[i], &levels_[i * size_t(nl)], &iters_[i * size_t(cap)], *results[i]);
+        else *results[i] = Result();
+      }
+    }
     return true;
+  }
+
+  // dense_tracking.cpp:378-444 (debug aid): |intensity residual| of every selected reference pixel that yields a constraint
+  // under `transformation` (reference -> current) at `level`, 0 elsewhere.  One sweep of the level on the device.
+  dvo::compat::ImageMat computeIntensityErrorImage(core::RgbdImagePyramid& reference, core::RgbdImagePyramid& current,
+                                                   const core::AffineTransformd& transformation, size_t level = 0) {
+    reference.compute(level + 1);
+    current.compute(level + 1);
+    const core::RgbdCamera& cam = reference.cameraPyramid().level(level);
+    const int w = int(cam.width()), h = int(cam.height());
+    double m[16];
+    dvo::compat::affine_to_rowmajor(transformation, m);
+    float T34[12];
+    for (int i = 0; i < 12; ++i) T34[i] = float(m[i]);
+    const float P0[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    std::vector<float> residuals(size_t(w) * h * 2);
+    dvo_hip_iteration_out out;
+    dvo::compat::ImageMat result = dvo::compat::image_create(h, w);
+    float* r = dvo::compat::image_ptr_mut(result);
+    dvo_hip_context* ctx = current.device_context();
+    const bool ok = core::dvo_hip_check(ctx, dvo_hip_level_iteration(ctx, reference.device_frame(), current.device_frame(), int(level),
+                                                                     selection_predicate_.intensity_threshold, selection_predicate_.depth_threshold,
+                                                                     T34, P0, 1, &out, residuals.data()), "dvo_hip_level_iteration");
+    for (size_t i = 0; i < size_t(w) * h; ++i) {
+      const float r0 = residuals[2 * i];
+      r[i] = (ok && r0 == r0) ? std::fabs(r0) : 0.0f;
+    }
+    return result;
   }
 
  private:
@@ -272,3 +389,44 @@ class DenseTracker {
 };
 
 }  // namespace dvo
+
+// ---- printers (dvo_core/include/dvo/dense_tracking.h:218-291; used by dvo_slam/src/keyframe_graph.cpp:360 and
+// dvo_benchmark/src/benchmark_slam.cpp:413) -- same fields in the same order and wording, so logs stay comparable ------------
+template <typename CharT, typename Traits>
+std::basic_ostream<CharT, Traits>& operator<<(std::basic_ostream<CharT, Traits>& out, const dvo::DenseTracker::Config& config) {
+  out << "First Level = " << config.FirstLevel << ", Last Level = " << config.LastLevel
+      << ", Max Iterations per Level = " << config.MaxIterationsPerLevel << ", Precision = " << config.Precision
+      << ", Mu = " << config.Mu << ", Use Initial Estimate = " << (config.UseInitialEstimate ? "true" : "false")
+      << ", Use Weighting = " << (config.UseWeighting ? "true" : "false")
+      << ", Scale Estimator = " << dvo::core::ScaleEstimators::str(config.ScaleEstimatorType)
+      << ", Scale Estimator Param = " << config.ScaleEstimatorParam
+      << ", Influence Function = " << dvo::core::InfluenceFunctions::str(config.InfluenceFuntionType)
+      << ", Influence Function Param = " << config.InfluenceFunctionParam
+      << ", Intensity Derivative Threshold = " << config.IntensityDerivativeThreshold
+      << ", Depth Derivative Threshold = " << config.DepthDerivativeThreshold;
+  return out;
+}
+
+template <typename CharT, typename Traits>
+std::basic_ostream<CharT, Traits>& operator<<(std::basic_ostream<CharT, Traits>& o, const dvo::DenseTracker::IterationStats& s) {
+  o << "Iteration: " << s.Id << " ValidConstraints: " << s.ValidConstraints << " DataLogLikelihood: " << s.TDistributionLogLikelihood
+    << " PriorLogLikelihood: " << s.PriorLogLikelihood << std::endl;
+  return o;
+}
+
+template <typename CharT, typename Traits>
+std::basic_ostream<CharT, Traits>& operator<<(std::basic_ostream<CharT, Traits>& o, const dvo::DenseTracker::LevelStats& s) {
+  static const char* const names[] = {"IterationsExceeded", "IncrementTooSmall", "LogLikelihoodDecreased", "TooFewConstraints"};
+  const int t = int(s.TerminationCriterion);
+  o << "Level: " << s.Id << " Pixel: " << s.ValidPixels << "/" << s.MaxValidPixels << " Termination: "
+    << (t >= 0 && t < 4 ? names[t] : "") << " Iterations: " << s.Iterations.size() << std::endl;
+  for (dvo::DenseTracker::IterationStatsVector::const_iterator it = s.Iterations.begin(); it != s.Iterations.end(); ++it) o << *it;
+  return o;
+}
+
+template <typename CharT, typename Traits>
+std::basic_ostream<CharT, Traits>& operator<<(std::basic_ostream<CharT, Traits>& o, const dvo::DenseTracker::Stats& s) {
+  o << s.Levels.size() << " levels" << std::endl;
+  for (dvo::DenseTracker::LevelStatsVector::const_iterator it = s.Levels.begin(); it != s.Levels.end(); ++it) o << *it;
+  return o;
+}

@@ -122,16 +122,36 @@ def ref_lib():
         L.ref_rank_update_2x6.argtypes = [C.c_int, fp, fp, fp]
         L.ref_intrinsics_scale.argtypes = [fp, C.c_float, fp]
         L.ref_convert_raw_depth.argtypes = [C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_float, fp]
-        L.ref_match.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, fp, C.POINTER(Config), C.POINTER(Result), C.POINTER(LevelStats), C.c_int,
-                                C.POINTER(IterationStats), C.c_int]
-        L.ref_match_batch.restype = C.c_double
-        L.ref_match_batch.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), C.POINTER(Config),
-                                      C.POINTER(Result), C.c_int, C.c_int]
-        L.ref_validate.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.POINTER(fp), C.POINTER(fp), C.POINTER(C.c_double), C.POINTER(Config), C.c_double,
-                                   C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int]
+        bind_public_api(L, "ref_")
         L.ref_level_planes.argtypes = [C.c_int, C.c_int, fp, fp, fp, C.c_int, fp, C.POINTER(C.c_uint8), fp, fp]
         _ref = L
     return _ref
+
+
+def bind_public_api(L, prefix):
+    """ctypes signatures of the entry points of oracle/ref_public_api.inc, exported as <prefix>match / match_batch / validate /
+    frontend by oracle/_ref (prefix "ref_", the reference's CPU tracker) and by tests/dropin (prefix "dropin_", the reference's
+    callers on the MI355X engine)."""
+    fp = C.POINTER(C.c_float)
+    f = getattr(L, prefix + "match")
+    f.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, fp, C.POINTER(Config), C.POINTER(Result), C.POINTER(LevelStats), C.c_int,
+                  C.POINTER(IterationStats), C.c_int]
+    f = getattr(L, prefix + "match_batch")
+    f.restype = C.c_double
+    f.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), C.POINTER(Config),
+                  C.POINTER(Result), C.c_int, C.c_int]
+    f = getattr(L, prefix + "validate")
+    f.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.POINTER(fp), C.POINTER(fp), C.POINTER(C.c_double), C.POINTER(Config), C.c_double,
+                  C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int]
+    f = getattr(L, prefix + "frontend")
+    f.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.POINTER(fp), C.POINTER(fp), C.c_void_p, C.c_double, C.c_double, C.c_double,
+                  C.POINTER(C.c_double), C.POINTER(C.c_int)]
+
+
+def _api(api, name):
+    """(library, prefix) -> bound function; default = the reference build"""
+    L, prefix = api if api else (ref_lib(), "ref_")
+    return getattr(L, prefix + name)
 
 
 def _fp(a):
@@ -302,9 +322,9 @@ def rank_update_2x6(J, alpha, mode=MATH):
     return A.reshape(6, 6)
 
 
-def ref_match(intensity_ref, depth_ref, intensity_cur, depth_cur, K, cfg, T_init=None):
-    """The REFERENCE's DenseTracker::match (oracle/_ref), same dict layout as match()."""
-    L = ref_lib()
+def ref_match(intensity_ref, depth_ref, intensity_cur, depth_cur, K, cfg, T_init=None, api=None):
+    """The REFERENCE's DenseTracker::match (oracle/_ref), same dict layout as match().  api = (library, prefix) runs the same
+    caller code of another build (tests/dropin)."""
     I0, Z0, I1, Z1 = [np.ascontiguousarray(a, dtype=np.float32) for a in (intensity_ref, depth_ref, intensity_cur, depth_cur)]
     h, w = I0.shape
     K = np.ascontiguousarray(K, dtype=np.float32)
@@ -316,7 +336,7 @@ def ref_match(intensity_ref, depth_ref, intensity_cur, depth_cur, K, cfg, T_init
     cap_it = nl * (cfg.max_iterations_per_level + 1)
     levels = (LevelStats * nl)()
     iters = (IterationStats * cap_it)()
-    rc = L.ref_match(w, h, _fp(K), _fp(I0), _fp(Z0), _fp(I1), _fp(Z1), C.byref(cfg), C.byref(res), levels, nl, iters, cap_it)
+    rc = _api(api, "match")(w, h, _fp(K), _fp(I0), _fp(Z0), _fp(I1), _fp(Z1), C.byref(cfg), C.byref(res), levels, nl, iters, cap_it)
     if rc != 0:
         raise RuntimeError("ref_match rc=%d" % rc)
     return dict(T=np.array(res.transformation).reshape(4, 4), information=np.array(res.information).reshape(6, 6),
@@ -339,10 +359,9 @@ def ref_level_planes(intensity, depth, K, level, want_points=False):
     return dict(planes=planes, mask=mask, K=Kl, n_selected=n, points=None if pts is None else pts[:n])
 
 
-def ref_match_batch(planes, K, cfg, n_matches=None, nthreads=1, T_inits=None):
+def ref_match_batch(planes, K, cfg, n_matches=None, nthreads=1, T_inits=None, api=None):
     """Throughput of the REFERENCE's DenseTracker::match (oracle/_ref): planes = list of (I_ref, Z_ref, I_cur, Z_cur) float32
     arrays; n_matches >= len(planes) matches are run round-robin on `nthreads` threads.  -> (T [n,4,4], seconds)."""
-    L = ref_lib()
     n = len(planes)
     n_matches = n_matches or n
     keep = [[np.ascontiguousarray(p[k], dtype=np.float32) for p in planes] for k in range(4)]
@@ -355,14 +374,13 @@ def ref_match_batch(planes, K, cfg, n_matches=None, nthreads=1, T_inits=None):
         for k, v in enumerate(T0.reshape(-1)):
             results[i].transformation[k] = v
     K = np.ascontiguousarray(K, dtype=np.float32)
-    secs = L.ref_match_batch(n, w, h, _fp(K), arrs[0], arrs[1], arrs[2], arrs[3], C.byref(cfg), results, n_matches, nthreads)
+    secs = _api(api, "match_batch")(n, w, h, _fp(K), arrs[0], arrs[1], arrs[2], arrs[3], C.byref(cfg), results, n_matches, nthreads)
     return np.stack([np.array(results[i].transformation).reshape(4, 4) for i in range(n)]), secs
 
 
-def ref_validate(intensity, depth, K, poses, odometry_cfg, min_constraint_ratio, min_entropy_coarse, min_entropy_fine, cross_threshold=1.0):
+def ref_validate(intensity, depth, K, poses, odometry_cfg, min_constraint_ratio, min_entropy_coarse, min_entropy_fine, cross_threshold=1.0, api=None):
     """The REFERENCE's ConstraintProposalValidator (oracle/_ref, see ref_bridge.cpp::ref_validate): the last keyframe against all
     others.  -> list of dict(ref, cur, score, T) for the surviving proposals."""
-    L = ref_lib()
     n = len(intensity)
     keepI = [np.ascontiguousarray(a, np.float32) for a in intensity]
     keepZ = [np.ascontiguousarray(a, np.float32) for a in depth]
@@ -373,15 +391,14 @@ def ref_validate(intensity, depth, K, poses, odometry_cfg, min_constraint_ratio,
     P = np.ascontiguousarray(np.asarray(poses, np.float64).reshape(n, 16))
     K = np.ascontiguousarray(K, dtype=np.float32)
     out = np.zeros((4 * n, 19))
-    m = L.ref_validate(n, w, h, _fp(K), I, Z, P.ctypes.data_as(C.POINTER(C.c_double)), C.byref(odometry_cfg), min_constraint_ratio,
+    m = _api(api, "validate")(n, w, h, _fp(K), I, Z, P.ctypes.data_as(C.POINTER(C.c_double)), C.byref(odometry_cfg), min_constraint_ratio,
                        min_entropy_coarse, min_entropy_fine, cross_threshold, out.ctypes.data_as(C.POINTER(C.c_double)), 4 * n)
     return [dict(ref=int(o[0]), cur=int(o[1]), score=float(o[2]), T=o[3:].reshape(4, 4).copy()) for o in out[:m]]
 
 
-def ref_frontend(intensity, depth, K, tracking_cfg, max_translational_distance=0.2, min_entropy_ratio=0.91, min_constraint_ratio=0.33):
+def ref_frontend(intensity, depth, K, tracking_cfg, max_translational_distance=0.2, min_entropy_ratio=0.91, min_constraint_ratio=0.33, api=None):
     """The REFERENCE's tracking front end (oracle/_ref, see ref_bridge.cpp::ref_frontend): KeyframeTracker::update() frame by frame.
     -> (poses [n,4,4], completed local maps after each frame [n])."""
-    L = ref_lib()
     n = len(intensity)
     keepI = [np.ascontiguousarray(a, np.float32) for a in intensity]
     keepZ = [np.ascontiguousarray(a, np.float32) for a in depth]
@@ -392,8 +409,6 @@ def ref_frontend(intensity, depth, K, tracking_cfg, max_translational_distance=0
     K = np.ascontiguousarray(K, dtype=np.float32)
     poses = np.zeros((n, 16))
     maps = np.zeros(n, np.int32)
-    L.ref_frontend.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.POINTER(fp), C.POINTER(fp), C.c_void_p, C.c_double, C.c_double, C.c_double,
-                               C.POINTER(C.c_double), C.POINTER(C.c_int)]
-    L.ref_frontend(n, w, h, _fp(K), I, Z, C.cast(C.byref(tracking_cfg), C.c_void_p), max_translational_distance, min_entropy_ratio,
+    _api(api, "frontend")(n, w, h, _fp(K), I, Z, C.cast(C.byref(tracking_cfg), C.c_void_p), max_translational_distance, min_entropy_ratio,
                    min_constraint_ratio, poses.ctypes.data_as(C.POINTER(C.c_double)), maps.ctypes.data_as(C.POINTER(C.c_int)))
     return poses.reshape(n, 4, 4), maps

@@ -194,3 +194,31 @@ def compare_runs(a, b):
                 summary["max_A_rel"] = max(summary["max_A_rel"], np.abs(ia["A"] - ib["A"]).max() / np.abs(ib["A"]).max())
     summary["T_err"] = twist_matrix_error(a["T"], b["T"])
     return summary
+
+
+# ---- the reference's own callers on the engine (tests/dropin) -------------------------------------------------------
+_dropin = None
+
+
+def dropin_api():
+    """(library, "dropin_") for the api= argument of pyoracle's ref_* wrappers: tests/dropin/_build/libdvo_dropin.so = the
+    reference's unmodified dvo_slam sources + the shared caller code, compiled against include/dvo/ and linked with libdvo_hip.so.
+    Built here when the reference tree is present (the built library travels to the GPU box); None when neither is there."""
+    global _dropin
+    if _dropin is None:
+        here = os.path.join(HERE, "dropin")
+        import dvo_slam_amd
+        dvo_slam_amd.build()
+        po.build()
+        if os.path.isdir("/root/reference/dvo_slam/src"):
+            subprocess.check_call(["make", "-C", here, "-s"])
+        path = os.path.join(here, "_build", "libdvo_dropin.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        po.bind_public_api(L, "dropin_")
+        L.dropin_engine.restype = C.c_char_p
+        L.dropin_level_fields.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                          C.POINTER(C.c_float)]
+        _dropin = (L, "dropin_")
+    return _dropin

@@ -1,0 +1,159 @@
+"""The drop-in claim, proven with the reference's own code: the reference's tracking front end
+(dvo_slam/src/{keyframe_tracker,local_tracker,local_map,tracking_result_evaluation,config}.cpp) and its loop-closure proposal
+validation (dvo_slam/src/constraints/*.cpp) are compiled UNMODIFIED against this engine's facade headers (include/dvo/) and
+linked with libdvo_hip.so (tests/dropin/Makefile).  The same caller code (oracle/ref_public_api.inc) then runs twice: behind
+oracle/_ref it drives the reference's CPU DenseTracker, behind tests/dropin it drives the MI355X engine.  Compared here:
+whole matches iteration by iteration, the front end frame by frame, the validator's decisions over ten scenes, and the public
+fields of RgbdImage.
+
+Both sides differ by design in the reference's order- / ISA-dependent quirks (approximate rcpps, MXCSR
+round-toward-zero, the scale pairing bug, the dropped log-likelihood tail), so the comparison is by tolerance; every bound below is
+the measured value with a margin, and the measured values are printed.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import common as cm
+from oracle import pyoracle as po
+
+FR1_HALF = (po.FR1_K * 0.5).astype(np.float32)
+
+
+def need_dropin():
+    api = cm.dropin_api()
+    if api is None or po.ref_lib() is None:
+        pytest.skip("neither the reference tree nor the prebuilt drop-in / reference libraries are present")
+    return api
+
+
+def test_dropin_library_is_the_reference_callers_on_this_engine():
+    """CPU tier: the library exists, exports the shared caller entry points and is backed by libdvo_hip (no second tracker inside)."""
+    api = need_dropin()
+    L = api[0]
+    for name in ("dropin_match", "dropin_match_batch", "dropin_validate", "dropin_frontend", "dropin_level_fields"):
+        assert hasattr(L, name)
+    assert L.dropin_engine().startswith(b"dvo_hip")
+    # the reference's own translation units are in there, compiled from /root/reference (symbols of dvo_slam::LocalTracker etc.),
+    # and dvo::DenseTracker::match is NOT a symbol of its own: the facade is header-only and forwards to the C-ABI
+    import subprocess
+    syms = subprocess.check_output(["nm", "-DC", "--defined-only", os.path.join(cm.HERE, "dropin", "_build", "libdvo_dropin.so")], text=True)
+    assert "dvo_slam::LocalTracker::update" in syms and "dvo_slam::constraints::ConstraintProposalValidator::validate" in syms
+    assert "dvo_slam::KeyframeTracker::update" in syms
+    assert "computeResidualsSse" not in syms and "dvo::core::RgbdImage::calculateDerivativeX" not in syms
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", os.path.join(cm.HERE, "dropin", "_build", "libdvo_dropin.so")], text=True)
+    assert "dvo_hip_match" in undefined and "dvo_hip_frame_create_f32" in undefined
+
+
+def planes_of(pair):
+    return (pair["grey_ref"].astype(np.float32), po.convert_raw_depth(pair["depth_ref"]),
+            pair["grey_cur"].astype(np.float32), po.convert_raw_depth(pair["depth_cur"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,w,h,first,last,iters,precision,mu,use_initial", [
+    (1234, 640, 480, 3, 0, 100, 5e-7, 0.0, False),    # BASELINE config 2
+    (7, 320, 240, 3, 1, 50, 1e-4, 0.05, True),        # benchmark.yaml
+    (11, 640, 480, 3, 1, 50, 1e-4, 0.05, True),
+    (21, 640, 480, 3, 3, 100, 5e-7, 0.0, False),      # the validator's screening stage
+])
+def test_whole_match_every_iteration_against_the_reference(seed, w, h, first, last, iters, precision, mu, use_initial):
+    """DenseTracker::match through the facade vs the reference's own match(), record by record: valid-constraint counts, increments
+    and log-likelihoods of the common iteration prefix of every level, and the final transform."""
+    api = need_dropin()
+    pair = cm.synth(seed, w, h)
+    cfg = po.make_config(first, last, iters, precision, mu, use_initial)
+    r = po.ref_match(*planes_of(pair), pair["K"], cfg)
+    g = po.ref_match(*planes_of(pair), pair["K"], cfg, api=api)
+    dT = np.abs(po.se3_log(np.linalg.inv(g["T"]) @ r["T"])).max()
+    worst_n = worst_x = 0.0
+    assert len(r["levels"]) == len(g["levels"])
+    for Lr, Lg in zip(r["levels"], g["levels"]):
+        assert Lr["id"] == Lg["id"] and Lr["valid_pixels"] == Lg["valid_pixels"]      # the point selection is exact
+        m = min(len(Lr["iterations"]), len(Lg["iterations"]))
+        assert m >= 1
+        n0 = Lr["iterations"][0]["n"]
+        for a, b in zip(Lr["iterations"][:m], Lg["iterations"][:m]):
+            worst_n = max(worst_n, abs(a["n"] - b["n"]) / max(n0, 1))
+            if np.isfinite(a["x"]).all() and np.isfinite(b["x"]).all():
+                worst_x = max(worst_x, np.abs(a["x"] - b["x"]).max())
+            # the reference's log-likelihood drops n mod 50 terms and uses the paired scale (Q6, Q7): a few per cent apart
+            assert abs(a["neg_ll"] - b["neg_ll"]) <= 0.1 * abs(a["neg_ll"])
+    print("seed %d %dx%d levels %d..%d: |twist(T_gpu^-1 T_ref)| %.2e, worst |dn|/n %.2e, worst |dx| %.2e" % (seed, w, h, first, last, dT, worst_n, worst_x))
+    assert dT < 5e-5 if last < first else dT < 2e-3       # one coarse level alone stops at the coarse level's resolution
+    assert worst_n < 0.08                                 # rcpps moves a few of the 100..500 constraints of the 80x60 level across a boundary
+    assert worst_x < 5e-3                                 # measured 1e-3 .. 3e-3 on the coarsest level, 1e-5 .. 3e-4 below
+
+
+@pytest.mark.gpu
+def test_reference_tracking_front_end_on_the_engine():
+    """The reference's KeyframeTracker -> LocalTracker -> LocalMap, unmodified, on the GPU facade vs on the reference's CPU tracker."""
+    api = need_dropin()
+    from dvo_slam_amd import datagen
+    n = 14
+    seq = datagen.synth_sequence(31, n, 320, 240)
+    I = [a.astype(np.float32) for a in seq["grey"]]
+    Z = [po.convert_raw_depth(a) for a in seq["depth"]]
+    cfg = po.make_config(3, 1, 50, 1e-4, 0.05, True)                       # dvo_benchmark/launch/benchmark.yaml
+    pr, mr = po.ref_frontend(I, Z, FR1_HALF, cfg, 0.2)                      # the reference's default selection thresholds
+    pg, mg = po.ref_frontend(I, Z, FR1_HALF, cfg, 0.2, api=api)
+    d = max(np.abs(po.se3_log(np.linalg.inv(a) @ b)).max() for a, b in zip(pr, pg))
+    print("completed local maps  reference:", mr.tolist(), " engine:", mg.tolist(), " max pose distance %.2e" % d)
+    assert mr.tolist() == mg.tolist() and mr[-1] >= 1
+    assert d < 3e-4                                                         # measured 8e-5 over 14 frames
+    for k in range(n):                                                      # and both stay on the true trajectory
+        assert np.abs(po.se3_log(np.linalg.inv(pg[k]) @ seq["poses"][k])).max() < 3e-3
+    # a tight distance threshold puts keyframe decisions on the threshold itself: the two may switch a frame apart, the poses stay close
+    pr, mr = po.ref_frontend(I, Z, FR1_HALF, cfg, 0.03)
+    pg, mg = po.ref_frontend(I, Z, FR1_HALF, cfg, 0.03, api=api)
+    print("tight threshold       reference:", mr.tolist(), " engine:", mg.tolist())
+    assert abs(int(mr[-1]) - int(mg[-1])) <= 2
+    assert max(np.abs(po.se3_log(np.linalg.inv(a) @ b)).max() for a, b in zip(pr, pg)) < 5e-2
+
+
+@pytest.mark.gpu
+def test_reference_proposal_validator_on_the_engine_over_ten_scenes():
+    """The reference's ConstraintProposalValidator + voters, unmodified, on the engine: decision disagreement rate against the same
+    code on the reference's CPU tracker, thresholds as KeyframeGraph sets them (not placed in gaps)."""
+    api = need_dropin()
+    from dvo_slam_amd import datagen
+    odometry = po.make_config(3, 1, 50, 1e-4, 0.05, True)
+    survivors = differing = 0
+    worst = 0.0
+    for seed in range(10):
+        seq = datagen.synth_sequence(100 + seed, 9, 320, 240)
+        I = [a.astype(np.float32) for a in seq["grey"]]
+        Z = [po.convert_raw_depth(a) for a in seq["depth"]]
+        a = po.ref_validate(I, Z, FR1_HALF, seq["poses"], odometry, 0.17, 0.005, 0.86)
+        b = po.ref_validate(I, Z, FR1_HALF, seq["poses"], odometry, 0.17, 0.005, 0.86, api=api)
+        sa, sb = [(x["ref"], x["cur"]) for x in a], [(x["ref"], x["cur"]) for x in b]
+        survivors += len(set(sa) | set(sb))
+        differing += len(set(sa) ^ set(sb))
+        for x in a:
+            for y in b:
+                if (x["ref"], x["cur"]) == (y["ref"], y["cur"]):
+                    worst = max(worst, np.abs(po.se3_log(np.linalg.inv(x["T"]) @ y["T"])).max())
+    print("validator: %d of %d surviving proposals decided differently over 10 scenes (16 proposals + twins each); "
+          "largest distance between common accepted transforms %.2e" % (differing, survivors, worst))
+    assert survivors >= 40
+    assert differing <= 0.12 * survivors          # measured 3 of 57: decisions that sit on a threshold
+    assert worst < 5e-4                           # measured 1.2e-4 (runs stopped at Precision 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [0, 2])
+def test_public_fields_of_rgbd_image_are_host_mirrors(level):
+    """RgbdImage::{intensity, depth, intensity_dx, ...} read as FIELDS (as the reference's callers do) after the calls that fill
+    them in the reference: bit-identical to the reference's own planes."""
+    api = need_dropin()
+    pair = cm.synth(5, 320, 240)
+    I0, Z0 = pair["grey_ref"].astype(np.float32), po.convert_raw_depth(pair["depth_ref"])
+    h, w = 240 >> level, 320 >> level
+    planes = np.zeros((6, h, w), np.float32)
+    n = api[0].dropin_level_fields(320, 240, po._fp(np.ascontiguousarray(pair["K"], np.float32)), po._fp(I0), po._fp(Z0), level, po._fp(planes))
+    assert n == w * h                                                          # point cloud columns
+    ref = po.ref_level_planes(I0, Z0, pair["K"], level)["planes"]
+    for k in range(6):
+        assert np.array_equal(np.isnan(planes[k]), np.isnan(ref[k]))
+        assert np.array_equal(np.nan_to_num(planes[k]), np.nan_to_num(ref[k]))
