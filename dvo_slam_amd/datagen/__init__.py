@@ -35,6 +35,7 @@ def lib():
         L.dvo_synth_pair.argtypes = [C.c_uint64, C.c_int, C.c_int, fp, u8, u16, u8, u16, dp]
         L.dvo_synth_batch.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, fp, u8, u16, u8, u16, dp, C.c_int]
         L.dvo_synth_sequence.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, fp, u8, u16, dp, C.c_int]
+        L.dvo_synth_sequence_noisy.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, fp, u8, u16, dp, C.c_double, C.c_double, C.c_double, C.c_int]
         _lib = L
     return _lib
 
@@ -60,14 +61,16 @@ def synth_batch(seed0, n, w=640, h=480, K=None, nthreads=None):
     return dict(grey_ref=gr, depth_ref=dr, grey_cur=gc, depth_cur=dc, xi_true=xi, K=K)
 
 
-def synth_sequence(seed, n, w=640, h=480, K=None, nthreads=None):
+def synth_sequence(seed, n, w=640, h=480, K=None, nthreads=None, depth_noise=0.0, grey_noise=1.5, exposure=0.0):
     """A camera sweep over one scene: dict(grey [n,h,w] u8, depth [n,h,w] u16, poses [n,4,4] camera->world (frame 0 =
-    identity), K).  match(frame k-1, frame k) should return poses[k-1]^-1 poses[k]."""
+    identity), K).  match(frame k-1, frame k) should return poses[k-1]^-1 poses[k].  depth_noise: multiples of the Kinect depth
+    uncertainty the reference assumes (dense_tracking_impl.cpp:122-128), Gaussian; grey_noise: half-width of the uniform intensity
+    noise in grey levels; exposure: amplitude of a smooth per-frame gain (1 +- exposure) and bias (+- 100 exposure grey levels) drift."""
     K = np.ascontiguousarray(FR1_K * (w / 640.0) if K is None else K, dtype=np.float32)
     grey = np.empty((n, h, w), np.uint8)
     depth = np.empty((n, h, w), np.uint16)
     poses = np.zeros((n, 4, 4))
-    lib().dvo_synth_sequence(seed, n, w, h, K.ctypes.data_as(C.POINTER(C.c_float)), grey.ctypes.data_as(C.POINTER(C.c_uint8)),
-                             depth.ctypes.data_as(C.POINTER(C.c_uint16)), poses.ctypes.data_as(C.POINTER(C.c_double)),
-                             nthreads or min(8, os.cpu_count() or 1))
+    lib().dvo_synth_sequence_noisy(seed, n, w, h, K.ctypes.data_as(C.POINTER(C.c_float)), grey.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                   depth.ctypes.data_as(C.POINTER(C.c_uint16)), poses.ctypes.data_as(C.POINTER(C.c_double)),
+                                   float(depth_noise), float(grey_noise), float(exposure), nthreads or min(16, os.cpu_count() or 1))
     return dict(grey=grey, depth=depth, poses=poses, K=K)

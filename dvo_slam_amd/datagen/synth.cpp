@@ -36,6 +36,10 @@ struct Pcg32 {
   }
   double uniform() { return (next() >> 8) * (1.0 / 16777216.0); }   // [0,1)
   double uniform(double a, double b) { return a + (b - a) * uniform(); }
+  double gaussian() {                                                 // Box-Muller, one value per call (the twin is dropped)
+    const double u1 = 1.0 - uniform(), u2 = uniform();
+    return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2);
+  }
 };
 
 struct Scene {
@@ -210,7 +214,11 @@ namespace {
 
 // one view of the scene from the camera whose camera->world transform is Mcw (world = the frame the analytic surface
 // is defined in): intersect each pixel ray with the surface  p.z = depth_at(project(p)),  p = R s d + t
-void render_view(const Scene& sc, const double Mcw[16], Pcg32& noise, Pcg32& holes, uint8_t* grey, uint16_t* depth) {
+// depth_noise: multiples of the Kinect depth uncertainty sigma(z) = 0.0012 + 0.0019 (z - 0.4)^2 m -- the sensor model the
+// reference itself assumes (dvo_core/src/dense_tracking_impl.cpp:122-128) -- added as zero-mean Gaussian noise before the
+// 1/5000 m quantisation; grey_noise: half-width of the uniform intensity noise in grey levels.
+void render_view(const Scene& sc, const double Mcw[16], Pcg32& noise, Pcg32& holes, uint8_t* grey, uint16_t* depth,
+                 double depth_noise = 0.0, double grey_noise = 1.5, double gain = 1.0, double bias = 0.0) {
   const int W = sc.W, H = sc.H;
   for (int v = 0; v < H; ++v)
     for (int u = 0; u < W; ++u) {
@@ -236,8 +244,13 @@ void render_view(const Scene& sc, const double Mcw[16], Pcg32& noise, Pcg32& hol
         s -= step;
       }
       g(s, p);
-      grey[size_t(v) * W + u] = quantise_grey(sc.texture(p) + noise.uniform(-1.5, 1.5));
-      depth[size_t(v) * W + u] = quantise_depth(s);
+      grey[size_t(v) * W + u] = quantise_grey(gain * sc.texture(p) + bias + noise.uniform(-grey_noise, grey_noise));
+      double z = s;
+      if (depth_noise > 0.0) {
+        const double sigma = 0.0012 + 0.0019 * (s - 0.4) * (s - 0.4);
+        z += depth_noise * sigma * noise.gaussian();
+      }
+      depth[size_t(v) * W + u] = quantise_depth(z);
     }
   punch_holes(depth, W, H, holes);
 }
@@ -247,8 +260,11 @@ void render_view(const Scene& sc, const double Mcw[16], Pcg32& noise, Pcg32& hol
 // A camera sweep over one scene: n frames, frame k seen from the pose  T_k = exp(xi(k)),  xi_i(k) = A_i sin(w_i k + phi_i)
 // (bounded excursion around the scene's defining view, per-frame motion of the order of 30 Hz hand-held footage).
 // poses: n row-major 4x4 camera->world transforms = the ground truth trajectory a replay is evaluated against.
-extern "C" void dvo_synth_sequence(uint64_t seed, int n, int W, int H, const float K[4], uint8_t* grey, uint16_t* depth, double* poses,
-                                   int nthreads) {
+// exposure: per-frame auto-exposure drift -- frame k is rendered with gain 1 + exposure * g_k and bias 100 * exposure * b_k grey
+// levels, g and b smooth pseudo-random sequences in [-1, 1] (sums of three incommensurate sinusoids): the brightness-constancy
+// violation every real sequence has and the photometric model does not know about.
+extern "C" void dvo_synth_sequence_noisy(uint64_t seed, int n, int W, int H, const float K[4], uint8_t* grey, uint16_t* depth, double* poses,
+                                         double depth_noise, double grey_noise, double exposure, int nthreads) {
   Pcg32 rng(seed * 0x9E3779B97F4A7C15ULL + 0x7654321ULL, seed + 23);
   Scene sc;
   sc.W = W; sc.H = H;
@@ -265,16 +281,30 @@ extern "C" void dvo_synth_sequence(uint64_t seed, int n, int W, int H, const flo
     for (int i = 0; i < 6; ++i) xi[i] = amp[i] * (std::sin(freq[i] * k + phase[i]) - std::sin(phase[i]));   // frame 0 = identity
     se3_exp_matrix(xi, poses + size_t(k) * 16);
   }
+  double ef[6], ep[6];
+  for (int i = 0; i < 6; ++i) {
+    ef[i] = rng.uniform(0.05, 0.6);                              // rad per frame: exposure changes over 10..120 frames
+    ep[i] = rng.uniform(0, 2.0 * M_PI);
+  }
   if (nthreads < 1) nthreads = 1;
   const size_t npx = size_t(W) * H;
   auto work = [&](int t) {
     for (int k = t; k < n; k += nthreads) {
       Pcg32 noise(seed * 977 + 2 * uint64_t(k) + 1, 29), holes(seed * 1543 + 2 * uint64_t(k) + 2, 31);
-      render_view(sc, poses + size_t(k) * 16, noise, holes, grey + k * npx, depth + k * npx);
+      const double g = (std::sin(ef[0] * k + ep[0]) + std::sin(ef[1] * k + ep[1]) + std::sin(ef[2] * k + ep[2])) / 3.0;
+      const double b = (std::sin(ef[3] * k + ep[3]) + std::sin(ef[4] * k + ep[4]) + std::sin(ef[5] * k + ep[5])) / 3.0;
+      render_view(sc, poses + size_t(k) * 16, noise, holes, grey + k * npx, depth + k * npx, depth_noise, grey_noise,
+                  1.0 + exposure * g, 100.0 * exposure * b);
     }
   };
   std::vector<std::thread> th;
   for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
   work(0);
   for (auto& x : th) x.join();
+}
+
+// the noise-free variant (depth quantisation and +-1.5 grey levels of intensity noise only)
+extern "C" void dvo_synth_sequence(uint64_t seed, int n, int W, int H, const float K[4], uint8_t* grey, uint16_t* depth, double* poses,
+                                   int nthreads) {
+  dvo_synth_sequence_noisy(seed, n, W, H, K, grey, depth, poses, 0.0, 1.5, 0.0, nthreads);
 }

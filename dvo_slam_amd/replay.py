@@ -70,3 +70,27 @@ def replay(assoc_file, backend, groundtruth_file=None, K=None):
         stamps.append(rgb_stamp)
         poses.append(trajectory.copy())
     return dict(stamps=np.asarray(stamps), poses=np.asarray(poses), failures=failures)
+
+
+def replay_arrays(grey, depth, backend, K, stamps=None):
+    """The same loop over frames held in memory (grey [n,h,w] u8, depth [n,h,w] u16): no image files in between.  -> dict(stamps,
+    poses [n,4,4] with frame 0 at the identity, relative [n-1,4,4], failures)."""
+    n, h, w = grey.shape
+    make_frame, match = backend(w, h, np.asarray(K, np.float32))
+    trajectory, relative = np.eye(4), np.eye(4)
+    reference = current = None
+    poses, rel, failures = [], [], 0
+    for k in range(n):
+        reference, current = current, make_frame(grey[k], depth[k])
+        if reference is not None:
+            T = match(reference, current, relative)
+            if T is None:
+                failures += 1
+                relative = np.eye(4)
+            else:
+                relative = T
+            rel.append(relative.copy())
+            trajectory = trajectory @ relative
+        poses.append(trajectory.copy())
+    return dict(stamps=np.arange(n) / 30.0 if stamps is None else np.asarray(stamps), poses=np.asarray(poses), relative=np.asarray(rel),
+                failures=failures)

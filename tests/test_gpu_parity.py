@@ -661,3 +661,51 @@ def test_random_whole_matches_against_oracle(gpu_ctx):
         assert s["T_err"] < max(2e-5, 30 * precision), what
         if s["structure_mismatch"] == 0:
             assert np.abs(g["information"] - o["information"]).max() <= 2e-3 * np.abs(o["information"]).max(), what
+
+
+@pytest.mark.gpu
+def test_config4_batch_of_1024_distinct_pairs(gpu_ctx):
+    """BASELINE config 4 at size: 1024 DISTINCT 640x480 pairs (seeds 0..1023, 2048 frames, 41 GB of device planes) aligned as ONE
+    batch, levels 3..0.  Every pair against the true motion of its synthetic scene; a sample of 32 against the oracle (MATH) and
+    against the reference's own match() (oracle/_ref); and the batch equals eight 128-pair batches of the same pairs."""
+    n, w, h = 1024, 640, 480
+    cfg = d.Config(FirstLevel=3, LastLevel=0)
+    trk = d.DenseTracker(cfg, gpu_ctx)
+    cam = d.RgbdCameraPyramid(w, h, po.FR1_K, gpu_ctx)
+    cam.build(4)
+    refs, curs, xi = [], [], []
+    for s in range(0, n, 128):                                  # generated and ingested 128 pairs at a time (host memory)
+        b = datagen.synth_batch(s, 128, w, h)
+        refs += [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(128)]
+        curs += [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(128)]
+        xi.append(b["xi_true"])
+    xi = np.concatenate(xi)
+    try:
+        gpu_ctx.set_option("rows_per_wave", 8)                  # pinned tile height: records do not depend on the batch size
+        out = trk.match_batch_arrays(refs, curs)
+        parts = [trk.match_batch_arrays(refs[s:s + 128], curs[s:s + 128]) for s in range(0, n, 128)]
+    finally:
+        gpu_ctx.set_option("rows_per_wave", 0)
+    assert np.isfinite(out["T"]).all() and np.isfinite(out["information"]).all()
+    err = np.array([np.abs(po.se3_log(out["T"][i]) - xi[i]).max() for i in range(n)])
+    print("1024 pairs: max / median distance to the true motion %.2e / %.2e, iterations per pair %.1f" % (err.max(), np.median(err), out["n_iterations"].mean()))
+    assert err.max() < 3e-4 and np.median(err) < 5e-5          # 12 % holes, +-1.5 grey levels of noise, 0.2 mm depth quantisation
+    for k in ("T", "information", "n_iterations", "entropy"):
+        assert np.array_equal(out[k], np.concatenate([p[k] for p in parts]), equal_nan=True), k
+    sample = list(range(0, n, 32))
+    ocfg = po.make_config(3, 0, 100, 5e-7, mode=po.MATH)
+    rcfg = po.make_config(3, 0, 100, 5e-7)
+    worst_m = worst_r = 0.0
+    have_ref = po.ref_lib() is not None
+    for i in sample:
+        pair = po.synth_pair(i, w, h)
+        oref, ocur = po.pyramids_from_pair(pair, 4)
+        o = po.match(oref, ocur, ocfg)
+        worst_m = max(worst_m, cm.twist_matrix_error(out["T"][i], o["T"]))
+        if have_ref:
+            r = po.ref_match(pair["grey_ref"].astype(np.float32), po.convert_raw_depth(pair["depth_ref"]), pair["grey_cur"].astype(np.float32),
+                             po.convert_raw_depth(pair["depth_cur"]), pair["K"], rcfg)
+            worst_r = max(worst_r, cm.twist_matrix_error(out["T"][i], r["T"]))
+    print("sample of %d: largest twist distance to the oracle (MATH) %.2e, to the reference's own match() %.2e" % (len(sample), worst_m, worst_r))
+    assert worst_m < 2e-6
+    assert worst_r < 5e-5

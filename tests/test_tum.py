@@ -255,3 +255,37 @@ def test_replay_loop_with_the_oracle_tracks_the_synthetic_sweep(tmp_path):
     run_sse = replay.replay(str(tmp_path / "assoc.txt"), oracle_backend(po.REF_SSE, YAML), str(tmp_path / "groundtruth.txt"))
     ate_sse = tum.evaluate_ate(gts, gtp, run_sse["stamps"], run_sse["poses"])
     assert abs(ate_sse["rmse"] - ate["rmse"]) < 1e-5, (ate, ate_sse)
+
+
+def test_long_replay_golden_is_reproducible_from_the_seed():
+    """tests/golden/replay_r02.npz (300 noisy 640x480 frames, trajectories of the REFERENCE's own match() and of both oracle
+    modes): the generator reproduces the frames of the first steps from the seed, the oracle reproduces its stored relative poses
+    bit for bit, and so does the reference's compiled code when oracle/_ref is present."""
+    import hashlib
+    from dvo_slam_amd import datagen
+    from oracle import pyoracle as po
+    from common import load_golden
+    gold = load_golden("replay_r02.npz")
+    seed, n, w, h = [int(v) for v in gold["seq"]]
+    k = 4
+    seq = datagen.synth_sequence(seed, k, w, h, depth_noise=float(gold["noise"][0]), grey_noise=float(gold["noise"][1]), exposure=float(gold["noise"][2]))
+    sums = [int(hashlib.sha1(seq["grey"][i].tobytes() + seq["depth"][i].tobytes()).hexdigest()[:15], 16) for i in range(k)]
+    assert sums == gold["checksums"][:k].tolist()
+    kw = dict(first_level=3, last_level=1, max_iterations=50, precision=1e-4, mu=0.05, use_initial_estimate=True)
+    frames = [(seq["grey"][i].astype(np.float32), po.convert_raw_depth(seq["depth"][i])) for i in range(k)]
+    for tag, mode in (("math", po.MATH), ("ref_sse", po.REF_SSE)):
+        cfg = po.make_config(mode=mode, **kw)
+        pyr = [po.Pyramid(I, Z, gold["K"], 4) for I, Z in frames]
+        rel = np.eye(4)
+        for i in range(1, k):
+            rel = po.match(pyr[i - 1], pyr[i], cfg, rel)["T"]
+            assert np.array_equal(rel, gold["benchmark_yaml_%s_relative" % tag][i - 1])
+    if po.ref_lib() is not None:
+        cfg = po.make_config(**kw)
+        rel = np.eye(4)
+        for i in range(1, k):
+            rel = po.ref_match(frames[i - 1][0], frames[i - 1][1], frames[i][0], frames[i][1], gold["K"], cfg, rel)["T"]
+            assert np.array_equal(rel, gold["benchmark_yaml_ref_relative"][i - 1])
+    # ref and its restatement agree over all 299 steps of both configurations
+    for name in ("benchmark_yaml", "strict_level0"):
+        assert np.array_equal(gold[name + "_ref_relative"], gold[name + "_ref_sse_relative"])
