@@ -1,15 +1,19 @@
 #!/usr/bin/env python
 """bench.py -- frame-pair alignments/s of the MI355X dense RGB-D alignment path (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-  re-ingest the raw planes of the batch's frames (u8 grey + u16 depth -> device pyramids, selection)  [SURVEY a11-a14]
+Workload = BASELINE config 4: `--pairs` (default 1024) independent 640x480 frame pairs, synthetic seeds 0..pairs-1, 4-level
+pyramid, FirstLevel 3, LastLevel 0 (finest level 640x480), MaxIterationsPerLevel 100, Precision 5e-7, Mu 0.  Pair i belongs
+to rank i mod N: the total is fixed, every GPU gets pairs/N of it (STRONG scaling); one all-gather of the 256-byte result
+records per step over RCCL when N > 1.
+
+A "step" is one pass of the hot path over the rank's whole shard, with the raw sensor planes already resident in HBM:
+  re-ingest the raw planes of the shard's frames (u8 grey + u16 depth -> device pyramids, selection)   [SURVEY a11-a14]
   + dvo_hip_match_batch: the coarse-to-fine Gauss-Newton alignment of every pair                      [SURVEY a1-a10]
-  (+ for N > 1: one all-gather of the 256-byte result records over RCCL)
-Workload at any N: `--pairs-per-gpu` (default 128) independent 640x480 pairs per GPU, 4-level pyramid, FirstLevel 3,
-LastLevel 0 (finest level 640x480), MaxIterationsPerLevel 100, Precision 5e-7, Mu 0 -- the per-GPU shard of
-BASELINE config 4 (1024 pairs over 8 GPUs), i.e. weak scaling; BASELINE config 2 (a single pair) is the same call
-with a batch of one and is reported as `single_pair_ms` (latency), because one 15 MB pair lives in the 256 MB
-Infinity Cache and cannot exercise HBM.
+`value` = pairs aligned per second of that loop (inputs resident in HBM when the timed region starts, as the bench contract
+prescribes).  The same loop fed from pinned HOST memory every step -- SURVEY.md 8d's "incl. H2D of 2 planes per frame" -- is
+measured right after it and reported beside it as `from_host` (PCIe-bound).  BASELINE config 2 (a single pair) is the same
+call with a batch of one and is reported as `single_pair_ms` (latency): one 15 MB pair lives in the 256 MB Infinity Cache and
+cannot exercise HBM.
 
 Launch: `python bench.py --gpus 1 --steps K --warmup W`, or for N > 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -33,9 +37,11 @@ BACKGROUND_BUILD_WORKGROUPS = 0      # cap on the workgroups of background build
 HBM_PEAK_GBPS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(pairs_np, cfg_kwargs, sample_pairs, reps):
-    """The oracle's quirk-faithful REF_SSE mode (kind 'port': the reference itself cannot be built here), one match per
-    host thread like the reference's tbb::parallel_reduce over proposals.  Checker code timed as a baseline only."""
+def cpu_baseline(pairs_np, cfg_kwargs, sample_pairs, per_thread, trials):
+    """The oracle's quirk-faithful REF_SSE mode (kind "port"; bit-identical to the reference's own match(), which is timed beside
+    it through oracle/_ref), one match per host thread at a time like the reference's tbb::parallel_reduce over proposals
+    (dvo_slam/src/keyframe_graph.cpp:576-593).  Checker code timed as a baseline only.  Every thread count is given `per_thread`
+    matches per thread, `trials` times; the median trial counts."""
     from oracle import pyoracle as po
     cores = len(os.sched_getaffinity(0))
     n = min(sample_pairs, pairs_np["grey_ref"].shape[0])
@@ -48,33 +54,39 @@ def cpu_baseline(pairs_np, cfg_kwargs, sample_pairs, reps):
         curs.append(c)
     cfg = po.make_config(mode=po.REF_SSE, **cfg_kwargs)
     po.match_batch(refs, curs, cfg, nthreads=min(cores, n))      # warm-up (also builds the per-pyramid caches)
-    # The reference's model: one match per host thread.  The path is memory-bound on the CPU too, so more threads are
-    # not always faster: try a few thread counts on the same sample and report the best one.
-    best = None
-    for threads in sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores}):
-        mult = max(reps, -(-2 * threads // n))           # every thread gets at least two matches (pyramids are shared read-only)
-        _, secs = po.match_batch(refs * mult, curs * mult, cfg, nthreads=threads)
-        rate = n * mult / secs
-        if best is None or rate > best[0]:
-            best = (rate, threads, n * mult)
-    n1 = min(n, 8)
-    _, t_single = po.match_batch(refs[:n1], curs[:n1], cfg, nthreads=1)
-    # The reference's own DenseTracker::match (oracle/_ref: its translation units compiled against stand-in Eigen/OpenCV headers)
-    # on the same sample -- bit-identical results, but slower than the port (the stand-in matrix algebra is naive, and every
-    # match re-selects the reference points like the reference does), so the port stays the quoted baseline.
+
+    def rate(threads):
+        m = per_thread * threads                                   # pyramids are shared read-only, pair k % n each
+        reps = -(-m // n)
+        runs = []
+        for _ in range(trials):
+            _, secs = po.match_batch((refs * reps)[:m], (curs * reps)[:m], cfg, nthreads=threads)
+            runs.append(m / secs)
+        return float(np.median(runs)), m
+    # The path is memory-bound on the CPU too, so more threads are not always faster: a few thread counts, best median reported.
+    candidates = sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores})
+    table = {t: rate(t) for t in candidates}
+    best_threads = max(table, key=lambda t: table[t][0])
+    single, m1 = rate(1)
     reference_note, reference_value = "", None
     if po.ref_lib() is not None:
         planes = [(pairs_np["grey_ref"][i].astype(np.float32), po.convert_raw_depth(pairs_np["depth_ref"][i]),
                    pairs_np["grey_cur"][i].astype(np.float32), po.convert_raw_depth(pairs_np["depth_cur"][i])) for i in range(min(n, 16))]
-        m = max(len(planes), 2 * best[1])
-        _, secs = po.ref_match_batch(planes, pairs_np["K"], cfg, n_matches=m, nthreads=best[1])
-        reference_value = m / secs
-        reference_note = "; the reference's own match() via oracle/_ref on %d threads: %.1f alignments/s" % (best[1], reference_value)
-    return dict(value=best[0], unit="alignments/s", cores=best[1], kind="port", reference_value=reference_value,
-                sample="%d matches over %d distinct synthetic 640x480 pairs (oracle REF_SSE mode, -O3 -march=native), best of "
-                       "%s threads on a %d-thread host = %d threads, one match per thread at a time; single thread: %.1f alignments/s"
-                       % (best[2], n, sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores}), cores, best[1], n1 / t_single) + reference_note,
-                single_thread_value=n1 / t_single, host_threads=cores)
+        m = per_thread * best_threads
+        runs = []
+        for _ in range(trials):
+            _, secs = po.ref_match_batch(planes, pairs_np["K"], cfg, n_matches=m, nthreads=best_threads)
+            runs.append(m / secs)
+        reference_value = float(np.median(runs))
+        reference_note = ("; the reference's own DenseTracker::match via oracle/_ref (its translation units compiled against stand-in "
+                          "Eigen/OpenCV headers, whose naive matrix algebra makes it slower than the port) on %d threads: %.1f alignments/s"
+                          % (best_threads, reference_value))
+    return dict(value=table[best_threads][0], unit="alignments/s", cores=best_threads, kind="port", reference_value=reference_value,
+                sample="%d matches (%d per thread, median of %d trials) over %d distinct synthetic 640x480 pairs, oracle REF_SSE mode "
+                       "(-O3 -march=native), one match per thread at a time; thread counts tried on the %d-thread host: %s; "
+                       "single thread: %.1f alignments/s" % (table[best_threads][1], per_thread, trials, n, cores,
+                                                             ", ".join("%d -> %.0f/s" % (t, table[t][0]) for t in candidates), single) + reference_note,
+                single_thread_value=single, host_threads=cores)
 
 
 def main():
@@ -82,9 +94,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs-per-gpu", type=int, default=128)
-    ap.add_argument("--cpu-sample-pairs", type=int, default=64)
-    ap.add_argument("--cpu-reps", type=int, default=4)
+    ap.add_argument("--pairs", type=int, default=1024, help="GLOBAL number of frame pairs (BASELINE config 4: 1024); every rank aligns pairs/N of them")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=32)
+    ap.add_argument("--cpu-matches-per-thread", type=int, default=10)
+    ap.add_argument("--cpu-trials", type=int, default=3)
+    ap.add_argument("--records-out", default="", help="rank 0 writes the gathered result records of the last step here (.npy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--build-workgroups", type=int, default=-1, help="cap on the workgroups of a background build kernel (library option build_workgroups; -1 = bench default)")
     ap.add_argument("--no-overlap", action="store_true", help="build each batch right before its match on one frame set (no build/match overlap)")
@@ -118,16 +132,18 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     comm_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
-    B = args.pairs_per_gpu
-    n_total = B * world
-    my_pairs = parallel.shard_indices(n_total, rank, world)      # pair i -> rank i mod N
+    n_total = args.pairs
+    my_pairs = parallel.shard_indices(n_total, rank, world)      # pair i -> rank i mod N (SURVEY.md 8e)
+    B = len(my_pairs)
+    if B < 1:
+        raise SystemExit("fewer pairs than ranks")
     # synthetic input, identical bytes on the CPU and GPU sides (seed = global pair index)
     if world > 1:
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max(1, min(8, (os.cpu_count() or 8) // world))) as ex:   # ctypes releases the GIL
+        with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 8) // world))) as ex:   # ctypes releases the GIL
             batches = list(ex.map(lambda i: datagen.synth_batch(i, 1, W, H, nthreads=1), my_pairs))
     else:
-        batches = [datagen.synth_batch(0, B, W, H)]
+        batches = [datagen.synth_batch(0, B, W, H, nthreads=min(32, os.cpu_count() or 8))]
     pairs_np = {k: np.concatenate([b[k] for b in batches]) for k in ("grey_ref", "depth_ref", "grey_cur", "depth_cur", "xi_true")}
     pairs_np["K"] = batches[0]["K"]
 
@@ -183,16 +199,15 @@ def main():
         last["information"] = res["information"].reshape(B, 6, 6)
         last["loglik"] = res["loglik"]
         if world > 1:
-            # the records of this batch travel (one all-gather, RCCL) while the next batch is aligned
-            out = last
-            tw = [_twist(T) for T in out["T"]]
-            rec = parallel.pack_records(tw, out["information"], out["loglik"])
+            # the records of this batch travel (one all-gather, RCCL) while the next batch is aligned; buffers allocated once
+            rec = parallel.pack_records(parallel.twists_of(last["T"]), last["information"], last["loglik"])
             if pending[0] is not None:
                 gathered[0] = pending[0].result()
-            pending[0] = parallel.gather_records_start(rec, n_total, rank, world, device=comm_dev)
+            pending[0] = gatherer.start(rec)
         return None
 
     pending, gathered = [None], [None]
+    gatherer = parallel.RecordGatherer(n_total, rank, world, device=comm_dev) if world > 1 else None
 
     def drain():
         if pending[0] is not None:
@@ -222,24 +237,32 @@ def main():
         elapsed = float(t.item())
 
     # ---- everything below is outside the timed region -------------------------------------------------------
-    twist_err = max(float(np.abs(_twist(T) - pairs_np["xi_true"][i]).max()) for i, T in enumerate(last["T"]))
+    twist_err = float(np.abs(parallel.twists_of(last["T"]) - pairs_np["xi_true"]).max())
+    if args.records_out and rank == 0:
+        full = gathered[0] if world > 1 else parallel.pack_records(parallel.twists_of(last["T"]), last["information"], last["loglik"])
+        np.save(args.records_out, full)
     nan_results = int((~np.isfinite(last["T"]).all(axis=(1, 2)) | ~np.isfinite(last["information"]).all(axis=(1, 2))).sum())
     t_match0 = time.perf_counter()
     tracker.match_batch_arrays(refs, curs)
     match_only_ms = (time.perf_counter() - t_match0) * 1e3
 
     # roofline of the dominant kernel: finest-level fused warp/residual/Jacobian/reduce sweep, HIP events on the context stream
-    k_ms = {lvl: tracker.time_residual_kernel(refs, curs, lvl, reps=20) for lvl in (0, 1, 2, 3)}
-    stream_ms = tracker.time_stream_mix(refs, curs, 0, reps=20)     # the same planes streamed in pixel order, nothing else
+    # (timed where the sweeps of a match run: after three Gauss-Newton steps on the level, i.e. at the converged transform with the
+    # t-distribution weights on -- not at the identity with unit weights)
+    k_ms = {lvl: min(tracker.time_residual_kernel(refs, curs, lvl, reps=10, warm_iterations=3) for _ in range(2)) for lvl in (0, 1, 2, 3)}
+    stream_ms = tracker.time_stream_mix(refs, curs, 0, reps=10)                       # the same planes streamed in pixel order, read only
+    stream_w_ms = tracker.time_stream_mix(refs, curs, 0, reps=10, with_write=True)   # ... plus the 8-B residual pair the sweep writes
     algo_bytes = ALGO_BYTES_PER_PIXEL * W * H * B
     achieved = algo_bytes / (k_ms[0] * 1e-3) / 1e9
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
                     traffic=_pmc_traffic(B), kernel="dvo_hip::k_residual_reduce_mfma<%d, true, false> (pyramid level 0, %d pairs per launch)" % (
                         args.rows_per_wave or _rows_per_wave(B), B),
                     kernel_ms=round(k_ms[0], 4), algorithmic_bytes_per_launch=algo_bytes,
+                    timed_at="converged transform, t-distribution weights on (3 warm-up Gauss-Newton steps on the level)",
                     bare_stream_ms=round(stream_ms, 4), bare_stream_frac=round(algo_bytes / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                    bare_stream_note="a kernel that only reads the same planes in pixel order and writes the 8-B pair (no gather, "
-                                     "arithmetic or reduction), timed the same way: what this part's memory system needs for the same bytes",
+                    bare_stream_with_write_ms=round(stream_w_ms, 4),
+                    bare_stream_note="kernels that only read the same planes in pixel order (no gather, arithmetic or reduction; the second "
+                                     "also writes the 8-B residual pair), timed the same way: what this part's memory system needs for the same bytes",
                     per_level_kernel_ms={str(k): round(v, 4) for k, v in k_ms.items()})
 
     # latency of BASELINE config 2: one 640x480 pair, 4 levels
@@ -301,16 +324,17 @@ def main():
         out = {
             "metric": "frame-pair alignments/s (640x480, 4-level pyramid) + finest-level HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "batch of %d independent 640x480 RGB-D frame pairs per GPU (per-GPU shard of BASELINE config 4), "
+            "config": {"workload": "%d pairs (BASELINE config 4): independent 640x480 RGB-D frame pairs, seeds 0..%d, pair i on rank i mod %d, "
                                    "4-level pyramid, FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0; "
-                                   "step = re-ingest one batch of raw planes from HBM (pyramids, sampling planes, point selection) + "
-                                   "coarse-to-fine match_batch of one batch%s" % (
-                                       B, "; build and match run back to back" if args.no_overlap else
-                                       "; the build of batch k+1 (build stream) overlaps the match of batch k, every step does one full build and one full match"),
-                       "pairs_per_gpu": B, "global_pairs_per_step": n_total, "width": W, "height": H,
-                       "parallelism": "independent pairs sharded round-robin over %d GPU(s), one all-gather of 256-B records per step" % world},
+                                   "step = every rank re-ingests the raw planes of its shard from HBM (pyramids, sampling planes, point "
+                                   "selection) and aligns it as one batch%s" % (
+                                       n_total, n_total - 1, world, "; build and match run back to back" if args.no_overlap else
+                                       "; the build of step k+1 (build stream) overlaps the match of step k, every step does one full build and one full match"),
+                       "pairs": n_total, "pairs_per_gpu": B, "width": W, "height": H,
+                       "parallelism": "independent pairs sharded round-robin over %d GPU(s) (fixed total: strong scaling), one all-gather of "
+                                      "256-B records per step" % world},
             "roofline": roofline,
             "match_only_ms_per_batch": round(match_only_ms, 3),
             "single_pair_ms": round(single_pair_ms, 3),
@@ -318,7 +342,7 @@ def main():
             "max_twist_error_vs_truth": twist_err, "nan_results": nan_results,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pairs_np, cfg_kwargs, args.cpu_sample_pairs, args.cpu_reps)
+            out["cpu_baseline"] = cpu_baseline(pairs_np, cfg_kwargs, args.cpu_sample_pairs, args.cpu_matches_per_thread, args.cpu_trials)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -338,27 +362,20 @@ def _rows_per_wave(pairs):
 
 def _pmc_traffic(pairs):
     """HBM bytes per launch of the finest-level kernel from the committed rocprofv3 --pmc passes (profiles/pmc_finest_kernel.json:
-    FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes, see scripts/pmc.sh).  bench.py cannot run the profiler itself; the number is
-    only reported when it was collected for the same batch size, else null."""
+    FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes, see scripts/pmc.sh).  bench.py cannot run the profiler itself.  The
+    number is reported only when it was collected for the same number of pairs per launch AND the record names the very source of
+    the sweep kernel that is compiled now (sha256 of align_mfma.hip + pixel_math.h) -- a stale record reads as null."""
+    import hashlib
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_finest_kernel.json")))
-        return rec["traffic_bytes_per_launch"] if rec["pairs_per_launch"] == pairs else None
+        h = hashlib.sha256()
+        for f in ("align_mfma.hip", "pixel_math.h"):
+            h.update(open(os.path.join(ROOT, "dvo_slam_amd", "csrc", f), "rb").read())
+        if rec.get("kernel_source_sha256") != h.hexdigest() or rec["pairs_per_launch"] != pairs:
+            return None
+        return rec["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
-
-
-def _twist(T):
-    """log of a 4x4 rigid transform as (v, omega) -- small-angle safe closed form, used only for reporting."""
-    R, t = T[:3, :3], T[:3, 3]
-    c = max(-1.0, min(1.0, (np.trace(R) - 1.0) / 2.0))
-    th = np.arccos(c)
-    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2.0
-    w = v * (1.0 + th * th / 6.0 if th < 1e-6 else th / np.sin(th))
-    O = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
-    th2 = float(w @ w)
-    cc = 1.0 / 12.0 if th2 < 1e-10 else (1.0 - np.sqrt(th2) * np.cos(np.sqrt(th2) / 2) / (2 * np.sin(np.sqrt(th2) / 2))) / th2
-    Vinv = np.eye(3) - 0.5 * O + cc * (O @ O)
-    return np.concatenate([Vinv @ t, w])
 
 
 if __name__ == "__main__":

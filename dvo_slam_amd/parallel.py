@@ -5,10 +5,14 @@ calls on a TBB thread pool (dvo_slam/src/keyframe_graph.cpp:576-593, dvo_slam/sr
 One process per GPU; pair i goes to rank i mod G; there is no communication while aligning.  The only exchange
 is one all-gather of fixed-size result records (twist[6] + upper-triangular information[21] + loglik + flags = 32
 doubles = 256 B per pair) per batch -- RCCL over xGMI when the process group's backend is "nccl", latency-bound.
+
+(Inside ONE process the same partitioning needs no collective at all: dvo::DenseTracker::matchBatch of the C++ facade runs
+one sub-batch per device on one host thread each and concatenates -- include/dvo/dense_tracking.h.)
 """
 import numpy as np
 
 RECORD = 32   # doubles per pair
+_IU = np.triu_indices(6)
 
 
 def shard_indices(n_pairs, rank, world_size):
@@ -16,58 +20,96 @@ def shard_indices(n_pairs, rank, world_size):
     return list(range(rank, n_pairs, world_size))
 
 
+def twists_of(T):
+    """log of rigid transforms [n,4,4] as (v, omega) rows [n,6] -- closed form, small-angle safe, vectorised (reporting and
+    the gathered records only; the device has its own se3_log)."""
+    T = np.asarray(T, np.float64).reshape(-1, 4, 4)
+    R, t = T[:, :3, :3], T[:, :3, 3]
+    c = np.clip((np.trace(R, axis1=1, axis2=2) - 1.0) * 0.5, -1.0, 1.0)
+    th = np.arccos(c)
+    axis = 0.5 * np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], axis=1)
+    small = th < 1e-6
+    scale = np.where(small, 1.0 + th * th / 6.0, th / np.where(small, 1.0, np.sin(th)))
+    w = axis * scale[:, None]
+    O = np.zeros((len(T), 3, 3))
+    O[:, 0, 1], O[:, 0, 2], O[:, 1, 0], O[:, 1, 2], O[:, 2, 0], O[:, 2, 1] = -w[:, 2], w[:, 1], w[:, 2], -w[:, 0], -w[:, 1], w[:, 0]
+    th2 = np.einsum("ij,ij->i", w, w)
+    tiny = th2 < 1e-10
+    a = np.sqrt(np.where(tiny, 1.0, th2))
+    cc = np.where(tiny, 1.0 / 12.0, (1.0 - a * np.cos(a / 2) / (2 * np.sin(a / 2))) / np.where(tiny, 1.0, th2))
+    Vinv = np.eye(3)[None] - 0.5 * O + cc[:, None, None] * (O @ O)
+    return np.concatenate([np.einsum("nij,nj->ni", Vinv, t), w], axis=1)
+
+
 def pack_records(twists, informations, logliks, flags=None):
     """-> float64 array [n, RECORD]: twist(6) | information upper triangle(21) | loglik | flag | pad(3)"""
-    n = len(twists)
+    twists = np.asarray(twists, np.float64).reshape(-1, 6)
+    n = twists.shape[0]
     rec = np.zeros((n, RECORD), np.float64)
-    iu = np.triu_indices(6)
-    for i in range(n):
-        rec[i, 0:6] = twists[i]
-        rec[i, 6:27] = np.asarray(informations[i])[iu]
-        rec[i, 27] = logliks[i]
-        rec[i, 28] = 0.0 if flags is None else flags[i]
+    rec[:, 0:6] = twists
+    rec[:, 6:27] = np.asarray(informations, np.float64).reshape(n, 6, 6)[:, _IU[0], _IU[1]]
+    rec[:, 27] = np.asarray(logliks, np.float64).reshape(n)
+    if flags is not None:
+        rec[:, 28] = np.asarray(flags, np.float64).reshape(n)
     return rec
 
 
 def unpack_records(rec):
-    iu = np.triu_indices(6)
-    twists = rec[:, 0:6].copy()
-    infos = np.zeros((rec.shape[0], 6, 6))
-    for i in range(rec.shape[0]):
-        infos[i][iu] = rec[i, 6:27]
-        infos[i] = infos[i] + infos[i].T - np.diag(np.diag(infos[i]))
-    return twists, infos, rec[:, 27].copy(), rec[:, 28].copy()
+    n = rec.shape[0]
+    infos = np.zeros((n, 6, 6))
+    infos[:, _IU[0], _IU[1]] = rec[:, 6:27]
+    infos[:, _IU[1], _IU[0]] = rec[:, 6:27]
+    return rec[:, 0:6].copy(), infos, rec[:, 27].copy(), rec[:, 28].copy()
 
 
 class PendingGather:
-    """An all-gather in flight (gather_records_start); result() waits for it and restores global pair order."""
+    """An all-gather in flight; result() waits for it and restores global pair order."""
 
-    def __init__(self, n_pairs, world_size, work, out, keep):
-        self.n_pairs, self.world_size, self.work, self.out, self.keep = n_pairs, world_size, work, out, keep
+    def __init__(self, gatherer, slot, work):
+        self.gatherer, self.slot, self.work = gatherer, slot, work
 
     def result(self):
+        g = self.gatherer
         if self.work is not None:
             self.work.wait()
-        full = np.zeros((self.n_pairs, RECORD), np.float64)
-        for r in range(self.world_size):
-            idx = shard_indices(self.n_pairs, r, self.world_size)
-            full[idx] = self.out[r][: len(idx)].cpu().numpy()
+        full = np.zeros((g.n_pairs, RECORD), np.float64)
+        for r in range(g.world_size):
+            idx = g.owners[r]
+            full[idx] = g.out[self.slot][r][: len(idx)].cpu().numpy()
         return full
 
 
+class RecordGatherer:
+    """The per-batch all-gather of result records with every tensor allocated ONCE (two slots: the records of batch k travel
+    while batch k+1 is being aligned).  Needs an initialised torch.distributed process group (backend "nccl" = RCCL on the GPUs,
+    "gloo" in CPU tests).  Ranks may own different numbers of pairs: blocks are padded to the largest share."""
+
+    def __init__(self, n_pairs, rank, world_size, device=None):
+        import torch
+        self.n_pairs, self.rank, self.world_size = n_pairs, rank, world_size
+        self.owners = [shard_indices(n_pairs, r, world_size) for r in range(world_size)]
+        per_rank = (n_pairs + world_size - 1) // world_size
+        self.stage = [torch.zeros((per_rank, RECORD), dtype=torch.float64).pin_memory() if device is not None and str(device) != "cpu"
+                      else torch.zeros((per_rank, RECORD), dtype=torch.float64) for _ in range(2)]
+        self.buf = [torch.zeros((per_rank, RECORD), dtype=torch.float64, device=device) for _ in range(2)]
+        self.out = [[torch.empty((per_rank, RECORD), dtype=torch.float64, device=device) for _ in range(world_size)] for _ in range(2)]
+        self.next = 0
+
+    def start(self, local_records):
+        import torch
+        import torch.distributed as dist
+        slot = self.next
+        self.next ^= 1
+        loc = np.ascontiguousarray(local_records, dtype=np.float64).reshape(-1, RECORD)
+        self.stage[slot][: loc.shape[0]] = torch.from_numpy(loc)
+        self.buf[slot].copy_(self.stage[slot], non_blocking=True)
+        work = dist.all_gather(self.out[slot], self.buf[slot], async_op=True)
+        return PendingGather(self, slot, work)
+
+
 def gather_records_start(local_records, n_pairs, rank, world_size, device=None):
-    """Start the all-gather of the per-rank record blocks (asynchronous: the collective of batch k travels while batch k+1
-    is being aligned).  Needs an initialised torch.distributed process group (backend "nccl" = RCCL on the GPUs, "gloo" in
-    CPU tests).  Ranks may own different numbers of pairs (n_pairs need not divide by world_size): blocks are padded."""
-    import torch
-    import torch.distributed as dist
-    per_rank = (n_pairs + world_size - 1) // world_size
-    buf = torch.zeros((per_rank, RECORD), dtype=torch.float64, device=device)
-    loc = torch.from_numpy(np.ascontiguousarray(local_records, dtype=np.float64).reshape(-1, RECORD))
-    buf[: loc.shape[0]] = loc.to(buf.device)
-    out = [torch.empty_like(buf) for _ in range(world_size)]
-    work = dist.all_gather(out, buf, async_op=True)
-    return PendingGather(n_pairs, world_size, work, out, (buf, loc))
+    """One-off form of RecordGatherer.start (allocates its buffers)."""
+    return RecordGatherer(n_pairs, rank, world_size, device).start(local_records)
 
 
 def gather_records(local_records, n_pairs, rank, world_size, device=None):

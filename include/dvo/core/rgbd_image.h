@@ -57,10 +57,17 @@ class DeviceContext {
     return r[size_t(device)];
   }
   static int deviceCount() { return dvo_hip_device_count(); }
-  // binds the calling thread to a device for the lifetime of the object
+  // a further, independent context on `device` (own streams and workspace), owned by the caller: dvo_hip_context_destroy
+  static dvo_hip_context* createAdditional(int device) {
+    dvo_hip_context* c = 0;
+    if (dvo_hip_context_create(device, &c) != DVO_HIP_OK) fail("dvo_hip_context_create", dvo_hip_last_error(0));
+    return c;
+  }
+  // binds the calling thread to a device (or to one particular context) for the lifetime of the object
   class Scope {
    public:
     explicit Scope(int device) : previous_(slot()) { slot() = forDevice(device); }
+    explicit Scope(dvo_hip_context* context) : previous_(slot()) { slot() = context; }
     ~Scope() { slot() = previous_; }
 
    private:

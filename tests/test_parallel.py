@@ -22,6 +22,14 @@ def test_shard_and_records_roundtrip():
     assert np.array_equal(par.gather_records(par.pack_records(tw, info, ll), 5, 0, 1), par.pack_records(tw, info, ll))
 
 
+def test_vectorised_twists_match_the_oracle_log():
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.normal(scale=0.3, size=(40, 6)), rng.normal(scale=1e-9, size=(4, 6)), np.zeros((1, 6))])
+    Ts = np.stack([po.se3_exp(x) for x in xs])
+    assert np.abs(par.twists_of(Ts) - xs).max() < 1e-12
+
+
 def _worker(rank, world, port, n_pairs, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -32,10 +40,13 @@ def _worker(rank, world, port, n_pairs, q):
     info = np.array([np.eye(6) * (i + 1) for i in idx]).reshape(-1, 6, 6)
     rec = par.pack_records(tw, info, [float(i) for i in idx], [rank] * len(idx))
     full = par.gather_records(rec, n_pairs, rank, world)
-    # the pipelined form bench.py uses: the gather of batch k is collected after batch k+1 has been started
-    first = par.gather_records_start(rec, n_pairs, rank, world)
-    second = par.gather_records_start(rec * 2.0, n_pairs, rank, world)
+    # the pipelined form bench.py uses: buffers allocated once, the gather of batch k collected after batch k+1 has been started
+    g = par.RecordGatherer(n_pairs, rank, world)
+    first = g.start(rec)
+    second = g.start(rec * 2.0)
     assert np.array_equal(first.result(), full) and np.array_equal(second.result(), full * 2.0)
+    third = g.start(rec * 3.0)                       # the first slot again
+    assert np.array_equal(third.result(), full * 3.0)
     dist.barrier()
     q.put((rank, full))
     dist.destroy_process_group()
@@ -62,3 +73,45 @@ def test_gather_world_size_2_gloo():
         assert np.allclose(tw[i], [i + 0.1 * k for k in range(6)])
         assert np.allclose(info[i], np.eye(6) * (i + 1))
         assert ll[i] == i and flag[i] == i % 2
+
+
+# ---- GPU tier: real device records through the N > 1 path -----------------------------------------------------------
+import json      # noqa: E402
+import subprocess  # noqa: E402
+import sys       # noqa: E402
+
+import pytest    # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.gpu
+def test_two_ranks_gather_the_records_of_one_rank(tmp_path):
+    """bench.py's N > 1 path with REAL alignments: two processes (sharing GPU 0, gloo -- the box has one GPU; on an 8-GPU node the
+    same code runs one rank per GPU over RCCL) align pair i on rank i mod 2 and all-gather the records; the gathered set equals
+    the records of a single process that aligns all pairs, bit for bit (tile height pinned)."""
+    common = ["--pairs", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-from-host", "--rows-per-wave", "8"]
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--records-out", one] + common,
+                       capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
+                        "--records-out", two] + common, capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    ja = json.loads([l for l in a.stdout.splitlines() if l.startswith("{")][-1])
+    jb = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
+    assert ja["n_gpus"] == 1 and jb["n_gpus"] == 2 and ja["scaling"] == jb["scaling"] == "strong"
+    assert ja["config"]["pairs"] == jb["config"]["pairs"] == 12 and jb["config"]["pairs_per_gpu"] == 6
+    ra, rb = np.load(one), np.load(two)
+    assert ra.shape == rb.shape == (12, par.RECORD)
+    assert np.array_equal(ra, rb)
+    assert ja["nan_results"] == 0 and ja["max_twist_error_vs_truth"] < 1e-4
