@@ -22,6 +22,31 @@
 namespace dvo_hip {
 
 typedef float __attribute__((ext_vector_type(4))) f32x4;
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+
+// The eight bilinear taps through buffer loads: the plane is a raw buffer resource held in scalar registers, a tap's address is
+// ONE 32-bit vector offset (tap (u0, v0)) plus a scalar row offset plus an immediate -- instead of a 64-bit vector address per
+// tap -- and the two depth-gradient taps of a row, adjacent in memory, travel as one 16-byte load.  Reads past the plane's end
+// return zero.
+struct TapPlanes {
+  __amdgpu_buffer_rsrc_t A, B;
+  int rowA, rowB;                                   // bytes per image row
+  __device__ __forceinline__ void fetch(int base, PixelTaps& t) const {
+    const int oa = base * 16, ob = base * 8;
+    const f32x4 a00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa, 0, 0));
+    const f32x4 a10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa + 16, 0, 0));
+    const f32x4 a01 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa, rowA, 0));
+    const f32x4 a11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa + 16, rowA, 0));
+    const f32x2 b00 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob, 0, 0));
+    const f32x2 b10 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob + 8, 0, 0));
+    const f32x2 b01 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob, rowB, 0));
+    const f32x2 b11 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob + 8, rowB, 0));
+    t.A00 = make_float4(a00.x, a00.y, a00.z, a00.w); t.A10 = make_float4(a10.x, a10.y, a10.z, a10.w);
+    t.A01 = make_float4(a01.x, a01.y, a01.z, a01.w); t.A11 = make_float4(a11.x, a11.y, a11.z, a11.w);
+    t.B00 = make_float2(b00.x, b00.y); t.B10 = make_float2(b10.x, b10.y);
+    t.B01 = make_float2(b01.x, b01.y); t.B11 = make_float2(b11.x, b11.y);
+  }
+};
 
 constexpr int kQuadStride = 264;                 // floats per component quad: 64 pixels x 4 + 8 skew (bank-conflict-free reads)
 constexpr int kSlabFloats = 4 * kQuadStride;     // per-wavefront LDS slab (4224 B)
@@ -59,8 +84,12 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
 #pragma unroll
   for (int i = 0; i < 4; ++i) Pp[i] = st.P_prev[i];
   const bool first = st.first != 0;
-  const GlobalLoad4 refR{(GlobalVec4)pp.refR}, curA{(GlobalVec4)pp.curA};
-  const GlobalLoad2 curB{(GlobalVec2)pp.curB};
+  const GlobalLoad4 refR{(GlobalVec4)pp.refR};
+  TapPlanes taps;
+  taps.A = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(pp.curA), 0, g.w * g.h * 16, 0x00020000);
+  taps.B = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.curB), 0, g.w * g.h * 8, 0x00020000);
+  taps.rowA = g.w * 16;
+  taps.rowB = g.w * 8;
 
   // the wavefront index is uniform: keeping it (and every row index derived from it) in scalar registers moves the row
   // bounds test, the row offsets and the ty table load from the vector ALU to the scalar unit
@@ -130,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     }
     const PixelProj p = pixel_project_flat(g, KT, in_image ? ref.x : nanv, tx_p, ty_p);
     PixelTaps t;
-    if (p.ok) pixel_fetch(g, curA, curB, p, t);               // lanes without a usable projection are masked out of `valid`
+    if (p.ok) taps.fetch(p.base, t);                          // lanes without a usable projection are masked out of `valid`
     PixelTerms o;
     const bool valid = pixel_finish_flat(g, ref, p, t, o) && p.ok;
     n_valid += __popcll(__ballot(valid));                     // exact count on the scalar unit
