@@ -40,7 +40,8 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce(
   if (!st.active) return;                            // wave-uniform: pair finished on this level
   const PairPtrs pp = pairs[pair];
   // pointers loaded from memory are generic; tell the compiler they are global so it emits global_load
-  const GlobalLoad4 refR{(GlobalVec4)pp.refR}, curA{(GlobalVec4)pp.curA};
+  const GlobalLoad2 refR{(GlobalVec2)pp.refR};
+  const GlobalLoad4 curA{(GlobalVec4)pp.curA};
   const GlobalLoad2 curB{(GlobalVec2)pp.curB};
 
   float KT[12], Pp[4];
@@ -64,7 +65,15 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce(
   // 64 lanes x 16 B = 1 KiB contiguous per wave; rows beyond the image read as "not selected"
   auto load_ref = [&](int k) -> float4 {
     const int v_r = row0 + k;
-    if (k < RPW && col_ok && v_r < g.h) return refR[v_r * g.w + u_r];
+    if (k < RPW && col_ok && v_r < g.h) {
+      // the reference plane holds {Zsel, I}; the intensity gradient is the clamped central difference of the frame build
+      // (pyramid_kernels.hip::derive_at), recomputed here from the four neighbours
+      const int at = v_r * g.w + u_r;
+      const float2 zi = refR[at];
+      const float left = refR[at - (u_r > 0 ? 1 : 0)].y, right = refR[at + (u_r < g.w - 1 ? 1 : 0)].y;
+      const float up = refR[at - (v_r > 0 ? g.w : 0)].y, down = refR[at + (v_r < g.h - 1 ? g.w : 0)].y;
+      return make_float4(zi.x, zi.y, (right - left) * 0.5f, (down - up) * 0.5f);
+    }
     return make_float4(nanv, 0.0f, 0.0f, 0.0f);
   };
   // blend, test, store the residual pair for the log-likelihood sweep, weight and accumulate
@@ -153,7 +162,7 @@ void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool 
   }
 }
 
-// The sweep's bytes without the sweep: every pixel's reference quad, current-frame quad and gradient pair are read in
+// The sweep's bytes without the sweep: every pixel's reference pair, current-frame quad and gradient pair are read in
 // pixel order and an 8-byte pair is written where the sweep writes its residuals.  No gather, no arithmetic, no reduction:
 // the time of this kernel is what the memory system needs for the sweep's algorithmic traffic (dvo_hip_time_stream_mix).
 // WRITE = false: the read side alone (what the default sweep moves since it keeps the residual pairs in registers).
@@ -163,10 +172,11 @@ __global__ __launch_bounds__(kBlock) void k_stream_mix(const PairPtrs* __restric
   float2* out = scratch + size_t(blockIdx.y) * n_px;
   float fold = 0.0f;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_px; i += gridDim.x * kBlock) {
-    const float4 r = pp.refR[i], a = pp.curA[i];
+    const float2 r = pp.refR[i];
+    const float4 a = pp.curA[i];
     const float2 b = pp.curB[i];
-    if constexpr (WRITE) out[i] = make_float2(r.x + a.y + b.x, r.w + a.z + b.y);
-    else fold += (r.x + a.y + b.x) + (r.w + a.z + b.y) + (r.y + r.z) + (a.x + a.w);
+    if constexpr (WRITE) out[i] = make_float2(r.x + a.y + b.x, r.y + a.z + b.y);
+    else fold += (r.x + a.y + b.x) + (r.y + a.z + b.y) + (a.x + a.w);
   }
   if constexpr (!WRITE) {
     // keep the loads alive with one store per workgroup

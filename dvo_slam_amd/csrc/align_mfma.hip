@@ -48,6 +48,15 @@ struct TapPlanes {
   }
 };
 
+// One row of the reference plane for a wavefront: the {Zsel, I} pair of every lane's pixel (64 lanes x 8 B = 512 B contiguous)
+// and the three intensities the central differences need from outside the wavefront's row: the pixels above and below (clamped
+// at the image border like the reference's derivative code, rgbd_image.cpp:419-489) and, in lanes 0 / 63, the pixel left / right
+// of the row segment.  The horizontal neighbours of the other lanes come from the adjacent lanes (DPP wave shift).
+// (Linear walk of a level narrower than a tile: all four neighbours are loaded, a segment wraps around image rows.)
+struct RefRow {
+  float z, i, up, down, left_or_edge, right;      // tiled: left_or_edge = the edge pixel (lanes 0 and 63 only), right unused
+};
+
 constexpr int kQuadStride = 264;                 // floats per component quad: 64 pixels x 4 + 8 skew (bank-conflict-free reads)
 constexpr int kSlabFloats = 4 * kQuadStride;     // per-wavefront LDS slab (4224 B)
 
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
 #pragma unroll
   for (int i = 0; i < 4; ++i) Pp[i] = st.P_prev[i];
   const bool first = st.first != 0;
-  const GlobalLoad4 refR{(GlobalVec4)pp.refR};
+  const __amdgpu_buffer_rsrc_t refR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.refR), 0, g.w * g.h * 8, 0x00020000);
   TapPlanes taps;
   taps.A = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(pp.curA), 0, g.w * g.h * 16, 0x00020000);
   taps.B = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.curB), 0, g.w * g.h * 8, 0x00020000);
@@ -130,11 +139,51 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   // pipelined over rows (taps of row k+1 in flight during the second half of row k): 104 registers, 4 waves per SIMD, +10 %.)
   const float P00 = Pp[0], P11 = Pp[3];
   const int u_c = LINEAR ? lane : min(u_r, g.w - 1);
+  auto load_f = [&](int pixel) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(refR, pixel * 8 + 4, 0, 0)); };
   auto load_ref = [&](int v_r) {                              // clamped: rows / segments past the end are masked by in_image
-    const int idx = LINEAR ? min(v_r * kTileW + lane, n_px - 1) : min(v_r, g.h - 1) * g.w + u_c;
-    return refR[idx];                                         // tiled: 64 lanes x 16 B = 1 KiB contiguous per wave
+    RefRow r;
+    if constexpr (LINEAR) {
+      const int idx = min(v_r * kTileW + lane, n_px - 1);
+      int row = int(float(idx) * inv_w);                      // idx < 2^24: one float multiply lands within one row of the quotient
+      int col = idx - row * g.w;
+      if (col < 0) { col += g.w; row -= 1; }
+      if (col >= g.w) { col -= g.w; row += 1; }
+      const f32x2 zi = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(refR, idx * 8, 0, 0));
+      r.z = zi.x; r.i = zi.y;
+      r.left_or_edge = load_f(idx - (col > 0 ? 1 : 0));
+      r.right = load_f(idx + (col < g.w - 1 ? 1 : 0));
+      r.up = load_f(idx - (row > 0 ? g.w : 0));
+      r.down = load_f(idx + (row < g.h - 1 ? g.w : 0));
+    } else {
+      const int v = min(v_r, g.h - 1);
+      const int idx = v * g.w + u_c;
+      const f32x2 zi = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(refR, idx * 8, 0, 0));   // 512 B contiguous per wave
+      r.z = zi.x; r.i = zi.y;
+      r.up = load_f(idx - (v > 0 ? g.w : 0));
+      r.down = load_f(idx + (v < g.h - 1 ? g.w : 0));
+      r.left_or_edge = 0.0f;
+      r.right = 0.0f;
+      if (lane == 0) r.left_or_edge = load_f(idx - (u_c > 0 ? 1 : 0));
+      if (lane == 63) r.left_or_edge = load_f(idx + (u_c < g.w - 1 ? 1 : 0));
+    }
+    return r;
   };
-  auto sweep_row = [&](int v_r, const float4 ref) __attribute__((always_inline)) {
+  // the reference quad {Zsel, I, Idx, Idy} the per-pixel stages work on: the gradient is the reference's central difference
+  // 0.5 (next - previous), same operation order as the frame build (pyramid_kernels.hip::derive_at), hence the same bits
+  auto ref_quad = [&](const RefRow& r) {
+    float left, right;
+    if constexpr (LINEAR) {
+      left = r.left_or_edge;
+      right = r.right;
+    } else {
+      const int ic = __builtin_bit_cast(int, r.i), ie = __builtin_bit_cast(int, r.left_or_edge);
+      right = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ie, ic, 0x130, 0xf, 0xf, false));   // wave_shl:1 -- lane l <- lane l + 1; lane 63 keeps the edge
+      left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ie, ic, 0x138, 0xf, 0xf, false));    // wave_shr:1 -- lane l <- lane l - 1; lane 0 keeps the edge
+    }
+    return make_float4(r.z, r.i, (right - left) * 0.5f, (r.down - r.up) * 0.5f);
+  };
+  auto sweep_row = [&](int v_r, const RefRow& ref_row) __attribute__((always_inline)) {
+    const float4 ref = ref_quad(ref_row);
     bool in_image;
     size_t pix;                                               // index of this lane's pixel in the level
     float tx_p, ty_p, cx;
@@ -197,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
-  float4 ref_a = load_ref(row0), ref_b = ref_a;
+  RefRow ref_a = load_ref(row0), ref_b = ref_a;
 #pragma unroll 1
   for (int k = 0; k < RPW; k += 2) {
     const int v_r = row0 + k * kWavesPerBlock;                // scalar: image row (tiled) or segment (linear)

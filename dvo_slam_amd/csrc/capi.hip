@@ -60,7 +60,7 @@ struct FrameLevel {
   float* Z = nullptr;
   float4* A = nullptr;
   float2* B = nullptr;
-  float4* R = nullptr;
+  float2* R = nullptr;
   bool has_current = false;    // A, B built (current-frame role)
   bool selected = false;       // R / count built for (ithr, dthr) (reference role)
   float ithr = 0, dthr = 0;
@@ -396,7 +396,7 @@ int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels
   size_t offs[kMaxLevels][5];
   for (int l = 0; l < levels; ++l) {
     const size_t n = size_t(cam->w[l]) * cam->h[l];
-    const size_t sz[5] = {n * 4, n * 4, n * 16, n * 8, n * 16};
+    const size_t sz[5] = {n * 4, n * 4, n * 16, n * 8, n * 8};
     for (int k = 0; k < 5; ++k) {
       offs[l][k] = total;
       total += align_up(sz[k], 256);
@@ -418,7 +418,7 @@ int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels
     L.Z = reinterpret_cast<float*>(base + offs[l][1]);
     L.A = reinterpret_cast<float4*>(base + offs[l][2]);
     L.B = reinterpret_cast<float2*>(base + offs[l][3]);
-    L.R = reinterpret_cast<float4*>(base + offs[l][4]);
+    L.R = reinterpret_cast<float2*>(base + offs[l][4]);
   }
   f->sel_count = reinterpret_cast<int*>(base + cnt_off);
   *out = f;

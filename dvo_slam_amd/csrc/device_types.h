@@ -43,7 +43,8 @@ struct LevelGeom {                    // identical for every pair of a batch (on
 };
 
 struct PairPtrs {                     // device planes of one pair at one level
-  const float4* refR;                 // {Z (NaN = not selected), I, Idx, Idy}   16 B / pixel, streamed
+  const float2* refR;                 // {Z (NaN = not selected), I}              8 B / pixel, streamed; the intensity gradient
+                                      // the Jacobian needs is the central difference of I, recomputed from the neighbours
   const float4* curA;                 // {I, Z, Idx, Idy}                        16 B / pixel, gathered
   const float2* curB;                 // {Zdx, Zdy}                               8 B / pixel, gathered
   const int* n_selected;              // device counter: selected reference pixels at this level
@@ -58,7 +59,7 @@ struct FrameBuildPtrs {                // one frame of a batched pyramid build
   float* Z[kMaxLevels];
   float4* A[kMaxLevels];
   float2* B[kMaxLevels];
-  float4* R[kMaxLevels];
+  float2* R[kMaxLevels];
   int* sel_count;                      // one counter per level
 };
 

@@ -17,7 +17,7 @@ void launch_build_from_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frame
 void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int max_workgroups);
 void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr,
                              int max_workgroups);
-void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float4* R, int* count, uint8_t* mask);
+void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float2* R, int* count, uint8_t* mask);
 void launch_unpack_plane(hipStream_t s, const float4* A, const float2* B, int n, int plane, float* out);
 
 // align_kernels.hip / align_mfma.hip

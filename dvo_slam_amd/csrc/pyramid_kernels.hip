@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
             f.B[0][at] = make_float2(zdx, zdy);
           } else {
             ok = z0 == z0 && zdx == zdx && zdy == zdy && (fabsf(idx) > ithr || fabsf(idy) > ithr || fabsf(zdx) > dthr || fabsf(zdy) > dthr);
-            f.R[0][at] = make_float4(ok ? z0 : nanv, i0, idx, idy);
+            f.R[0][at] = make_float2(ok ? z0 : nanv, i0);
           }
         }
         if (ROLE == 1) count += __popcll(__ballot(ok));         // wave-uniform
@@ -250,7 +250,7 @@ __global__ void k_derive_reference(const FrameBuildPtrs* __restrict__ tbl, int l
         const Derivs d = derive_at(f.I[level], f.Z[level], w, h, x, y);
         ok = d.z0 == d.z0 && d.zdx == d.zdx && d.zdy == d.zdy &&
              (fabsf(d.idx) > ithr || fabsf(d.idy) > ithr || fabsf(d.zdx) > dthr || fabsf(d.zdy) > dthr);
-        f.R[level][size_t(y) * w + x] = make_float4(ok ? d.z0 : __builtin_nanf(""), d.i0, d.idx, d.idy);
+        f.R[level][size_t(y) * w + x] = make_float2(ok ? d.z0 : __builtin_nanf(""), d.i0);
       }
       count += __popcll(__ballot(ok));      // wave-uniform
     }
@@ -271,7 +271,7 @@ __global__ void k_zero_counts(const FrameBuildPtrs* __restrict__ tbl, int n_fram
 
 // re-selection with other thresholds (PointSelection with a different predicate), one frame
 __global__ void k_select_pack(const float4* __restrict__ A, const float2* __restrict__ B, int n, float ithr, float dthr,
-                              float4* __restrict__ R, int* __restrict__ count, uint8_t* __restrict__ mask) {
+                              float2* __restrict__ R, int* __restrict__ count, uint8_t* __restrict__ mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
   if (i < n) {
@@ -279,7 +279,7 @@ __global__ void k_select_pack(const float4* __restrict__ A, const float2* __rest
     const float2 b = B[i];
     ok = a.y == a.y && b.x == b.x && b.y == b.y &&
          (fabsf(a.z) > ithr || fabsf(a.w) > ithr || fabsf(b.x) > dthr || fabsf(b.y) > dthr);
-    R[i] = make_float4(ok ? a.y : __builtin_nanf(""), a.x, a.z, a.w);
+    R[i] = make_float2(ok ? a.y : __builtin_nanf(""), a.x);
     if (mask) mask[i] = ok ? 1 : 0;
   }
   const unsigned long long ballot = __ballot(ok);
@@ -339,7 +339,7 @@ void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_fra
   k_derive_reference<<<dim3(capped_grid(tx, ty, n_frames, max_workgroups)), dim3(64, 4), 0, s>>>(tbl, level, w, h, ithr, dthr, tx, ty, n_frames);
 }
 
-void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float4* R, int* count, uint8_t* mask) {
+void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float2* R, int* count, uint8_t* mask) {
   k_select_pack<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(A, B, n, ithr, dthr, R, count, mask);
 }
 

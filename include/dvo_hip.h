@@ -240,7 +240,7 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs,
                                  dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
                                  int level, int warm_iterations, int reps, float* avg_ms);
 
-/* The yardstick for that number: a kernel that only streams the same planes of the same pairs in pixel order (16 + 16 + 8 B
+/* The yardstick for that number: a kernel that only streams the same planes of the same pairs in pixel order (8 + 16 + 8 B
  * read per pixel; with_write != 0: plus the 8 B per pixel the sweep writes for the log-likelihood pass) -- no gather, no
  * arithmetic, no reduction.  What the memory system needs for the sweep's algorithmic traffic on this part. */
 int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
