@@ -4,6 +4,7 @@
 // The host never touches pixels or poses: it uploads two raw planes per frame, enqueues kernels on the
 // context's HIP stream and polls one integer ("pairs still iterating") every few iterations.
 #include <hip/hip_runtime.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <algorithm>
 #include <cmath>
@@ -198,6 +199,15 @@ struct dvo_hip_context {
 };
 
 namespace {
+
+// roctx ranges with the phase names of the reference's own (commented-out) stopwatches inside match()
+// (dvo_core/src/dense_tracking.cpp:154-158, 222, 246, 309, 325, 349): "prep" = per-level set-up, "err" = passes 1-4 (the sweep and
+// the log-likelihood pass), "linsys" = pass 5 + solve (the solver step); plus "build" for the frame construction.  They bracket
+// the ENQUEUE of a phase on the host (rocprofv3 --marker-trace shows them next to the kernel trace); free when no tool listens.
+struct Range {
+  explicit Range(const char* name) { roctxRangePushA(name); }
+  ~Range() { roctxRangePop(); }
+};
 
 #define DVO_HIP_TRY(ctx, expr)                                                                   \
   do {                                                                                            \
@@ -449,6 +459,7 @@ bool aligned_to(const void* p, size_t a) { return reinterpret_cast<uintptr_t>(p)
 // thresholds) and leaves a copy of the raw planes in the frame unless the current-role planes make it redundant.
 int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, const void* const* grey, const void* const* raw,
                  float depth_scale, int role = -1, float ithr = 0.0f, float dthr = 0.0f) {
+  Range range("build");
   const CameraGeom* cam = frames[0]->cam;
   const int levels = frames[0]->levels;
   std::vector<FrameBuildPtrs> host(n);
@@ -645,6 +656,7 @@ void make_plan(const dvo_hip_context* ctx, const CameraGeom* cam, const dvo_hip_
 // buildAccelerationStructure for the current frames, PointSelection::select for the reference frames (both cached per
 // frame and level); enqueued on the context's main stream
 int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg) {
+  Range range("build");
   int rc = wait_for_build(ctx, n, refs);
   if (rc == DVO_HIP_OK) rc = wait_for_build(ctx, n, curs);
   if (rc != DVO_HIP_OK) return rc;
@@ -760,7 +772,13 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   for (int level = cfg->first_level; level >= cfg->last_level; --level) {
     const LevelGeom& g = bp.geom[level];
     const PairPtrs* pp = bp.pair_ptrs + size_t(level) * n;
-    launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);
+    static const char* const kPrep[kMaxLevels] = {"prep L0", "prep L1", "prep L2", "prep L3", "prep L4", "prep L5", "prep L6", "prep L7"};
+    static const char* const kErr[kMaxLevels] = {"err L0", "err L1", "err L2", "err L3", "err L4", "err L5", "err L6", "err L7"};
+    static const char* const kLinsys[kMaxLevels] = {"linsys L0", "linsys L1", "linsys L2", "linsys L3", "linsys L4", "linsys L5", "linsys L6", "linsys L7"};
+    {
+      Range range(kPrep[level]);
+      launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);
+    }
     // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
     // (measured, scripts/ab_match.py fused_ll_pixels: 128 pairs 2.152 -> 2.117 ms with level 1 fused; 16 pairs 0.756 -> 0.799, one
     // pair 0.524 -> 0.547: a lone workgroup per pair is slower than 32 blocks when the chip is empty)
@@ -771,8 +789,12 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // end of the level are no-ops (workgroups exit on !active).
     auto enqueue_chunk = [&](int count) {
       for (int c = 0; c < count; ++c, ++step) {
-        launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch);
-        if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, kLlBlocksPerPair);
+        {
+          Range range(kErr[level]);
+          launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch);
+          if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, kLlBlocksPerPair);
+        }
+        Range range(kLinsys[level]);
         launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, kLlBlocksPerPair, fused_ll ? scratch : nullptr, d_levels, d_iters,
                            tallies + step, w.host_status + step);
       }

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/pmc
 cd /tmp
-run() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc/$name -o $name -- python $R/scripts/kernel_driver.py 128 0 5 > $R/gpurun_out/pmc/$name.log 2>&1; echo "$name rc=$?"; }
+run() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc/$name -o $name -- python $R/scripts/kernel_driver.py ${PMC_PAIRS:-1024} 0 3 > $R/gpurun_out/pmc/$name.log 2>&1; echo "$name rc=$?"; }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE
 run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS
 run fetch FETCH_SIZE
@@ -33,10 +33,15 @@ for f in glob.glob('gpurun_out/pmc/*/*counter_collection.csv'):
     for c, v in per.items():
         big = [x for x in v if x > 0.5 * max(v)]
         vals[c] = sum(big) / len(big)
+import hashlib, os
+h = hashlib.sha256()
+for f in ("align_mfma.hip", "pixel_math.h"):
+    h.update(open(os.path.join("dvo_slam_amd", "csrc", f), "rb").read())
+pairs = int(os.environ.get("PMC_PAIRS", "1024"))
 if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
-    rec = dict(pairs_per_launch=128, level=0, fetch_size_kb=vals['FETCH_SIZE'], write_size_kb=vals['WRITE_SIZE'],
+    rec = dict(pairs_per_launch=pairs, level=0, kernel_source_sha256=h.hexdigest(), fetch_size_kb=vals['FETCH_SIZE'], write_size_kb=vals['WRITE_SIZE'],
                fetch_correction=2.0, traffic_bytes_per_launch=(2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0,
-               algorithmic_bytes_per_launch=40.0 * 640 * 480 * 128,
+               algorithmic_bytes_per_launch=40.0 * 640 * 480 * pairs,
                note="rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (scripts/pmc.sh); FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)")
     json.dump(rec, open('gpurun_out/pmc/pmc_finest_kernel.json', 'w'), indent=1)
     print(rec)

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/pmc2
 cd /tmp
-run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc2/$name -o $name -- python $R/scripts/kernel_driver.py 128 0 5 > $R/gpurun_out/pmc2/$name.log 2>&1; echo "$name rc=$?"; tail -2 $R/gpurun_out/pmc2/$name.log | cut -c1-300; }
+run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc2/$name -o $name -- python $R/scripts/kernel_driver.py ${PMC_PAIRS:-128} 0 3 > $R/gpurun_out/pmc2/$name.log 2>&1; echo "$name rc=$?"; tail -2 $R/gpurun_out/pmc2/$name.log | cut -c1-300; }
 run a GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY
 run b SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_LDS
 run c TA_TA_BUSY_sum TA_BUSY_avr TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_TOTAL_CACHE_ACCESSES_sum
