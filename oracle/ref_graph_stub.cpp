@@ -35,7 +35,9 @@ cv::Mat KeyframeGraph::computeIntensityErrorImage(int, bool) const { std::abort(
 void KeyframeGraph::debugLoopClosureConstraint(int, int) const { std::abort(); }
 
 namespace visualization {
-void GraphVisualizer::setGraph(KeyframeGraph*) { std::abort(); }   // only reached with a visualizer, the bridge passes none
-void GraphVisualizer::update() { std::abort(); }
+// (no-ops that do not touch `this`: benchmark_slam.cpp hands KeyframeTracker an UNINITIALISED GraphVisualizer* when no
+// visualisation is configured, dvo_benchmark/src/benchmark_slam.cpp:358, 407 -- reference behaviour, left alone)
+void GraphVisualizer::setGraph(KeyframeGraph*) {}
+void GraphVisualizer::update() {}
 }  // namespace visualization
 }  // namespace dvo_slam

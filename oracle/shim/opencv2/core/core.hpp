@@ -101,7 +101,21 @@ class Mat {
   Mat mul(const Mat&) const { std::abort(); }
   template <typename V> void setTo(const V&, const Mat& = Mat()) { std::abort(); }
   void copyTo(Mat&) const { std::abort(); }
-  template <typename V> void convertTo(Mat&, V, double = 1, double = 0) const { std::abort(); }
+  // element-wise conversion between the depths the reference's loaders use (u8 / u16 / f32 sources to f32), any channel count
+  void convertTo(Mat& dst, int rtype, double alpha = 1, double beta = 0) const {
+    const int cn = channels(), ddepth = rtype & 7;
+    if (ddepth != CV_32F) std::abort();
+    Mat out(rows, cols, CV_MAKETYPE(CV_32F, cn));
+    const size_t n = size_t(rows) * cols * cn;
+    float* o = reinterpret_cast<float*>(out.data);
+    switch (type_ & 7) {
+      case CV_8U: for (size_t i = 0; i < n; ++i) o[i] = float(double(data[i]) * alpha + beta); break;
+      case CV_16U: for (size_t i = 0; i < n; ++i) o[i] = float(double(reinterpret_cast<const unsigned short*>(data)[i]) * alpha + beta); break;
+      case CV_32F: for (size_t i = 0; i < n; ++i) o[i] = float(double(reinterpret_cast<const float*>(data)[i]) * alpha + beta); break;
+      default: std::abort();
+    }
+    dst = out;
+  }
   Mat clone() const { Mat m(rows, cols, type_); if (data) std::memcpy(m.data, data, step * size_t(rows)); return m; }
  protected:
   int type_;
