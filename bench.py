@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="build each batch right before its match on one frame set (no build/match overlap)")
     ap.add_argument("--no-from-host", action="store_true", help="skip the PCIe-inclusive leg (raw planes handed over in pinned host memory)")
     ap.add_argument("--rows-per-wave", type=int, default=0)
+    ap.add_argument("--resident-group", type=int, default=0, help="workgroups per pair in the resident match kernel (0 = as many as fit); "
+                    "with --rows-per-wave: records that do not depend on the batch size")
     ap.add_argument("--iters-per-sync", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses GPU 0 (with --backend gloo)")
@@ -157,6 +159,8 @@ def main():
     ctx = d.Context(local_rank)
     if args.rows_per_wave:
         ctx.set_option("rows_per_wave", args.rows_per_wave)
+    if args.resident_group:
+        ctx.set_option("resident_group", args.resident_group)
     if args.iters_per_sync:
         ctx.set_option("iters_per_sync", args.iters_per_sync)
     if not args.no_overlap:

@@ -64,7 +64,7 @@ EXPORTS = [
     "dvo_hip_frame_update_raw_device", "dvo_hip_frames_update_raw_device", "dvo_hip_frames_update_raw", "dvo_hip_frames_update_raw_device_as", "dvo_hip_frames_update_raw_as", "dvo_hip_upload_wait",
     "dvo_hip_host_alloc", "dvo_hip_host_free", "dvo_hip_frames_prepare", "dvo_hip_frame_destroy", "dvo_hip_frame_info", "dvo_hip_frame_download_plane", "dvo_hip_frame_select",
     "dvo_hip_match", "dvo_hip_match_batch", "dvo_hip_level_iteration", "dvo_hip_time_residual_kernel", "dvo_hip_time_stream_mix",
-    "dvo_hip_set_option", "dvo_hip_version",
+    "dvo_hip_set_option", "dvo_hip_get_counter", "dvo_hip_version",
 ]
 
 
@@ -127,6 +127,7 @@ def lib():
     L.dvo_hip_time_residual_kernel.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, fp]
     L.dvo_hip_time_stream_mix.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, fp]
     L.dvo_hip_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.dvo_hip_get_counter.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
     L.dvo_hip_version.restype = C.c_char_p
     _lib = L
     return L

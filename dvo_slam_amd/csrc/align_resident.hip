@@ -1,0 +1,551 @@
+// align_resident.hip -- a whole coarse-to-fine alignment (or its coarse levels) in ONE launch: the latency path.
+//
+// The multi-launch path (capi.hip::run_batch) spends one to three launches per Gauss-Newton iteration; for a lone pair, or the two
+// pairs LocalTracker aligns per frame (dvo_slam/src/local_tracker.cpp:180-184), nearly all of a match is launch floor (5 us per
+// dependent launch on this queue) and memory round trips of a few-microsecond kernels (profiles/r01_v_single_pair_timeline.txt:
+// 64 launches, 0.5 ms).  Here a pair is owned by a GROUP of G resident workgroups of 8 wavefronts for the whole match:
+//
+//   per iteration   every wavefront of the group sweeps its 64-pixel segments of the level (same per-pixel arithmetic and the
+//                   same Gram accumulation on the matrix cores as align_mfma.hip; residual pairs go to the pair's scratch and are
+//                   read back by the SAME wavefront only), the workgroup folds its wavefronts into one canonical partial row,
+//     exchange A    the G rows travel between the workgroups of the group (below); every workgroup adds them in the same order in
+//                   float64 and derives the same scale / precision P (dense_tracking.cpp:295),
+//     exchange B    every workgroup sums log(1 + 0.2 r^T P r) over ITS residuals; the G partial sums travel the same way,
+//     solver        lane 0 of EVERY workgroup runs the reference's loop body (solver_logic.h::gn_step: accept / revert, 6x6 solve,
+//                   SE(3) update, termination) on its own LDS copy of the pair's state -- redundantly and deterministically, so the
+//                   group needs no third exchange and no broadcast of the new pose; workgroup 0 writes the iteration record.
+//   levels          follow each other inside the kernel (gn_level_begin); the host is not involved until the launch ends.
+//
+// The exchange is the "LL" protocol of collective libraries: a row is 8-byte slots {value, sequence number}, written with relaxed
+// agent-scope stores and polled with relaxed agent-scope loads (sc1: through the non-coherent per-XCD L2s).  An aligned 8-byte
+// access is single-copy atomic, so a slot whose sequence number is current carries current data -- no flag, no fence and ONE round
+// trip when the data is there.  Rows are double-buffered by the parity of the exchange count; a workgroup can only lap a reader by
+// two exchanges after that reader has itself written the next one.  All workgroups of a launch are co-resident (cooperative launch
+// when G > 1); polling is bounded, a group that times out raises the error word and leaves (the host reports DVO_HIP_ERR_HIP).
+// With G = 1 (large batches, coarse levels) there is no exchange and no residency requirement at all.
+#include "align_common.h"
+#include "solver_logic.h"
+
+namespace dvo_hip {
+
+namespace {
+
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+
+constexpr int kQuadStride = 264;                 // as in align_mfma.hip: per-wavefront operand slab, bank-conflict-free
+constexpr int kSlabFloats = 4 * kQuadStride;
+constexpr int kSpinLimit = 1 << 18;              // polls before a group gives up (a fraction of a second)
+
+struct Taps {                                     // the eight bilinear taps through buffer loads (see align_mfma.hip::TapPlanes)
+  __amdgpu_buffer_rsrc_t A, B;
+  int rowA, rowB;
+  __device__ __forceinline__ void fetch(int base, PixelTaps& t) const {
+    const int oa = base * 16, ob = base * 8;
+    const f32x4 a00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa, 0, 0));
+    const f32x4 a10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa + 16, 0, 0));
+    const f32x4 a01 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa, rowA, 0));
+    const f32x4 a11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa + 16, rowA, 0));
+    const f32x2 b00 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob, 0, 0));
+    const f32x2 b10 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob + 8, 0, 0));
+    const f32x2 b01 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob, rowB, 0));
+    const f32x2 b11 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob + 8, rowB, 0));
+    t.A00 = make_float4(a00.x, a00.y, a00.z, a00.w); t.A10 = make_float4(a10.x, a10.y, a10.z, a10.w);
+    t.A01 = make_float4(a01.x, a01.y, a01.z, a01.w); t.A11 = make_float4(a11.x, a11.y, a11.z, a11.w);
+    t.B00 = make_float2(b00.x, b00.y); t.B10 = make_float2(b10.x, b10.y);
+    t.B01 = make_float2(b01.x, b01.y); t.B11 = make_float2(b11.x, b11.y);
+  }
+};
+
+struct RefSeg {                                   // one 64-pixel segment of the reference plane: {Zsel, I} and the four neighbours of I
+  float z, i, left, right, up, down;
+};
+
+__device__ __forceinline__ unsigned long long slot_pack(unsigned value_bits, unsigned seq) {
+  return (static_cast<unsigned long long>(seq) << 32) | value_bits;
+}
+__device__ __forceinline__ void slot_store(unsigned long long* p, unsigned value_bits, unsigned seq) {
+  __hip_atomic_store(p, slot_pack(value_bits, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One slot of every row of a group in ONE round trip: the caller's lane polls rows q, q + kGatherLanes, ... (at most
+// kResidentMaxGroup / kGatherLanes loads in flight) until all carry sequence number `seq`, and hands them to `consume` in row order.
+// false: timed out.
+constexpr int kGatherLanes = 4;
+constexpr int kGatherRows = kResidentMaxGroup / kGatherLanes;
+template <typename F>
+__device__ __forceinline__ bool slot_gather(const unsigned long long* group_rows, int G, int q, int parity, int slot, unsigned seq, F&& consume) {
+  unsigned long long v[kGatherRows];
+  int spins = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < kGatherRows; ++r) {
+      const int j = q + r * kGatherLanes;
+      if (j < G) {
+        v[r] = __hip_atomic_load(group_rows + (size_t(j) * 2 + parity) * kResidentSlots + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok &= unsigned(v[r] >> 32) == seq;
+      }
+    }
+    if (ok) break;
+    if (++spins > kSpinLimit) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int r = 0; r < kGatherRows; ++r)
+    if (q + r * kGatherLanes < G) consume(unsigned(v[r]));
+  return true;
+}
+
+// values every lane reads from LDS or from a table are the same in all lanes, but the compiler cannot know: say so, so that the
+// loops and branches they steer stay scalar and the plane pointers stay in scalar registers (buffer resources)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ const T* uniform(const T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
+  return reinterpret_cast<const T*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+constexpr int kQuietPollGroup = 16;              // groups with more active workgroups than this watch one slot per row first
+
+// a POD copied inside LDS by one wavefront (its lanes' LDS operations execute in order: no barrier)
+template <typename T>
+__device__ __forceinline__ void wave_copy(T* dst, const T* src, int lane) {
+  static_assert(sizeof(T) % 4 == 0, "POD must be a multiple of 4 bytes");
+  const unsigned* s = reinterpret_cast<const unsigned*>(src);
+  unsigned* d = reinterpret_cast<unsigned*>(dst);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < int(sizeof(T) / 4); i += 64) d[i] = s[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T>
+__device__ __forceinline__ void coop_copy(T* dst, const T* src) {
+  static_assert(sizeof(T) % 4 == 0, "POD must be a multiple of 4 bytes");
+  const unsigned* s = reinterpret_cast<const unsigned*>(src);
+  unsigned* d = reinterpret_cast<unsigned*>(dst);
+  for (int i = threadIdx.x; i < int(sizeof(T) / 4); i += blockDim.x) d[i] = s[i];
+}
+
+}  // namespace
+
+#ifdef DVO_RESIDENT_CLOCKS
+// experiment build only (scripts/ubench/resident_clocks.py): where an iteration's time goes, 100 MHz wall clock, workgroup 0
+__device__ unsigned long long g_resident_clk[16];
+#define CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); g_resident_clk[i] += now_ - clk_prev_; clk_prev_ = now_; } } while (0)
+extern "C" int dvo_hip_debug_resident_clocks(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_resident_clk), sizeof(g_resident_clk)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_resident_clk), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define CLK(i) ((void)0)
+#endif
+
+__global__ __launch_bounds__(kResidentBlock) void k_match_resident(const ResidentArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float slab_mem[];          // kResidentWaves slabs of kSlabFloats
+  __shared__ PairState st, st_before;                                       // st_before: the state a speculative pass started from
+  __shared__ dvo_hip_level_stats lvl, lvl_before;
+  __shared__ dvo_hip_iteration_stats rec[2];                                // the records of the pass in flight and the one before
+  __shared__ double sums[2][kAccStride];                                    // likewise its reduced accumulators
+  __shared__ double sums_q[kGatherLanes][kAccStride];
+  __shared__ float2 res_lds[kResidentWaves][kResidentRowsLds][kTileW];      // the residual pairs of a wavefront's first segments
+  __shared__ double ll_group[kResidentMaxGroup];
+  __shared__ double ll_waves[kResidentWaves];
+  __shared__ double ll_mine;                                                // this workgroup's log-likelihood sum of the pending pass
+  __shared__ GnSpeculation speculation;
+  __shared__ int counts[kResidentWaves];
+  __shared__ int rec_slot[2];                                               // record index of rec[i], -1: nothing to write out
+  __shared__ int bail, pending, level_over;
+
+  const int G = a.group, tid = threadIdx.x;
+  const int pair = blockIdx.x / G, wg = blockIdx.x - pair * G;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // wavefront 0 of a workgroup is its solver: it holds no segments, so that the loop body starts the moment the exchange is through
+  // while the other seven sum the log-likelihood of their residuals next to it
+  const bool sweeper = wave > 0;
+  const int gw = wg * kResidentSweepers + (wave - 1), W = G * kResidentSweepers;   // this sweeping wavefront among the group's
+  unsigned long long* group_rows = a.exchange + size_t(pair) * G * 2 * kResidentSlots;
+  unsigned long long* my_rows = group_rows + size_t(wg) * 2 * kResidentSlots;
+  unsigned seq = a.sequence_base;
+
+#ifdef DVO_RESIDENT_CLOCKS
+  unsigned long long clk_prev_ = wall_clock64();
+#endif
+  if (tid == 0) { bail = 0; pending = 0; ll_mine = 0.0; rec_slot[0] = rec_slot[1] = -1; }
+  if (a.T_init) {
+    if (tid == 0) gn_init_pair(st, a.prm, a.T_init + size_t(pair) * 16);
+  } else {
+    coop_copy(&st, &a.states[pair]);
+  }
+  __syncthreads();
+
+  // which entries of the 16x16 Gram matrix make up accumulator `tid` of the canonical partial row (device_types.h; vector layout:
+  // components 0..5 = J0, 6..11 = J1, 12 = r0, 13 = r1): e1, and e2 for the symmetrised blocks (-1: none)
+  int fold_e1 = -1, fold_e2 = -1;
+  if (tid > kAccN && tid < kNumAcc) {
+    const int k = tid;
+    auto E = [](int r, int c) { return r * 16 + c; };
+    if (k == kAccS) fold_e1 = E(12, 12);
+    else if (k == kAccS + 1) fold_e1 = E(12, 13);
+    else if (k == kAccS + 2) fold_e1 = E(13, 13);
+    else if (k < kAccB00) {
+      const int blockId = (k - kAccJ00) / 21;               // 0: J0J0, 1: J1J1, 2: J0J1 symmetrised
+      int o = (k - kAccJ00) % 21, i = 0;
+      while (o >= 6 - i) { o -= 6 - i; ++i; }
+      const int j = i + o;
+      if (blockId == 0) fold_e1 = E(i, j);
+      else if (blockId == 1) fold_e1 = E(6 + i, 6 + j);
+      else { fold_e1 = E(i, 6 + j); fold_e2 = E(j, 6 + i); }
+    } else if (k < kAccB01) fold_e1 = E(k - kAccB00, 12);
+    else if (k < kAccB11) { fold_e1 = E(k - kAccB01, 13); fold_e2 = E(6 + (k - kAccB01), 12); }
+    else fold_e1 = E(6 + (k - kAccB11), 13);
+  }
+
+  float* my = slab_mem + wave * kSlabFloats;
+  f32x4* wr = reinterpret_cast<f32x4*>(my + lane * 4);
+  const float* rd = my + ((lane >> 2) & 3) * kQuadStride + (lane >> 4) * 4 + (lane & 3);
+  const float nanv = __builtin_nanf("");
+
+  for (int level = a.first_level; level >= a.last_level; --level) {
+    const LevelGeom g = a.geom[level];
+    PairPtrs pp = a.pair_ptrs[size_t(level) * a.n_pairs + pair];
+    pp.refR = uniform(pp.refR);
+    pp.curA = uniform(pp.curA);
+    pp.curB = uniform(pp.curB);
+    pp.n_selected = uniform(pp.n_selected);
+    const int level_slot = uniform(st.n_levels);                              // the record gn_level_begin is about to open
+    const bool have_level = level_slot < a.prm.cap_levels;
+    dvo_hip_level_stats* lvl_global = a.levels + size_t(pair) * a.prm.cap_levels + level_slot;
+    SolverParams local = a.prm;                                               // gn_* address levels[n_levels - 1] and
+    local.cap_levels = have_level ? level_slot + 1 : 0;                       // iters[n_iters_total]: biased so that those are in LDS
+    __syncthreads();
+    if (tid == 0) {
+      gn_level_begin(st, local, g, level, *pp.n_selected, &lvl - level_slot);
+      level_over = 0;
+      rec_slot[0] = rec_slot[1] = -1;
+    }
+    __syncthreads();
+
+    const int n_px = g.w * g.h, n_seg = (n_px + kTileW - 1) / kTileW;
+    // workgroups beyond the level's segments have nothing to sweep: their rows are zero and are neither written nor read
+    const int G_act = min(G, (n_seg + kResidentSweepers - 1) / kResidentSweepers);
+    const float inv_w = 1.0f / float(g.w);
+    const __amdgpu_buffer_rsrc_t refR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.refR), 0, n_px * 8, 0x00020000);
+    Taps taps;
+    taps.A = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(pp.curA), 0, n_px * 16, 0x00020000);
+    taps.B = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.curB), 0, n_px * 8, 0x00020000);
+    taps.rowA = g.w * 16;
+    taps.rowB = g.w * 8;
+    float2* residuals = a.scratch + size_t(pair) * n_px;
+
+    auto locate = [&](int idx, int& row, int& col) {          // idx < 2^24: one float multiply lands within one row of the quotient
+      row = int(float(idx) * inv_w);
+      col = idx - row * g.w;
+      if (col < 0) { col += g.w; row -= 1; }
+      if (col >= g.w) { col -= g.w; row += 1; }
+    };
+    auto load_i = [&](int pixel) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(refR, pixel * 8 + 4, 0, 0)); };
+    auto load_seg = [&](int seg) {
+      RefSeg r;
+      const int idx = min(seg * kTileW + lane, n_px - 1);
+      int row, col;
+      locate(idx, row, col);
+      const f32x2 zi = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(refR, idx * 8, 0, 0));
+      r.z = zi.x; r.i = zi.y;
+      r.left = load_i(idx - (col > 0 ? 1 : 0));               // clamped like the reference's derivative code, rgbd_image.cpp:419-489
+      r.right = load_i(idx + (col < g.w - 1 ? 1 : 0));
+      r.up = load_i(idx - (row > 0 ? g.w : 0));
+      r.down = load_i(idx + (row < g.h - 1 ? g.w : 0));
+      return r;
+    };
+    // the wavefront's first reference segment does not change over the iterations of a level: it stays in registers
+    RefSeg seg0 = load_seg(min(max(gw, 0), n_seg - 1));
+    CLK(0);                                                    // level begin (and the kernel's prologue)
+
+    int pass = 0;                                              // exchanges of this level so far (selects the double buffers)
+    for (;;) {
+      const int cur = pass & 1, prev = cur ^ 1;
+      const bool do_sweep = uniform(st.active) != 0;          // 0: the level is over but for the verdict on its last pass
+      // ---- sweep: this wavefront's segments gw, gw + W, ... at the (speculatively advanced) estimate ---------------------------
+      f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+      int n_valid = 0;
+      if (do_sweep && sweeper && gw < n_seg) {
+        float KT[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) KT[i] = st.KT[i];
+        const float P00 = st.P_prev[0], P2x = st.P_prev[1] + st.P_prev[2], P11 = st.P_prev[3];
+        const bool first = st.first != 0;
+        RefSeg now = seg0;
+        int held = 0;                                         // segments of this wavefront so far (scalar)
+#pragma unroll 1
+        for (int seg = gw; seg < n_seg; seg += W) {
+          RefSeg nxt = now;
+          if (seg + W < n_seg) nxt = load_seg(seg + W);       // requested before this segment is processed
+          const float4 ref = make_float4(now.z, now.i, (now.right - now.left) * 0.5f, (now.down - now.up) * 0.5f);
+          const int idx = seg * kTileW + lane;
+          const bool in_image = idx < n_px;
+          int row, col;
+          locate(in_image ? idx : 0, row, col);
+          const float tx_p = g.tx[col], ty_p = g.ty[row];
+          const PixelProj p = pixel_project_flat(g, KT, in_image ? ref.x : nanv, tx_p, ty_p);
+          PixelTaps t;
+          if (p.ok) taps.fetch(p.base, t);
+          PixelTerms o;
+          const bool valid = pixel_finish_flat(g, ref, p, t, o) && p.ok;
+          n_valid += __popcll(__ballot(valid));
+          {
+            const float2 rr = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);   // NaN: no constraint (and past the end)
+            if (held < kResidentRowsLds) res_lds[wave][held][lane] = rr;
+            else if (in_image) residuals[idx] = rr;
+            ++held;
+          }
+          if (valid) {
+            const float sw = first ? 1.0f : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);   // previous pass' precision (Q11)
+            float J0[6], J1[6];
+            jacobian_rows_fast(o, sw, tx_p, ty_p, fmaf(tx_p, tx_p, 1.0f), fmaf(ty_p, ty_p, 1.0f), J0, J1);
+            wr[0] = f32x4{J0[0], J0[1], J0[2], J0[3]};
+            wr[kQuadStride / 4] = f32x4{J0[4], J0[5], J1[0], J1[1]};
+            wr[2 * (kQuadStride / 4)] = f32x4{J1[2], J1[3], J1[4], J1[5]};
+            wr[3 * (kQuadStride / 4)] = f32x4{sw * o.r0, sw * o.r1, 0.0f, 0.0f};
+          } else {
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            wr[0] = zero;
+            wr[kQuadStride / 4] = zero;
+            wr[2 * (kQuadStride / 4)] = zero;
+            wr[3 * (kQuadStride / 4)] = zero;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int grp = 0; grp < 16; grp += 2) {
+            const float a0 = rd[grp * 16], a1 = rd[grp * 16 + 16];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc1, 0, 0, 0);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          now = nxt;
+        }
+      }
+      CLK(1);                                                  // sweep (thread 0's wavefront)
+      // ---- fold the workgroup's wavefronts into the canonical partial row (device_types.h) -----------------------------------
+#pragma unroll
+      for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
+      if (lane == 0) counts[wave] = n_valid;
+      __syncthreads();
+      float row_value = 0.0f;
+      if (tid < kNumAcc) {
+        auto Gm = [&](int e) {
+          float t = 0.0f;
+#pragma unroll
+          for (int wv = 1; wv < kResidentWaves; ++wv) t += slab_mem[wv * kSlabFloats + e];
+          return t;
+        };
+        if (tid == kAccN) {
+          int c = 0;
+#pragma unroll
+          for (int wv = 1; wv < kResidentWaves; ++wv) c += counts[wv];
+          row_value = float(c);
+        } else {
+          row_value = Gm(fold_e1);
+          if (fold_e2 >= 0) row_value += Gm(fold_e2);
+        }
+      }
+      CLK(2);                                                  // waiting for the other wavefronts + fold
+      // ---- the exchange: partial rows of this pass and log-likelihood sums of the pass before it, one round trip ----------------
+      if (G > 1) {
+        seq += 1;
+        const int parity = seq & 1;
+        unsigned long long* mine = my_rows + parity * kResidentSlots;
+        if (wg < G_act && !((a.flags & kResidentFlagWithhold) && wg == 1)) {
+          if (tid < kNumAcc) slot_store(mine + tid, __float_as_uint(row_value), seq);
+          if (tid == kNumAcc) {
+            const unsigned long long bits = __double_as_longlong(ll_mine);
+            slot_store(mine + kResidentSlotLl, unsigned(bits), seq);
+            slot_store(mine + kResidentSlotLl + 1, unsigned(bits >> 32), seq);
+          }
+        }
+        const int k = tid & 127, q = tid >> 7;                // lane group q of slot k adds rows q, q + 4, ...
+        if (G_act > kQuietPollGroup && !(a.flags & kResidentFlagNoQuietPoll)) {
+          // many rows: a failed poll of everything by everybody (G x 85 x G loads) drowns the fabric the sweeps of the slower
+          // workgroups need.  One wavefront watches one slot per row until the rows have been started, then everybody reads.
+          if (wave == 0 && lane < G_act) {
+            int spins = 0;
+            while (unsigned(__hip_atomic_load(group_rows + (size_t(lane) * 2 + parity) * kResidentSlots + kAccN, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT) >> 32) != seq) {
+              if (++spins > kSpinLimit) { bail = 1; break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+          __syncthreads();
+        }
+        if (k < kNumAcc) {
+          double t = 0.0;
+          if (!slot_gather(group_rows, G_act, q, parity, k, seq, [&](unsigned bits) { t += double(__uint_as_float(bits)); })) bail = 1;
+          sums_q[q][k] = t;
+        } else if (k >= 96 && q < 2) {                        // the log-likelihood sum of workgroup j: both halves
+          const int j = (k - 96) + 32 * q;
+          if (j < G_act) {
+            const unsigned long long* src = group_rows + (size_t(j) * 2 + parity) * kResidentSlots + kResidentSlotLl;
+            unsigned long long lo = 0, hi = 0;
+            int spins = 0;
+            for (;;) {
+              lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (unsigned(lo >> 32) == seq && unsigned(hi >> 32) == seq) break;
+              if (++spins > kSpinLimit) { bail = 1; break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            ll_group[j] = __longlong_as_double((hi << 32) | (lo & 0xffffffffull));
+          }
+        }
+        __syncthreads();
+        if (tid < kNumAcc) sums[cur][tid] = (sums_q[0][tid] + sums_q[1][tid]) + (sums_q[2][tid] + sums_q[3][tid]);
+      } else {
+        if (tid < kNumAcc) sums[cur][tid] = double(row_value);
+        if (tid == 0) ll_group[0] = ll_mine;
+      }
+      if (tid >= kNumAcc && tid < kAccStride) sums[cur][tid] = 0.0;
+      __syncthreads();
+      if (uniform(bail)) break;
+      CLK(3);                                                  // exchange
+      // ---- wavefront 0: the reference's loop body, redundantly (and identically) in every workgroup of the group; wavefronts
+      //      1..7 meanwhile: the log-likelihood of THIS pass over their own residuals (dense_tracking_impl.cpp:406-425), which
+      //      travels with the next exchange ------------------------------------------------------------------------------------------
+      if (wave == 0) {
+        int restore = 0;
+        if (lane == 0 && pending) {                            // the verdict on the pass before this one
+          double ll_sum = 0.0;
+          for (int j = 0; j < G_act; ++j) ll_sum += ll_group[j];
+          if (!gn_commit_loglik(st, speculation, ll_sum, rec[prev])) restore = 1;
+          pending = 0;
+        }
+        restore = uniform(restore);
+        if (restore) {
+          // rejected: back to the state that pass started from, and once more in full form, which takes the revert path and ends
+          // the level (dense_tracking.cpp:312-317); the sweep just done at the estimate it would have produced is dropped
+          wave_copy(&st, &st_before, lane);
+          wave_copy(&lvl, &lvl_before, lane);
+          if (lane == 0) {
+            double ll_sum = 0.0;
+            for (int j = 0; j < G_act; ++j) ll_sum += ll_group[j];
+            GnSpeculation replay = speculation;
+            replay.replay_reject = 1;
+            SolverParams prm = local;
+            prm.cap_iters = st.n_iters_total + 1;
+            gn_step(st, prm, g, sums[prev], ll_sum, &lvl - level_slot, &rec[prev] - st.n_iters_total, &replay);
+            level_over = 1;
+          }
+        } else if (!do_sweep) {
+          if (lane == 0) level_over = 1;                       // the last pass was accepted and had ended the level itself
+        } else {
+          wave_copy(&st_before, &st, lane);
+          wave_copy(&lvl_before, &lvl, lane);
+          if (lane == 0) {
+            SolverParams prm = local;
+            prm.cap_iters = st.n_iters_total + 1;
+            rec_slot[cur] = st.n_iters_total;
+            speculation.replay_reject = 0;
+            gn_step(st, prm, g, sums[cur], 0.0, &lvl - level_slot, &rec[cur] - st.n_iters_total, &speculation);
+            pending = speculation.needs_loglik;
+            if (!pending) level_over = 1;                      // too few constraints: over without a log-likelihood
+          }
+        }
+        CLK(6);                                                // solver
+#ifdef DVO_RESIDENT_CLOCKS
+        if (tid == 0 && blockIdx.x == 0) g_resident_clk[15] += 1;
+#endif
+      } else if (do_sweep) {
+        float C[3], P[4];
+        const int n = scale_from_sums(sums[cur], C, P);
+        double ll = 0.0;
+        if (n >= 6 && gw < n_seg) {
+          double prod = 1.0;
+          int exponent = 0, factors = 0, held = 0;
+          for (int seg = gw; seg < n_seg; seg += W, ++held) {
+            const int idx = seg * kTileW + lane;
+            float2 r = make_float2(nanv, nanv);
+            if (held < kResidentRowsLds) r = res_lds[wave][held][lane];
+            else if (idx < n_px) r = residuals[idx];
+            if (r.x == r.x) prod *= 1.0 + 0.2 * double(mahalanobis(r.x, r.y, P));
+            if (++factors == 8) {                             // eight factors at most between renormalisations (align_common.h)
+              int e;
+              prod = frexp(prod, &e);
+              exponent += e;
+              factors = 0;
+            }
+          }
+          ll = log(prod) + double(exponent) * 0.6931471805599453094;
+        }
+        ll = wave_sum_double(ll);
+        if (lane == 0) ll_waves[wave] = ll;
+      }
+      __syncthreads();
+      const bool over = uniform(level_over) != 0, wait_ll = uniform(pending) != 0;
+      // the record of the pass before is final now; so is this pass' if the level ended without waiting for a log-likelihood
+      if (wg == 0) {
+        const int done_prev = uniform(rec_slot[prev]);
+        if (done_prev >= 0 && done_prev < a.prm.cap_iters) coop_copy(a.iters + size_t(pair) * a.prm.cap_iters + done_prev, &rec[prev]);
+        const int done_cur = uniform(rec_slot[cur]);
+        if (over && !wait_ll && do_sweep && done_cur >= 0 && done_cur < a.prm.cap_iters)
+          coop_copy(a.iters + size_t(pair) * a.prm.cap_iters + done_cur, &rec[cur]);
+      }
+      if (over) break;
+      if (tid == 0) {                                          // read by the next exchange, a barrier from here
+        double t = 0.0;
+#pragma unroll
+        for (int wv = 1; wv < kResidentWaves; ++wv) t += ll_waves[wv];
+        ll_mine = t;
+      }
+      pass += 1;
+    }
+    if (uniform(bail)) break;
+    __syncthreads();
+    if (wg == 0 && have_level) coop_copy(lvl_global, &lvl);
+  }
+  if (uniform(bail)) {
+    if (tid == 0) __hip_atomic_store(a.error_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  __syncthreads();
+  if (wg == 0) {
+    coop_copy(&a.states[pair], &st);
+    if (a.results) {                                          // the match ends here: dense_tracking.cpp:368-373
+      __threadfence();                                         // the level and iteration records this workgroup wrote
+      __syncthreads();
+      if (tid == 0) gn_finish(st, a.prm, a.levels + size_t(pair) * a.prm.cap_levels, a.iters + size_t(pair) * a.prm.cap_iters, a.results + pair);
+    }
+  }
+  CLK(7);
+}
+
+size_t resident_dynamic_lds() { return size_t(kResidentWaves) * kSlabFloats * sizeof(float); }
+
+hipError_t launch_match_resident(hipStream_t s, const ResidentArgs& args, bool cooperative) {
+  static bool configured[64] = {};                            // the attribute is per device (callers hold their context's lock;
+  const size_t lds = resident_dynamic_lds();                  //  two contexts racing here set the same value twice)
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  if (device >= 64 || !configured[device]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resident), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    if (device < 64) configured[device] = true;
+  }
+  const dim3 grid(args.n_pairs * args.group), block(kResidentBlock);
+  if (args.group > 1 && cooperative) {
+    ResidentArgs copy = args;
+    void* params[] = {&copy};
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_match_resident), grid, block, params, unsigned(lds), s);
+  }
+  k_match_resident<<<grid, block, lds, s>>>(args);
+  return hipGetLastError();
+}
+
+}  // namespace dvo_hip

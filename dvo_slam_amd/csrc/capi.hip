@@ -152,6 +152,9 @@ struct Workspace {
   size_t host_status_words = 0;
   std::string err;
   bool created = false;
+  // resident match kernel: the exchange rows of the workgroup groups and the sequence numbers used so far
+  DevBuf exchange;
+  unsigned resident_sequence = 0;
 };
 
 struct dvo_hip_context {
@@ -169,6 +172,16 @@ struct dvo_hip_context {
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
   int opt_fused_ll_pixels = 0;     // largest level (pixels) whose log-likelihood sweep runs inside the solver workgroup (0 = by batch size)
   int opt_variant = 5;             // schedule of the reduce kernel: 5 = Gram accumulation on the matrix cores (default)
+  // the resident match kernel (align_resident.hip): -1 = levels whose sweep is short enough for the groups that fit (default),
+  // 0 = never (launches per iteration only), 1 = every level
+  int opt_resident = -1;
+  int opt_resident_rows = 0;       // "short enough": segments per wavefront and iteration at most (0 = kResidentRowsDefault)
+  int opt_resident_group = 0;      // workgroups per pair (0 = as many as fit, up to kResidentMaxGroup)
+  int resident_timeouts = 0;       // batches that had to be repeated because a group timed out (see run_batch)
+  long long resident_launches = 0;
+  int opt_resident_flags = 0;      // kResidentFlag* (measurement and test hooks)
+  int opt_resident_cooperative = 0; // launch groups through hipLaunchCooperativeKernel (a separate hardware queue: +0.1 ms per launch)
+  int compute_units = 0;
   std::vector<CameraGeom*> cameras;
   Workspace ws[1];
   DevBuf misc, build_tbl, role_tbl_cur, role_tbl_ref, prep_tbl_cur, prep_tbl_ref;
@@ -245,7 +258,7 @@ void workspace_destroy(Workspace& w) {
   if (!w.created) return;
   (void)hipStreamSynchronize(w.stream);
   for (DevBuf* b : {&w.states, &w.pair_ptrs, &w.partials, &w.scratch, &w.ll_partials, &w.lvl_stats, &w.it_stats, &w.results,
-                    &w.t_init, &w.counters})
+                    &w.t_init, &w.counters, &w.exchange})
     b->release();
   if (w.host_status) (void)hipHostFree(w.host_status);
   w.host_status = nullptr;
@@ -735,6 +748,73 @@ int ensure_host_status(Workspace& w, size_t n_steps) {
   return DVO_HIP_OK;
 }
 
+// ---- the resident kernel: which levels, how many workgroups per pair ------------------------------------------------------------
+constexpr int kResidentRowsDefault = 12;      // segments per wavefront and iteration up to which a level runs resident
+constexpr int kResidentErrorWord = 0;         // index into Workspace::host_status (the per-step words start behind it)
+
+struct ResidentPlan {
+  int group = 1;                               // workgroups per pair
+  int levels = 0;                              // leading levels (first_level, first_level - 1, ...) that run resident
+};
+
+ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const BatchPlan& bp) {
+  ResidentPlan rp;
+  if (ctx->opt_resident == 0) return rp;
+  const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+  // all workgroups of a launch with groups must be resident at once: one workgroup (8 wavefronts, up to 256 registers) per compute unit
+  int group = 1;
+  while (group * 2 <= kResidentMaxGroup && bp.n * group * 2 <= cus) group *= 2;
+  if (ctx->opt_resident_group > 0) group = std::min(group, ctx->opt_resident_group);
+  rp.group = group;
+  const int rows_max = ctx->opt_resident_rows > 0 ? ctx->opt_resident_rows : kResidentRowsDefault;
+  for (int level = cfg->first_level; level >= cfg->last_level; --level) {
+    const int segments = (bp.cam->w[level] * bp.cam->h[level] + kTileW - 1) / kTileW;
+    const int rows = (segments + group * kResidentSweepers - 1) / (group * kResidentSweepers);
+    if (ctx->opt_resident != 1 && rows > rows_max) break;
+    if (size_t(bp.cam->w[level]) * bp.cam->h[level] >= (size_t(1) << 24)) break;   // the kernel locates a pixel with one float multiply
+    rp.levels += 1;
+  }
+  return rp;
+}
+
+int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, const BatchPlan& bp, const ResidentPlan& rp) {
+  hipStream_t s = w.stream;
+  ResidentArgs args;
+  std::memset(&args, 0, sizeof(args));
+  for (int l = cfg->last_level; l <= cfg->first_level; ++l) args.geom[l] = bp.geom[l];
+  args.pair_ptrs = bp.pair_ptrs;
+  args.states = w.states.as<PairState>();
+  args.levels = w.lvl_stats.as<dvo_hip_level_stats>();
+  args.iters = w.it_stats.as<dvo_hip_iteration_stats>();
+  args.T_init = w.t_init.as<double>();
+  args.scratch = w.scratch.as<float2>();
+  args.error_word = w.host_status + kResidentErrorWord;
+  args.prm = bp.prm;
+  args.n_pairs = bp.n;
+  args.group = rp.group;
+  args.first_level = cfg->first_level;
+  args.last_level = cfg->first_level - rp.levels + 1;
+  args.flags = ctx->opt_resident_flags;
+  args.results = args.last_level == cfg->last_level ? w.results.as<dvo_hip_result>() : nullptr;
+  ctx->resident_launches += 1;
+  if (rp.group > 1) {
+    const size_t bytes = size_t(bp.n) * rp.group * 2 * kResidentSlots * sizeof(unsigned long long);
+    const bool grown = bytes > w.exchange.bytes;
+    DVO_WS_TRY(w, w.exchange.reserve(bytes));
+    // sequence numbers never repeat between launches; when they would wrap (or the rows are new / in doubt) the rows are cleared
+    const unsigned need = 2u * unsigned(rp.levels) * unsigned(cfg->max_iterations_per_level) + 4u;
+    if (grown || w.resident_sequence > 0xffffffffu - need - 1u) {
+      DVO_WS_TRY(w, hipMemsetAsync(w.exchange.p, 0, w.exchange.bytes, s));
+      w.resident_sequence = 0;
+    }
+    args.exchange = w.exchange.as<unsigned long long>();
+    args.sequence_base = w.resident_sequence;
+    w.resident_sequence += need;
+  }
+  DVO_WS_TRY(w, launch_match_resident(s, args, ctx->opt_resident_cooperative != 0));
+  return DVO_HIP_OK;
+}
+
 // The coarse-to-fine Gauss-Newton driver of a batch (dense_tracking.cpp:131-376 for every pair at once).
 int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
               dvo_hip_result* results, dvo_hip_level_stats* levels, int cap_levels, dvo_hip_iteration_stats* iters, int cap_iters) {
@@ -768,8 +848,18 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   unsigned long long* tallies = w.counters.as<unsigned long long>();
   const int per_level = cfg->max_iterations_per_level;
   const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 1;
-  int step = 0;
-  for (int level = cfg->first_level; level >= cfg->last_level; --level) {
+  int step = kResidentErrorWord + 1;                        // status word 0 belongs to the resident kernel
+  // The coarse levels -- for a small batch every level -- run inside ONE launch (align_resident.hip): no launch per iteration, no
+  // host poll, the pairs of a batch do not wait for each other.
+  const ResidentPlan rp = plan_resident(ctx, cfg, bp);
+  int level_from = cfg->first_level;
+  if (rp.levels > 0) {
+    Range range("resident");
+    rc = run_resident(ctx, w, cfg, bp, rp);
+    if (rc != DVO_HIP_OK) return rc;
+    level_from = cfg->first_level - rp.levels;
+  }
+  for (int level = level_from; level >= cfg->last_level; --level) {
     const LevelGeom& g = bp.geom[level];
     const PairPtrs* pp = bp.pair_ptrs + size_t(level) * n;
     static const char* const kPrep[kMaxLevels] = {"prep L0", "prep L1", "prep L2", "prep L3", "prep L4", "prep L5", "prep L6", "prep L7"};
@@ -777,7 +867,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     static const char* const kLinsys[kMaxLevels] = {"linsys L0", "linsys L1", "linsys L2", "linsys L3", "linsys L4", "linsys L5", "linsys L6", "linsys L7"};
     {
       Range range(kPrep[level]);
-      launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);
+      launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);   // (first level: initialises the pairs too)
     }
     // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
     // (measured, scripts/ab_match.py fused_ll_pixels: 128 pairs 2.152 -> 2.117 ms with level 1 fused; 16 pairs 0.756 -> 0.799, one
@@ -816,8 +906,9 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     }
   }
 
-  launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());
+  if (level_from >= cfg->last_level) launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());   // else: done by the resident launch
   DVO_WS_TRY(w, hipMemcpyAsync(results, w.results.p, size_t(n) * sizeof(dvo_hip_result), hipMemcpyDeviceToHost, s));
+  const bool resident_used = rp.levels > 0;
   std::vector<dvo_hip_level_stats> hl;
   std::vector<dvo_hip_iteration_stats> hi;
   if (levels && cap_levels > 0) {
@@ -830,6 +921,20 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   }
   DVO_WS_TRY(w, hipStreamSynchronize(s));
   DVO_WS_TRY(w, hipGetLastError());
+  if (resident_used && w.host_status[kResidentErrorWord] != 0) {
+    // A group of the resident kernel gave up waiting for its peers: its workgroups were not all on the device at once (the
+    // device is shared with another process that does the same, or a compute-unit mask shrank it).  Nothing is wrong with the
+    // batch: it runs again, one launch per step, and the context stops using groups.
+    w.resident_sequence = 0xffffffffu;                       // the exchange rows are in an unknown state: cleared before the next use
+    ctx->resident_timeouts += 1;
+    ctx->opt_resident_group = 1;
+    for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, &tinit[size_t(i) * 16], 16 * sizeof(double));
+    const int keep = ctx->opt_resident;
+    ctx->opt_resident = 0;
+    rc = run_batch(ctx, n, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
+    ctx->opt_resident = keep;
+    return rc;
+  }
   bool truncated = false;
   for (int i = 0; i < n; ++i) {
     if (!hl.empty()) {
@@ -868,6 +973,15 @@ int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_
 
 extern "C" {
 
+int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value) {
+  if (!ctx || !key || !value) return DVO_HIP_ERR_INVALID;
+  std::unique_lock<std::recursive_mutex> guard(ctx->mutex);
+  if (std::strcmp(key, "resident_launches") == 0) *value = ctx->resident_launches;
+  else if (std::strcmp(key, "resident_timeouts") == 0) *value = ctx->resident_timeouts;
+  else return fail(ctx, DVO_HIP_ERR_INVALID, "unknown counter");
+  return DVO_HIP_OK;
+}
+
 const char* dvo_hip_version(void) { return "dvo_hip 0.1 (gfx950)"; }
 
 int dvo_hip_device_count(void) {
@@ -896,6 +1010,7 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
   }
   dvo_hip_context* ctx = new dvo_hip_context();
   ctx->device = device;
+  if (hipDeviceGetAttribute(&ctx->compute_units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->compute_units = 0;
   int rc = workspace_create(ctx, 0);
   if (rc != DVO_HIP_OK) {
     g_create_error = "context setup: " + ctx->err;
@@ -963,6 +1078,29 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "variant") == 0) {
     if (value != 0 && value != 5) return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0 (all-VALU schedule) or 5 (matrix-core schedule)");
     ctx->opt_variant = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "resident") == 0) {
+    if (value < -1 || value > 1) return fail(ctx, DVO_HIP_ERR_INVALID, "resident must be -1 (automatic), 0 (off) or 1 (every level)");
+    ctx->opt_resident = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "resident_flags") == 0) {
+    ctx->opt_resident_flags = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "resident_cooperative") == 0) {
+    ctx->opt_resident_cooperative = value != 0;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "resident_rows") == 0) {
+    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "resident_rows must be >= 0");
+    ctx->opt_resident_rows = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "resident_group") == 0) {
+    if (value < 0 || value > kResidentMaxGroup || (value & (value - 1))) return fail(ctx, DVO_HIP_ERR_INVALID, "resident_group must be 0 or a power of two <= 64");
+    ctx->opt_resident_group = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "build_workgroups") == 0) {

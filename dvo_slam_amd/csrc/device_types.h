@@ -100,4 +100,34 @@ struct SolverParams {
   int want_condition_number;          // gn_finish also computes the eigenvalue range of the information matrix
 };
 
+// ---- the resident match kernel (align_resident.hip): one group of workgroups owns a pair for a whole run of levels ----
+constexpr int kResidentWaves = 8;                    // wavefronts per workgroup (512 threads: the solver lane needs > 128 registers)
+constexpr int kResidentSweepers = kResidentWaves - 1;  // wavefront 0 is the workgroup's solver
+constexpr int kResidentRowsLds = 12;                 // residual pairs of a wavefront's first segments stay in LDS (the rest: scratch)
+constexpr int kResidentBlock = kResidentWaves * 64;
+constexpr int kResidentMaxGroup = 64;                // workgroups per pair at most (power of two)
+constexpr int kResidentSlots = 96;                   // 8-byte {value, sequence} slots of an exchange row: the 85 accumulators, ...
+constexpr int kResidentSlotLl = 88;                  // ... and the two halves of the workgroup's float64 log-likelihood sum
+
+constexpr int kResidentFlagNoQuietPoll = 2;           // measurement: everybody polls every slot from the start
+constexpr int kResidentFlagWithhold = 4;              // test hook: workgroup 1 of every group withholds its rows (its peers time out)
+
+struct ResidentArgs {
+  LevelGeom geom[kMaxLevels];                         // per absolute level
+  const PairPtrs* pair_ptrs;                          // device [levels][n_pairs]
+  PairState* states;
+  dvo_hip_level_stats* levels;
+  dvo_hip_iteration_stats* iters;
+  const double* T_init;                               // non-null: the pairs are initialised here (the launch starts the match)
+  float2* scratch;                                    // residual pairs, n_pairs x pixels of the level
+  unsigned long long* exchange;                       // [n_pairs][group][2][kResidentSlots], used when group > 1
+  int* error_word;                                    // pinned host word: set when a group timed out
+  SolverParams prm;
+  int n_pairs, group;                                 // group: workgroups per pair (power of two)
+  int first_level, last_level;                        // the levels this launch runs, coarse to fine
+  unsigned sequence_base;                             // exchange sequence numbers of this launch start above it
+  dvo_hip_result* results;                            // non-null: the launch ends the match and writes the results (gn_finish)
+  int flags;                                          // kResidentFlag*
+};
+
 }  // namespace dvo_hip

@@ -32,6 +32,10 @@ void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_
 void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,
                    const float2* scratch, double* ll_partials, int blocks_per_pair);
 
+// align_resident.hip: levels first_level..last_level of every pair in one launch.  The n_pairs * group workgroups must fit the
+// device at once when group > 1 (one per compute unit); `cooperative` launches them through hipLaunchCooperativeKernel.
+hipError_t launch_match_resident(hipStream_t s, const ResidentArgs& args, bool cooperative);
+
 // solver_kernels.hip
 void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, const double* T_init);
 void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,

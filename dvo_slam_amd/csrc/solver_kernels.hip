@@ -46,6 +46,19 @@ __device__ __forceinline__ void publish_step(unsigned long long* step_tally, int
     __hip_atomic_store(host_status, int(now >> 32) | kStepDoneFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+#ifdef DVO_SOLVER_CLOCKS
+// experiment build only (scripts/ubench/solver_clocks.sh): where the time of a solver step goes, 100 MHz wall clock
+__device__ unsigned long long g_solver_clk[16];
+#define CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); g_solver_clk[i] += now_ - clk_prev_; clk_prev_ = now_; } } while (0)
+extern "C" int dvo_hip_debug_solver_clocks(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_solver_clk), sizeof(g_solver_clk)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_solver_clk), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define CLK(i) ((void)0)
+#endif
+
 __global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
                                                         const float* __restrict__ partials,
                                                         const double* __restrict__ ll_partials, int ll_blocks_per_pair,
@@ -53,6 +66,9 @@ __global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n
                                                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters,
                                                         unsigned long long* step_tally, int* host_status) {
   const int pair = blockIdx.x;
+#ifdef DVO_SOLVER_CLOCKS
+  unsigned long long clk_prev_ = wall_clock64();
+#endif
   if (!states[pair].active) {         // uniform
     if (threadIdx.x == 0) publish_step(step_tally, host_status, n_pairs, false);
     return;
@@ -69,11 +85,13 @@ __global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n
   __shared__ int rec_index;
   coop_copy(&st, &states[pair]);
   __syncthreads();
+  CLK(0);
   const int level_slot = st.n_levels - 1;
   dvo_hip_level_stats* lvl_global = levels + size_t(pair) * prm.cap_levels + level_slot;
   const bool have_level = level_slot >= 0 && level_slot < prm.cap_levels;
   if (have_level) coop_copy(&lvl, lvl_global);
   reduce_partials(partials, pair, g.tiles_x * g.tiles_y, sh, sums);   // same routine, same order as k_loglik: identical n, S, P
+  CLK(1);
   if (scratch_for_fused_ll) {
     // coarse levels: the log-likelihood sweep is small enough for this workgroup, which saves a launch per iteration
     float C[3], P[4];
@@ -84,6 +102,7 @@ __global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n
     if ((threadIdx.x & 63) == 0) ll_waves[threadIdx.x >> 6] = t;
     __syncthreads();
   }
+  CLK(2);
   if (threadIdx.x == 0) {
     double ll_sum = 0.0;
     if (scratch_for_fused_ll) {
@@ -98,12 +117,18 @@ __global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n
     local.cap_levels = have_level ? level_slot + 1 : 0;
     local.cap_iters = rec_index + 1;
     gn_step(st, local, g, sums, ll_sum, &lvl - level_slot, &rec - rec_index);
+    CLK(3);
     publish_step(step_tally, host_status, n_pairs, st.active != 0);
+    CLK(4);
   }
   __syncthreads();
   coop_copy(&states[pair], &st);
   if (have_level) coop_copy(lvl_global, &lvl);
   if (rec_index < prm.cap_iters) coop_copy(iters + size_t(pair) * prm.cap_iters + rec_index, &rec);
+  CLK(5);
+#ifdef DVO_SOLVER_CLOCKS
+  if (threadIdx.x == 0 && blockIdx.x == 0) g_solver_clk[15] += 1;
+#endif
 }
 
 __global__ void k_finish(const PairState* states, int n_pairs, SolverParams prm, const dvo_hip_level_stats* levels,

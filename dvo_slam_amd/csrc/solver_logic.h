@@ -112,10 +112,23 @@ DVO_HD void gn_level_end(PairState& st, const SolverParams& prm, dvo_hip_level_s
   st.active = 0;
 }
 
+// The resident kernel (align_resident.hip) runs the loop body BEFORE the log-likelihood of the pass is known -- as if the pass were
+// accepted -- and settles the accept / revert question one exchange later (gn_commit_loglik): everything below except the
+// error bookkeeping is independent of the log-likelihood sum.
+struct GnSpeculation {
+  double half_n_logdet;               // 0.5 n log det P of the pass (the log-likelihood without its data term)
+  int needs_loglik;                   // out: 0 = the pass ended the level without a log-likelihood (too few constraints)
+  int replay_reject;                  // in: 1 = full form of a pass gn_commit_loglik has rejected (the decision is not taken twice)
+};
+
 // One pass of the loop body after the residual sweep: dense_tracking.cpp:273-357.
 // sums = the kNumAcc accumulators reduced over all tiles; ll_sum = sum log(1 + 0.2 r^T P r).
+// spec != null, replay_reject == 0: speculative form -- ll_sum is ignored, the pass is treated as accepted, st.error /
+// st.last_error and rec.tdist_loglik are left for gn_commit_loglik.  replay_reject == 1: the full form, taking the revert path.
 DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, const double* sums, double ll_sum,
-                    dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters) {
+                    dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, GnSpeculation* spec = nullptr) {
+  const bool speculate = spec && !spec->replay_reject;
+  if (spec) spec->needs_loglik = 0;
   if (!st.active) return;
   dvo_hip_iteration_stats dummy;
   dvo_hip_iteration_stats& rec = (st.n_iters_total < prm.cap_iters) ? iters[st.n_iters_total] : dummy;
@@ -146,8 +159,9 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   const double det = double(P[0]) * double(P[3]) - double(P[1]) * double(P[2]);
   // the reference's log-likelihood is a float (computeCompleteDataLogLikelihood returns float into `float ll`, :297,
   // impl:406-425): the rounding decides `Error < LastError` at the noise floor, so it is part of the algorithm
-  const double ll = double(float(0.5 * double(n) * log(det) - 3.5 * ll_sum));
-  rec.tdist_loglik = -ll;
+  const double half_n_logdet = 0.5 * double(n) * log(det);
+  const double ll = double(float(half_n_logdet - 3.5 * ll_sum));
+  if (!speculate) rec.tdist_loglik = -ll;
   for (int i = 0; i < 4; ++i) rec.tdist_precision[i] = double(P[i]);
   double li[6] = {0, 0, 0, 0, 0, 0};
   double sq = 0;
@@ -157,9 +171,15 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   }
   rec.prior_loglik = prm.mu * sq;                            // :302
 
-  st.last_error = st.error;
-  st.error = -ll;
-  const bool accept = st.error < st.last_error;              // :312
+  bool accept = true;
+  if (speculate) {
+    spec->half_n_logdet = half_n_logdet;
+    spec->needs_loglik = 1;
+  } else {
+    st.last_error = st.error;
+    st.error = -ll;
+    accept = st.error < st.last_error && !spec;              // :312
+  }
   if (!accept) {
     st.initial = st.initial_old;
     st.estimate = st.estimate_old;
@@ -197,6 +217,18 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   } else {
     gn_level_end(st, prm, levels);
   }
+}
+
+// The accept test of a pass that gn_step ran speculatively: true = accepted (the error chain moves on, the record gets its
+// log-likelihood); false = the caller restores the state from before that gn_step call and runs it again in full form, which
+// then takes the revert path (dense_tracking.cpp:312-317).
+DVO_HD bool gn_commit_loglik(PairState& st, const GnSpeculation& spec, double ll_sum, dvo_hip_iteration_stats& rec) {
+  const double ll = double(float(spec.half_n_logdet - 3.5 * ll_sum));   // float like the reference's, see gn_step
+  if (!(-ll < st.error)) return false;
+  rec.tdist_loglik = -ll;
+  st.last_error = st.error;
+  st.error = -ll;
+  return true;
 }
 
 // dense_tracking.cpp:368-373

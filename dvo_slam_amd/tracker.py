@@ -41,6 +41,12 @@ class Context:
     def set_option(self, key, value):
         self.check(self._lib.dvo_hip_set_option(self.ptr, key.encode(), int(value)))
 
+    def counter(self, key):
+        """An event counter of the context ("resident_launches", "resident_timeouts")."""
+        v = C.c_longlong(0)
+        self.check(self._lib.dvo_hip_get_counter(self.ptr, key.encode(), C.byref(v)))
+        return v.value
+
     @property
     def stream(self):
         return self._lib.dvo_hip_context_stream(self.ptr)

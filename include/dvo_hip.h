@@ -254,8 +254,18 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * "fused_ll_pixels" (largest level, in pixels, whose log-likelihood sweep runs inside the solver
  * workgroup instead of a launch of its own; 0 = 160x120, and 320x240 for batches of 64 pairs and more),
  * "condition_number" (1: results carry the condition number of the information
- * matrix, ~20 us of extra serial work per batch; default 0). */
+ * matrix, ~20 us of extra serial work per batch; default 0),
+ * "resident" (-1 default: small batches and coarse levels run in ONE launch per match, each pair owned by a group of resident
+ * workgroups -- the latency path; 0: one to three launches per Gauss-Newton step always; 1: every level
+ * resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
+ * pass; default 12), "resident_group" (workgroups per pair, a power of two <= 64; 0 = as many as fit the device),
+ * "resident_cooperative" (1: groups are launched with hipLaunchCooperativeKernel), "resident_flags" (measurement / test hooks). */
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
+
+/* Event counters of a context.  key: "resident_launches" (matches, or coarse-level runs, done by the resident kernel),
+ * "resident_timeouts" (batches repeated on the launch-per-step path because a workgroup group of the resident kernel waited
+ * in vain for its peers -- the device was shared with another such kernel; the results are those of the repeat). */
+int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value);
 
 const char* dvo_hip_version(void);
 

@@ -36,6 +36,10 @@ int main(int argc, char** argv) {
   std::vector<dvo_hip_context*> contexts;
   for (int c = 0; c < n_contexts; ++c)
     contexts.push_back(c < devices ? dvo::core::DeviceContext::forDevice(c) : dvo::core::DeviceContext::createAdditional(c % devices));
+  // sub-batches of different sizes would otherwise get different numbers of workgroups per pair in the resident kernel, i.e.
+  // another summation order: pinned, like rows_per_wave for the launch path, so that the records can be compared to the bit
+  for (size_t c = 0; c < contexts.size(); ++c)
+    if (dvo_hip_set_option(contexts[c], "resident_group", 16) != DVO_HIP_OK) return 2;
 
   // pair p = (frame p, frame p + 1), both frames created on context p mod n (a frame shared by two pairs on different contexts
   // is uploaded to each, as SURVEY.md 8e prescribes)

@@ -125,8 +125,8 @@ def test_match_batch_over_several_device_contexts_in_one_process(tmp_path):
         out = subprocess.check_output([exe, str(tmp_path / "assoc.txt"), str(contexts)], text=True)
         runs[contexts] = np.array([[float(v) for v in line.split()] for line in out.strip().split("\n")])
         assert runs[contexts].shape == (7, 16)
-    # 7 pairs over 2 or 3 contexts give sub-batches of 4+3 / 3+2+2 pairs: below 8 pairs the tile heights of a 320x240 pyramid do
-    # not depend on the batch size, so the records are bit-identical
+    # 7 pairs over 2 or 3 contexts give sub-batches of 4+3 / 3+2+2 pairs: with the group size of the resident kernel pinned (the
+    # driver does) a pair's record does not depend on its sub-batch, so the records are bit-identical
     assert np.array_equal(runs[1], runs[2]) and np.array_equal(runs[1], runs[3])
     for k in range(7):
         true = np.linalg.inv(seq["poses"][k]) @ seq["poses"][k + 1]

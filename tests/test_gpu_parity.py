@@ -503,8 +503,9 @@ def test_role_aware_ingest_is_bit_identical(gpu_ctx, w, h, levels):
 
 @pytest.mark.gpu
 def test_large_ragged_batch_equals_its_pairs(gpu_ctx):
-    """603 pairs in one batch (frames shared between pairs, a batch size that divides nothing).  With the tile height pinned
-    (option rows_per_wave) a pair's record is bit-identical whatever else is in the launch: a batch of 603, of 77 in another
+    """603 pairs in one batch (frames shared between pairs, a batch size that divides nothing).  With the tile height of the launch
+    path and the group size of the resident kernel pinned (options rows_per_wave, resident_group) a pair's record is bit-identical
+    whatever else is in the launch: a batch of 603, of 77 in another
     order, of one.  With the default heuristic the tile height of a level follows the batch size, the per-tile partial sums group
     differently, and the records agree to rounding."""
     n_distinct, n = 9, 603
@@ -530,9 +531,11 @@ def test_large_ragged_batch_equals_its_pairs(gpu_ctx):
         return big, other, singles
     try:
         gpu_ctx.set_option("rows_per_wave", 4)
+        gpu_ctx.set_option("resident_group", 1)
         big, other, singles = run_all()
     finally:
         gpu_ctx.set_option("rows_per_wave", 0)
+        gpu_ctx.set_option("resident_group", 0)
     def same(a, b, k, what):
         # the log-likelihood sweep groups its partial sums by batch-size class (inside the solver workgroup for full batches,
         # more loads in flight for small ones): that one number may differ in its last bits
@@ -660,7 +663,10 @@ def test_random_whole_matches_against_oracle(gpu_ctx):
         assert s["max_iter_count_diff"] <= 2, what
         assert s["T_err"] < max(2e-5, 30 * precision), what
         if s["structure_mismatch"] == 0:
-            assert np.abs(g["information"] - o["information"]).max() <= 2e-3 * np.abs(o["information"]).max(), what
+            # (a single pixel whose validity flips at an estimate 1e-7 apart weighs 1/n of the normal equations: the smallest case
+            #  here, 61x68 at level 1, has 424 constraints)
+            n_last = min(it["n"] for it in o["levels"][-1]["iterations"])
+            assert np.abs(g["information"] - o["information"]).max() <= (2e-3 + 8.0 / max(n_last, 1)) * np.abs(o["information"]).max(), what
 
 
 @pytest.mark.gpu
@@ -681,11 +687,13 @@ def test_config4_batch_of_1024_distinct_pairs(gpu_ctx):
         xi.append(b["xi_true"])
     xi = np.concatenate(xi)
     try:
-        gpu_ctx.set_option("rows_per_wave", 8)                  # pinned tile height: records do not depend on the batch size
+        gpu_ctx.set_option("rows_per_wave", 8)                  # pinned tile height and group size: records do not depend on the batch size
+        gpu_ctx.set_option("resident_group", 1)
         out = trk.match_batch_arrays(refs, curs)
         parts = [trk.match_batch_arrays(refs[s:s + 128], curs[s:s + 128]) for s in range(0, n, 128)]
     finally:
         gpu_ctx.set_option("rows_per_wave", 0)
+        gpu_ctx.set_option("resident_group", 0)
     assert np.isfinite(out["T"]).all() and np.isfinite(out["information"]).all()
     err = np.array([np.abs(po.se3_log(out["T"][i]) - xi[i]).max() for i in range(n)])
     print("1024 pairs: max / median distance to the true motion %.2e / %.2e, iterations per pair %.1f" % (err.max(), np.median(err), out["n_iterations"].mean()))

@@ -1,0 +1,158 @@
+"""The resident match kernel (dvo_slam_amd/csrc/align_resident.hip: a whole match, or its coarse levels, in one launch; every pair
+owned by a group of workgroups) against the launch-per-step path of the same library and against the oracle.
+
+The two paths run the same per-pixel arithmetic and the same state machine (solver_logic.h) but add the per-pixel contributions in
+a different order, so they agree like two batch-size classes of the launch path do: constraint counts exactly, increments and
+results to the precision of the stopping rule; an iteration more or less at the noise floor is possible, not seen on these inputs."""
+import numpy as np
+import pytest
+
+import common as cm
+import dvo_slam_amd as d
+from dvo_slam_amd import datagen
+from oracle import pyoracle as po
+from test_gpu_parity import gpu_pyramids, run_gpu_match
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ctx(gpu_ctx):
+    yield gpu_ctx
+    for key, value in (("resident", -1), ("resident_group", 0), ("resident_rows", 0), ("resident_flags", 0), ("resident_cooperative", 0)):
+        gpu_ctx.set_option(key, value)
+
+
+def stats_of(ctx, cfg, refs, curs, T0=None):
+    trk = d.DenseTracker(cfg, ctx)
+    results = [d.Result() for _ in refs]
+    if T0 is not None:
+        for r in results:
+            r.Transformation = T0.copy()
+    trk.match_batch(refs, curs, results, with_stats=True)
+    return results
+
+
+def same_structure(a, b):
+    return ([L.Id for L in a.Statistics.Levels] == [L.Id for L in b.Statistics.Levels]
+            and [len(L.Iterations) for L in a.Statistics.Levels] == [len(L.Iterations) for L in b.Statistics.Levels]
+            and [L.TerminationCriterion for L in a.Statistics.Levels] == [L.TerminationCriterion for L in b.Statistics.Levels])
+
+
+@pytest.mark.parametrize("seed,w,h,first,last,mu,init,precision", [
+    (1234, 640, 480, 3, 0, 0.0, False, 5e-7),     # BASELINE config 2
+    (5, 640, 480, 3, 1, 0.05, True, 1e-4),        # benchmark.yaml: prior, initial estimate
+    (9, 131, 97, 2, 0, 0.0, False, 5e-7),         # ragged sizes
+    (4321, 1280, 960, 4, 0, 0.0, False, 1e-4),    # BASELINE config 5 (level 0: 19200 segments, residuals spill to scratch)
+])
+@pytest.mark.parametrize("group", [0, 1, 2, 16])
+def test_resident_match_equals_launch_path_and_oracle(ctx, seed, w, h, first, last, mu, init, precision, group):
+    pair = cm.synth(seed, w, h)
+    gref, gcur = gpu_pyramids(ctx, pair, first + 1)
+    cfg = d.Config(FirstLevel=first, LastLevel=last, Mu=mu, UseInitialEstimate=init, Precision=precision, MaxIterationsPerLevel=50 if init else 100)
+    T0 = po.se3_exp(0.5 * pair["xi_true"]) if init else None
+    ctx.set_option("resident", 0)
+    base = stats_of(ctx, cfg, [gref], [gcur], T0)[0]
+    before = ctx.counter("resident_launches")
+    ctx.set_option("resident", 1)                                          # every level, whatever the sweep length
+    ctx.set_option("resident_group", group)
+    res = stats_of(ctx, cfg, [gref], [gcur], T0)[0]
+    assert ctx.counter("resident_launches") == before + 1 and ctx.counter("resident_timeouts") == 0
+    shape = lambda r: [(L.Id, len(L.Iterations), L.TerminationCriterion) for L in r.Statistics.Levels]
+    # the same passes; the verdict on the LAST pass of a level may differ where successive log-likelihoods are closer than the two
+    # paths' rounding (the 131x97 case: pass 9 of level 1 is "accepted, increment too small" on one path, "rejected" on the other)
+    assert [x[:2] for x in shape(res)] == [x[:2] for x in shape(base)], (shape(res), shape(base))
+    if seed != 9:
+        assert same_structure(res, base), (shape(res), shape(base))
+    worst_n = worst_ll = worst_x = 0.0
+    for La, Lb in zip(res.Statistics.Levels, base.Statistics.Levels):
+        assert La.ValidPixels == Lb.ValidPixels and La.MaxValidPixels == Lb.MaxValidPixels
+        if La.Id == first:
+            assert La.Iterations[0].ValidConstraints == Lb.Iterations[0].ValidConstraints   # same estimate, same arithmetic: exact
+        for ia, ib in zip(La.Iterations, Lb.Iterations):
+            worst_n = max(worst_n, abs(ia.ValidConstraints - ib.ValidConstraints))
+            if np.isfinite(ib.TDistributionLogLikelihood):
+                worst_ll = max(worst_ll, abs(ia.TDistributionLogLikelihood - ib.TDistributionLogLikelihood) / abs(ib.TDistributionLogLikelihood))
+            if np.isfinite(ib.EstimateIncrement).all() and np.isfinite(ia.EstimateIncrement).all():
+                worst_x = max(worst_x, np.abs(ia.EstimateIncrement - ib.EstimateIncrement).max())
+    dT = cm.twist_matrix_error(res.Transformation, base.Transformation)
+    print("group %d: constraint counts differ by at most %d, -ll by %.1e relative, increments by %.1e, result by %.1e" % (group, worst_n, worst_ll, worst_x, dT))
+    # the estimates of the two paths drift apart by rounding (1e-7 per pass); the log-likelihood moves with the estimate
+    assert worst_n <= 4 and worst_ll < 1e-4 and worst_x < 5e-6
+    assert dT < 2e-6
+    assert np.abs(res.Information - base.Information).max() <= 1e-3 * np.abs(base.Information).max()
+    assert res.LogLikelihood == pytest.approx(base.LogLikelihood, rel=1e-5)
+    # and against the oracle, with the bounds of test_full_match_against_oracle
+    oref, ocur = cm.oracle_pyramids(pair, first + 1)
+    o = po.match(oref, ocur, cm.oracle_config_from(cfg, po.MATH), T0)
+    assert cm.twist_matrix_error(res.Transformation, o["T"]) < (2e-5 if precision > 1e-6 else 1e-6)
+
+
+def test_default_policy_uses_the_resident_kernel_for_small_batches_only(ctx):
+    b = datagen.synth_batch(3, 40, 320, 240)
+    cam = d.RgbdCameraPyramid(320, 240, b["K"], ctx)
+    cam.build(3)
+    refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(40)]
+    curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(40)]
+    cfg = d.Config(FirstLevel=2, LastLevel=0, Precision=5e-7)
+    ctx.set_option("resident", 0)
+    base = stats_of(ctx, cfg, refs, curs)
+    ctx.set_option("resident", -1)
+    for n in (1, 2, 5, 40):                                               # 40 pairs: groups of 4, the finest level stays on the launch path
+        before = ctx.counter("resident_launches")
+        res = stats_of(ctx, cfg, refs[:n], curs[:n])
+        assert ctx.counter("resident_launches") == before + 1
+        for a, bb in zip(res, base):
+            assert same_structure(a, bb) or abs(sum(len(L.Iterations) for L in a.Statistics.Levels) - sum(len(L.Iterations) for L in bb.Statistics.Levels)) <= 2
+            assert cm.twist_matrix_error(a.Transformation, bb.Transformation) < 5e-6
+    # a pair's result does not depend on its neighbours in the batch, given the group size (2 and 3 pairs: 64 workgroups each)
+    two, five = stats_of(ctx, cfg, refs[:2], curs[:2]), stats_of(ctx, cfg, refs[:3], curs[:3])
+    for a, bb in zip(two, five):
+        assert np.array_equal(a.Transformation, bb.Transformation) and np.array_equal(a.Information, bb.Information)
+
+
+def test_resident_edge_cases_follow_the_state_machine(ctx):
+    """No constraints at all, the iteration cap, and a level that ends on its first pass: the same records as the launch path."""
+    h, w = 120, 160
+    I = np.random.default_rng(0).uniform(0, 255, (h, w)).astype(np.float32)
+    Z = np.full((h, w), np.nan, np.float32)
+    cam = d.RgbdCameraPyramid(w, h, po.FR1_K / 4, ctx)
+    cam.build(3)
+    a, b = cam.create(I, Z), cam.create(I, Z)
+    pair = cm.synth(3, 100, 76)
+    gref, gcur = gpu_pyramids(ctx, pair, 2)
+    runs = {}
+    for mode in (0, 1):
+        ctx.set_option("resident", mode)
+        runs[mode] = (stats_of(ctx, d.Config(FirstLevel=2, LastLevel=0), [a], [b])[0],
+                      stats_of(ctx, d.Config(FirstLevel=1, LastLevel=0, MaxIterationsPerLevel=3, Precision=0.0), [gref], [gcur])[0],
+                      stats_of(ctx, d.Config(FirstLevel=1, LastLevel=0, MaxIterationsPerLevel=1), [gref], [gcur])[0])
+    empty, capped, single = runs[1]
+    assert empty.isNaN() and np.allclose(empty.Transformation, np.eye(4))
+    assert [L.TerminationCriterion for L in empty.Statistics.Levels] == [1, 1, 1]
+    assert all(len(L.Iterations) == 1 and L.Iterations[0].ValidConstraints == 0 for L in empty.Statistics.Levels)
+    for x, y in zip(runs[1], runs[0]):
+        assert same_structure(x, y)
+        assert np.allclose(x.Transformation, y.Transformation, atol=2e-6) and np.array_equal(np.isnan(x.Information), np.isnan(y.Information))
+    assert all(len(L.Iterations) <= 3 for L in capped.Statistics.Levels) and all(len(L.Iterations) == 1 for L in single.Statistics.Levels)
+
+
+def test_a_group_that_waits_in_vain_falls_back_to_the_launch_path(ctx):
+    """Test hook: workgroup 1 of every group withholds its rows.  Its peers give up after a bounded number of polls, the kernel
+    raises the error word, and the library repeats the batch one launch per step: same result, one time-out counted."""
+    pair = cm.synth(11, 320, 240)
+    gref, gcur = gpu_pyramids(ctx, pair, 3)
+    cfg = d.Config(FirstLevel=2, LastLevel=0, Precision=5e-7)
+    ctx.set_option("resident", 0)
+    base = stats_of(ctx, cfg, [gref], [gcur])[0]
+    ctx.set_option("resident", -1)
+    ctx.set_option("resident_flags", 4)
+    before = ctx.counter("resident_timeouts")
+    res = stats_of(ctx, cfg, [gref], [gcur])[0]
+    assert ctx.counter("resident_timeouts") == before + 1
+    assert np.array_equal(res.Transformation, base.Transformation) and same_structure(res, base)
+    ctx.set_option("resident_flags", 0)
+    ctx.set_option("resident_group", 0)                                   # (the library had stopped using groups)
+    again = stats_of(ctx, cfg, [gref], [gcur])[0]
+    assert ctx.counter("resident_timeouts") == before + 1
+    assert cm.twist_matrix_error(again.Transformation, base.Transformation) < 2e-6

@@ -97,8 +97,8 @@ def _free_port():
 def test_two_ranks_gather_the_records_of_one_rank(tmp_path):
     """bench.py's N > 1 path with REAL alignments: two processes (sharing GPU 0, gloo -- the box has one GPU; on an 8-GPU node the
     same code runs one rank per GPU over RCCL) align pair i on rank i mod 2 and all-gather the records; the gathered set equals
-    the records of a single process that aligns all pairs, bit for bit (tile height pinned)."""
-    common = ["--pairs", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-from-host", "--rows-per-wave", "8"]
+    the records of a single process that aligns all pairs, bit for bit (tile height and group size pinned)."""
+    common = ["--pairs", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-from-host", "--rows-per-wave", "8", "--resident-group", "1"]
     one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
     a = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--records-out", one] + common,
                        capture_output=True, text=True, timeout=600)

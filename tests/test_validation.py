@@ -170,8 +170,11 @@ def test_batched_validation_on_the_device_matches_the_sequential_oracle(tmp_path
     # the one-match-per-proposal route through the same facade decides identically
     seq_out = parse_output(subprocess.check_output([build_validator_check(), "gpu_sequential", assoc, gt], text=True))
     assert [(g["ref"], g["cur"]) for g in seq_out] == [(g["ref"], g["cur"]) for g in got]
-    # same arithmetic; only the tile height (hence the float summation grouping) may differ between batch sizes
-    assert all(np.allclose(a["T"], b["T"], rtol=0, atol=1e-9) for a, b in zip(seq_out, got))
+    # same arithmetic; the float summation grouping differs between batch sizes (tile height on the launch path, workgroups per pair
+    # in the resident kernel), and these runs stop at Precision 1e-4
+    worst = max(np.abs(np.asarray(a["T"]) - np.asarray(b["T"])).max() for a, b in zip(seq_out, got))
+    print("largest difference between the batched and the one-by-one transforms: %.1e" % worst)
+    assert worst < 1e-5
     for g, p in zip(got, want):
         assert g["score"] == pytest.approx(p.total_score(), rel=1e-4)   # log-likelihood ratios of runs stopped at Precision 1e-4
         assert np.abs(po.se3_log(np.linalg.inv(g["T"]) @ p.result["T"])).max() < 2e-6
