@@ -24,6 +24,13 @@
 // when G > 1); polling is bounded, a group that times out raises the error word and leaves (the host reports DVO_HIP_ERR_HIP).
 // With G = 1 (large batches, coarse levels) there is no exchange and no residency requirement at all.
 #include "align_common.h"
+#ifdef DVO_RESIDENT_CLOCKS
+namespace dvo_hip {
+__device__ unsigned long long g_resident_clk[32];
+__device__ unsigned long long g_gn_prev;
+}
+#define DVO_GN_CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); if (i) dvo_hip::g_resident_clk[16 + (i)] += now_ - dvo_hip::g_gn_prev; dvo_hip::g_gn_prev = now_; } } while (0)
+#endif
 #include "solver_logic.h"
 
 namespace dvo_hip {
@@ -135,11 +142,10 @@ __device__ __forceinline__ void coop_copy(T* dst, const T* src) {
 
 #ifdef DVO_RESIDENT_CLOCKS
 // experiment build only (scripts/ubench/resident_clocks.py): where an iteration's time goes, 100 MHz wall clock, workgroup 0
-__device__ unsigned long long g_resident_clk[16];
 #define CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); g_resident_clk[i] += now_ - clk_prev_; clk_prev_ = now_; } } while (0)
-extern "C" int dvo_hip_debug_resident_clocks(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_resident_clk), sizeof(g_resident_clk)) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_resident_clk), z, sizeof(z)) != hipSuccess) return -1; }
+extern "C" int dvo_hip_debug_resident_clocks(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_resident_clk), sizeof(g_resident_clk)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_resident_clk), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
 #else
@@ -427,35 +433,51 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
           pending = 0;
         }
         restore = uniform(restore);
+        // One call site of the loop body for both of its uses (the float64 solver is inlined once):
+        //   restore: the pass before was rejected -- back to the state it started from and once more in full form, which takes the
+        //            revert path and ends the level (dense_tracking.cpp:312-317); the sweep just done at the estimate it would have
+        //            produced is dropped;
+        //   else:    this pass, speculatively (the level may already be over: then only the verdict was due).
         if (restore) {
-          // rejected: back to the state that pass started from, and once more in full form, which takes the revert path and ends
-          // the level (dense_tracking.cpp:312-317); the sweep just done at the estimate it would have produced is dropped
           wave_copy(&st, &st_before, lane);
           wave_copy(&lvl, &lvl_before, lane);
-          if (lane == 0) {
-            double ll_sum = 0.0;
-            for (int j = 0; j < G_act; ++j) ll_sum += ll_group[j];
-            GnSpeculation replay = speculation;
-            replay.replay_reject = 1;
-            SolverParams prm = local;
-            prm.cap_iters = st.n_iters_total + 1;
-            gn_step(st, prm, g, sums[prev], ll_sum, &lvl - level_slot, &rec[prev] - st.n_iters_total, &replay);
-            level_over = 1;
-          }
-        } else if (!do_sweep) {
-          if (lane == 0) level_over = 1;                       // the last pass was accepted and had ended the level itself
-        } else {
+        } else if (do_sweep) {
           wave_copy(&st_before, &st, lane);
           wave_copy(&lvl_before, &lvl, lane);
-          if (lane == 0) {
+        }
+        const int which = restore ? prev : cur;
+        if (restore || do_sweep) {                             // the record's 51 NaNs by the whole wavefront, not by the solver lane
+          unsigned long long* words = reinterpret_cast<unsigned long long*>(&rec[which]);
+          for (int i = lane; i < int(sizeof(dvo_hip_iteration_stats) / 8); i += 64) words[i] = 0x7ff8000000000000ull;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) {
+          if (restore || do_sweep) {
+            double ll_sum = 0.0;
+            if (restore)
+              for (int j = 0; j < G_act; ++j) ll_sum += ll_group[j];
             SolverParams prm = local;
             prm.cap_iters = st.n_iters_total + 1;
-            rec_slot[cur] = st.n_iters_total;
-            speculation.replay_reject = 0;
-            gn_step(st, prm, g, sums[cur], 0.0, &lvl - level_slot, &rec[cur] - st.n_iters_total, &speculation);
-            pending = speculation.needs_loglik;
-            if (!pending) level_over = 1;                      // too few constraints: over without a log-likelihood
+            if (!restore) rec_slot[cur] = st.n_iters_total;
+            speculation.replay_reject = restore;
+            speculation.record_prefilled = 1;
+            speculation.defer_information = 1;
+            gn_step(st, prm, g, sums[which], ll_sum, &lvl - level_slot, &rec[which] - st.n_iters_total, &speculation);
+            pending = restore ? 0 : speculation.needs_loglik;
+            if (restore || !pending) level_over = 1;           // (not pending: too few constraints, over without a log-likelihood)
+          } else {
+            level_over = 1;                                    // the last pass was accepted and had ended the level itself
+            speculation.information_ready = 0;
           }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (uniform(speculation.information_ready)) {          // rec.information = A_last, 72 words by the wavefront
+          const unsigned* src = reinterpret_cast<const unsigned*>(st.A_last);
+          unsigned* dst = reinterpret_cast<unsigned*>(rec[which].information);
+          for (int i = lane; i < 72; i += 64) dst[i] = src[i];
         }
         CLK(6);                                                // solver
 #ifdef DVO_RESIDENT_CLOCKS

@@ -14,6 +14,10 @@
 #include "pixel_math.h"
 #include "se3_device.h"
 
+#ifndef DVO_GN_CLK
+#define DVO_GN_CLK(i) ((void)0)       // experiment builds stamp the stages of gn_step (scripts/ubench/build_clocks.sh)
+#endif
+
 namespace dvo_hip {
 
 DVO_HD double dvo_nan() { return __builtin_nan(""); }
@@ -119,6 +123,11 @@ struct GnSpeculation {
   double half_n_logdet;               // 0.5 n log det P of the pass (the log-likelihood without its data term)
   int needs_loglik;                   // out: 0 = the pass ended the level without a log-likelihood (too few constraints)
   int replay_reject;                  // in: 1 = full form of a pass gn_commit_loglik has rejected (the decision is not taken twice)
+  // The record of a pass is 51 doubles of stores for one lane.  A caller with idle lanes next to the solver lane takes the
+  // bulk of it off the serial path:
+  int record_prefilled;               // in: every 8-byte word of the record already holds NaN
+  int defer_information;              // in: rec.information is left to the caller, who copies st.A_last when information_ready
+  int information_ready;              // out
 };
 
 // One pass of the loop body after the residual sweep: dense_tracking.cpp:273-357.
@@ -128,8 +137,9 @@ struct GnSpeculation {
 DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, const double* sums, double ll_sum,
                     dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, GnSpeculation* spec = nullptr) {
   const bool speculate = spec && !spec->replay_reject;
-  if (spec) spec->needs_loglik = 0;
+  if (spec) spec->needs_loglik = spec->information_ready = 0;
   if (!st.active) return;
+  DVO_GN_CLK(0);
   dvo_hip_iteration_stats dummy;
   dvo_hip_iteration_stats& rec = (st.n_iters_total < prm.cap_iters) ? iters[st.n_iters_total] : dummy;
   st.n_iters_total += 1;
@@ -138,13 +148,16 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   const int n = int(sums[kAccN] + 0.5);
   rec.id = st.iteration;
   rec.valid_constraints = n;
-  rec.tdist_loglik = dvo_nan();
-  rec.prior_loglik = dvo_nan();
   rec.tdist_mean[0] = rec.tdist_mean[1] = 0.0;              // Q8
-  for (int i = 0; i < 4; ++i) rec.tdist_precision[i] = dvo_nan();
-  for (int i = 0; i < 6; ++i) rec.increment[i] = dvo_nan();
-  for (int i = 0; i < 36; ++i) rec.information[i] = dvo_nan();
+  if (!(spec && spec->record_prefilled)) {
+    rec.tdist_loglik = dvo_nan();
+    rec.prior_loglik = dvo_nan();
+    for (int i = 0; i < 4; ++i) rec.tdist_precision[i] = dvo_nan();
+    for (int i = 0; i < 6; ++i) rec.increment[i] = dvo_nan();
+    for (int i = 0; i < 36; ++i) rec.information[i] = dvo_nan();
+  }
 
+  DVO_GN_CLK(1);                                             // record initialised
   if (n < 6) {                                               // :276-284
     st.initial = st.initial_old;
     st.estimate = st.estimate_old;
@@ -170,6 +183,7 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
     for (int i = 0; i < 6; ++i) sq += li[i] * li[i];
   }
   rec.prior_loglik = prm.mu * sq;                            // :302
+  DVO_GN_CLK(2);                                             // precision, log det, prior
 
   bool accept = true;
   if (speculate) {
@@ -204,12 +218,20 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
     A[i * 6 + i] += prm.mu;
     b[i] += prm.mu * li[i];
   }
+  DVO_GN_CLK(3);                                             // contraction
   solve6(A, b, st.x);                                        // :347
+  DVO_GN_CLK(4);                                             // 6x6 solve
   for (int i = 0; i < 6; ++i) rec.increment[i] = st.x[i];
-  for (int i = 0; i < 36; ++i) { rec.information[i] = A[i]; st.A_last[i] = A[i]; }
+  if (spec && spec->defer_information) {
+    for (int i = 0; i < 36; ++i) st.A_last[i] = A[i];
+    spec->information_ready = 1;
+  } else {
+    for (int i = 0; i < 36; ++i) { rec.information[i] = A[i]; st.A_last[i] = A[i]; }
+  }
   st.iteration += 1;
 
   const double xn = inf_norm6(st.x);
+  DVO_GN_CLK(5);                                             // record / A_last copies
   if (xn > prm.precision && st.iteration < prm.max_iterations) {   // :357
     for (int i = 0; i < 4; ++i) st.P_prev[i] = P[i];         // next pass weights use this P (Q11)
     st.first = 0;
@@ -217,6 +239,7 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   } else {
     gn_level_end(st, prm, levels);
   }
+  DVO_GN_CLK(6);                                             // exp, inverse, two products, K T
 }
 
 // The accept test of a pass that gn_step ran speculatively: true = accepted (the error chain moves on, the record gets its

@@ -17,7 +17,7 @@ refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)]
 curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)]
 trk = d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0.0), ctx)
 L = C.CDLL(_lib.LIB_PATH)
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 for _ in range(3):
     out = trk.match_batch_arrays(refs, curs)
 L.dvo_hip_debug_resident_clocks(buf, 1)
@@ -33,3 +33,6 @@ print("pairs %d group %d: match %.3f ms host-side; %.1f iterations per match; ke
 for i, nm in enumerate(names):
     print("  %-24s %8.1f" % (nm, v[i]))
 print("  %-24s %8.1f" % ("sum", v[:8].sum()))
+print("inside gn_step (us per match):")
+for i, nm in enumerate(["record initialised", "precision, log det, prior", "contraction", "6x6 solve", "record / A_last copies", "exp, inverse, products, K T"]):
+    print("  %-28s %8.1f" % (nm, v[17 + i]))
