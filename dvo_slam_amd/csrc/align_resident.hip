@@ -183,7 +183,9 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
   unsigned long long clk_prev_ = wall_clock64();
 #endif
   if (tid == 0) { bail = 0; pending = 0; ll_mine = 0.0; rec_slot[0] = rec_slot[1] = -1; }
-  if (a.T_init) {
+  if (a.use_inline) {
+    if (tid == 0) gn_init_pair(st, a.prm, a.inline_T + size_t(pair) * 16);
+  } else if (a.T_init) {
     if (tid == 0) gn_init_pair(st, a.prm, a.T_init + size_t(pair) * 16);
   } else {
     coop_copy(&st, &a.states[pair]);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
 
   for (int level = a.first_level; level >= a.last_level; --level) {
     const LevelGeom g = a.geom[level];
-    PairPtrs pp = a.pair_ptrs[size_t(level) * a.n_pairs + pair];
+    PairPtrs pp = a.use_inline ? a.inline_ptrs[level * a.n_pairs + pair] : a.pair_ptrs[size_t(level) * a.n_pairs + pair];
     pp.refR = uniform(pp.refR);
     pp.curA = uniform(pp.curA);
     pp.curB = uniform(pp.curB);
@@ -541,7 +543,27 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
     if (a.results) {                                          // the match ends here: dense_tracking.cpp:368-373
       __threadfence();                                         // the level and iteration records this workgroup wrote
       __syncthreads();
-      if (tid == 0) gn_finish(st, a.prm, a.levels + size_t(pair) * a.prm.cap_levels, a.iters + size_t(pair) * a.prm.cap_iters, a.results + pair);
+      const dvo_hip_level_stats* my_levels = a.levels + size_t(pair) * a.prm.cap_levels;
+      const dvo_hip_iteration_stats* my_iters = a.iters + size_t(pair) * a.prm.cap_iters;
+      // composed in LDS (gn_finish reads its own output back) and written out by the workgroup: a.results may be host memory
+      __shared__ dvo_hip_result result;
+      if (tid == 0) gn_finish(st, a.prm, my_levels, my_iters, &result);
+      __syncthreads();
+      coop_copy(a.results + pair, &result);
+      if (a.done_word) {
+        if (a.host_levels) {                                   // the statistics the caller asked for, straight into its (pinned) arrays
+          const int nl = min(uniform(st.n_levels), a.prm.cap_levels), ni = min(uniform(st.n_iters_total), a.prm.cap_iters);
+          const unsigned* src = reinterpret_cast<const unsigned*>(my_levels);
+          unsigned* dst = reinterpret_cast<unsigned*>(a.host_levels + size_t(pair) * a.prm.cap_levels);
+          for (int i = tid; i < nl * int(sizeof(dvo_hip_level_stats) / 4); i += kResidentBlock) dst[i] = src[i];
+          src = reinterpret_cast<const unsigned*>(my_iters);
+          dst = reinterpret_cast<unsigned*>(a.host_iters + size_t(pair) * a.prm.cap_iters);
+          for (int i = tid; i < ni * int(sizeof(dvo_hip_iteration_stats) / 4); i += kResidentBlock) dst[i] = src[i];
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(a.done_word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
   CLK(7);

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <mutex>
@@ -39,6 +40,25 @@ struct DevBuf {
   }
   void release() {
     if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct PinnedBuf {               // host memory the device can write (mapped, coherent), grown on demand
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    release();
+    hipError_t e = hipHostMalloc(&p, n, hipHostMallocCoherent | hipHostMallocMapped);
+    if (e == hipSuccess) bytes = n;
+    else p = nullptr;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
     p = nullptr;
     bytes = 0;
   }
@@ -155,6 +175,10 @@ struct Workspace {
   // resident match kernel: the exchange rows of the workgroup groups and the sequence numbers used so far
   DevBuf exchange;
   unsigned resident_sequence = 0;
+  // ... and, when it runs a whole match of a small batch, where it leaves results and statistics: pinned host memory the host
+  // thread reads as soon as the kernel has counted the pairs done (no copy command, no stream synchronisation)
+  PinnedBuf direct_results, direct_levels, direct_iters, direct_done;
+  bool needs_drain = false;        // a batch ended early: the stream is drained before buffers are reused
 };
 
 struct dvo_hip_context {
@@ -179,6 +203,11 @@ struct dvo_hip_context {
   int opt_resident_group = 0;      // workgroups per pair (0 = as many as fit, up to kResidentMaxGroup)
   int resident_timeouts = 0;       // batches that had to be repeated because a group timed out (see run_batch)
   long long resident_launches = 0;
+  // where the host thread's time of dvo_hip_match_batch goes (ns, accumulated): before the first launch of the batch, enqueueing,
+  // waiting for the device, after the device is done
+  long long host_ns[4] = {0, 0, 0, 0};
+  long long host_batches = 0;
+  std::chrono::steady_clock::time_point batch_entry;
   int opt_resident_flags = 0;      // kResidentFlag* (measurement and test hooks)
   int opt_resident_cooperative = 0; // launch groups through hipLaunchCooperativeKernel (a separate hardware queue: +0.1 ms per launch)
   int compute_units = 0;
@@ -263,6 +292,7 @@ void workspace_destroy(Workspace& w) {
   if (w.host_status) (void)hipHostFree(w.host_status);
   w.host_status = nullptr;
   w.host_status_words = 0;
+  for (PinnedBuf* b : {&w.direct_results, &w.direct_levels, &w.direct_iters, &w.direct_done}) b->release();
   (void)hipStreamDestroy(w.stream);
   w.created = false;
 }
@@ -621,7 +651,8 @@ struct BatchPlan {
   const CameraGeom* cam = nullptr;
   std::vector<int> rpw;          // per absolute level
   std::vector<LevelGeom> geom;   // per absolute level
-  PairPtrs* pair_ptrs = nullptr; // device [levels][n]
+  PairPtrs* pair_ptrs = nullptr; // device [levels][n] (null when the table only travels in kernel arguments)
+  std::vector<PairPtrs> host_ptrs;   // the same table on the host
 };
 
 int validate_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg) {
@@ -680,7 +711,8 @@ int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, 
 }
 
 // Device scratch for n pairs + the per-level pointer tables
-int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, BatchPlan& bp) {
+int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, BatchPlan& bp,
+                    bool upload_table = true) {
   const int n = bp.n, need_levels = cfg->first_level + 1;
   size_t max_tiles = 1;
   for (int l = cfg->last_level; l <= cfg->first_level; ++l) max_tiles = std::max(max_tiles, size_t(bp.geom[l].tiles_x) * bp.geom[l].tiles_y);
@@ -695,7 +727,8 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
   DVO_WS_TRY(w, w.results.reserve(size_t(n) * sizeof(dvo_hip_result)));
   DVO_WS_TRY(w, w.t_init.reserve(size_t(n) * 16 * sizeof(double)));
   DVO_WS_TRY(w, w.counters.reserve(size_t(bp.cap_iters + 8) * sizeof(unsigned long long)));
-  std::vector<PairPtrs> host(size_t(n) * need_levels);
+  std::vector<PairPtrs>& host = bp.host_ptrs;
+  host.assign(size_t(n) * need_levels, PairPtrs());
   for (int l = cfg->last_level; l <= cfg->first_level; ++l)
     for (int i = 0; i < n; ++i) {
       PairPtrs& p = host[size_t(l) * n + i];
@@ -704,8 +737,11 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
       p.curB = curs[i]->lv[l].B;
       p.n_selected = refs[i]->sel_count + l;
     }
-  DVO_WS_TRY(w, w.tables->upload(w.stream, w.pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs)));
-  bp.pair_ptrs = w.pair_ptrs.as<PairPtrs>();
+  bp.pair_ptrs = nullptr;
+  if (upload_table) {
+    DVO_WS_TRY(w, w.tables->upload(w.stream, w.pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs)));
+    bp.pair_ptrs = w.pair_ptrs.as<PairPtrs>();
+  }
   return DVO_HIP_OK;
 }
 
@@ -735,6 +771,37 @@ int wait_for_step(Workspace& w, int step, int* active) {
   }
 }
 
+// The direct path of the resident kernel: spin on the pinned word in which the kernel counts the pairs whose results (and statistics)
+// are complete in pinned host memory; a group that timed out raises the error word instead (the caller repeats the batch).
+int wait_for_direct(Workspace& w, int n_pairs) {
+  volatile int* done = w.direct_done.as<int>();
+  volatile int* error_word = w.host_status + 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1;; ++spins) {
+    if (*done >= n_pairs) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return DVO_HIP_OK;
+    }
+    if (*error_word != 0) return DVO_HIP_OK;
+    if ((spins & 0xfffff) == 0) {
+      const hipError_t q = hipStreamQuery(w.stream);
+      if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();
+      if (q == hipSuccess && *done < n_pairs && *error_word == 0) {   // the kernel is gone and has not reported: it never ran
+        w.err = "match: the resident kernel ended without reporting its pairs";
+        return DVO_HIP_ERR_HIP;
+      }
+      if (q != hipSuccess && q != hipErrorNotReady) {
+        w.err = std::string("match: stream failed while the resident kernel ran: ") + hipGetErrorString(q);
+        return DVO_HIP_ERR_HIP;
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+        w.err = "match: timed out waiting for the resident kernel";
+        return DVO_HIP_ERR_HIP;
+      }
+    }
+  }
+}
+
 // pinned status words the device writes (publish_step): coherent + mapped, so that a system-scope store is visible to the
 // polling host thread whatever HIP_HOST_COHERENT says
 int ensure_host_status(Workspace& w, size_t n_steps) {
@@ -755,12 +822,19 @@ constexpr int kResidentErrorWord = 0;         // index into Workspace::host_stat
 struct ResidentPlan {
   int group = 1;                               // workgroups per pair
   int levels = 0;                              // leading levels (first_level, first_level - 1, ...) that run resident
+  bool direct = false;                         // the whole match of a small batch: results and statistics land in pinned host memory
 };
+
+constexpr int kResidentDirectPairs = 16;
 
 ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const BatchPlan& bp) {
   ResidentPlan rp;
   if (ctx->opt_resident == 0) return rp;
   const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+  // more pairs than compute units: the workgroups would run in shifts, and the launch path, which gives every phase the whole chip,
+  // is as fast (measured: 256 pairs -3 %, 512 pairs +1.6 % against it).  (Not with a pinned group size: the caller asks for
+  // records that do not depend on the batch size, so the choice of path must not either.)
+  if (ctx->opt_resident < 0 && ctx->opt_resident_group == 0 && bp.n > cus) return rp;
   // all workgroups of a launch with groups must be resident at once: one workgroup (8 wavefronts, up to 256 registers) per compute unit
   int group = 1;
   while (group * 2 <= kResidentMaxGroup && bp.n * group * 2 <= cus) group *= 2;
@@ -774,10 +848,12 @@ ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg
     if (size_t(bp.cam->w[level]) * bp.cam->h[level] >= (size_t(1) << 24)) break;   // the kernel locates a pixel with one float multiply
     rp.levels += 1;
   }
+  rp.direct = rp.levels == cfg->first_level - cfg->last_level + 1 && bp.n <= kResidentDirectPairs;
   return rp;
 }
 
-int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, const BatchPlan& bp, const ResidentPlan& rp) {
+int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, const BatchPlan& bp, const ResidentPlan& rp,
+                 const double* tinit, bool want_stats) {
   hipStream_t s = w.stream;
   ResidentArgs args;
   std::memset(&args, 0, sizeof(args));
@@ -796,6 +872,25 @@ int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, 
   args.last_level = cfg->first_level - rp.levels + 1;
   args.flags = ctx->opt_resident_flags;
   args.results = args.last_level == cfg->last_level ? w.results.as<dvo_hip_result>() : nullptr;
+  if (bp.n <= kResidentInline) {                               // no table in device memory, no copy commands in front of the launch
+    args.use_inline = 1;
+    for (int l = cfg->last_level; l <= cfg->first_level; ++l)
+      for (int i = 0; i < bp.n; ++i) args.inline_ptrs[l * bp.n + i] = bp.host_ptrs[size_t(l) * bp.n + i];
+    std::memcpy(args.inline_T, tinit, size_t(bp.n) * 16 * sizeof(double));
+  }
+  if (rp.direct) {
+    DVO_WS_TRY(w, w.direct_results.reserve(size_t(bp.n) * sizeof(dvo_hip_result)));
+    DVO_WS_TRY(w, w.direct_done.reserve(64));
+    args.results = w.direct_results.as<dvo_hip_result>();
+    args.done_word = w.direct_done.as<int>();
+    *static_cast<volatile int*>(args.done_word) = 0;
+    if (want_stats) {
+      DVO_WS_TRY(w, w.direct_levels.reserve(size_t(bp.n) * bp.cap_levels * sizeof(dvo_hip_level_stats)));
+      DVO_WS_TRY(w, w.direct_iters.reserve(size_t(bp.n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats)));
+      args.host_levels = w.direct_levels.as<dvo_hip_level_stats>();
+      args.host_iters = w.direct_iters.as<dvo_hip_iteration_stats>();
+    }
+  }
   ctx->resident_launches += 1;
   if (rp.group > 1) {
     const size_t bytes = size_t(bp.n) * rp.group * 2 * kResidentSlots * sizeof(unsigned long long);
@@ -822,22 +917,33 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   hipStream_t s = w.stream;
   BatchPlan bp;
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
-  int rc = prepare_buffers(w, cfg, refs, curs, bp);
+  // The coarse levels -- for a small batch every level -- run inside ONE launch (align_resident.hip): no launch per iteration, no
+  // host poll, the pairs of a batch do not wait for each other.
+  const ResidentPlan rp = plan_resident(ctx, cfg, bp);
+  const bool tables_inline = rp.direct && n <= kResidentInline;   // plane pointers and initial guesses travel as kernel arguments
+  int rc = prepare_buffers(w, cfg, refs, curs, bp, !tables_inline);
   if (rc != DVO_HIP_OK) return rc;
 
   // initial guesses (Result.Transformation is in/out, dense_tracking.cpp:137-147)
   std::vector<double> tinit(size_t(n) * 16);
   for (int i = 0; i < n; ++i) std::memcpy(&tinit[size_t(i) * 16], results[i].transformation, 16 * sizeof(double));
-  DVO_WS_TRY(w, w.tables->upload(s, w.t_init.p, tinit.data(), tinit.size() * sizeof(double)));
+  if (!tables_inline) DVO_WS_TRY(w, w.tables->upload(s, w.t_init.p, tinit.data(), tinit.size() * sizeof(double)));
   // per-step tallies (device) and status words (pinned host memory the device writes, see publish_step)
   const size_t n_steps = size_t(bp.cap_iters) + 8;
-  // a batch that failed half-way (time-out, HIP error) may have left steps queued: nothing of it may still be running when the
+  // a batch that ended early (time-out, HIP error) may have left steps queued: nothing of it may still be running when the
   // status words and tallies are reset
-  DVO_WS_TRY(w, hipStreamSynchronize(s));
+  if (w.needs_drain) DVO_WS_TRY(w, hipStreamSynchronize(s));
+  w.needs_drain = true;                                        // until this batch has come to its regular end
   rc = ensure_host_status(w, n_steps);
   if (rc != DVO_HIP_OK) return rc;
-  std::memset(w.host_status, 0, n_steps * sizeof(int));
-  DVO_WS_TRY(w, hipMemsetAsync(w.counters.p, 0, n_steps * sizeof(unsigned long long), s));
+  if (rp.direct) {
+    w.host_status[kResidentErrorWord] = 0;
+  } else {
+    // (the previous batch may have ended on the host's side before the device was through with the step words: the direct path)
+    DVO_WS_TRY(w, hipStreamSynchronize(s));
+    std::memset(w.host_status, 0, n_steps * sizeof(int));
+    DVO_WS_TRY(w, hipMemsetAsync(w.counters.p, 0, n_steps * sizeof(unsigned long long), s));
+  }
 
   PairState* states = w.states.as<PairState>();
   dvo_hip_level_stats* d_levels = w.lvl_stats.as<dvo_hip_level_stats>();
@@ -849,13 +955,12 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   const int per_level = cfg->max_iterations_per_level;
   const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 1;
   int step = kResidentErrorWord + 1;                        // status word 0 belongs to the resident kernel
-  // The coarse levels -- for a small batch every level -- run inside ONE launch (align_resident.hip): no launch per iteration, no
-  // host poll, the pairs of a batch do not wait for each other.
-  const ResidentPlan rp = plan_resident(ctx, cfg, bp);
+  const auto t_launch = std::chrono::steady_clock::now();
   int level_from = cfg->first_level;
+  const bool want_stats = (levels && cap_levels > 0) || (iters && cap_iters > 0);
   if (rp.levels > 0) {
     Range range("resident");
-    rc = run_resident(ctx, w, cfg, bp, rp);
+    rc = run_resident(ctx, w, cfg, bp, rp, tinit.data(), want_stats);
     if (rc != DVO_HIP_OK) return rc;
     level_from = cfg->first_level - rp.levels;
   }
@@ -906,21 +1011,44 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     }
   }
 
-  if (level_from >= cfg->last_level) launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());   // else: done by the resident launch
-  DVO_WS_TRY(w, hipMemcpyAsync(results, w.results.p, size_t(n) * sizeof(dvo_hip_result), hipMemcpyDeviceToHost, s));
   const bool resident_used = rp.levels > 0;
   std::vector<dvo_hip_level_stats> hl;
   std::vector<dvo_hip_iteration_stats> hi;
-  if (levels && cap_levels > 0) {
-    hl.resize(size_t(n) * bp.cap_levels);
-    DVO_WS_TRY(w, hipMemcpyAsync(hl.data(), d_levels, hl.size() * sizeof(dvo_hip_level_stats), hipMemcpyDeviceToHost, s));
+  const dvo_hip_level_stats* hl_src = nullptr;
+  const dvo_hip_iteration_stats* hi_src = nullptr;
+  std::chrono::steady_clock::time_point t_enqueued, t_done;
+  if (rp.direct) {
+    // the kernel writes results (and statistics) into pinned host memory and counts the pairs done: the host thread watches that
+    // word -- no copy command, no stream synchronisation on the way out
+    t_enqueued = std::chrono::steady_clock::now();
+    rc = wait_for_direct(w, n);
+    if (rc != DVO_HIP_OK) return rc;
+    t_done = std::chrono::steady_clock::now();
+    if (w.host_status[kResidentErrorWord] == 0) {
+      std::memcpy(results, w.direct_results.p, size_t(n) * sizeof(dvo_hip_result));
+      if (levels && cap_levels > 0) hl_src = w.direct_levels.as<dvo_hip_level_stats>();
+      if (iters && cap_iters > 0) hi_src = w.direct_iters.as<dvo_hip_iteration_stats>();
+    } else {
+      DVO_WS_TRY(w, hipStreamSynchronize(s));                  // every group has to be gone before the batch is repeated
+    }
+  } else {
+    if (level_from >= cfg->last_level) launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());   // else: done by the resident launch
+    DVO_WS_TRY(w, hipMemcpyAsync(results, w.results.p, size_t(n) * sizeof(dvo_hip_result), hipMemcpyDeviceToHost, s));
+    if (levels && cap_levels > 0) {
+      hl.resize(size_t(n) * bp.cap_levels);
+      DVO_WS_TRY(w, hipMemcpyAsync(hl.data(), d_levels, hl.size() * sizeof(dvo_hip_level_stats), hipMemcpyDeviceToHost, s));
+      hl_src = hl.data();
+    }
+    if (iters && cap_iters > 0) {
+      hi.resize(size_t(n) * bp.cap_iters);
+      DVO_WS_TRY(w, hipMemcpyAsync(hi.data(), d_iters, hi.size() * sizeof(dvo_hip_iteration_stats), hipMemcpyDeviceToHost, s));
+      hi_src = hi.data();
+    }
+    t_enqueued = std::chrono::steady_clock::now();
+    DVO_WS_TRY(w, hipStreamSynchronize(s));
+    DVO_WS_TRY(w, hipGetLastError());
+    t_done = std::chrono::steady_clock::now();
   }
-  if (iters && cap_iters > 0) {
-    hi.resize(size_t(n) * bp.cap_iters);
-    DVO_WS_TRY(w, hipMemcpyAsync(hi.data(), d_iters, hi.size() * sizeof(dvo_hip_iteration_stats), hipMemcpyDeviceToHost, s));
-  }
-  DVO_WS_TRY(w, hipStreamSynchronize(s));
-  DVO_WS_TRY(w, hipGetLastError());
   if (resident_used && w.host_status[kResidentErrorWord] != 0) {
     // A group of the resident kernel gave up waiting for its peers: its workgroups were not all on the device at once (the
     // device is shared with another process that does the same, or a compute-unit mask shrank it).  Nothing is wrong with the
@@ -931,23 +1059,34 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, &tinit[size_t(i) * 16], 16 * sizeof(double));
     const int keep = ctx->opt_resident;
     ctx->opt_resident = 0;
+    w.needs_drain = true;
     rc = run_batch(ctx, n, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
     ctx->opt_resident = keep;
     return rc;
   }
   bool truncated = false;
   for (int i = 0; i < n; ++i) {
-    if (!hl.empty()) {
+    if (hl_src) {
       const int nl = std::min(results[i].n_levels, std::min(cap_levels, bp.cap_levels));
-      std::memcpy(levels + size_t(i) * cap_levels, &hl[size_t(i) * bp.cap_levels], size_t(nl) * sizeof(dvo_hip_level_stats));
+      std::memcpy(levels + size_t(i) * cap_levels, hl_src + size_t(i) * bp.cap_levels, size_t(nl) * sizeof(dvo_hip_level_stats));
       truncated |= results[i].n_levels > cap_levels;
     }
-    if (!hi.empty()) {
+    if (hi_src) {
       const int ni = std::min(results[i].n_iterations_total, std::min(cap_iters, bp.cap_iters));
-      std::memcpy(iters + size_t(i) * cap_iters, &hi[size_t(i) * bp.cap_iters], size_t(ni) * sizeof(dvo_hip_iteration_stats));
+      std::memcpy(iters + size_t(i) * cap_iters, hi_src + size_t(i) * bp.cap_iters, size_t(ni) * sizeof(dvo_hip_iteration_stats));
       truncated |= results[i].n_iterations_total > cap_iters;
     }
   }
+  {
+    using std::chrono::duration_cast;
+    using std::chrono::nanoseconds;
+    ctx->host_ns[0] += duration_cast<nanoseconds>(t_launch - ctx->batch_entry).count();
+    ctx->host_ns[1] += duration_cast<nanoseconds>(t_enqueued - t_launch).count();
+    ctx->host_ns[2] += duration_cast<nanoseconds>(t_done - t_enqueued).count();
+    ctx->host_ns[3] += duration_cast<nanoseconds>(std::chrono::steady_clock::now() - t_done).count();
+    ctx->host_batches += 1;
+  }
+  w.needs_drain = false;
   if (truncated) {
     w.err = "match: statistics arrays too small (results are valid)";
     return DVO_HIP_ERR_CAPACITY;
@@ -978,6 +1117,11 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
   std::unique_lock<std::recursive_mutex> guard(ctx->mutex);
   if (std::strcmp(key, "resident_launches") == 0) *value = ctx->resident_launches;
   else if (std::strcmp(key, "resident_timeouts") == 0) *value = ctx->resident_timeouts;
+  else if (std::strcmp(key, "host_batches") == 0) *value = ctx->host_batches;
+  else if (std::strcmp(key, "host_ns_prepare") == 0) *value = ctx->host_ns[0];
+  else if (std::strcmp(key, "host_ns_enqueue") == 0) *value = ctx->host_ns[1];
+  else if (std::strcmp(key, "host_ns_wait") == 0) *value = ctx->host_ns[2];
+  else if (std::strcmp(key, "host_ns_finish") == 0) *value = ctx->host_ns[3];
   else return fail(ctx, DVO_HIP_ERR_INVALID, "unknown counter");
   return DVO_HIP_OK;
 }
@@ -1454,6 +1598,7 @@ int dvo_hip_match_batch(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const*
       for (int k = 0; k < 16; ++k)
         if (!std::isfinite(results[i].transformation[k]))
           return fail(ctx, DVO_HIP_ERR_INVALID, "match: provided initialization is NaN (dense_tracking.cpp:139)");
+  ctx->batch_entry = std::chrono::steady_clock::now();
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   rc = ensure_batch_roles(ctx, n_pairs, references, currents, cfg);
   if (rc != DVO_HIP_OK) return rc;

@@ -109,6 +109,7 @@ constexpr int kResidentMaxGroup = 64;                // workgroups per pair at m
 constexpr int kResidentSlots = 96;                   // 8-byte {value, sequence} slots of an exchange row: the 85 accumulators, ...
 constexpr int kResidentSlotLl = 88;                  // ... and the two halves of the workgroup's float64 log-likelihood sum
 
+constexpr int kResidentInline = 4;                   // pairs whose plane pointers and initial guesses travel in the kernel arguments
 constexpr int kResidentFlagNoQuietPoll = 2;           // measurement: everybody polls every slot from the start
 constexpr int kResidentFlagWithhold = 4;              // test hook: workgroup 1 of every group withholds its rows (its peers time out)
 
@@ -126,7 +127,17 @@ struct ResidentArgs {
   int n_pairs, group;                                 // group: workgroups per pair (power of two)
   int first_level, last_level;                        // the levels this launch runs, coarse to fine
   unsigned sequence_base;                             // exchange sequence numbers of this launch start above it
-  dvo_hip_result* results;                            // non-null: the launch ends the match and writes the results (gn_finish)
+  dvo_hip_result* results;                            // non-null: the launch ends the match and writes the results (gn_finish);
+                                                      // may be pinned host memory
+  // n_pairs <= kResidentInline: no table uploads in front of the launch
+  PairPtrs inline_ptrs[kMaxLevels * kResidentInline]; // [level][pair]
+  double inline_T[kResidentInline * 16];
+  int use_inline;
+  // non-null (with results): the pair's level and iteration records are copied here (pinned host memory, same layout as `levels` /
+  // `iters`) and *done_word is incremented (system scope) when everything of the pair has been written
+  dvo_hip_level_stats* host_levels;
+  dvo_hip_iteration_stats* host_iters;
+  int* done_word;
   int flags;                                          // kResidentFlag*
 };
 

@@ -264,7 +264,9 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 
 /* Event counters of a context.  key: "resident_launches" (matches, or coarse-level runs, done by the resident kernel),
  * "resident_timeouts" (batches repeated on the launch-per-step path because a workgroup group of the resident kernel waited
- * in vain for its peers -- the device was shared with another such kernel; the results are those of the repeat). */
+ * in vain for its peers -- the device was shared with another such kernel; the results are those of the repeat),
+ * "host_batches" and "host_ns_prepare" / "host_ns_enqueue" / "host_ns_wait" / "host_ns_finish" (nanoseconds the calling thread spent
+ * in dvo_hip_match_batch before its first launch, enqueueing, waiting for the device and afterwards; accumulated). */
 int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value);
 
 const char* dvo_hip_version(void);

@@ -8,7 +8,7 @@ import dvo_slam_amd as d
 from dvo_slam_amd import datagen
 from dvo_slam_amd.parallel import twists_of
 
-sizes = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 16, 128]
+sizes = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 4, 16, 128]
 ctx = d.default_context()
 nmax = max(sizes)
 b = datagen.synth_batch(0, nmax, 640, 480)
@@ -40,3 +40,13 @@ for n in sizes:
         dit = np.abs(out["n_iterations"].astype(int) - base["n_iterations"].astype(int)).max()
         line += "   resident=%2d %.3f ms (|dtwist| %.1e, |diters| %d)" % (mode, t, dT, dit)
     print(line, flush=True)
+    if "--host" in sys.argv:
+        for mode in (0, -1):
+            ctx.set_option("resident", mode)
+            keys = ("host_batches", "host_ns_prepare", "host_ns_enqueue", "host_ns_wait", "host_ns_finish")
+            c0 = [ctx.counter(k) for k in keys]
+            _, t = run(n, reps)
+            c1 = [ctx.counter(k) for k in keys]
+            nb = c1[0] - c0[0]
+            print("      resident=%2d: %.3f ms per call; inside the library, us per batch: prepare %.1f, enqueue %.1f, wait %.1f, finish %.1f"
+                  % ((mode, t) + tuple((b - a) / nb / 1e3 for a, b in zip(c0[1:], c1[1:]))), flush=True)
