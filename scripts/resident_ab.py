@@ -10,6 +10,8 @@ from dvo_slam_amd.parallel import twists_of
 
 sizes = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 4, 16, 128]
 ctx = d.default_context()
+if "--cooperative" in sys.argv:
+    ctx.set_option("resident_cooperative", 1)      # groups through hipLaunchCooperativeKernel
 nmax = max(sizes)
 b = datagen.synth_batch(0, nmax, 640, 480)
 cam = d.RgbdCameraPyramid(640, 480, b["K"], ctx); cam.build(4)
