@@ -130,6 +130,15 @@ __device__ __forceinline__ void wave_copy(T* dst, const T* src, int lane) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ... and out of LDS into global memory
+template <typename T>
+__device__ __forceinline__ void wave_copy_out(T* dst, const T* src, int lane) {
+  static_assert(sizeof(T) % 4 == 0, "POD must be a multiple of 4 bytes");
+  const unsigned* s = reinterpret_cast<const unsigned*>(src);
+  unsigned* d = reinterpret_cast<unsigned*>(dst);
+  for (int i = lane; i < int(sizeof(T) / 4); i += 64) d[i] = s[i];
+}
+
 template <typename T>
 __device__ __forceinline__ void coop_copy(T* dst, const T* src) {
   static_assert(sizeof(T) % 4 == 0, "POD must be a multiple of 4 bytes");
@@ -162,11 +171,10 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
   __shared__ float2 res_lds[kResidentWaves][kResidentRowsLds][kTileW];      // the residual pairs of a wavefront's first segments
   __shared__ double ll_group[kResidentMaxGroup];
   __shared__ double ll_waves[kResidentWaves];
-  __shared__ double ll_mine;                                                // this workgroup's log-likelihood sum of the pending pass
   __shared__ GnSpeculation speculation;
   __shared__ int counts[kResidentWaves];
   __shared__ int rec_slot[2];                                               // record index of rec[i], -1: nothing to write out
-  __shared__ int bail, pending, level_over;
+  __shared__ int bail, pending, level_over, kt_ready;
 
   const int G = a.group, tid = threadIdx.x;
   const int pair = blockIdx.x / G, wg = blockIdx.x - pair * G;
@@ -182,7 +190,8 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
 #ifdef DVO_RESIDENT_CLOCKS
   unsigned long long clk_prev_ = wall_clock64();
 #endif
-  if (tid == 0) { bail = 0; pending = 0; ll_mine = 0.0; rec_slot[0] = rec_slot[1] = -1; }
+  if (tid == 0) { bail = 0; pending = 0; rec_slot[0] = rec_slot[1] = -1; }
+  if (tid < kResidentWaves) ll_waves[tid] = 0.0;
   if (a.use_inline) {
     if (tid == 0) gn_init_pair(st, a.prm, a.inline_T + size_t(pair) * 16);
   } else if (a.T_init) {
@@ -235,6 +244,7 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
     if (tid == 0) {
       gn_level_begin(st, local, g, level, *pp.n_selected, &lvl - level_slot);
       level_over = 0;
+      kt_ready = 0;
       rec_slot[0] = rec_slot[1] = -1;
     }
     __syncthreads();
@@ -373,8 +383,11 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
         unsigned long long* mine = my_rows + parity * kResidentSlots;
         if (wg < G_act && !((a.flags & kResidentFlagWithhold) && wg == 1)) {
           if (tid < kNumAcc) slot_store(mine + tid, __float_as_uint(row_value), seq);
-          if (tid == kNumAcc) {
-            const unsigned long long bits = __double_as_longlong(ll_mine);
+          if (tid == kNumAcc) {                                // the log-likelihood sum of the pass before (its wavefronts' parts)
+            double ll_wg = 0.0;
+#pragma unroll
+            for (int wv = 1; wv < kResidentWaves; ++wv) ll_wg += ll_waves[wv];
+            const unsigned long long bits = __double_as_longlong(ll_wg);
             slot_store(mine + kResidentSlotLl, unsigned(bits), seq);
             slot_store(mine + kResidentSlotLl + 1, unsigned(bits >> 32), seq);
           }
@@ -417,7 +430,12 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
         if (tid < kNumAcc) sums[cur][tid] = (sums_q[0][tid] + sums_q[1][tid]) + (sums_q[2][tid] + sums_q[3][tid]);
       } else {
         if (tid < kNumAcc) sums[cur][tid] = double(row_value);
-        if (tid == 0) ll_group[0] = ll_mine;
+        if (tid == 0) {
+          double mine = 0.0;
+#pragma unroll
+          for (int wv = 1; wv < kResidentWaves; ++wv) mine += ll_waves[wv];
+          ll_group[0] = mine;
+        }
       }
       if (tid >= kNumAcc && tid < kAccStride) sums[cur][tid] = 0.0;
       __syncthreads();
@@ -425,14 +443,22 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
       CLK(3);                                                  // exchange
       // ---- wavefront 0: the reference's loop body, redundantly (and identically) in every workgroup of the group; wavefronts
       //      1..7 meanwhile: the log-likelihood of THIS pass over their own residuals (dense_tracking_impl.cpp:406-425), which
-      //      travels with the next exchange ------------------------------------------------------------------------------------------
+      //      travels with the next exchange.  They do not wait for the whole loop body: gn_step publishes `ticket` in kt_ready
+      //      the moment the next sweep's inputs (KT, P_prev, first, active) are in place and writes records, A_last and the
+      //      prior's `initial` behind that, while the sweep is already running. -------------------------------------------------------
+      const int ticket = pass + 1;
+      bool over;
       if (wave == 0) {
         int restore = 0;
-        if (lane == 0 && pending) {                            // the verdict on the pass before this one
-          double ll_sum = 0.0;
-          for (int j = 0; j < G_act; ++j) ll_sum += ll_group[j];
-          if (!gn_commit_loglik(st, speculation, ll_sum, rec[prev])) restore = 1;
-          pending = 0;
+        if (uniform(pending)) {                                // the verdict on the pass before this one
+          double ll_sum = lane < G_act ? ll_group[lane] : 0.0;  // a fixed tree: the same bits in every workgroup of the group
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) ll_sum += __shfl_xor(ll_sum, off, 64);
+          if (lane == 0) {
+            if (!gn_commit_loglik(st, speculation, ll_sum, rec[prev])) restore = 1;
+            pending = 0;
+            speculation.half_n_logdet = restore ? ll_sum : 0.0;   // (kept for the replay below)
+          }
         }
         restore = uniform(restore);
         // One call site of the loop body for both of its uses (the float64 solver is inlined once):
@@ -456,21 +482,25 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
         }
         if (lane == 0) {
           if (restore || do_sweep) {
-            double ll_sum = 0.0;
-            if (restore)
-              for (int j = 0; j < G_act; ++j) ll_sum += ll_group[j];
+            const double ll_sum = restore ? speculation.half_n_logdet : 0.0;
             SolverParams prm = local;
             prm.cap_iters = st.n_iters_total + 1;
             if (!restore) rec_slot[cur] = st.n_iters_total;
             speculation.replay_reject = restore;
             speculation.record_prefilled = 1;
             speculation.defer_information = 1;
+            speculation.release_word = &kt_ready;
+            speculation.release_value = ticket;
             gn_step(st, prm, g, sums[which], ll_sum, &lvl - level_slot, &rec[which] - st.n_iters_total, &speculation);
             pending = restore ? 0 : speculation.needs_loglik;
             if (restore || !pending) level_over = 1;           // (not pending: too few constraints, over without a log-likelihood)
           } else {
             level_over = 1;                                    // the last pass was accepted and had ended the level itself
             speculation.information_ready = 0;
+          }
+          if (kt_ready != ticket) {                            // the paths that end the level did not get as far as the release
+            __threadfence_block();
+            kt_ready = ticket;
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -480,53 +510,54 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
           const unsigned* src = reinterpret_cast<const unsigned*>(st.A_last);
           unsigned* dst = reinterpret_cast<unsigned*>(rec[which].information);
           for (int i = lane; i < 72; i += 64) dst[i] = src[i];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        over = uniform(level_over) != 0;
+        // the record of the pass before is final now; so is this pass' if the level ended without waiting for a log-likelihood
+        if (wg == 0) {
+          const int done_prev = uniform(rec_slot[prev]);
+          if (done_prev >= 0 && done_prev < a.prm.cap_iters) wave_copy_out(a.iters + size_t(pair) * a.prm.cap_iters + done_prev, &rec[prev], lane);
+          const int done_cur = uniform(rec_slot[cur]);
+          if (over && !uniform(pending) && do_sweep && done_cur >= 0 && done_cur < a.prm.cap_iters)
+            wave_copy_out(a.iters + size_t(pair) * a.prm.cap_iters + done_cur, &rec[cur], lane);
         }
         CLK(6);                                                // solver
 #ifdef DVO_RESIDENT_CLOCKS
         if (tid == 0 && blockIdx.x == 0) g_resident_clk[15] += 1;
 #endif
-      } else if (do_sweep) {
-        float C[3], P[4];
-        const int n = scale_from_sums(sums[cur], C, P);
-        double ll = 0.0;
-        if (n >= 6 && gw < n_seg) {
-          double prod = 1.0;
-          int exponent = 0, factors = 0, held = 0;
-          for (int seg = gw; seg < n_seg; seg += W, ++held) {
-            const int idx = seg * kTileW + lane;
-            float2 r = make_float2(nanv, nanv);
-            if (held < kResidentRowsLds) r = res_lds[wave][held][lane];
-            else if (idx < n_px) r = residuals[idx];
-            if (r.x == r.x) prod *= 1.0 + 0.2 * double(mahalanobis(r.x, r.y, P));
-            if (++factors == 8) {                             // eight factors at most between renormalisations (align_common.h)
-              int e;
-              prod = frexp(prod, &e);
-              exponent += e;
-              factors = 0;
+      } else {
+        if (do_sweep) {
+          float C[3], P[4];
+          const int n = scale_from_sums(sums[cur], C, P);
+          double ll = 0.0;
+          if (n >= 6 && gw < n_seg) {
+            double prod = 1.0;
+            int exponent = 0, factors = 0, held = 0;
+            for (int seg = gw; seg < n_seg; seg += W, ++held) {
+              const int idx = seg * kTileW + lane;
+              float2 r = make_float2(nanv, nanv);
+              if (held < kResidentRowsLds) r = res_lds[wave][held][lane];
+              else if (idx < n_px) r = residuals[idx];
+              if (r.x == r.x) prod *= 1.0 + 0.2 * double(mahalanobis(r.x, r.y, P));
+              if (++factors == 8) {                           // eight factors at most between renormalisations (align_common.h)
+                int e;
+                prod = frexp(prod, &e);
+                exponent += e;
+                factors = 0;
+              }
             }
+            ll = log(prod) + double(exponent) * 0.6931471805599453094;
           }
-          ll = log(prod) + double(exponent) * 0.6931471805599453094;
+          ll = wave_sum_double(ll);
+          if (lane == 0) ll_waves[wave] = ll;
         }
-        ll = wave_sum_double(ll);
-        if (lane == 0) ll_waves[wave] = ll;
-      }
-      __syncthreads();
-      const bool over = uniform(level_over) != 0, wait_ll = uniform(pending) != 0;
-      // the record of the pass before is final now; so is this pass' if the level ended without waiting for a log-likelihood
-      if (wg == 0) {
-        const int done_prev = uniform(rec_slot[prev]);
-        if (done_prev >= 0 && done_prev < a.prm.cap_iters) coop_copy(a.iters + size_t(pair) * a.prm.cap_iters + done_prev, &rec[prev]);
-        const int done_cur = uniform(rec_slot[cur]);
-        if (over && !wait_ll && do_sweep && done_cur >= 0 && done_cur < a.prm.cap_iters)
-          coop_copy(a.iters + size_t(pair) * a.prm.cap_iters + done_cur, &rec[cur]);
+        while (*static_cast<volatile int*>(&kt_ready) != ticket) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        over = *static_cast<volatile int*>(&level_over) != 0;
       }
       if (over) break;
-      if (tid == 0) {                                          // read by the next exchange, a barrier from here
-        double t = 0.0;
-#pragma unroll
-        for (int wv = 1; wv < kResidentWaves; ++wv) t += ll_waves[wv];
-        ll_mine = t;
-      }
       pass += 1;
     }
     if (uniform(bail)) break;

@@ -7,9 +7,15 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define DVO_HD __host__ __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DVO_FENCE_BLOCK() __threadfence_block()
+#else
+#define DVO_FENCE_BLOCK() ((void)0)
+#endif
 #else
 #include <math.h>
 #define DVO_HD inline
+#define DVO_FENCE_BLOCK() ((void)0)
 #ifndef __host__
 #define __host__
 #endif

@@ -33,13 +33,9 @@ DVO_HD double inf_norm6(const double* v) {
 }
 
 // inc = exp(x); initial = inc^-1 * initial; estimate = inc * estimate; KT = float(K * estimate)
-// (dense_tracking.cpp:259-263)
-DVO_HD void gn_begin_iteration(PairState& st, const LevelGeom& g) {
+// (dense_tracking.cpp:259-263), in two halves: what the next residual sweep needs ...
+DVO_HD void gn_advance_estimate(PairState& st, const LevelGeom& g) {
   se3_exp(st.x, st.inc);
-  SE3d inv;
-  se3_inverse(st.inc, inv);
-  st.initial_old = st.initial;
-  se3_mul(inv, st.initial, st.initial);
   st.estimate_old = st.estimate;
   se3_mul(st.inc, st.estimate, st.estimate);
   float T[12];
@@ -48,6 +44,17 @@ DVO_HD void gn_begin_iteration(PairState& st, const LevelGeom& g) {
     T[i * 4 + 3] = float(st.estimate.t[i]);
   }
   make_KT(g.fx, g.fy, g.ox, g.oy, T, st.KT);
+}
+// ... and what it does not (the prior's `initial` only enters the next solve)
+DVO_HD void gn_advance_initial(PairState& st) {
+  SE3d inv;
+  se3_inverse(st.inc, inv);
+  st.initial_old = st.initial;
+  se3_mul(inv, st.initial, st.initial);
+}
+DVO_HD void gn_begin_iteration(PairState& st, const LevelGeom& g) {
+  gn_advance_estimate(st, g);
+  gn_advance_initial(st);
 }
 
 // dense_tracking.cpp:137-150
@@ -128,7 +135,19 @@ struct GnSpeculation {
   int record_prefilled;               // in: every 8-byte word of the record already holds NaN
   int defer_information;              // in: rec.information is left to the caller, who copies st.A_last when information_ready
   int information_ready;              // out
+  // in: a word (shared with the wavefronts that sweep) that receives release_value, after a block-level fence, as soon as
+  // everything the next residual sweep reads is in place (KT, P_prev, first, active -- or the end of the level); the rest of
+  // the pass (records, A_last, the prior's `initial`) is written behind it
+  volatile int* release_word;
+  int release_value;
 };
+
+DVO_HD void gn_release_sweep(GnSpeculation* spec) {
+  if (spec && spec->release_word) {
+    DVO_FENCE_BLOCK();
+    *spec->release_word = spec->release_value;
+  }
+}
 
 // One pass of the loop body after the residual sweep: dense_tracking.cpp:273-357.
 // sums = the kNumAcc accumulators reduced over all tiles; ll_sum = sum log(1 + 0.2 r^T P r).
@@ -221,6 +240,19 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   DVO_GN_CLK(3);                                             // contraction
   solve6(A, b, st.x);                                        // :347
   DVO_GN_CLK(4);                                             // 6x6 solve
+  st.iteration += 1;
+  const double xn = inf_norm6(st.x);
+  const bool go_on = xn > prm.precision && st.iteration < prm.max_iterations;   // :357
+  if (go_on) {
+    for (int i = 0; i < 4; ++i) st.P_prev[i] = P[i];         // next pass weights use this P (Q11)
+    st.first = 0;
+    gn_advance_estimate(st, g);
+  } else {
+    gn_level_end(st, prm, levels);
+  }
+  DVO_GN_CLK(5);                                             // exp, product, K T
+  gn_release_sweep(spec);
+  // behind the release: nothing below is read by the next residual sweep
   for (int i = 0; i < 6; ++i) rec.increment[i] = st.x[i];
   if (spec && spec->defer_information) {
     for (int i = 0; i < 36; ++i) st.A_last[i] = A[i];
@@ -228,18 +260,8 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   } else {
     for (int i = 0; i < 36; ++i) { rec.information[i] = A[i]; st.A_last[i] = A[i]; }
   }
-  st.iteration += 1;
-
-  const double xn = inf_norm6(st.x);
-  DVO_GN_CLK(5);                                             // record / A_last copies
-  if (xn > prm.precision && st.iteration < prm.max_iterations) {   // :357
-    for (int i = 0; i < 4; ++i) st.P_prev[i] = P[i];         // next pass weights use this P (Q11)
-    st.first = 0;
-    gn_begin_iteration(st, g);
-  } else {
-    gn_level_end(st, prm, levels);
-  }
-  DVO_GN_CLK(6);                                             // exp, inverse, two products, K T
+  if (go_on) gn_advance_initial(st);
+  DVO_GN_CLK(6);                                             // record, A_last, inverse, product
 }
 
 // The accept test of a pass that gn_step ran speculatively: true = accepted (the error chain moves on, the record gets its
