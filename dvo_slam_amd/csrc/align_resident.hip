@@ -247,7 +247,8 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
       kt_ready = 0;
       rec_slot[0] = rec_slot[1] = -1;
     }
-    __syncthreads();
+    // (the barrier that publishes the level's first estimate comes after the wavefronts have asked for their first reference
+    //  segment: that round trip runs under lane 0's se3 log / exp)
 
     const int n_px = g.w * g.h, n_seg = (n_px + kTileW - 1) / kTileW;
     // workgroups beyond the level's segments have nothing to sweep: their rows are zero and are neither written nor read
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
     };
     // the wavefront's first reference segment does not change over the iterations of a level: it stays in registers
     RefSeg seg0 = load_seg(min(max(gw, 0), n_seg - 1));
+    __syncthreads();
     CLK(0);                                                    // level begin (and the kernel's prologue)
 
     int pass = 0;                                              // exchanges of this level so far (selects the double buffers)

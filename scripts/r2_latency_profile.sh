@@ -19,3 +19,4 @@ for mode in 0 -1; do
   [ -n "$f" ] && python scripts/timeline_last.py "$f" > $O/timeline_resident_$mode.txt 2>&1 && tail -12 $O/timeline_resident_$mode.txt
   rm -rf $O/prof$mode
 done
+timeout 100 python scripts/resident_ab_yaml.py > $O/ab_frontend_config.txt 2>&1; cat $O/ab_frontend_config.txt | cut -c1-200
