@@ -290,25 +290,31 @@ def main():
             pinned.depth[i][:] = pairs_np["depth_ref"][i]
             pinned.depth[B + i][:] = pairs_np["depth_cur"][i]
 
-        def host_build(k):   # this leg is bound by the PCIe link (4.3 ms per step), not by the host: plain lists will do
-            d.update_raw_host_batch(sets[k][:B], pinned.grey[:B], pinned.depth[:B], role="reference", config=cfg)
-            d.update_raw_host_batch(sets[k][B:], pinned.grey[B:], pinned.depth[B:], role="current", config=cfg)
+        # the same C loop as the timed one, fed from the host arrays (one foreign call per step: with 1024 pairs per step building
+        # 4096 ctypes entries per step in Python had become a quarter of the step)
+        pipe.set_host_planes(pinned.grey[:B], pinned.depth[:B], pinned.grey[B:], pinned.depth[B:])
+
+        def host_build(k):
+            pipe.step_host(now=None, nxt=k)
 
         def host_step(j):
-            host_build((j + 1) % n_sets)
-            out_h = tracker.match_batch_arrays(ref_sets[j % n_sets], cur_sets[j % n_sets])
-            return out_h
+            res = pipe.step_host(now=j % n_sets, nxt=(j + 1) % n_sets)
+            return {"T": res["transformation"].reshape(B, 4, 4)}
 
         if n_sets > 1:
             host_build(0)
         for j in range(2):
             host_step(j)
         barrier()
+        keys = ("host_batches", "host_ns_prepare", "host_ns_enqueue", "host_ns_wait", "host_ns_finish")
+        c0 = [ctx.counter(k) for k in keys]
         t_h = time.perf_counter()
         for j in range(args.steps):
             out_h = host_step(j)
         barrier()
         el_h = time.perf_counter() - t_h
+        c1 = [ctx.counter(k) for k in keys]
+        host_split = {k[8:]: round((b - a) / max(c1[0] - c0[0], 1) / 1e6, 3) for k, a, b in zip(keys[1:], c0[1:], c1[1:])}
         if world > 1:
             t = torch.tensor([el_h], dtype=torch.float64, device=comm_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -317,6 +323,7 @@ def main():
         from_host = {"value": round(n_total * args.steps / el_h, 2), "unit": "alignments/s", "ms_per_step": round(el_h / args.steps * 1e3, 3),
                      "h2d_bytes_per_step_per_gpu": bytes_step, "h2d_GBps_per_gpu": round(bytes_step * args.steps / el_h / 1e9, 2),
                      "same_results": bool(np.array_equal(out_h["T"], last["T"])),
+                     "host_thread_ms_per_match_call": host_split,
                      "note": "raw planes (u8 grey + u16 depth of both frames of every pair, 1.84 MB per pair) DMA-ed from pinned host "
                              "memory every step; reported beside `value`, never as it"}
         d.upload_wait(ctx)

@@ -5,6 +5,9 @@
 //
 // Reference call pattern it stands for: dvo_benchmark/src/benchmark_slam.cpp:327-383 (load pair -> create pyramid -> track),
 // with the proposals of dvo_slam/src/keyframe_graph.cpp:576-593 as the source of independent pairs.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "dvo_hip.h"
@@ -28,6 +31,34 @@ int dvo_stream_step(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next_refs
   static const double identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, identity, sizeof(identity));   // Result is in/out
   return dvo_hip_match_batch(ctx, n, now_refs, now_curs, cfg, results, nullptr, 0, nullptr, 0);
+}
+
+// The same step fed from HOST memory (SURVEY.md 8d config 4 "incl. H2D of 2 planes per frame"): the raw planes of `next` are DMA-ed
+// from pinned host memory on the upload stream, built on the build stream, while `now` is aligned on the main stream.
+int dvo_stream_step_host(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next_refs, dvo_hip_frame* const* next_curs,
+                         const uint8_t* const* grey_ref, const uint16_t* const* raw_ref, const uint8_t* const* grey_cur,
+                         const uint16_t* const* raw_cur, float depth_scale, dvo_hip_frame* const* now_refs, dvo_hip_frame* const* now_curs,
+                         const dvo_hip_config* cfg, dvo_hip_result* results) {
+  static const bool trace = std::getenv("DVO_STREAM_TRACE") != nullptr;   // where the host thread's time of a step goes (stderr)
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = DVO_HIP_OK;
+  if (next_refs) {
+    rc = dvo_hip_frames_update_raw_as(ctx, n, next_refs, grey_ref, raw_ref, depth_scale, DVO_HIP_ROLE_REFERENCE, cfg);
+    if (rc != DVO_HIP_OK) return rc;
+    rc = dvo_hip_frames_update_raw_as(ctx, n, next_curs, grey_cur, raw_cur, depth_scale, DVO_HIP_ROLE_CURRENT, cfg);
+    if (rc != DVO_HIP_OK) return rc;
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  if (!now_refs) return rc;
+  static const double identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, identity, sizeof(identity));
+  rc = dvo_hip_match_batch(ctx, n, now_refs, now_curs, cfg, results, nullptr, 0, nullptr, 0);
+  if (trace) {
+    const auto t2 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "step_host: enqueue of the next batch %.2f ms, match %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                 std::chrono::duration<double, std::milli>(t2 - t1).count());
+  }
+  return rc;
 }
 
 }  // extern "C"

@@ -23,6 +23,7 @@ def _load():
         vp = C.c_void_p
         pp = C.POINTER(vp)
         L.dvo_stream_step.argtypes = [vp, C.c_int, pp, pp, pp, pp, pp, pp, C.c_float, pp, pp, C.POINTER(_lib.Config), C.POINTER(_lib.Result)]
+        L.dvo_stream_step_host.argtypes = L.dvo_stream_step.argtypes
         _pipe = L
     return _pipe
 
@@ -41,6 +42,22 @@ class StreamPipeline:
         self.cres = (_lib.Result * self.n)()
         self.results = np.frombuffer(self.cres, dtype=_RESULT_DTYPE)      # view: fields of the last aligned batch
         self.L = _load()
+
+    def set_host_planes(self, grey_ref, depth_ref, grey_cur, depth_cur):
+        """Host arrays (pinned, uint8 / uint16, C-contiguous, n each) the raw planes of every batch are DMA-ed from by step_host."""
+        vp = C.c_void_p
+        self.host_ptrs = [(vp * self.n)(*[vp(a.ctypes.data) for a in arrays]) for arrays in (grey_ref, depth_ref, grey_cur, depth_cur)]
+
+    def step_host(self, now=None, nxt=None):
+        """step() with the raw planes of `nxt` coming from the host arrays of set_host_planes."""
+        nr = self.ref_sets[nxt].handles if nxt is not None else None
+        nc = self.cur_sets[nxt].handles if nxt is not None else None
+        ar = self.ref_sets[now].handles if now is not None else None
+        ac = self.cur_sets[now].handles if now is not None else None
+        g_ref, z_ref, g_cur, z_cur = self.host_ptrs
+        self.ctx.check(self.L.dvo_stream_step_host(self.ctx.ptr, self.n, nr, nc, g_ref, z_ref, g_cur, z_cur, self.scale, ar, ac,
+                                                   C.byref(self.ccfg), self.cres))
+        return self.results
 
     def step(self, now=None, nxt=None):
         """Re-ingest buffer `nxt` (None: skip) and align buffer `now` (None: skip).  Returns the result view."""

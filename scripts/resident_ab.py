@@ -13,7 +13,8 @@ ctx = d.default_context()
 if "--cooperative" in sys.argv:
     ctx.set_option("resident_cooperative", 1)      # groups through hipLaunchCooperativeKernel
 nmax = max(sizes)
-b = datagen.synth_batch(0, nmax, 640, 480)
+seed0 = int([a.split("=")[1] for a in sys.argv if a.startswith("--seed=")][0]) if any(a.startswith("--seed=") for a in sys.argv) else 0
+b = datagen.synth_batch(seed0, nmax, 640, 480)
 cam = d.RgbdCameraPyramid(640, 480, b["K"], ctx); cam.build(4)
 refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(nmax)]
 curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(nmax)]
