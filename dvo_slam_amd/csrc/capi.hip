@@ -1184,11 +1184,7 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
   e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->build_stream, hipStreamNonBlocking, prio_least);
   for (int i = 0; i < dvo_hip_context::kBuildRing && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->build_events[i], hipEventDisableTiming);
-  // The transfers get a stream of the HIGH priority class: streams of one class share a small pool of hardware queues, and a
-  // queue executes its packets in order -- on the main stream's queue the barrier that orders the stream behind a 0.9 GB copy
-  // held back the match kernels queued after it (from_host with 1024 pairs per step: 49.6 ms, i.e. DMA + build + match in a row,
-  // instead of 34 ms, the DMA alone)
-  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->upload_stream, hipStreamNonBlocking, prio_greatest);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->upload_done, hipEventDisableTiming);
   if (e != hipSuccess) {
     g_create_error = std::string("context setup (build stream): ") + hipGetErrorString(e);
