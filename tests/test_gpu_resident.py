@@ -156,3 +156,25 @@ def test_a_group_that_waits_in_vain_falls_back_to_the_launch_path(ctx):
     again = stats_of(ctx, cfg, [gref], [gcur])[0]
     assert ctx.counter("resident_timeouts") == before + 1
     assert cm.twist_matrix_error(again.Transformation, base.Transformation) < 2e-6
+
+
+def test_resident_groups_next_to_a_busy_build_stream(ctx):
+    """A large frame build (build stream) is in flight while single pairs are aligned by full groups of 64 workgroups: the groups
+    may have to wait for compute units, never in vain -- same records as on an idle device, no time-out, no fall-back."""
+    b = datagen.synth_batch(21, 96, 640, 480)
+    cam = d.RgbdCameraPyramid(640, 480, b["K"], ctx)
+    cam.build(4)
+    cfg = d.Config(FirstLevel=3, LastLevel=0, Precision=5e-7)
+    trk = d.DenseTracker(cfg, ctx)
+    refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(4)]
+    curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(4)]
+    quiet = [trk.match_batch_arrays([refs[i]], [curs[i]]) for i in range(4)]
+    others = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(4, 96)]
+    before = ctx.counter("resident_timeouts"), ctx.counter("resident_launches")
+    for rep in range(6):
+        d.update_raw_host_batch(others, [b["grey_ref"][i] for i in range(4, 96)], [b["depth_ref"][i] for i in range(4, 96)], role="current", config=cfg)
+        for i in range(4):
+            out = trk.match_batch_arrays([refs[i]], [curs[i]])
+            assert np.array_equal(out["T"], quiet[i]["T"]) and np.array_equal(out["information"], quiet[i]["information"])
+    d.upload_wait(ctx)
+    assert ctx.counter("resident_timeouts") == before[0] and ctx.counter("resident_launches") == before[1] + 24
