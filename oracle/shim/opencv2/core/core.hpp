@@ -3,7 +3,8 @@
 // pointers.  Not OpenCV.
 #pragma once
 
-#include <cassert>   // (pulled in transitively by the real header; the reference relies on that)
+#include <cassert>
+#include <chrono>   // (pulled in transitively by the real header; the reference relies on that)
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
@@ -56,8 +57,9 @@ struct Size {
   bool operator!=(const Size& o) const { return !(*this == o); }
 };
 
-inline long long getTickCount() { return 0; }
-inline double getTickFrequency() { return 1.0; }
+// (dvo::util::stopwatch times with these: nanoseconds of the steady clock)
+inline long long getTickCount() { return static_cast<long long>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count()); }
+inline double getTickFrequency() { return 1e9; }
 
 class Mat {
  public:
