@@ -17,36 +17,9 @@
 // conflict-free ds_write_b128; the MFMA operand for pixel group g (lane l <- component l&15 of pixel 4g + l>>4)
 // is one conflict-free ds_read_b32 at a constant offset.  A == B (the sqrt(w)-scaled vector on both sides).
 // The LDS slab is private to the wavefront, so the row loop contains no barrier.
-#include "align_common.h"
+#include "sweep_parts.h"
 
 namespace dvo_hip {
-
-typedef float __attribute__((ext_vector_type(4))) f32x4;
-typedef float __attribute__((ext_vector_type(2))) f32x2;
-
-// The eight bilinear taps through buffer loads: the plane is a raw buffer resource held in scalar registers, a tap's address is
-// ONE 32-bit vector offset (tap (u0, v0)) plus a scalar row offset plus an immediate -- instead of a 64-bit vector address per
-// tap -- and the two depth-gradient taps of a row, adjacent in memory, travel as one 16-byte load.  Reads past the plane's end
-// return zero.
-struct TapPlanes {
-  __amdgpu_buffer_rsrc_t A, B;
-  int rowA, rowB;                                   // bytes per image row
-  __device__ __forceinline__ void fetch(int base, PixelTaps& t) const {
-    const int oa = base * 16, ob = base * 8;
-    const f32x4 a00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa, 0, 0));
-    const f32x4 a10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa + 16, 0, 0));
-    const f32x4 a01 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa, rowA, 0));
-    const f32x4 a11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa + 16, rowA, 0));
-    const f32x2 b00 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob, 0, 0));
-    const f32x2 b10 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob + 8, 0, 0));
-    const f32x2 b01 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob, rowB, 0));
-    const f32x2 b11 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob + 8, rowB, 0));
-    t.A00 = make_float4(a00.x, a00.y, a00.z, a00.w); t.A10 = make_float4(a10.x, a10.y, a10.z, a10.w);
-    t.A01 = make_float4(a01.x, a01.y, a01.z, a01.w); t.A11 = make_float4(a11.x, a11.y, a11.z, a11.w);
-    t.B00 = make_float2(b00.x, b00.y); t.B10 = make_float2(b10.x, b10.y);
-    t.B01 = make_float2(b01.x, b01.y); t.B11 = make_float2(b11.x, b11.y);
-  }
-};
 
 // One row of the reference plane for a wavefront: the {Zsel, I} pair of every lane's pixel (64 lanes x 8 B = 512 B contiguous)
 // and the three intensities the central differences need from outside the wavefront's row: the pixels above and below (clamped
@@ -56,9 +29,6 @@ struct TapPlanes {
 struct RefRow {
   float z, i, up, down, left_or_edge, right;      // tiled: left_or_edge = the edge pixel (lanes 0 and 63 only), right unused
 };
-
-constexpr int kQuadStride = 264;                 // floats per component quad: 64 pixels x 4 + 8 skew (bank-conflict-free reads)
-constexpr int kSlabFloats = 4 * kQuadStride;     // per-wavefront LDS slab (4224 B)
 
 // LINEAR: the level is walked as one row of w*h pixels in 64-pixel segments (LevelGeom::linear) -- same per-pixel arithmetic,
 // the pixel coordinates come from a division instead of the tile position.
@@ -268,26 +238,16 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   // components 0..5 = J0, 6..11 = J1, 12 = r0, 13 = r1
   const int k = threadIdx.x;
   if (k < kNumAcc) {
-    auto G = [&](int r, int c) {
-      const int e = r * 16 + c;
-      return (slab[0][e] + slab[1][e]) + (slab[2][e] + slab[3][e]);
-    };
+    auto G = [&](int e) { return (slab[0][e] + slab[1][e]) + (slab[2][e] + slab[3][e]); };
     float v;
-    if (k == kAccN) v = float((counts[0] + counts[1]) + (counts[2] + counts[3]));
-    else if (k == kAccS) v = G(12, 12);
-    else if (k == kAccS + 1) v = G(12, 13);
-    else if (k == kAccS + 2) v = G(13, 13);
-    else if (k < kAccB00) {
-      const int blockId = (k - kAccJ00) / 21;                // 0: J0J0, 1: J1J1, 2: J0J1 symmetrised
-      int o = (k - kAccJ00) % 21, i = 0;
-      while (o >= 6 - i) { o -= 6 - i; ++i; }                // upper-triangular row-major index -> (i, j)
-      const int j = i + o;
-      if (blockId == 0) v = G(i, j);
-      else if (blockId == 1) v = G(6 + i, 6 + j);
-      else v = G(i, 6 + j) + G(j, 6 + i);
-    } else if (k < kAccB01) v = G(k - kAccB00, 12);
-    else if (k < kAccB11) v = G(k - kAccB01, 13) + G(6 + (k - kAccB01), 12);
-    else v = G(6 + (k - kAccB11), 13);
+    if (k == kAccN) {
+      v = float((counts[0] + counts[1]) + (counts[2] + counts[3]));
+    } else {
+      int e1, e2;
+      gram_entries_of_accumulator(k, e1, e2);
+      v = G(e1);
+      if (e2 >= 0) v += G(e2);
+    }
     partials[(size_t(pair) * tiles + tile) * kAccStride + k] = v;
   }
 }

@@ -32,37 +32,15 @@ __device__ unsigned long long g_gn_prev;
 #define DVO_GN_CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); if (i) dvo_hip::g_resident_clk[16 + (i)] += now_ - dvo_hip::g_gn_prev; dvo_hip::g_gn_prev = now_; } } while (0)
 #endif
 #include "solver_logic.h"
+#include "sweep_parts.h"
 
 namespace dvo_hip {
 
 namespace {
 
-typedef float __attribute__((ext_vector_type(4))) f32x4;
-typedef float __attribute__((ext_vector_type(2))) f32x2;
-
-constexpr int kQuadStride = 264;                 // as in align_mfma.hip: per-wavefront operand slab, bank-conflict-free
-constexpr int kSlabFloats = 4 * kQuadStride;
 constexpr int kSpinLimit = 1 << 18;              // polls before a group gives up (a fraction of a second)
 
-struct Taps {                                     // the eight bilinear taps through buffer loads (see align_mfma.hip::TapPlanes)
-  __amdgpu_buffer_rsrc_t A, B;
-  int rowA, rowB;
-  __device__ __forceinline__ void fetch(int base, PixelTaps& t) const {
-    const int oa = base * 16, ob = base * 8;
-    const f32x4 a00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa, 0, 0));
-    const f32x4 a10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa + 16, 0, 0));
-    const f32x4 a01 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa, rowA, 0));
-    const f32x4 a11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(A, oa + 16, rowA, 0));
-    const f32x2 b00 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob, 0, 0));
-    const f32x2 b10 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob + 8, 0, 0));
-    const f32x2 b01 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob, rowB, 0));
-    const f32x2 b11 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(B, ob + 8, rowB, 0));
-    t.A00 = make_float4(a00.x, a00.y, a00.z, a00.w); t.A10 = make_float4(a10.x, a10.y, a10.z, a10.w);
-    t.A01 = make_float4(a01.x, a01.y, a01.z, a01.w); t.A11 = make_float4(a11.x, a11.y, a11.z, a11.w);
-    t.B00 = make_float2(b00.x, b00.y); t.B10 = make_float2(b10.x, b10.y);
-    t.B01 = make_float2(b01.x, b01.y); t.B11 = make_float2(b11.x, b11.y);
-  }
-};
+typedef TapPlanes Taps;
 
 struct RefSeg {                                   // one 64-pixel segment of the reference plane: {Zsel, I} and the four neighbours of I
   float z, i, left, right, up, down;
@@ -201,27 +179,9 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
   }
   __syncthreads();
 
-  // which entries of the 16x16 Gram matrix make up accumulator `tid` of the canonical partial row (device_types.h; vector layout:
-  // components 0..5 = J0, 6..11 = J1, 12 = r0, 13 = r1): e1, and e2 for the symmetrised blocks (-1: none)
+  // the Gram entries that make up accumulator `tid` of the canonical partial row, looked up once
   int fold_e1 = -1, fold_e2 = -1;
-  if (tid > kAccN && tid < kNumAcc) {
-    const int k = tid;
-    auto E = [](int r, int c) { return r * 16 + c; };
-    if (k == kAccS) fold_e1 = E(12, 12);
-    else if (k == kAccS + 1) fold_e1 = E(12, 13);
-    else if (k == kAccS + 2) fold_e1 = E(13, 13);
-    else if (k < kAccB00) {
-      const int blockId = (k - kAccJ00) / 21;               // 0: J0J0, 1: J1J1, 2: J0J1 symmetrised
-      int o = (k - kAccJ00) % 21, i = 0;
-      while (o >= 6 - i) { o -= 6 - i; ++i; }
-      const int j = i + o;
-      if (blockId == 0) fold_e1 = E(i, j);
-      else if (blockId == 1) fold_e1 = E(6 + i, 6 + j);
-      else { fold_e1 = E(i, 6 + j); fold_e2 = E(j, 6 + i); }
-    } else if (k < kAccB01) fold_e1 = E(k - kAccB00, 12);
-    else if (k < kAccB11) { fold_e1 = E(k - kAccB01, 13); fold_e2 = E(6 + (k - kAccB01), 12); }
-    else fold_e1 = E(6 + (k - kAccB11), 13);
-  }
+  if (tid > kAccN && tid < kNumAcc) gram_entries_of_accumulator(tid, fold_e1, fold_e2);
 
   float* my = slab_mem + wave * kSlabFloats;
   f32x4* wr = reinterpret_cast<f32x4*>(my + lane * 4);

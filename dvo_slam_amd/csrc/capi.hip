@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -850,6 +851,42 @@ int ensure_host_status(Workspace& w, size_t n_steps) {
 }
 
 // ---- the resident kernel: which levels, how many workgroups per pair ------------------------------------------------------------
+// Workgroups of a group wait for each other, so all groups in flight on a device must be on it together: contexts of one process
+// (one per host thread, like the reference's one DenseTracker per TBB worker) share the device's compute units through this
+// budget -- a launch with groups waits until its workgroups fit next to those already in flight.  (Another PROCESS on the same
+// device is not seen here; there a group can time out, and the batch is repeated on the launch path.)
+struct ResidentBudget {
+  std::mutex m;
+  std::condition_variable cv;
+  int in_flight = 0;
+  static ResidentBudget& of(int device) {
+    static ResidentBudget budgets[64];
+    return budgets[device >= 0 && device < 64 ? device : 63];
+  }
+  struct Hold {
+    ResidentBudget* b = nullptr;
+    int n = 0;
+    Hold() = default;
+    Hold(const Hold&) = delete;
+    Hold& operator=(const Hold&) = delete;
+    void take(ResidentBudget& budget, int workgroups, int capacity) {
+      std::unique_lock<std::mutex> lock(budget.m);
+      budget.cv.wait(lock, [&] { return budget.in_flight == 0 || budget.in_flight + workgroups <= capacity; });
+      budget.in_flight += workgroups;
+      b = &budget;
+      n = workgroups;
+    }
+    ~Hold() {
+      if (!b) return;
+      {
+        std::lock_guard<std::mutex> lock(b->m);
+        b->in_flight -= n;
+      }
+      b->cv.notify_all();
+    }
+  };
+};
+
 constexpr int kResidentRowsDefault = 12;      // segments per wavefront and iteration up to which a level runs resident
 constexpr int kResidentErrorWord = 0;         // index into Workspace::host_status (the per-step words start behind it)
 
@@ -992,6 +1029,9 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   const auto t_launch = std::chrono::steady_clock::now();
   int level_from = cfg->first_level;
   const bool want_stats = (levels && cap_levels > 0) || (iters && cap_iters > 0);
+  ResidentBudget::Hold compute_units;                          // released when this batch is through with the device
+  if (rp.levels > 0 && rp.group > 1)
+    compute_units.take(ResidentBudget::of(ctx->device), n * rp.group, ctx->compute_units > 0 ? ctx->compute_units : 256);
   if (rp.levels > 0) {
     Range range("resident");
     rc = run_resident(ctx, w, cfg, bp, rp, tinit.data(), want_stats);
