@@ -897,6 +897,7 @@ struct ResidentPlan {
 };
 
 constexpr int kResidentDirectPairs = 16;
+constexpr size_t kResidentDirectStatsBytes = size_t(64) << 20;
 
 ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const BatchPlan& bp) {
   ResidentPlan rp;
@@ -919,7 +920,8 @@ ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg
     if (size_t(bp.cam->w[level]) * bp.cam->h[level] >= (size_t(1) << 24)) break;   // the kernel locates a pixel with one float multiply
     rp.levels += 1;
   }
-  rp.direct = rp.levels == cfg->first_level - cfg->last_level + 1 && bp.n <= kResidentDirectPairs;
+  rp.direct = rp.levels == cfg->first_level - cfg->last_level + 1 && bp.n <= kResidentDirectPairs &&
+              size_t(bp.n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats) <= kResidentDirectStatsBytes;   // (pinned, if asked for)
   return rp;
 }
 
@@ -968,8 +970,9 @@ int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, 
     const bool grown = bytes > w.exchange.bytes;
     DVO_WS_TRY(w, w.exchange.reserve(bytes));
     // sequence numbers never repeat between launches; when they would wrap (or the rows are new / in doubt) the rows are cleared
-    const unsigned need = 2u * unsigned(rp.levels) * unsigned(cfg->max_iterations_per_level) + 4u;
-    if (grown || w.resident_sequence > 0xffffffffu - need - 1u) {
+    const unsigned long long need64 = 2ull * unsigned(rp.levels) * unsigned(cfg->max_iterations_per_level) + 4ull;
+    const unsigned need = need64 < 0x40000000ull ? unsigned(need64) : 0x40000000u;   // (more exchanges than that do not happen)
+    if (grown || need64 >= 0x40000000ull || w.resident_sequence > 0xffffffffu - need - 1u) {
       DVO_WS_TRY(w, hipMemsetAsync(w.exchange.p, 0, w.exchange.bytes, s));
       w.resident_sequence = 0;
     }
