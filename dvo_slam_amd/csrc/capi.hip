@@ -887,7 +887,7 @@ struct ResidentBudget {
   };
 };
 
-constexpr int kResidentRowsDefault = 12;      // segments per wavefront and iteration up to which a level runs resident
+constexpr int kResidentRowsDefault = 24;      // segments per wavefront and iteration up to which a level runs resident
 constexpr int kResidentErrorWord = 0;         // index into Workspace::host_status (the per-step words start behind it)
 
 struct ResidentPlan {

@@ -258,7 +258,7 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * "resident" (-1 default: small batches and coarse levels run in ONE launch per match, each pair owned by a group of resident
  * workgroups -- the latency path; 0: one to three launches per Gauss-Newton step always; 1: every level
  * resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
- * pass; default 12), "resident_group" (workgroups per pair, a power of two <= 64; 0 = as many as fit the device),
+ * pass; default 24), "resident_group" (workgroups per pair, a power of two <= 64; 0 = as many as fit the device),
  * "resident_cooperative" (1: groups are launched with hipLaunchCooperativeKernel), "resident_flags" (measurement / test hooks). */
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 
