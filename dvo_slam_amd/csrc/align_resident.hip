@@ -141,8 +141,8 @@ extern "C" int dvo_hip_debug_resident_clocks(unsigned long long* out32, int rese
 
 __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const ResidentArgs a) {
   extern __shared__ __attribute__((aligned(16))) float slab_mem[];          // kResidentWaves slabs of kSlabFloats
-  __shared__ PairState st, st_before;                                       // st_before: the state a speculative pass started from
-  __shared__ dvo_hip_level_stats lvl, lvl_before;
+  __shared__ PairState st, st_before[2];                                    // st_before[p & 1]: the state pass p's loop body started from
+  __shared__ dvo_hip_level_stats lvl, lvl_before[2];
   __shared__ dvo_hip_iteration_stats rec[2];                                // the records of the pass in flight and the one before
   __shared__ double sums[2][kAccStride];                                    // likewise its reduced accumulators
   __shared__ double sums_q[kGatherLanes][kAccStride];
@@ -209,6 +209,10 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
     }
     // (the barrier that publishes the level's first estimate comes after the wavefronts have asked for their first reference
     //  segment: that round trip runs under lane 0's se3 log / exp)
+    if (wave == 0) {                                           // the state the first pass starts from (see `restore` below)
+      wave_copy(&st_before[0], &st, lane);
+      wave_copy(&lvl_before[0], &lvl, lane);
+    }
 
     const int n_px = g.w * g.h, n_seg = (n_px + kTileW - 1) / kTileW;
     // workgroups beyond the level's segments have nothing to sweep: their rows are zero and are neither written nor read
@@ -429,11 +433,15 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
         //            produced is dropped;
         //   else:    this pass, speculatively (the level may already be over: then only the verdict was due).
         if (restore) {
-          wave_copy(&st, &st_before, lane);
-          wave_copy(&lvl, &lvl_before, lane);
-        } else if (do_sweep) {
-          wave_copy(&st_before, &st, lane);
-          wave_copy(&lvl_before, &lvl, lane);
+          // st_before was taken when the pass before had run its loop body, i.e. before the verdict on the pass before THAT moved the
+          // error chain on; a failed verdict leaves the chain alone, so the live values are the ones that belong to the restored state
+          const double error_now = st.error, last_error_now = st.last_error;
+          wave_copy(&st, &st_before[prev], lane);               // (the rejected pass is the one before this: parity `prev`)
+          wave_copy(&lvl, &lvl_before[prev], lane);
+          if (lane == 0) { st.error = error_now; st.last_error = last_error_now; }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         const int which = restore ? prev : cur;
         if (restore || do_sweep) {                             // the record's 51 NaNs by the whole wavefront, not by the solver lane
@@ -477,6 +485,12 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         over = uniform(level_over) != 0;
+        // the state the NEXT pass starts from, kept for the case that its verdict is a rejection (off the sweepers' path: they are
+        // released)
+        if (!over) {
+          wave_copy(&st_before[prev], &st, lane);               // (the next pass has the parity of the one before this)
+          wave_copy(&lvl_before[prev], &lvl, lane);
+        }
         // the record of the pass before is final now; so is this pass' if the level ended without waiting for a log-likelihood
         if (wg == 0) {
           const int done_prev = uniform(rec_slot[prev]);

@@ -851,10 +851,12 @@ int ensure_host_status(Workspace& w, size_t n_steps) {
 }
 
 // ---- the resident kernel: which levels, how many workgroups per pair ------------------------------------------------------------
-// Workgroups of a group wait for each other, so all groups in flight on a device must be on it together: contexts of one process
-// (one per host thread, like the reference's one DenseTracker per TBB worker) share the device's compute units through this
-// budget -- a launch with groups waits until its workgroups fit next to those already in flight.  (Another PROCESS on the same
-// device is not seen here; there a group can time out, and the batch is repeated on the launch path.)
+// Workgroups of a group wait for each other, so all groups in flight on a device must be on it together.  Contexts of one process
+// (one per host thread, like the reference's one DenseTracker per TBB worker) therefore take turns: one launch with groups per
+// device at a time.  (Letting launches that fit next to each other run together was tried: on some boxes one launch in seven then
+// saw a group time out -- and the batch repeated on the launch path, with that path's rounding -- although the workgroups of
+// both fit the device; the cause was not found.  Another PROCESS on the same device is not seen here; there a group can time
+// out, and the batch is repeated on the launch path.)
 struct ResidentBudget {
   std::mutex m;
   std::condition_variable cv;
@@ -871,7 +873,8 @@ struct ResidentBudget {
     Hold& operator=(const Hold&) = delete;
     void take(ResidentBudget& budget, int workgroups, int capacity) {
       std::unique_lock<std::mutex> lock(budget.m);
-      budget.cv.wait(lock, [&] { return budget.in_flight == 0 || budget.in_flight + workgroups <= capacity; });
+      (void)capacity;
+      budget.cv.wait(lock, [&] { return budget.in_flight == 0; });
       budget.in_flight += workgroups;
       b = &budget;
       n = workgroups;

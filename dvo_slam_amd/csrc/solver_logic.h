@@ -191,7 +191,8 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   const double det = double(P[0]) * double(P[3]) - double(P[1]) * double(P[2]);
   // the reference's log-likelihood is a float (computeCompleteDataLogLikelihood returns float into `float ll`, :297,
   // impl:406-425): the rounding decides `Error < LastError` at the noise floor, so it is part of the algorithm
-  const double half_n_logdet = 0.5 * double(n) * log(det);
+  // (speculative form: the logarithm is only needed by the verdict one exchange later, it is taken behind the release)
+  const double half_n_logdet = speculate ? 0.0 : 0.5 * double(n) * log(det);
   const double ll = double(float(half_n_logdet - 3.5 * ll_sum));
   if (!speculate) rec.tdist_loglik = -ll;
   for (int i = 0; i < 4; ++i) rec.tdist_precision[i] = double(P[i]);
@@ -206,7 +207,6 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
 
   bool accept = true;
   if (speculate) {
-    spec->half_n_logdet = half_n_logdet;
     spec->needs_loglik = 1;
   } else {
     st.last_error = st.error;
@@ -253,6 +253,7 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   DVO_GN_CLK(5);                                             // exp, product, K T
   gn_release_sweep(spec);
   // behind the release: nothing below is read by the next residual sweep
+  if (speculate) spec->half_n_logdet = 0.5 * double(n) * log(det);
   for (int i = 0; i < 6; ++i) rec.increment[i] = st.x[i];
   if (spec && spec->defer_information) {
     for (int i = 0; i < 36; ++i) st.A_last[i] = A[i];

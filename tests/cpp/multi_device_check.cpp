@@ -67,6 +67,12 @@ int main(int argc, char** argv) {
     if (results[p].isNaN() || results[p].Statistics.Levels.size() != 3) return 4;
   }
   keep.clear();
+  for (size_t c = 0; c < contexts.size(); ++c) {               // (stderr: did a workgroup group ever wait in vain?)
+    long long timeouts = 0, launches = 0;
+    dvo_hip_get_counter(contexts[c], "resident_timeouts", &timeouts);
+    dvo_hip_get_counter(contexts[c], "resident_launches", &launches);
+    std::fprintf(stderr, "context %zu: %lld resident launches, %lld time-outs\n", c, launches, timeouts);
+  }
   for (int c = devices; c < n_contexts; ++c) dvo_hip_context_destroy(contexts[size_t(c)]);
   return 0;
 }
