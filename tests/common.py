@@ -59,6 +59,7 @@ def emul_lib():
         L.emul_level_iteration.argtypes = [C.POINTER(EmulLevel), fp, fp, C.c_int, C.POINTER(hl.IterationOut), fp]
         L.emul_match.argtypes = [C.POINTER(EmulLevel), C.POINTER(hl.Config), C.POINTER(hl.Result), C.POINTER(hl.LevelStats), C.c_int,
                                  C.POINTER(hl.IterationStats), C.c_int]
+        L.emul_match_speculative.argtypes = L.emul_match.argtypes
         L.emul_set_schedule.argtypes = [C.c_int]
         L.emul_set_schedule.restype = None
         L.emul_se3_exp.argtypes = [dp, dp]
@@ -103,8 +104,9 @@ class EmulPair:
         return dict(rc=rc, n=out.n, n_selected=out.n_selected, cov=np.array(out.scale_cov), P=np.array(out.precision).reshape(2, 2),
                     neg_ll=out.neg_loglik, A=np.array(out.A).reshape(6, 6), b=np.array(out.b), residuals=res)
 
-    def match(self, cfg, T_init=None):
-        """cfg: dvo_slam_amd.Config. Returns the same dict layout as pyoracle.match."""
+    def match(self, cfg, T_init=None, speculative=False, raw=False):
+        """cfg: dvo_slam_amd.Config. Returns the same dict layout as pyoracle.match.  speculative: the control flow of the resident
+        kernel (emul_match_speculative).  raw: also the raw bytes of result + level + iteration records (for bit comparisons)."""
         ccfg = cfg.to_c()
         res = hl.Result()
         T0 = np.eye(4) if T_init is None else np.asarray(T_init, dtype=np.float64)
@@ -114,9 +116,14 @@ class EmulPair:
         cap = nl * cfg.MaxIterationsPerLevel
         levels = (hl.LevelStats * nl)()
         iters = (hl.IterationStats * cap)()
-        rc = emul_lib().emul_match(self.arr, C.byref(ccfg), C.byref(res), levels, nl, iters, cap)
+        fn = emul_lib().emul_match_speculative if speculative else emul_lib().emul_match
+        rc = fn(self.arr, C.byref(ccfg), C.byref(res), levels, nl, iters, cap)
         assert rc == 0
-        return result_to_dict(res, levels, iters)
+        out = result_to_dict(res, levels, iters)
+        if raw:
+            used = sum(levels[i].n_iterations for i in range(res.n_levels))
+            out["raw"] = (bytes(res), bytes(levels)[: res.n_levels * C.sizeof(hl.LevelStats)], bytes(iters)[: used * C.sizeof(hl.IterationStats)])
+        return out
 
 
 def result_to_dict(res, levels, iters):

@@ -209,6 +209,90 @@ int emul_match(const emul_level* levels, const dvo_hip_config* cfg, dvo_hip_resu
   return 0;
 }
 
+// The same match with the control flow of the resident kernel (dvo_slam_amd/csrc/align_resident.hip, the block its solver wavefront
+// runs after every exchange): the loop body runs SPECULATIVELY, before the log-likelihood of its pass is known; the verdict arrives
+// one pass later (gn_commit_loglik); a rejection restores the state the pass started from (double-buffered snapshots, the error
+// chain taken from the live state) and runs the loop body once more in full form, which takes the revert path.  The sweeps are
+// the host sweeps above, so this driver must reproduce emul_match bit for bit: state, results, level and iteration records.
+int emul_match_speculative(const emul_level* levels, const dvo_hip_config* cfg, dvo_hip_result* result,
+                           dvo_hip_level_stats* lstats, int cap_levels, dvo_hip_iteration_stats* istats, int cap_iters) {
+  SolverParams prm;
+  prm.max_iterations = cfg->max_iterations_per_level;
+  prm.first_level = cfg->first_level;
+  prm.last_level = cfg->last_level;
+  prm.use_initial_estimate = cfg->use_initial_estimate;
+  prm.precision = cfg->precision;
+  prm.mu = cfg->mu;
+  prm.cap_iters = cap_iters;
+  prm.cap_levels = cap_levels;
+  prm.max_points_level0 = levels[0].w * levels[0].h;
+  prm.want_condition_number = 1;
+  PairState st;
+  std::memset(&st, 0, sizeof(st));
+  gn_init_pair(st, prm, result->transformation);
+  volatile int release_word = 0;
+  for (int level = cfg->first_level; level >= cfg->last_level; --level) {
+    LevelCtx c;
+    make_level(levels[level], c);
+    const int slot = st.n_levels;
+    gn_level_begin(st, prm, c.g, level, levels[level].n_selected, lstats);
+    PairState st_before[2];
+    dvo_hip_level_stats lvl_before[2];
+    st_before[0] = st;
+    if (slot < cap_levels) lvl_before[0] = lstats[slot];
+    double sums[2][kNumAcc];
+    std::vector<float> res;
+    GnSpeculation spec;
+    std::memset(&spec, 0, sizeof(spec));
+    bool pending = false;
+    double ll_pending = 0.0;
+    int rec_pending = -1;
+    for (int pass = 0;; ++pass) {
+      const int cur = pass & 1, prev = cur ^ 1;
+      const bool do_sweep = st.active != 0;
+      if (do_sweep) sweep(c, st.KT, st.P_prev, st.first != 0, sums[cur], res);     // at the speculatively advanced estimate
+      bool restore = false, over = false;
+      if (pending) {                                                                // the verdict on the pass before
+        dvo_hip_iteration_stats dummy;
+        dvo_hip_iteration_stats& rec = rec_pending < cap_iters ? istats[rec_pending] : dummy;
+        restore = !gn_commit_loglik(st, spec, ll_pending, rec);
+        pending = false;
+      }
+      if (restore) {
+        const double error_now = st.error, last_error_now = st.last_error;
+        st = st_before[prev];
+        if (slot < cap_levels) lstats[slot] = lvl_before[prev];
+        st.error = error_now;
+        st.last_error = last_error_now;
+        GnSpeculation replay = spec;
+        replay.replay_reject = 1;
+        gn_step(st, prm, c.g, sums[prev], ll_pending, lstats, istats, &replay);
+        over = true;
+      } else if (!do_sweep) {
+        over = true;
+      } else {
+        rec_pending = st.n_iters_total;
+        spec.replay_reject = 0;
+        spec.record_prefilled = 0;
+        spec.defer_information = 1;
+        spec.release_word = &release_word;
+        spec.release_value = pass + 1;
+        gn_step(st, prm, c.g, sums[cur], 0.0, lstats, istats, &spec);
+        if (spec.information_ready && rec_pending < cap_iters)
+          for (int i = 0; i < 36; ++i) istats[rec_pending].information[i] = st.A_last[i];
+        pending = spec.needs_loglik != 0;
+        if (!pending) over = true;
+        else ll_pending = loglik_sum(res, sums[cur]);                               // travels with the next exchange
+      }
+      if (over) break;
+      st_before[prev] = st;                                                         // what the next pass starts from
+      if (slot < cap_levels) lvl_before[prev] = lstats[slot];
+    }
+  }
+  gn_finish(st, prm, lstats, istats, result);
+  return 0;
+}
+
 // exposed for unit tests of the device SE(3) / solve code
 void emul_se3_exp(const double x[6], double T[16]) {
   SE3d S;

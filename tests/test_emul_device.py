@@ -99,6 +99,37 @@ def test_state_machine_against_oracle_driver(seed, first, last, mu, init, precis
     assert e["entropy"] == pytest.approx(ko["entropy"], abs=2e-2) and e["constraint_ratio"] == pytest.approx(ko["constraint_ratio"], abs=2e-3)
 
 
+@pytest.mark.parametrize("seed,w,h,first,last,mu,init,precision,cap", [
+    (1234, 320, 240, 3, 0, 0.0, False, 5e-7, 100), (1234, 320, 240, 3, 0, 0.0, False, 1e-4, 100), (2, 320, 240, 3, 1, 0.05, True, 1e-4, 50),
+    (3, 320, 240, 2, 2, 0.0, False, 5e-7, 100), (9, 131, 97, 2, 0, 0.0, False, 5e-7, 100), (5, 160, 120, 2, 0, 0.5, True, 1e-5, 4),
+    (6, 160, 120, 2, 0, 0.0, False, 0.0, 3), (7, 96, 72, 1, 0, 0.0, False, 5e-7, 1)])
+def test_speculative_control_flow_of_the_resident_kernel_is_the_state_machine(seed, w, h, first, last, mu, init, precision, cap):
+    """The resident kernel runs gn_step before the log-likelihood of a pass is known and settles accept / revert one exchange later
+    (gn_commit_loglik; a rejection restores the snapshot the pass started from and replays the pass in full form).  On the host,
+    with the same sweeps, that control flow must leave the very same bits as the plain loop: result, level records, iteration
+    records -- over levels that end on a rejection, on a small increment, on the iteration cap and on too few constraints."""
+    pair = cm.synth(seed, w, h)
+    ref, cur = cm.oracle_pyramids(pair, first + 1)
+    ep = cm.EmulPair(ref, cur, first + 1)
+    cfg = d.Config(FirstLevel=first, LastLevel=last, Mu=mu, UseInitialEstimate=init, Precision=precision, MaxIterationsPerLevel=cap)
+    T0 = po.se3_exp(0.5 * pair["xi_true"]) if init else None
+    plain = ep.match(cfg, T0, raw=True)
+    spec = ep.match(cfg, T0, speculative=True, raw=True)
+    assert [(L["id"], len(L["iterations"]), L["termination"]) for L in spec["levels"]] == [(L["id"], len(L["iterations"]), L["termination"]) for L in plain["levels"]]
+    assert spec["raw"] == plain["raw"]
+
+
+def test_speculative_control_flow_without_constraints():
+    h, w = 60, 80
+    I = np.random.default_rng(0).uniform(0, 255, (h, w)).astype(np.float32)
+    Z = np.full((h, w), np.nan, np.float32)
+    ref, cur = po.Pyramid(I, Z, po.FR1_K / 8, 2), po.Pyramid(I, Z, po.FR1_K / 8, 2)
+    ep = cm.EmulPair(ref, cur, 2)
+    cfg = d.Config(FirstLevel=1, LastLevel=0)
+    plain, spec = ep.match(cfg, raw=True), ep.match(cfg, speculative=True, raw=True)
+    assert [L["termination"] for L in spec["levels"]] == [1, 1] and spec["raw"] == plain["raw"]
+
+
 def test_sym6_eigenvalues_and_degenerate_statistics():
     L = cm.emul_lib()
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
