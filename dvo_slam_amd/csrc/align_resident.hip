@@ -1,28 +1,36 @@
 // align_resident.hip -- a whole coarse-to-fine alignment (or its coarse levels) in ONE launch: the latency path.
 //
-// The multi-launch path (capi.hip::run_batch) spends one to three launches per Gauss-Newton iteration; for a lone pair, or the two
-// pairs LocalTracker aligns per frame (dvo_slam/src/local_tracker.cpp:180-184), nearly all of a match is launch floor (5 us per
-// dependent launch on this queue) and memory round trips of a few-microsecond kernels (profiles/r01_v_single_pair_timeline.txt:
-// 64 launches, 0.5 ms).  Here a pair is owned by a GROUP of G resident workgroups of 8 wavefronts for the whole match:
+// The launch path (capi.hip::run_batch) spends one to three launches per Gauss-Newton iteration; for a lone pair, or the two pairs
+// LocalTracker aligns per frame (dvo_slam/src/local_tracker.cpp:180-184), nearly all of a match is launch floor (5 us per
+// dependent launch on this queue) and memory round trips of few-microsecond kernels (profiles/r02_d_single_pair_timeline.txt:
+// 66 launches, 0.5 ms).  Here a pair is owned by a GROUP of G resident workgroups of 8 wavefronts for the whole match
+// ("The latency path"):
 //
-//   per iteration   every wavefront of the group sweeps its 64-pixel segments of the level (same per-pixel arithmetic and the
-//                   same Gram accumulation on the matrix cores as align_mfma.hip; residual pairs go to the pair's scratch and are
-//                   read back by the SAME wavefront only), the workgroup folds its wavefronts into one canonical partial row,
-//     exchange A    the G rows travel between the workgroups of the group (below); every workgroup adds them in the same order in
-//                   float64 and derives the same scale / precision P (dense_tracking.cpp:295),
-//     exchange B    every workgroup sums log(1 + 0.2 r^T P r) over ITS residuals; the G partial sums travel the same way,
-//     solver        lane 0 of EVERY workgroup runs the reference's loop body (solver_logic.h::gn_step: accept / revert, 6x6 solve,
-//                   SE(3) update, termination) on its own LDS copy of the pair's state -- redundantly and deterministically, so the
-//                   group needs no third exchange and no broadcast of the new pose; workgroup 0 writes the iteration record.
-//   levels          follow each other inside the kernel (gn_level_begin); the host is not involved until the launch ends.
+//   sweep      wavefronts 1..7 of every workgroup sweep their 64-pixel segments of the level (the per-pixel arithmetic and the Gram
+//              accumulation on the matrix cores of align_mfma.hip; residual pairs stay in LDS, or in scratch read back by the SAME
+//              wavefront only); the workgroup folds its wavefronts into one canonical partial row;
+//   exchange   ONE per pass: the rows travel between the workgroups of the group (below) together with the partial log-likelihood
+//              sums of the pass BEFORE; every workgroup adds them in the same order in float64 and derives the same scale /
+//              precision P (dense_tracking.cpp:295);
+//   loop body  wavefront 0 (no segments) of EVERY workgroup runs the reference's loop body (solver_logic.h::gn_step: 6x6 solve,
+//              SE(3) update, termination) on its own LDS copy of the pair's state -- redundantly and identically, so the new pose
+//              needs no broadcast.  It runs speculatively: the pass is treated as accepted, the sweeping wavefronts are released
+//              the moment the next estimate is in place (the rest of the body is written behind the release), they sum
+//              log(1 + 0.2 r^T P r) over their residuals next to it, and the accept / revert question is settled one exchange
+//              later (gn_commit_loglik); a rejection restores the state the pass started from and runs the body in full form, which
+//              takes the reference's revert path.  tests/test_emul_device.py runs this control flow on the host against the plain
+//              loop: the same bits;
+//   levels     follow each other inside the kernel (gn_level_begin); the host is not involved until the launch ends, and for small
+//              batches not even then: results and statistics go to pinned host memory and a done word (capi.hip, direct path).
 //
 // The exchange is the "LL" protocol of collective libraries: a row is 8-byte slots {value, sequence number}, written with relaxed
 // agent-scope stores and polled with relaxed agent-scope loads (sc1: through the non-coherent per-XCD L2s).  An aligned 8-byte
 // access is single-copy atomic, so a slot whose sequence number is current carries current data -- no flag, no fence and ONE round
-// trip when the data is there.  Rows are double-buffered by the parity of the exchange count; a workgroup can only lap a reader by
-// two exchanges after that reader has itself written the next one.  All workgroups of a launch are co-resident (cooperative launch
-// when G > 1); polling is bounded, a group that times out raises the error word and leaves (the host reports DVO_HIP_ERR_HIP).
-// With G = 1 (large batches, coarse levels) there is no exchange and no residency requirement at all.
+// trip when the data is there.  Rows are double-buffered by the parity of the exchange count; a workgroup can run at most one
+// exchange ahead of its peers.  All workgroups of a launch with G > 1 must be on the device together (one per compute unit; the
+// host sizes G accordingly and lets such launches take turns); polling is bounded: a group that waits in vain raises the error
+// word and leaves, and the host repeats the batch on the launch path.  With G = 1 (large batches, coarse levels) there is no
+// exchange and no residency requirement at all.
 #include "align_common.h"
 #ifdef DVO_RESIDENT_CLOCKS
 namespace dvo_hip {
