@@ -52,7 +52,7 @@ def emul_lib():
         deps = [src] + [os.path.join(ROOT, "dvo_slam_amd", "csrc", f) for f in
                         ("pixel_math.h", "solver_logic.h", "se3_device.h", "device_types.h", "hd_compat.h")]
         if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-            subprocess.check_call(["g++", "-O2", "-march=native", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unknown-pragmas",
+            subprocess.check_call(["g++", "-O2", "-march=native", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unknown-pragmas", "-pthread",
                                    "-shared", "-o", out, src])
         L = C.CDLL(out)
         fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
@@ -60,6 +60,7 @@ def emul_lib():
         L.emul_match.argtypes = [C.POINTER(EmulLevel), C.POINTER(hl.Config), C.POINTER(hl.Result), C.POINTER(hl.LevelStats), C.c_int,
                                  C.POINTER(hl.IterationStats), C.c_int]
         L.emul_match_speculative.argtypes = L.emul_match.argtypes
+        L.emul_exchange_stress.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint]
         L.emul_set_schedule.argtypes = [C.c_int]
         L.emul_set_schedule.restype = None
         L.emul_se3_exp.argtypes = [dp, dp]

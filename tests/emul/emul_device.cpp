@@ -6,6 +6,9 @@
 // CPU-only test tier.  It is never linked into libdvo_hip.so and is not a fallback: the product has none.
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../dvo_slam_amd/csrc/solver_logic.h"
@@ -291,6 +294,45 @@ int emul_match_speculative(const emul_level* levels, const dvo_hip_config* cfg, 
   }
   gn_finish(st, prm, lstats, istats, result);
   return 0;
+}
+
+// The exchange of the resident kernel (align_resident.hip: rows of 8-byte {value, sequence number} slots, relaxed stores, relaxed
+// polling loads, rows double-buffered by the parity of the exchange count) with host threads in the place of workgroups: every
+// thread does `exchanges` rounds of  write my row -> gather everybody's rows of this round -> check the sum , at its own, randomly
+// disturbed pace.  Returns the number of rounds in which a thread gathered anything but the values of that very round (0 = the
+// protocol never hands out stale or torn rows, however far the fastest thread runs ahead -- it cannot pass the round its slowest
+// peer has not written yet).
+int emul_exchange_stress(int group, int exchanges, int slots, unsigned seed) {
+  std::vector<std::atomic<unsigned long long>> rows(size_t(group) * 2 * slots);
+  for (auto& r : rows) r.store(0, std::memory_order_relaxed);
+  std::atomic<int> bad(0);
+  auto value = [](int t, int k, int s) { return unsigned(t * 2654435761u + k * 40503u + s * 97u); };
+  auto worker = [&](int t) {
+    unsigned rng = seed * 747796405u + unsigned(t) * 2891336453u + 1u;
+    for (int k = 1; k <= exchanges; ++k) {
+      rng = rng * 1664525u + 1013904223u;
+      if ((rng >> 28) == 0) std::this_thread::sleep_for(std::chrono::microseconds((rng >> 8) & 63));   // a slow sweep now and then
+      const int parity = k & 1;
+      for (int s = 0; s < slots; ++s)
+        rows[(size_t(t) * 2 + parity) * slots + s].store((static_cast<unsigned long long>(unsigned(k)) << 32) | value(t, k, s), std::memory_order_relaxed);
+      for (int s = 0; s < slots; ++s) {
+        unsigned long long sum = 0, want = 0;
+        for (int j = 0; j < group; ++j) {
+          unsigned long long v;
+          do {
+            v = rows[(size_t(j) * 2 + parity) * slots + s].load(std::memory_order_relaxed);
+          } while (unsigned(v >> 32) != unsigned(k));
+          sum += unsigned(v);
+          want += value(j, k, s);
+        }
+        if (sum != want) bad.fetch_add(1);
+      }
+    }
+  };
+  std::vector<std::thread> threads;
+  for (int t = 0; t < group; ++t) threads.emplace_back(worker, t);
+  for (auto& th : threads) th.join();
+  return bad.load();
 }
 
 // exposed for unit tests of the device SE(3) / solve code

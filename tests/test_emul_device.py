@@ -130,6 +130,13 @@ def test_speculative_control_flow_without_constraints():
     assert [L["termination"] for L in spec["levels"]] == [1, 1] and spec["raw"] == plain["raw"]
 
 
+@pytest.mark.parametrize("group", [2, 5, 12])
+def test_exchange_protocol_of_the_resident_kernel_with_host_threads(group):
+    """8-byte {value, sequence number} slots, rows double-buffered by the parity of the exchange count, relaxed stores and polling
+    loads: threads at randomly disturbed paces never gather a stale or torn row."""
+    assert cm.emul_lib().emul_exchange_stress(group, 1500, 24, 12345 + group) == 0
+
+
 def test_sym6_eigenvalues_and_degenerate_statistics():
     L = cm.emul_lib()
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
