@@ -130,7 +130,7 @@ def test_speculative_control_flow_without_constraints():
     assert [L["termination"] for L in spec["levels"]] == [1, 1] and spec["raw"] == plain["raw"]
 
 
-@pytest.mark.parametrize("group", [2, 5, 12])
+@pytest.mark.parametrize("group", [2, 5, 9])
 def test_exchange_protocol_of_the_resident_kernel_with_host_threads(group):
     """8-byte {value, sequence number} slots, rows double-buffered by the parity of the exchange count, relaxed stores and polling
     loads: threads at randomly disturbed paces never gather a stale or torn row."""
