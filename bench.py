@@ -278,6 +278,24 @@ def main():
         lat.append((time.perf_counter() - t1) * 1e3)
     single_pair_ms = float(np.median(lat[2:]))
 
+    # ... of the two pairs the tracking front end aligns per frame (dvo_slam/src/local_tracker.cpp:180-184), in this configuration
+    # and in the front end's own (dvo_ros/cfg/dvo.cfg defaults = dvo_benchmark/launch/benchmark.yaml: levels 3..1, Precision 1e-4, Mu 0.05,
+    # initial estimate), and of one pair on the launch-per-step path (option resident 0) for comparison
+    def median_ms(fn, reps=12):
+        t = []
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            fn()
+            t.append((time.perf_counter() - t1) * 1e3)
+        return round(float(np.median(t[2:])), 3)
+    latency = {"pairs_1": round(single_pair_ms, 3), "pairs_2": median_ms(lambda: tracker.match_batch_arrays(refs[:2], curs[:2]))}
+    front_end = d.DenseTracker(d.Config(FirstLevel=3, LastLevel=1, MaxIterationsPerLevel=50, Precision=1e-4, Mu=0.05, UseInitialEstimate=True), ctx)
+    guess = np.stack([np.eye(4)] * len(refs[:2]))
+    latency["front_end_config_pairs_2"] = median_ms(lambda: front_end.match_batch_arrays(refs[:2], curs[:2], T_init=guess))
+    ctx.set_option("resident", 0)
+    latency["pairs_1_launch_path"] = median_ms(lambda: tracker.match(refs[0], curs[0], one, with_stats=False))
+    ctx.set_option("resident", -1)
+
     # PCIe-inclusive leg (never `value`): the same pipeline, but every step's raw planes are handed over in pinned HOST memory
     # (SURVEY.md 8d config 4 "incl. H2D of 2 planes per frame") -- DMA on the upload stream, build on the build stream, match on
     # the main stream, three batches in flight
@@ -349,6 +367,7 @@ def main():
             "roofline": roofline,
             "match_only_ms_per_batch": round(match_only_ms, 3),
             "single_pair_ms": round(single_pair_ms, 3),
+            "latency_ms": latency,
             "from_host": from_host,
             "max_twist_error_vs_truth": twist_err, "nan_results": nan_results,
         }
