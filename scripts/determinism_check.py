@@ -1,3 +1,5 @@
+#!/usr/bin/env python
+"""Run-to-run determinism of the match: the same batch 300 times, every result compared bitwise with the first (1, 2, 8, 40 pairs)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
