@@ -103,7 +103,10 @@ struct SolverParams {
 // ---- the resident match kernel (align_resident.hip): one group of workgroups owns a pair for a whole run of levels ----
 constexpr int kResidentWaves = 8;                    // wavefronts per workgroup (512 threads: the solver lane needs > 128 registers)
 constexpr int kResidentSweepers = kResidentWaves - 1;  // wavefront 0 is the workgroup's solver
-constexpr int kResidentRowsLds = 12;                 // residual pairs of a wavefront's first segments stay in LDS (the rest: scratch)
+constexpr int kResidentRowsLds = 3;                  // residual pairs of a wavefront's first segments stay in LDS (the rest: scratch).
+                                                     // Not more: the kernel is faster with less than 64 KB of LDS per workgroup (12 rows =
+                                                     // 91 KB: the front end's 0.17-ms match took 0.178 ms), and the coarse levels, where the
+                                                     // passes are, give a wavefront one to three segments
 constexpr int kResidentBlock = kResidentWaves * 64;
 constexpr int kResidentMaxGroup = 64;                // workgroups per pair at most (power of two)
 constexpr int kResidentSlots = 96;                   // 8-byte {value, sequence} slots of an exchange row: the 85 accumulators, ...
