@@ -148,13 +148,13 @@ extern "C" int dvo_hip_debug_resident_clocks(unsigned long long* out32, int rese
 #endif
 
 __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const ResidentArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float slab_mem[];          // kResidentWaves slabs of kSlabFloats
+  extern __shared__ __attribute__((aligned(16))) float slab_mem[];          // one slab of kSlabFloats per SWEEPING wavefront
   __shared__ PairState st, st_before[2];                                    // st_before[p & 1]: the state pass p's loop body started from
   __shared__ dvo_hip_level_stats lvl, lvl_before[2];
   __shared__ dvo_hip_iteration_stats rec[2];                                // the records of the pass in flight and the one before
   __shared__ double sums[2][kAccStride];                                    // likewise its reduced accumulators
   __shared__ double sums_q[kGatherLanes][kAccStride];
-  __shared__ float2 res_lds[kResidentWaves][kResidentRowsLds][kTileW];      // the residual pairs of a wavefront's first segments
+  __shared__ float2 res_lds[kResidentSweepers][kResidentRowsLds][kTileW];   // the residual pairs of a sweeping wavefront's first segments
   __shared__ double ll_group[kResidentMaxGroup];
   __shared__ double ll_waves[kResidentWaves];
   __shared__ GnSpeculation speculation;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
   int fold_e1 = -1, fold_e2 = -1;
   if (tid > kAccN && tid < kNumAcc) gram_entries_of_accumulator(tid, fold_e1, fold_e2);
 
-  float* my = slab_mem + wave * kSlabFloats;
+  float* my = slab_mem + (sweeper ? wave - 1 : 0) * kSlabFloats;              // (wavefront 0 never touches it)
   f32x4* wr = reinterpret_cast<f32x4*>(my + lane * 4);
   const float* rd = my + ((lane >> 2) & 3) * kQuadStride + (lane >> 4) * 4 + (lane & 3);
   const float nanv = __builtin_nanf("");
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
           n_valid += __popcll(__ballot(valid));
           {
             const float2 rr = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);   // NaN: no constraint (and past the end)
-            if (held < kResidentRowsLds) res_lds[wave][held][lane] = rr;
+            if (held < kResidentRowsLds) res_lds[wave - 1][held][lane] = rr;
             else if (in_image) residuals[idx] = rr;
             ++held;
           }
@@ -328,7 +328,8 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
       CLK(1);                                                  // sweep (thread 0's wavefront)
       // ---- fold the workgroup's wavefronts into the canonical partial row (device_types.h) -----------------------------------
 #pragma unroll
-      for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
+      for (int i = 0; i < 4; ++i)
+        if (sweeper) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
       if (lane == 0) counts[wave] = n_valid;
       __syncthreads();
       float row_value = 0.0f;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
         auto Gm = [&](int e) {
           float t = 0.0f;
 #pragma unroll
-          for (int wv = 1; wv < kResidentWaves; ++wv) t += slab_mem[wv * kSlabFloats + e];
+          for (int wv = 0; wv < kResidentSweepers; ++wv) t += slab_mem[wv * kSlabFloats + e];
           return t;
         };
         if (tid == kAccN) {
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
             for (int seg = gw; seg < n_seg; seg += W, ++held) {
               const int idx = seg * kTileW + lane;
               float2 r = make_float2(nanv, nanv);
-              if (held < kResidentRowsLds) r = res_lds[wave][held][lane];
+              if (held < kResidentRowsLds) r = res_lds[wave - 1][held][lane];
               else if (idx < n_px) r = residuals[idx];
               if (r.x == r.x) prod *= 1.0 + 0.2 * double(mahalanobis(r.x, r.y, P));
               if (++factors == 8) {                           // eight factors at most between renormalisations (align_common.h)
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
   CLK(7);
 }
 
-size_t resident_dynamic_lds() { return size_t(kResidentWaves) * kSlabFloats * sizeof(float); }
+size_t resident_dynamic_lds() { return size_t(kResidentSweepers) * kSlabFloats * sizeof(float); }
 
 hipError_t launch_match_resident(hipStream_t s, const ResidentArgs& args, bool cooperative) {
   static bool configured[64] = {};                            // the attribute is per device (callers hold their context's lock;
