@@ -40,6 +40,7 @@ __device__ unsigned long long g_gn_prev;
 #define DVO_GN_CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); if (i) dvo_hip::g_resident_clk[16 + (i)] += now_ - dvo_hip::g_gn_prev; dvo_hip::g_gn_prev = now_; } } while (0)
 #endif
 #include "solver_logic.h"
+#include "linear_walk.h"
 #include "sweep_parts.h"
 
 namespace dvo_hip {
@@ -234,12 +235,7 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
     taps.rowB = g.w * 8;
     float2* residuals = a.scratch + size_t(pair) * n_px;
 
-    auto locate = [&](int idx, int& row, int& col) {          // idx < 2^24: one float multiply lands within one row of the quotient
-      row = int(float(idx) * inv_w);
-      col = idx - row * g.w;
-      if (col < 0) { col += g.w; row -= 1; }
-      if (col >= g.w) { col -= g.w; row += 1; }
-    };
+    auto locate = [&](int idx, int& row, int& col) { locate_pixel(idx, g.w, inv_w, row, col); };
     auto load_i = [&](int pixel) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(refR, pixel * 8 + 4, 0, 0)); };
     auto load_seg = [&](int seg) {
       RefSeg r;

@@ -50,7 +50,7 @@ def emul_lib():
         src = os.path.join(HERE, "emul", "emul_device.cpp")
         out = os.path.join(HERE, "emul", "libemul_device.so")
         deps = [src] + [os.path.join(ROOT, "dvo_slam_amd", "csrc", f) for f in
-                        ("pixel_math.h", "solver_logic.h", "se3_device.h", "device_types.h", "hd_compat.h")]
+                        ("pixel_math.h", "solver_logic.h", "se3_device.h", "device_types.h", "hd_compat.h", "linear_walk.h")]
         if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
             subprocess.check_call(["g++", "-O2", "-march=native", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unknown-pragmas", "-pthread",
                                    "-shared", "-o", out, src])
@@ -61,6 +61,7 @@ def emul_lib():
                                  C.POINTER(hl.IterationStats), C.c_int]
         L.emul_match_speculative.argtypes = L.emul_match.argtypes
         L.emul_exchange_stress.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint]
+        L.emul_locate_check.argtypes = [C.c_int, C.c_int]
         L.emul_set_schedule.argtypes = [C.c_int]
         L.emul_set_schedule.restype = None
         L.emul_se3_exp.argtypes = [dp, dp]

@@ -11,6 +11,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../dvo_slam_amd/csrc/linear_walk.h"
 #include "../../dvo_slam_amd/csrc/solver_logic.h"
 
 using namespace dvo_hip;
@@ -335,6 +336,18 @@ int emul_exchange_stress(int group, int exchanges, int slots, unsigned seed) {
   for (int t = 0; t < group; ++t) threads.emplace_back(worker, t);
   for (auto& th : threads) th.join();
   return bad.load();
+}
+
+// every flat pixel index of a w x h level through the division-free row / column computation of the linear walk: mismatches
+int emul_locate_check(int w, int h) {
+  const float inv_w = 1.0f / float(w);
+  int bad = 0;
+  for (int idx = 0; idx < w * h; ++idx) {
+    int row, col;
+    locate_pixel(idx, w, inv_w, row, col);
+    bad += (row != idx / w || col != idx % w);
+  }
+  return bad;
 }
 
 // exposed for unit tests of the device SE(3) / solve code

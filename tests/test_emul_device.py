@@ -137,6 +137,14 @@ def test_exchange_protocol_of_the_resident_kernel_with_host_threads(group):
     assert cm.emul_lib().emul_exchange_stress(group, 1500, 24, 12345 + group) == 0
 
 
+def test_linear_walk_locates_every_pixel():
+    """Row and column of a flat pixel index by one float multiply and two corrections (linear_walk.h), for every index of level sizes
+    up to the 2^24-pixel limit the callers enforce."""
+    for w, h in ((640, 480), (320, 240), (160, 120), (80, 60), (131, 97), (65, 48), (1280, 960), (1919, 1079), (4096, 4095), (3, 5)):
+        assert w * h < (1 << 24)
+        assert cm.emul_lib().emul_locate_check(w, h) == 0, (w, h)
+
+
 def test_sym6_eigenvalues_and_degenerate_statistics():
     L = cm.emul_lib()
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
