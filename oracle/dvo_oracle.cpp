@@ -200,6 +200,16 @@ static Weights8 make_weights(const Intrinsics& K) {
   return W;
 }
 
+// the quirk bits of a semantic mode (dvo_oracle.h): REF_SSE = all of them, MATH = none, DVO_ORACLE_QUIRKS | bits = those bits
+static inline int quirks_of(int mode) {
+  if (mode == DVO_ORACLE_REF_SSE) return DVO_ORACLE_Q_ALL;
+  if (mode == DVO_ORACLE_MATH) return 0;
+  return mode & DVO_ORACLE_Q_ALL;
+}
+// the residual pass of a mode: MATH proper keeps its own scalar restatement (residual_pass_math), everything else runs the
+// SSE restatement with the mode's quirk bits
+static inline bool uses_math_residuals(int mode) { return mode == DVO_ORACLE_MATH; }
+
 // KT = K * T(3x4) in float, Eigen coefficient order (dense_tracking_impl.cpp:142-148)
 static void make_KT(const Intrinsics& K, const float T[12], float KT[12]) {
   for (int j = 0; j < 4; ++j) {
@@ -228,7 +238,11 @@ static inline __m128 hsum2(__m128 a, __m128 b, __m128 c, __m128 d) {
  * of their pair partner, so they are processed one at a time with the same lane arithmetic.
  */
 static int residual_pass_ref(const RefPoint* pts, int n_pts, const Level& cur, const float T[12], const Weights8& W,
-                             Scratch& S, const int* pix_in, bool track_pixels) {
+                             Scratch& S, const int* pix_in, bool track_pixels, int quirks = DVO_ORACLE_Q_ALL) {
+  // quirk by quirk (dvo_oracle.h): without Q1 the projection divides exactly, without Q2 the loop rounds to nearest (and
+  // converts with truncation, = floor on the accepted range), without Q3 an odd trailing point is kept.  No quirk = the
+  // arithmetic of residual_pass_math, bit for bit (tests/test_oracle.py).
+  const bool approx_rcp = (quirks & DVO_ORACLE_Q_RCP_PROJECTION) != 0, rz = (quirks & DVO_ORACLE_Q_ROUND_TOWARD_ZERO) != 0;
   float KT[12];
   make_KT(cur.K, T, KT);
   const __m128 r1 = _mm_loadu_ps(KT + 0), r2 = _mm_loadu_ps(KT + 4), r3 = _mm_loadu_ps(KT + 8);
@@ -240,17 +254,17 @@ static int residual_pass_ref(const RefPoint* pts, int n_pts, const Level& cur, c
   const __m128 zsel = _mm_castsi128_ps(_mm_setr_epi32(0, -1, 0, 0));
 
   const unsigned old_mode = _MM_GET_ROUNDING_MODE();
-  _MM_SET_ROUNDING_MODE(_MM_ROUND_TOWARD_ZERO);
+  if (rz) _MM_SET_ROUNDING_MODE(_MM_ROUND_TOWARD_ZERO);
 
-  const int n_used = n_pts & ~1;
+  const int n_used = (quirks & DVO_ORACLE_Q_DROP_ODD) ? (n_pts & ~1) : n_pts;
   int out = 0;
   for (int i = 0; i < n_used; ++i) {
     const RefPoint& rp = pts[i];
     const __m128 p = _mm_load_ps(rp.p);
     const __m128 xyz = hsum2(_mm_mul_ps(r1, p), _mm_mul_ps(r2, p), _mm_mul_ps(r3, p), _mm_mul_ps(r3, p));  // [x y z z]
     const __m128 zz = _mm_shuffle_ps(xyz, xyz, _MM_SHUFFLE(2, 2, 2, 2));
-    const __m128 uv = _mm_mul_ps(xyz, _mm_rcp_ps(zz));                      // [u v . .]
-    const __m128i uvi = _mm_cvtps_epi32(uv);                                 // truncation under RZ
+    const __m128 uv = approx_rcp ? _mm_mul_ps(xyz, _mm_rcp_ps(zz)) : _mm_div_ps(xyz, zz);   // [u v . .]
+    const __m128i uvi = rz ? _mm_cvtps_epi32(uv) : _mm_cvttps_epi32(uv);     // truncation under RZ
     const __m128 uv0 = _mm_cvtepi32_ps(uvi);
     const __m128 f1 = _mm_sub_ps(uv, uv0);
     const __m128 f0 = _mm_sub_ps(ones, f1);
@@ -336,7 +350,7 @@ static inline float mahalanobis(const float* r, const float P[4]) {
 // Pass 2 (dense_tracking_impl.cpp:640-707): t-distribution weights, nu = 5, mean = 0
 static void weights_pass(const float* res, int n, const float P[4], float* w, int mode) {
   int i = 0;
-  if (mode == DVO_ORACLE_REF_SSE) {
+  if (quirks_of(mode) & DVO_ORACLE_Q_RCP_WEIGHTS) {
     const int n4 = n & ~3;
     for (; i < n4; i += 4) {   // groups of four use the approximate reciprocal
       alignas(16) float d[4];
@@ -351,7 +365,7 @@ static void weights_pass(const float* res, int n, const float P[4], float* w, in
 // (odd n) adds the full outer product (w d) d^T coefficient by coefficient, so c10 = (w y) x can differ from c01 = (w x) y
 // in the last bit; the SSE part writes one value to both.
 static void scale_pass(const float* res, const float* w, int n, int mode, float C[4]) {
-  if (mode == DVO_ORACLE_REF_SSE) {
+  if (quirks_of(mode) & DVO_ORACLE_Q_SCALE_PAIRING) {
     const float scale = 1.0f / float(size_t(n) - 2 - 1);
     float a0 = 0, a1 = 0, a3 = 0;
     const int n2 = n & ~1;
@@ -373,6 +387,16 @@ static void scale_pass(const float* res, const float* w, int n, int mode, float 
     C[0] = a0; C[1] = a1; C[2] = a3; C[3] = a2;
   } else {
     double s0 = 0, s1 = 0, s3 = 0;
+    if (mode & DVO_ORACLE_X_PAIRING_F64) {
+      // experiment (tests/golden/make_quirk_table.py): the pairing of Q6 as a formula -- sum_k (w_2k + w_2k+1) r_2k r_2k^T, a
+      // function of the compaction RANKS only, which a GPU could compute with a scan -- without the float sequential rounding
+      const int n2 = n & ~1;
+      for (int i = 0; i < n2; i += 2) {
+        const double x = res[2 * i], y = res[2 * i + 1], ww = double(w[i]) + double(w[i + 1]);
+        s0 += ww * x * x; s1 += ww * x * y; s3 += ww * y * y;
+      }
+      if (n & 1) { const double x = res[2 * n2], y = res[2 * n2 + 1], ww = w[n2]; s0 += ww * x * x; s1 += ww * x * y; s3 += ww * y * y; }
+    } else
     for (int i = 0; i < n; ++i) {
       const double x = res[2 * i], y = res[2 * i + 1], ww = w[i];
       s0 += ww * x * x; s1 += ww * x * y; s3 += ww * y * y;
@@ -394,7 +418,7 @@ static void invert2(const float C[4], float P[4]) {
 
 // Pass 4 (dense_tracking_impl.cpp:406-425). Returns ll.
 static double loglik_pass(const float* res, int n, const float P[4], int mode) {
-  if (mode == DVO_ORACLE_REF_SSE) {
+  if (quirks_of(mode) & DVO_ORACLE_Q_LOGLIK_TAIL) {
     double sum = 0.0, acc = 1.0;
     for (int i = 0; i < n; ++i) {
       acc *= (1.0 + 0.2 * mahalanobis(res + 2 * i, P));
@@ -426,7 +450,7 @@ static inline void jacobian_rows(const RefPoint& e, float J0[6], float J1[6]) {
 
 // Pass 5 (least_squares.cpp:58-64, math_sse.cpp:82-207). A row-major 6x6 (symmetric), b.
 static void normal_equations(const RefPoint* pe, const float* w, int n, const float P[4], int mode, double A[36], double b[6]) {
-  if (mode == DVO_ORACLE_REF_SSE) {
+  if (quirks_of(mode) & DVO_ORACLE_Q_FLOAT_NORMAL_EQ) {
     float blk[24];   // six row-major 2x2 blocks (0,0)(0,2)(0,4)(2,2)(2,4)(4,4)
     float bf[6];
     std::memset(blk, 0, sizeof(blk));
@@ -570,8 +594,8 @@ static int match_impl(oracle_pyramid* ref, oracle_pyramid* cur, const oracle_con
       float Tf[12];
       for (int i = 0; i < 12; ++i) Tf[i] = float(M[i]);        // :263
 
-      const int n = (cfg.mode == DVO_ORACLE_REF_SSE)
-                        ? residual_pass_ref(R.sel.p, n_sel, C, Tf, W, S, nullptr, false)
+      const int n = !uses_math_residuals(cfg.mode)
+                        ? residual_pass_ref(R.sel.p, n_sel, C, Tf, W, S, nullptr, false, quirks_of(cfg.mode))
                         : residual_pass_math(R.sel.p, n_sel, C, Tf, W, S, nullptr, false);
       is->valid_constraints = n;
       if (n < 6) {                                              // :276-284
@@ -752,8 +776,8 @@ int oracle_level_iteration(oracle_pyramid* ref, oracle_pyramid* cur, int level, 
   Scratch S;
   ensure_scratch(S, std::max(npx, size_t(16)), true);
   const Weights8 W = make_weights(C.K);
-  const int n = (mode == DVO_ORACLE_REF_SSE) ? residual_pass_ref(R.sel.p, n_sel, C, T34, W, S, pix.data(), true)
-                                             : residual_pass_math(R.sel.p, n_sel, C, T34, W, S, pix.data(), true);
+  const int n = !uses_math_residuals(mode) ? residual_pass_ref(R.sel.p, n_sel, C, T34, W, S, pix.data(), true, quirks_of(mode))
+                                           : residual_pass_math(R.sel.p, n_sel, C, T34, W, S, pix.data(), true);
   std::memset(out, 0, sizeof(*out));
   out->n = n;
   out->n_selected = n_sel;
@@ -796,7 +820,7 @@ int oracle_pass_residuals(int mode, int n, const float* points, const float* acc
   Scratch S;
   ensure_scratch(S, size_t(n) + 2, false);
   const Weights8 W = make_weights(cur.K);
-  const int n_out = mode == DVO_ORACLE_REF_SSE ? residual_pass_ref(pts.p, n, cur, T, W, S, nullptr, false)
+  const int n_out = !uses_math_residuals(mode) ? residual_pass_ref(pts.p, n, cur, T, W, S, nullptr, false, quirks_of(mode))
                                                : residual_pass_math(pts.p, n, cur, T, W, S, nullptr, false);
   for (int i = 0; i < n_out; ++i) {
     std::memcpy(out_points + size_t(i) * 12, S.points_error.p[i].p, 4 * sizeof(float));
@@ -826,7 +850,7 @@ int oracle_solve6(const double A[36], const double b[6], double x[6]) { return l
 void oracle_rank_update_2x6(const float* J, int n, const float alpha[4], int mode, double A[36]) {
   // the fixture shape of dvo_core/src/sse_test.cpp:32-102 : A = sum_i J_i^T alpha J_i
   std::vector<RefPoint> dummy;
-  if (mode == DVO_ORACLE_REF_SSE) {
+  if (quirks_of(mode) & DVO_ORACLE_Q_FLOAT_NORMAL_EQ) {
     float blk[24];
     std::memset(blk, 0, sizeof(blk));
     for (int i = 0; i < n; ++i) {

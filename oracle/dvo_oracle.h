@@ -51,6 +51,24 @@ extern "C" {
 
 enum { DVO_ORACLE_REF_SSE = 0, DVO_ORACLE_MATH = 1 };
 
+/* Quirk by quirk: mode = DVO_ORACLE_QUIRKS | any of the bits below selects exactly those order-/ISA-dependent behaviours of
+ * the reference on top of the MATH semantics (SURVEY.md section 8a quirk list).  DVO_ORACLE_QUIRKS | DVO_ORACLE_Q_ALL is
+ * REF_SSE and DVO_ORACLE_QUIRKS alone is MATH, bit for bit (tests/test_oracle.py) -- so the distance between the reference's
+ * trajectory and the exact arithmetic's can be attributed (tests/golden/make_quirk_table.py). */
+enum {
+  DVO_ORACLE_QUIRKS = 0x100,
+  DVO_ORACLE_Q_RCP_PROJECTION = 1,     /* Q1: u = x * _mm_rcp_ps(z)            dense_tracking_impl.cpp:192 */
+  DVO_ORACLE_Q_RCP_WEIGHTS = 2,        /* Q1: w = 7 * _mm_rcp_ps(5 + r^T P r)  dense_tracking_impl.cpp:700 */
+  DVO_ORACLE_Q_ROUND_TOWARD_ZERO = 4,  /* Q2: MXCSR RZ inside the residual loop  dense_tracking_impl.cpp:165-167 */
+  DVO_ORACLE_Q_DROP_ODD = 8,           /* Q3: odd trailing point ignored         dense_tracking_impl.cpp:169 */
+  DVO_ORACLE_Q_SCALE_PAIRING = 16,     /* Q6: first residual of each pair used twice, float accumulation  :614-615 */
+  DVO_ORACLE_Q_LOGLIK_TAIL = 32,       /* Q7: n mod 50 terms dropped, products of 50                      :406-425 */
+  DVO_ORACLE_Q_FLOAT_NORMAL_EQ = 64,   /* float sequential 2x2-blocked accumulation of A, b               math_sse.cpp:82-178 */
+  DVO_ORACLE_Q_ALL = 127,
+  /* experiment, not part of REF_SSE: the pairing of Q6 as a formula over the compaction ranks, accumulated in float64 */
+  DVO_ORACLE_X_PAIRING_F64 = 0x200
+};
+
 /* termination criteria, same numbering as dense_tracking.h:71-81 */
 enum {
   DVO_ORACLE_ITERATIONS_EXCEEDED = 0,

@@ -14,6 +14,11 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 REF_SSE = 0
 MATH = 1
+# quirk by quirk (dvo_oracle.h): mode = QUIRKS | bits; QUIRKS | Q_ALL == REF_SSE and QUIRKS alone == MATH, bit for bit
+QUIRKS = 0x100
+Q_RCP_PROJECTION, Q_RCP_WEIGHTS, Q_ROUND_TOWARD_ZERO, Q_DROP_ODD, Q_SCALE_PAIRING, Q_LOGLIK_TAIL, Q_FLOAT_NORMAL_EQ = 1, 2, 4, 8, 16, 32, 64
+Q_ALL = 127
+X_PAIRING_F64 = 0x200      # experiment (not part of REF_SSE): the pairing of Q6 as a formula over the compaction ranks, float64 sums
 
 TERMINATION = {0: "IterationsExceeded", 1: "IncrementTooSmall", 2: "LogLikelihoodDecreased", 3: "TooFewConstraints", -1: "unset"}
 

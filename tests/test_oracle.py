@@ -188,6 +188,33 @@ def test_ref_sse_quirks_are_present():
     assert abs(-ll - s["neg_ll"]) / abs(ll) < 1e-5
 
 
+def test_quirk_by_quirk_modes_span_math_to_ref_sse():
+    """mode = QUIRKS | bits (oracle/dvo_oracle.h): no bit is MATH and every bit is REF_SSE, bit for bit, for whole matches and
+    for single linearisations -- so the modes in between attribute the distance between the two (profiles/r03_quirk_table.txt).
+    And the attribution itself, per match: the approximate reciprocal in the projection (Q1, dense_tracking_impl.cpp:192) is
+    what separates the reference from the exact arithmetic."""
+    for seed, (w, h) in ((7, (160, 120)), (3, (320, 240))):
+        pair = cm.synth(seed, w, h)
+        ref, cur = cm.oracle_pyramids(pair, 3)
+        T34 = po.se3_exp(np.array([0.002, -0.001, 0.001, 0.003, -0.002, 0.001]))[:3]
+        for a, b in ((po.MATH, po.QUIRKS), (po.REF_SSE, po.QUIRKS | po.Q_ALL)):
+            x = po.level_iteration(ref, cur, 0, T34, first=False, P_prev=np.array([900.0, 3.0, 3.0, 400.0], np.float32), mode=a, want_residuals=True)
+            y = po.level_iteration(ref, cur, 0, T34, first=False, P_prev=np.array([900.0, 3.0, 3.0, 400.0], np.float32), mode=b, want_residuals=True)
+            assert x["n"] == y["n"] and np.array_equal(x["A"], y["A"]) and np.array_equal(x["b"], y["b"]) and x["neg_ll"] == y["neg_ll"]
+            assert np.array_equal(x["residuals"], y["residuals"], equal_nan=True)
+        for kw in (dict(first_level=2, last_level=0), dict(first_level=2, last_level=1, max_iterations=50, precision=1e-4, mu=0.05)):
+            run = {m: po.match(ref, cur, po.make_config(mode=m, **kw)) for m in
+                   (po.MATH, po.REF_SSE, po.QUIRKS, po.QUIRKS | po.Q_ALL, po.QUIRKS | po.Q_RCP_PROJECTION,
+                    po.QUIRKS | po.Q_ALL & ~po.Q_RCP_PROJECTION)}
+            for a, b in ((po.MATH, po.QUIRKS), (po.REF_SSE, po.QUIRKS | po.Q_ALL)):
+                assert np.array_equal(run[a]["T"], run[b]["T"]) and np.array_equal(run[a]["information"], run[b]["information"])
+                assert [len(L["iterations"]) for L in run[a]["levels"]] == [len(L["iterations"]) for L in run[b]["levels"]]
+            d = lambda m: cm.twist_matrix_error(run[m]["T"], run[po.REF_SSE]["T"])
+            print(seed, kw, "to the reference: MATH %.2e, MATH + Q1p %.2e, all but Q1p %.2e" % (d(po.MATH), d(po.QUIRKS | po.Q_RCP_PROJECTION), d(po.QUIRKS | po.Q_ALL & ~po.Q_RCP_PROJECTION)))
+            assert d(po.QUIRKS | po.Q_RCP_PROJECTION) < 0.35 * d(po.MATH)          # Q1p alone closes most of the distance ...
+            assert d(po.QUIRKS | po.Q_ALL & ~po.Q_RCP_PROJECTION) > 0.65 * d(po.MATH)   # ... and all the others together do not
+
+
 def test_match_recovers_true_motion_both_modes():
     pair = cm.synth(1234)
     ref, cur = cm.oracle_pyramids(pair, 4)
