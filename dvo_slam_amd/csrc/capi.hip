@@ -84,6 +84,7 @@ struct FrameLevel {
   float4* A = nullptr;
   float2* B = nullptr;
   float2* R = nullptr;
+  float2* C = nullptr;         // {I, Z} of a current frame for the window sweep (null: not kept at this level)
   bool has_current = false;    // A, B built (current-frame role)
   bool selected = false;       // R / count built for (ithr, dthr) (reference role)
   float ithr = 0, dthr = 0;
@@ -184,6 +185,7 @@ struct PinnedRing {
 struct Workspace {
   hipStream_t stream = nullptr;
   DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters;
+  DevBuf win_fallbacks;          // one 64-bit counter: lanes of the window sweep whose taps were fetched from memory (align_window.hip)
   PinnedRing* tables = nullptr;  // the context's ring for small uploads
   int* host_status = nullptr;    // pinned: one word per Gauss-Newton step of a batch, written by the device (k_solver_step)
   size_t host_status_words = 0;
@@ -313,7 +315,7 @@ void workspace_destroy(Workspace& w) {
   if (!w.created) return;
   (void)hipStreamSynchronize(w.stream);
   for (DevBuf* b : {&w.states, &w.pair_ptrs, &w.partials, &w.scratch, &w.ll_partials, &w.lvl_stats, &w.it_stats, &w.results,
-                    &w.t_init, &w.counters, &w.exchange})
+                    &w.t_init, &w.counters, &w.exchange, &w.win_fallbacks})
     b->release();
   if (w.host_status) (void)hipHostFree(w.host_status);
   w.host_status = nullptr;
@@ -429,7 +431,10 @@ void level_tiles(int w, int h, int rows_per_wave, bool linear, int* tiles_x, int
   }
 }
 
-bool level_is_linear(const dvo_hip_context* ctx, int w) { return ctx->opt_variant == 5 && w % kTileW != 0; }
+bool level_is_linear(const dvo_hip_context* ctx, int w) { return ctx->opt_variant >= 5 && w % kTileW != 0; }
+
+// the sweep that stages the current frame's window in LDS (align_window.hip, variants 6 / 7) handles this level; its tile is 64 x 16
+bool level_uses_window(const dvo_hip_context* ctx, int w, int h) { return ctx->opt_variant >= 6 && w % kTileW == 0 && w < 32768 && h < 32768; }
 
 LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int rows_per_wave) {
   LevelGeom g;
@@ -445,6 +450,7 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
 // rows of 64 pixels each wavefront sweeps: large tiles amortise the 85-value wave reduction, small tiles
 // keep all 256 CUs busy when the batch is small
 int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_pairs) {
+  if (level_uses_window(ctx, cam->w[level], cam->h[level])) return 4;
   if (ctx->opt_rows_per_wave > 0) return ctx->opt_rows_per_wave;
   const int candidates[4] = {8, 4, 2, 1};   // measured (profiles/r01_c_tile_sweep.txt): 8 rows is at or near the optimum on every level
   // The tallest tile that still yields this many workgroups.  Fewer, taller tiles also mean fewer partial rows for the
@@ -762,6 +768,10 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
   DVO_WS_TRY(w, w.results.reserve(size_t(n) * sizeof(dvo_hip_result)));
   DVO_WS_TRY(w, w.t_init.reserve(size_t(n) * 16 * sizeof(double)));
   DVO_WS_TRY(w, w.counters.reserve(size_t(bp.cap_iters + 8) * sizeof(unsigned long long)));
+  if (!w.win_fallbacks.p) {
+    DVO_WS_TRY(w, w.win_fallbacks.reserve(64));
+    DVO_WS_TRY(w, hipMemsetAsync(w.win_fallbacks.p, 0, 64, w.stream));
+  }
   std::vector<PairPtrs>& host = bp.host_ptrs;
   host.assign(size_t(n) * need_levels, PairPtrs());
   for (int l = cfg->last_level; l <= cfg->first_level; ++l)
@@ -771,6 +781,7 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
       p.curA = curs[i]->lv[l].A;
       p.curB = curs[i]->lv[l].B;
       p.n_selected = refs[i]->sel_count + l;
+      p.curC = curs[i]->lv[l].C;
     }
   bp.pair_ptrs = nullptr;
   if (upload_table) {
@@ -1066,7 +1077,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       for (int c = 0; c < count; ++c, ++step) {
         {
           Range range(kErr[level]);
-          launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch);
+          launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch, w.win_fallbacks.as<unsigned long long>());
           if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, kLlBlocksPerPair);
         }
         Range range(kLinsys[level]);
@@ -1197,6 +1208,14 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
   std::unique_lock<std::recursive_mutex> guard(ctx->mutex);
   if (std::strcmp(key, "resident_launches") == 0) *value = ctx->resident_launches;
   else if (std::strcmp(key, "resident_timeouts") == 0) *value = ctx->resident_timeouts;
+  else if (std::strcmp(key, "window_fallbacks") == 0) {
+    unsigned long long v = 0;
+    if (ctx->ws[0].win_fallbacks.p) {
+      DVO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      DVO_HIP_TRY(ctx, hipMemcpy(&v, ctx->ws[0].win_fallbacks.p, sizeof(v), hipMemcpyDeviceToHost));
+    }
+    *value = (long long)v;
+  }
   else if (std::strcmp(key, "host_batches") == 0) *value = ctx->host_batches;
   else if (std::strcmp(key, "host_ns_prepare") == 0) *value = ctx->host_ns[0];
   else if (std::strcmp(key, "host_ns_enqueue") == 0) *value = ctx->host_ns[1];
@@ -1302,7 +1321,8 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "variant") == 0) {
-    if (value != 0 && value != 5) return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0 (all-VALU schedule) or 5 (matrix-core schedule)");
+    if (value != 0 && value != 5 && value != 6 && value != 7)
+      return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0 (all-VALU schedule), 5 (matrix-core schedule), 6 or 7 (current-frame window staged in LDS)");
     ctx->opt_variant = value;
     return DVO_HIP_OK;
   }
@@ -1737,7 +1757,8 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
   DVO_HIP_TRY(ctx, hipMemsetAsync(states, 0, sizeof(PairState), s));
   launch_set_fixed_state(s, states, g, d_T, d_P, first_iteration_on_level ? 1 : 0);
   const PairPtrs* pp = bp.pair_ptrs + size_t(level);
-  launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>());
+  launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>(),
+                         ctx->ws[0].win_fallbacks.as<unsigned long long>());
   launch_loglik(s, g, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>(), ctx->ws[0].ll_partials.as<double>(), kLlBlocksPerPair);
   int n_sel = 0;
   DVO_HIP_TRY(ctx, hipMemcpyAsync(&n_sel, reference->sel_count + level, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1778,7 +1799,8 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs, dvo_hip_fram
   launch_init_pairs(s, states, bp.n, bp.prm, w.t_init.as<double>());
   launch_level_begin(s, states, bp.n, bp.prm, g, level, pp, w.lvl_stats.as<dvo_hip_level_stats>());
   auto sweep = [&]() {
-    launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, bp.n, w.partials.as<float>(), w.scratch.as<float2>());
+    launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, bp.n, w.partials.as<float>(), w.scratch.as<float2>(),
+                           w.win_fallbacks.as<unsigned long long>());
   };
   // `warm_iterations` Gauss-Newton steps first: the timed sweeps then run where the sweeps of a match run -- at the transform
   // the solver moved to, with the t-distribution weights on (first = 0) -- instead of at the identity with unit weights

@@ -48,6 +48,8 @@ struct PairPtrs {                     // device planes of one pair at one level
   const float4* curA;                 // {I, Z, Idx, Idy}                        16 B / pixel, gathered
   const float2* curB;                 // {Zdx, Zdy}                               8 B / pixel, gathered
   const int* n_selected;              // device counter: selected reference pixels at this level
+  const float2* curC;                 // {I, Z}                                   8 B / pixel: the plane the window sweep stages in LDS
+                                      // (align_window.hip); null when the frame has none at this level (the sweep then reads A.xy)
 };
 
 struct FrameBuildPtrs {                // one frame of a batched pyramid build
@@ -60,6 +62,7 @@ struct FrameBuildPtrs {                // one frame of a batched pyramid build
   float4* A[kMaxLevels];
   float2* B[kMaxLevels];
   float2* R[kMaxLevels];
+  float2* C[kMaxLevels];               // {I, Z} of a current frame (null: not kept at this level)
   int* sel_count;                      // one counter per level
 };
 

@@ -230,6 +230,29 @@ DVO_HD PixelProj pixel_project_flat(const LevelGeom& g, const float* KT, float Z
   return p;
 }
 
+// The same projection for the sweep that stages the current frame in LDS (align_window.hip): returns the tap corner as (u0, v0)
+// instead of a plane index, and leaves X / Y to the caller (it recomputes them where it needs them).
+DVO_HD PixelProj pixel_project_uv_flat(const LevelGeom& g, const float* KT, float Z, float tx, float ty, int& u0, int& v0) {
+#pragma clang fp contract(off)
+  PixelProj p;
+  p.Z = Z;
+  const float X = tx * Z, Y = ty * Z;
+  p.X = X; p.Y = Y;
+  const float qx = (KT[0] * X + KT[1] * Y) + (KT[2] * Z + KT[3]);
+  const float qy = (KT[4] * X + KT[5] * Y) + (KT[6] * Z + KT[7]);
+  const float qz = (KT[8] * X + KT[9] * Y) + (KT[10] * Z + KT[11]);
+  p.qz = qz;
+  const float u = qx / qz, v = qy / qz;
+  p.ok = u >= 0.0f && u <= float(g.w - 2) && v >= 0.0f && v <= float(g.h - 2);
+  const float uf = floorf(u), vf = floorf(v);
+  p.a1 = u - uf;
+  p.b1 = v - vf;
+  u0 = int(uf);
+  v0 = int(vf);
+  p.base = 0;
+  return p;
+}
+
 // blend, NaN / occlusion tests, residual and gradient rows of a lane whose taps were fetched; everything is computed, the
 // return value says whether the pixel is a constraint
 DVO_HD bool pixel_finish_flat(const LevelGeom& g, const float4 ref, const PixelProj& p, const PixelTaps& t, PixelTerms& o) {
