@@ -13,8 +13,9 @@
 //
 //   phase A  per wavefront: stream its 4 reference rows, project (dense_tracking_impl.cpp:148-203), keep the projection in
 //            registers (8 per row), reduce the tap bounding box (DPP + one LDS exchange between the four wavefronts)
-//   phase B  the workgroup loads the window [x0, x0 + 80) x [y0, y0 + 28) -- coordinates clamped to the image, so that the
-//            clamped central differences at the image border come out of the same subtraction -- into LDS
+//   phase B  the workgroup loads the window [x0, x0 + 80) x [y0, y0 + 28) of the current frame's 8-byte {I, Z} plane (PairPtrs::curC)
+//            -- coordinates clamped to the image, so that the clamped central differences at the image border come out of the
+//            same subtraction -- into LDS, 16 bytes per load
 //   phase C  per wavefront and row: 12 LDS reads, gradients, bilinear blend, residual, weight, Jacobian, Gram accumulation on
 //            the matrix cores (sweep_parts.h); lanes whose taps fall outside the window (a tile that straddles a depth
 //            discontinuity under a large motion) fetch their 12 pixels from memory instead -- correct for any motion
@@ -28,31 +29,67 @@ namespace dvo_hip {
 
 constexpr int kWinRPW = 4;                              // rows per wavefront: a 64 x 16 tile per workgroup
 constexpr int kWinPitch = 80;                           // window columns: 64 + the taps' reach (3) + 13 of motion / parallax
-constexpr int kWinRows = kWavesPerBlock * kWinRPW + 12; // window rows
-constexpr int kWinCells = kWinPitch * kWinRows;         // 2240 cells x 8 B = 17.9 KB
-constexpr int kWinLoads = (kWinCells + kBlock - 1) / kBlock;
+// phase B: a thread owns one PAIR of window columns (16 B: the window starts at an even image column) and every sixth row
+constexpr int kWinPairs = kWinPitch / 2;                // 40 column pairs
+constexpr int kWinRowGroups = kBlock / kWinPairs;       // 6 (240 of the 256 threads load)
+constexpr int kWinLoads = 5;                            // loads of 16 B per thread
+constexpr int kWinRows = kWinRowGroups * kWinLoads;     // 30 window rows: 16 + the taps' reach (3) + 11
+constexpr int kWinCells = kWinPitch * kWinRows;         // 2400 cells x 8 B = 19.2 KB
+constexpr int kNoProjection = 0x7fff7fff;               // WinRowState::uv of a lane without a usable projection
 
-// wavefront-wide minimum of a signed int through DPP (row_shr 1, 2, 4, 8; row_bcast 15, 31): valid in lane 63.  Lanes without a
-// source keep their own value (old = v), which is neutral for min.
-__device__ __forceinline__ int wave_min_lane63(int v) {
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
-  return v;
+// The operand slab of a wavefront.  f32 Gram: the layout of sweep_parts.h (4224 B).  f16 Gram: one 80-byte row per pixel --
+// 16 halfs "hi", 16 halfs "lo", 16 B of padding (conflict-free 16-byte stores: 80 i mod 128 are eight distinct 16-byte slots) --
+// read back with the LDS transpose read ds_read_b64_tr_b16 (5120 B).
+constexpr int kHalfRow = 40;                            // halfs per pixel row
+constexpr int kWinSlabFloats = 64 * kHalfRow / 2;       // 1280 floats = 5120 B >= kSlabFloats
+static_assert(kWinSlabFloats >= kSlabFloats, "the f32 layout must fit the slab");
+constexpr float kResidualScale = 256.0f;                // the two residual components are lifted out of the f16 subnormal range
+
+typedef short __attribute__((ext_vector_type(2))) i16x2;
+
+// wavefront-wide minimum / maximum of packed pairs of 16-bit integers through DPP (row_shr 1, 2, 4, 8; row_bcast 15, 31): valid in
+// lane 63.  Lanes without a source keep their own value, which is neutral.
+__device__ __forceinline__ void wave_minmax_pk16_lane63(int& lo, int& hi) {
+#define DVO_STAGE(ctrl, rmask)                                                                                     \
+  {                                                                                                                \
+    const int a = __builtin_amdgcn_update_dpp(lo, lo, ctrl, rmask, 0xf, false);                                    \
+    const int b = __builtin_amdgcn_update_dpp(hi, hi, ctrl, rmask, 0xf, false);                                    \
+    lo = __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(i16x2, lo), __builtin_bit_cast(i16x2, a))); \
+    hi = __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(i16x2, hi), __builtin_bit_cast(i16x2, b))); \
+  }
+  DVO_STAGE(0x111, 0xf) DVO_STAGE(0x112, 0xf) DVO_STAGE(0x114, 0xf) DVO_STAGE(0x118, 0xf) DVO_STAGE(0x142, 0xa) DVO_STAGE(0x143, 0xc)
+#undef DVO_STAGE
 }
 
 struct WinRowState {                                    // what phase A leaves for phase C, per row and lane
   float z, i, gx, gy;                                   // the reference quad {Zsel, I, Idx, Idy}
   float qz, a1, b1;                                     // transformed depth, bilinear weights of the +1 taps
-  int uv;                                               // u0 | v0 << 16 of tap (u0, v0); -1: no usable projection
+  int uv;                                               // u0 | v0 << 16 of tap (u0, v0); kNoProjection: no usable projection
 };
 
 typedef _Float16 __attribute__((ext_vector_type(8))) f16x8;
 typedef __fp16 __attribute__((__vector_size__(4 * sizeof(__fp16)))) fp16x4;
 typedef __fp16 __attribute__((ext_vector_type(2))) fp16x2;
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+
+// v = hi + lo with hi, lo in f16 (round toward zero: hi never exceeds the f16 range, it saturates; lo = v - hi is exact in f32);
+// two components per call, packed as the two halves of a register
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+  const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - float(h.x), b - float(h.y));
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+// matrix operand of 32 pixels (k index) x 16 components from the pixel-major f16 image: lane (i = l & 15, g = l >> 4) gets the
+// eight k-values 8 g .. 8 g + 7 of component i (scripts/ubench/gram_f16.hip)
+__device__ __forceinline__ f16x8 read_operand_f16(const _Float16* img, int lane, int chunk32) {
+  const int i = lane & 15, gq = lane >> 4;
+  const _Float16* p0 = img + (chunk32 * 32 + 8 * gq + (i >> 2)) * kHalfRow + (i & 3) * 4;
+  const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p0);
+  const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p0 + 4 * kHalfRow));
+  return f16x8{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
+}
 
 // F16: Gram accumulation on the f16 matrix pipe (variant 7)
 template <bool F16>
@@ -75,48 +112,47 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
 #pragma unroll
   for (int i = 0; i < 4; ++i) Pp[i] = st.P_prev[i];
   const bool first = st.first != 0;
-  const __amdgpu_buffer_rsrc_t refR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.refR), 0, g.w * g.h * 8, 0x00020000);
-  // the current frame's {I, Z}: its own 8-byte plane when the frame has one, else the first half of the 16-byte taps
-  const int cshift = pp.curC ? 3 : 4;
-  const __amdgpu_buffer_rsrc_t curC = __builtin_amdgcn_make_buffer_rsrc(
-      pp.curC ? static_cast<void*>(const_cast<float2*>(pp.curC)) : static_cast<void*>(const_cast<float4*>(pp.curA)), 0, (g.w * g.h) << cshift, 0x00020000);
+  const int plane_bytes = g.w * g.h * 8;
+  const __amdgpu_buffer_rsrc_t refR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.refR), 0, plane_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t curC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.curC), 0, plane_bytes, 0x00020000);
+  // the residual pairs of this pair (for the log-likelihood pass): one store per row, the row offset in a scalar register
+  const __amdgpu_buffer_rsrc_t resid = __builtin_amdgcn_make_buffer_rsrc(scratch + size_t(pair) * size_t(g.w) * g.h, 0, plane_bytes, 0x00020000);
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int u_r = (tile % g.tiles_x) * kTileW + lane;
+  const int u_r = (tile % g.tiles_x) * kTileW + lane;          // < g.w: the level's width is a multiple of the tile's
   const int row0 = (tile / g.tiles_x) * (kWavesPerBlock * RPW) + wave;
-  const size_t pix_base = size_t(pair) * size_t(g.w) * g.h;
+  const int row_bytes = g.w * 8;
   const float nanv = __builtin_nanf("");
-  const bool col_ok = u_r < g.w;
-  const float tx_u = g.tx[col_ok ? u_r : 0];
+  const float tx_u = g.tx[u_r];
   const float cx_u = fmaf(tx_u, tx_u, 1.0f);
   const float P00 = Pp[0], P11 = Pp[3], P2x = Pp[1] + Pp[2];
-  const int u_c = min(u_r, g.w - 1);
 
-  __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kSlabFloats];
+  __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kWinSlabFloats];
   __shared__ __attribute__((aligned(16))) float2 win[kWinCells];
-  __shared__ __attribute__((aligned(16))) int bbox[kWavesPerBlock][4];
+  __shared__ __attribute__((aligned(16))) int bbox[kWavesPerBlock][2];
   __shared__ int counts[kWavesPerBlock];
   float* my = slab[wave];
 
   // ---- phase A: reference rows, projection, tap bounding box -------------------------------------------------------------------
-  auto load_f = [&](int pixel) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(refR, pixel * 8 + 4, 0, 0)); };
+  // Loads: the lane's byte offset in a row is a constant of the kernel, the row offset a scalar.  The horizontal neighbours of a
+  // pixel come from the adjacent lanes; lanes 0 and 63 load the pixel beside the row segment (clamped at the image border like the
+  // reference's derivative code, rgbd_image.cpp:419-489), the other lanes load their own pixel again: one unconditional load.
+  const int off_px = u_r * 8;
+  const int off_edge = (lane == 0 ? max(u_r - 1, 0) : lane == 63 ? min(u_r + 1, g.w - 1) : u_r) * 8 + 4;
   WinRowState rs[RPW];
-  int umin = 0x7fff, vmin = 0x7fff, umax_n = 0x7fff, vmax_n = 0x7fff;     // maxima as minima of the negated value
+  int uv_min = kNoProjection, uv_max = 0;                      // packed (u0, v0) extremes over the lanes with a projection
   {
-    float zv[RPW], iv[RPW];
-    float up[RPW], down[RPW], edge[RPW];
+    float zv[RPW], iv[RPW], up[RPW], down[RPW], edge[RPW];
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {                            // all loads of the four rows first: one round trip
       const int v = min(row0 + k * kWavesPerBlock, g.h - 1);
-      const int idx = v * g.w + u_c;
-      const f32x2 zi = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(refR, idx * 8, 0, 0));
+      const int soff = v * row_bytes;
+      const f32x2 zi = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(refR, off_px, soff, 0));
       zv[k] = zi.x;
       iv[k] = zi.y;
-      up[k] = load_f(idx - (v > 0 ? g.w : 0));
-      down[k] = load_f(idx + (v < g.h - 1 ? g.w : 0));
-      edge[k] = 0.0f;
-      if (lane == 0) edge[k] = load_f(idx - (u_c > 0 ? 1 : 0));
-      if (lane == 63) edge[k] = load_f(idx + (u_c < g.w - 1 ? 1 : 0));
+      up[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(refR, off_px + 4, soff - (v > 0 ? row_bytes : 0), 0));
+      down[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(refR, off_px + 4, soff + (v < g.h - 1 ? row_bytes : 0), 0));
+      edge[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(refR, off_edge, soff, 0));
     }
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
@@ -124,63 +160,74 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
       const int ic = __builtin_bit_cast(int, iv[k]), ie = __builtin_bit_cast(int, edge[k]);
       const float right = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ie, ic, 0x130, 0xf, 0xf, false));   // wave_shl:1
       const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ie, ic, 0x138, 0xf, 0xf, false));    // wave_shr:1
-      const bool in_image = col_ok && v_r < g.h;
+      const float z = v_r < g.h ? zv[k] : nanv;                // rows below the image: no depth
       const float ty_p = g.ty[min(v_r, g.h - 1)];
       int u0, v0;
-      const PixelProj p = pixel_project_uv_flat(g, KT, in_image ? zv[k] : nanv, tx_u, ty_p, u0, v0);
-      rs[k].z = in_image ? zv[k] : nanv;
+      const PixelProj p = pixel_project_uv_flat<true>(g, KT, z, tx_u, ty_p, u0, v0);
+      const int uv = u0 | (v0 << 16);
+      rs[k].z = z;
       rs[k].i = iv[k];
       rs[k].gx = (right - left) * 0.5f;
       rs[k].gy = (down[k] - up[k]) * 0.5f;
       rs[k].qz = p.qz;
       rs[k].a1 = p.a1;
       rs[k].b1 = p.b1;
-      rs[k].uv = p.ok ? (u0 | (v0 << 16)) : -1;
-      if (p.ok) {
-        umin = min(umin, u0); vmin = min(vmin, v0);
-        umax_n = min(umax_n, -u0); vmax_n = min(vmax_n, -v0);
-      }
+      rs[k].uv = p.ok ? uv : kNoProjection;
+      uv_min = __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(i16x2, uv_min), __builtin_bit_cast(i16x2, rs[k].uv)));
+      uv_max = __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(i16x2, uv_max), __builtin_bit_cast(i16x2, p.ok ? uv : 0)));
     }
   }
-  {
-    const int a = wave_min_lane63(umin), b = wave_min_lane63(vmin), c = wave_min_lane63(umax_n), d = wave_min_lane63(vmax_n);
-    if (lane == 63) {
-      bbox[wave][0] = a; bbox[wave][1] = b; bbox[wave][2] = c; bbox[wave][3] = d;
-    }
+  wave_minmax_pk16_lane63(uv_min, uv_max);
+  if (lane == 63) {
+    bbox[wave][0] = uv_min; bbox[wave][1] = uv_max;
   }
   __syncthreads();
-  int x0, y0, ww, wh;                                          // window origin (image coordinates, may be -1) and the extent in use
+  int x0, y0, ww, wh;                                          // window origin (image coordinates, may be -1 / -2) and the extent in use
   {
-    int a = 0x7fff, b = 0x7fff, c = 0x7fff, d = 0x7fff;
+    i16x2 lo = __builtin_bit_cast(i16x2, bbox[0][0]), hi = __builtin_bit_cast(i16x2, bbox[0][1]);
 #pragma unroll
-    for (int w4 = 0; w4 < kWavesPerBlock; ++w4) {
-      a = min(a, bbox[w4][0]); b = min(b, bbox[w4][1]); c = min(c, bbox[w4][2]); d = min(d, bbox[w4][3]);
+    for (int w4 = 1; w4 < kWavesPerBlock; ++w4) {
+      lo = __builtin_elementwise_min(lo, __builtin_bit_cast(i16x2, bbox[w4][0]));
+      hi = __builtin_elementwise_max(hi, __builtin_bit_cast(i16x2, bbox[w4][1]));
     }
-    a = __builtin_amdgcn_readfirstlane(a); b = __builtin_amdgcn_readfirstlane(b);
-    c = __builtin_amdgcn_readfirstlane(c); d = __builtin_amdgcn_readfirstlane(d);
-    x0 = a - 1; y0 = b - 1;
-    ww = a == 0x7fff ? 0 : min(-c + 3 - x0, kWinPitch);        // columns x0 .. umax + 2
-    wh = a == 0x7fff ? 0 : min(-d + 3 - y0, kWinRows);
+    const int lo_s = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lo)), hi_s = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi));
+    const int umin = lo_s & 0xffff, vmin = (lo_s >> 16) & 0xffff, umax = hi_s & 0xffff, vmax = (hi_s >> 16) & 0xffff;
+    x0 = (umin - 1) & ~1; y0 = vmin - 1;                       // even: a 16-byte load holds two window cells
+    ww = umin == 0x7fff ? 0 : min(umax + 3 - x0, kWinPitch);   // columns x0 .. umax + 2
+    wh = umin == 0x7fff ? 0 : min(vmax + 3 - y0, kWinRows);
   }
 
   // ---- phase B: the window into LDS ----------------------------------------------------------------------------------------------
+  // Thread t loads column pair t % 40 of rows t / 40, t / 40 + 6, ...: the column arithmetic (clamping, the two border cases) is
+  // done once per thread, a load costs a row clamp and one multiply-add.  Image width and window origin are even, so a pair lies
+  // entirely inside the image, entirely left of it (both cells = column 0) or entirely right of it (both = column w - 1).  Cells
+  // outside the extent in use are requested beyond the end of the plane: the buffer load returns zeros without touching memory.
   {
-    f32x2 cell[kWinLoads];
+    const int t = threadIdx.x;
+    const int rg = t / kWinPairs, cxp = t - rg * kWinPairs;
+    if (rg < kWinRowGroups) {
+      const int x = x0 + 2 * cxp;
+      const int xl = min(max(x, 0), g.w - 2) * 8;
+      const bool col_needed = 2 * cxp < ww;
+      f32x4 cell[kWinLoads];
 #pragma unroll
-    for (int j = 0; j < kWinLoads; ++j) {
-      const int e = int(threadIdx.x) + j * kBlock;
-      const int cy = e / kWinPitch, cx = e - cy * kWinPitch;
-      cell[j] = f32x2{0.0f, 0.0f};
-      if (cy < wh && cx < ww) {
-        const int x = min(max(x0 + cx, 0), g.w - 1), y = min(max(y0 + cy, 0), g.h - 1);
-        cell[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(curC, (y * g.w + x) << cshift, 0, 0));
+      for (int j = 0; j < kWinLoads; ++j) {
+        const int cy = rg + j * kWinRowGroups;
+        const int y = min(max(y0 + cy, 0), g.h - 1);
+        const int off = col_needed && cy < wh ? y * row_bytes + xl : 0x7ffffff0;
+        cell[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(curC, off, 0, 0));
       }
-    }
+      if (x < 0) {
 #pragma unroll
-    for (int j = 0; j < kWinLoads; ++j) {
-      const int e = int(threadIdx.x) + j * kBlock;
-      const int cy = e / kWinPitch, cx = e - cy * kWinPitch;
-      if (cy < wh && cx < ww) win[e] = make_float2(cell[j].x, cell[j].y);
+        for (int j = 0; j < kWinLoads; ++j) { cell[j].z = cell[j].x; cell[j].w = cell[j].y; }
+      }
+      if (x >= g.w) {
+#pragma unroll
+        for (int j = 0; j < kWinLoads; ++j) { cell[j].x = cell[j].z; cell[j].y = cell[j].w; }
+      }
+      f32x4* dst = reinterpret_cast<f32x4*>(win) + t;
+#pragma unroll
+      for (int j = 0; j < kWinLoads; ++j) dst[j * kWinRowGroups * kWinPairs] = cell[j];
     }
   }
   __syncthreads();
@@ -195,10 +242,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
   for (int k = 0; k < RPW; ++k) {
     const int v_r = row0 + k * kWavesPerBlock;
     const WinRowState& r = rs[k];
-    const bool ok = r.uv >= 0;
+    const bool ok = r.uv != kNoProjection;
     const int u0 = r.uv & 0xffff, v0 = r.uv >> 16;
     const int cx = u0 - x0 - 1, cy = v0 - y0 - 1;              // the 4 x 4 neighbourhood's corner in the window (>= 0 by construction)
-    const bool in_win = ok && cx + 3 < kWinPitch && cy + 3 < kWinRows;
+    // (no projection: u0 = 0x7fff, cx out of range)
+    const bool in_win = unsigned(cx) < unsigned(kWinPitch - 3) && unsigned(cy) < unsigned(kWinRows - 3);
     f32x2 P[4][4];
     {
       // every lane reads (lanes without a neighbourhood in the window: cell 0; their values are never used): no divergent region
@@ -221,17 +269,18 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
         for (int cc = 0; cc < 4; ++cc)
           if ((rr == 1 || rr == 2) || (cc == 1 || cc == 2)) {
             const int x = min(max(u0 - 1 + cc, 0), g.w - 1), y = min(max(v0 - 1 + rr, 0), g.h - 1);
-            P[rr][cc] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(curC, (y * g.w + x) << cshift, 0, 0));
+            P[rr][cc] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(curC, (y * g.w + x) * 8, 0, 0));
           }
     }
     PixelTaps t;
     {
 #pragma clang fp contract(off)
-      // tap (i, j) = P[j + 1][i + 1]; its gradients are the clamped central differences of the frame build (derive_at): (next - previous) * 0.5
+      // tap (i, j) = P[j + 1][i + 1]; its gradient channels are the clamped central differences of the frame build (derive_at),
+      // (next - previous) * 0.5 -- here WITHOUT the factor 0.5, which pixel_finish_flat_d applies to the four blended channels
+      // instead of to the sixteen differences (a multiplication by a power of two commutes with every rounding of the blend)
 #define DVO_TAP(i, j, Aq, Bq)                                                                                        \
-  Aq = make_float4(P[j + 1][i + 1].x, P[j + 1][i + 1].y, (P[j + 1][i + 2].x - P[j + 1][i].x) * 0.5f,               \
-                   (P[j + 2][i + 1].x - P[j][i + 1].x) * 0.5f);                                                     \
-  Bq = make_float2((P[j + 1][i + 2].y - P[j + 1][i].y) * 0.5f, (P[j + 2][i + 1].y - P[j][i + 1].y) * 0.5f);
+  Aq = make_float4(P[j + 1][i + 1].x, P[j + 1][i + 1].y, P[j + 1][i + 2].x - P[j + 1][i].x, P[j + 2][i + 1].x - P[j][i + 1].x); \
+  Bq = make_float2(P[j + 1][i + 2].y - P[j + 1][i].y, P[j + 2][i + 1].y - P[j][i + 1].y);
       DVO_TAP(0, 0, t.A00, t.B00)
       DVO_TAP(1, 0, t.A10, t.B10)
       DVO_TAP(0, 1, t.A01, t.B01)
@@ -244,10 +293,53 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
     p.qz = r.qz; p.a1 = r.a1; p.b1 = r.b1; p.base = 0; p.ok = ok;
     const float4 ref = make_float4(r.z, r.i, r.gx, r.gy);
     PixelTerms o;
-    const bool valid = pixel_finish_flat(g, ref, p, t, o) && ok;
+    const bool valid = pixel_finish_flat_d(g, ref, p, t, o) && ok;
     n_valid += __popcll(__ballot(valid));
-    const bool in_image = col_ok && v_r < g.h;
-    if (in_image) scratch[pix_base + size_t(v_r) * g.w + u_r] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);
+    if (v_r < g.h) {                                           // (uniform)
+      const f32x2 rr2 = valid ? f32x2{o.r0, o.r1} : f32x2{nanv, nanv};
+      typedef unsigned __attribute__((__vector_size__(2 * sizeof(unsigned)))) u32v2;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32v2, rr2), resid, off_px, v_r * row_bytes, 0);
+    }
+    if constexpr (F16) {
+      u32x4* hw = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(my) + lane * (kHalfRow * 2));
+      if (valid) {
+        const float sw = first ? 1.0f : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
+        float J0[6], J1[6];
+        jacobian_rows_fast(o, sw, tx_u, ty_p, cx_u, fmaf(ty_p, ty_p, 1.0f), J0, J1);
+        const float sr = sw * kResidualScale;
+        unsigned hh[7], ll[7];
+        split_pair(J0[0], J0[1], hh[0], ll[0]);
+        split_pair(J0[2], J0[3], hh[1], ll[1]);
+        split_pair(J0[4], J0[5], hh[2], ll[2]);
+        split_pair(J1[0], J1[1], hh[3], ll[3]);
+        split_pair(J1[2], J1[3], hh[4], ll[4]);
+        split_pair(J1[4], J1[5], hh[5], ll[5]);
+        split_pair(sr * o.r0, sr * o.r1, hh[6], ll[6]);
+        hw[0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+        hw[1] = u32x4{hh[4], hh[5], hh[6], 0u};
+        hw[2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+        hw[3] = u32x4{ll[4], ll[5], ll[6], 0u};
+      } else {
+        // (volatile: keeps the compiler from merging these stores with the ones above behind fifteen register moves per row)
+        typedef volatile __attribute__((address_space(3))) u32x4* LdsQuadPtr;   // (still an LDS store, not a flat one)
+        LdsQuadPtr hz = (LdsQuadPtr)hw;
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        hz[0] = zero; hz[1] = zero; hz[2] = zero; hz[3] = zero;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const _Float16* img = reinterpret_cast<const _Float16*>(my);
+#pragma unroll
+      for (int chunk = 0; chunk < 2; ++chunk) {
+        const f16x8 h = read_operand_f16(img, lane, chunk), l = read_operand_f16(img + 16, lane, chunk);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, h, acc0, 0, 0, 0);      // H H^T
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, l, acc1, 0, 0, 0);      // S = H L^T ; G = H H^T + S + S^T
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
     if (valid) {
       const float sw = first ? 1.0f : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
       float J0[6], J1[6];
@@ -276,8 +368,27 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
     __builtin_amdgcn_wave_barrier();
   }
 
+  if constexpr (F16) {
+    // G = H H^T + S + S^T, entry (row, col) of lane l, register i: row = (l >> 4) * 4 + i, col = l & 15; S^T through the slab.
+    // The two residual components (12, 13) carry the factor kResidualScale.
 #pragma unroll
-  for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
+    for (int i = 0; i < 4; ++i) my[256 + ((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc1[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int col = lane & 15;
+    const float cs = col >= 12 ? 1.0f / kResidualScale : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (lane >> 4) * 4 + i;
+      const float rsc = row >= 12 ? 1.0f / kResidualScale : 1.0f;
+      const float st = my[256 + col * 16 + row];
+      my[row * 16 + col] = ((acc0[i] + acc1[i]) + st) * (cs * rsc);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
+  }
   if (lane == 0) counts[wave] = n_valid;
   if (fallback_count) {
     const unsigned long long lanes = __ballot(n_fallback != 0);
@@ -311,8 +422,8 @@ void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const Pair
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(kBlock);
-  (void)f16;
-  k_sweep_window<false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+  if (f16) k_sweep_window<true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+  else k_sweep_window<false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
 }
 
 }  // namespace dvo_hip

@@ -478,11 +478,12 @@ int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels
   f->cam = cam;
   size_t total = align_up(size_t(w) * h * 3, 256);   // u8 grey + u16 depth staging
   *raw_off = 0;
-  size_t offs[kMaxLevels][5];
+  size_t offs[kMaxLevels][6];
   for (int l = 0; l < levels; ++l) {
     const size_t n = size_t(cam->w[l]) * cam->h[l];
-    const size_t sz[5] = {n * 4, n * 4, n * 16, n * 8, n * 8};
-    for (int k = 0; k < 5; ++k) {
+    // (C = {I, Z} of a current frame, the plane the window sweep stages in LDS: levels that sweep can handle)
+    const size_t sz[6] = {n * 4, n * 4, n * 16, n * 8, n * 8, cam->w[l] % kTileW == 0 ? n * 8 : 0};
+    for (int k = 0; k < 6; ++k) {
       offs[l][k] = total;
       total += align_up(sz[k], 256);
     }
@@ -513,6 +514,7 @@ int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels
     L.A = reinterpret_cast<float4*>(base + offs[l][2]);
     L.B = reinterpret_cast<float2*>(base + offs[l][3]);
     L.R = reinterpret_cast<float2*>(base + offs[l][4]);
+    L.C = cam->w[l] % kTileW == 0 ? reinterpret_cast<float2*>(base + offs[l][5]) : nullptr;
   }
   f->sel_count = reinterpret_cast<int*>(base + cnt_off);
   *out = f;
@@ -525,8 +527,9 @@ void fill_build_ptrs(dvo_hip_frame* f, FrameBuildPtrs& p) {
   p.keep_grey = nullptr;
   p.keep_raw = nullptr;
   for (int l = 0; l < f->levels; ++l) {
-    p.I[l] = f->lv[l].I; p.Z[l] = f->lv[l].Z; p.A[l] = f->lv[l].A; p.B[l] = f->lv[l].B; p.R[l] = f->lv[l].R;
+    p.I[l] = f->lv[l].I; p.Z[l] = f->lv[l].Z; p.A[l] = f->lv[l].A; p.B[l] = f->lv[l].B; p.R[l] = f->lv[l].R; p.C[l] = f->lv[l].C;
   }
+  for (int l = f->levels; l < kMaxLevels; ++l) p.C[l] = nullptr;
   p.sel_count = f->sel_count;
 }
 

@@ -230,8 +230,33 @@ DVO_HD PixelProj pixel_project_flat(const LevelGeom& g, const float* KT, float Z
   return p;
 }
 
+// nx / d and ny / d, CORRECTLY ROUNDED like the IEEE division (what the oracle's MATH mode computes), without the range scaling and
+// special-case fix-up of the compiler's division sequence (v_div_scale x 2, v_div_fmas, v_div_fixup per quotient): one refined
+// reciprocal shared by both quotients, then per quotient the two remainder corrections of that very sequence -- q = n r,
+// q += r (n - d q) twice, every remainder exact in a fused multiply-add.  13 instead of ~24 vector instructions per pixel.  Valid
+// where the division's own scaling is not needed: |d| and |n / d| well inside the normal range -- here d is a depth in metres and
+// only quotients in [0, 32768) are ever used; zero, infinite and NaN operands give a quotient that fails the bounds test like the
+// IEEE result does.  Checked bit for bit against the IEEE division on the device (scripts/ubench/div_check.hip: 2^32 operand pairs)
+// and by every parity test of the sweep that uses it (valid counts and residuals bit-exact against the oracle).
+DVO_HD void divide2_correctly_rounded(float nx, float ny, float d, float& u, float& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r = __builtin_amdgcn_rcpf(d);                 // 1 ulp
+  r = fmaf(fmaf(-d, r, 1.0f), r, r);                  // one Newton step
+  float q = nx * r;
+  q = fmaf(fmaf(-d, q, nx), r, q);
+  u = fmaf(fmaf(-d, q, nx), r, q);
+  q = ny * r;
+  q = fmaf(fmaf(-d, q, ny), r, q);
+  v = fmaf(fmaf(-d, q, ny), r, q);
+#else
+  u = nx / d;
+  v = ny / d;
+#endif
+}
+
 // The same projection for the sweep that stages the current frame in LDS (align_window.hip): returns the tap corner as (u0, v0)
 // instead of a plane index, and leaves X / Y to the caller (it recomputes them where it needs them).
+template <bool SHORT_DIVISION = false>
 DVO_HD PixelProj pixel_project_uv_flat(const LevelGeom& g, const float* KT, float Z, float tx, float ty, int& u0, int& v0) {
 #pragma clang fp contract(off)
   PixelProj p;
@@ -242,7 +267,13 @@ DVO_HD PixelProj pixel_project_uv_flat(const LevelGeom& g, const float* KT, floa
   const float qy = (KT[4] * X + KT[5] * Y) + (KT[6] * Z + KT[7]);
   const float qz = (KT[8] * X + KT[9] * Y) + (KT[10] * Z + KT[11]);
   p.qz = qz;
-  const float u = qx / qz, v = qy / qz;
+  float u, v;
+  if (SHORT_DIVISION) {
+    divide2_correctly_rounded(qx, qy, qz, u, v);
+  } else {
+    u = qx / qz;
+    v = qy / qz;
+  }
   p.ok = u >= 0.0f && u <= float(g.w - 2) && v >= 0.0f && v <= float(g.h - 2);
   const float uf = floorf(u), vf = floorf(v);
   p.a1 = u - uf;
@@ -277,6 +308,37 @@ DVO_HD bool pixel_finish_flat(const LevelGeom& g, const float4 ref, const PixelP
   o.gzx = (1.0f * g.fx) * cZx;
   o.gzy = (1.0f * g.fy) * cZy;
   o.X = p.X; o.Y = p.Y; o.Z = p.Z;
+  return (cI == cI && cZ == cZ) && (cIx == cIx && cIy == cIy) && (cZx == cZx && cZy == cZy) && o.r1 > -20.0f * sigma;   // Q9, Q5
+}
+
+// The same for taps whose four gradient channels are plain differences next - previous, i.e. TWICE the stored central differences
+// (the sweep that derives them from staged {I, Z} pixels, align_window.hip): the factor 0.5 is applied to the four blended
+// channels.  Bit-identical to blending the halved differences: a multiplication by 0.5 is exact and commutes with the rounding of
+// every product and fused multiply-add of the blend (no value here comes near the subnormal range: intensities are multiples of
+// 2^-8 at the finest level a sweep of this kind handles, depths of 2e-4, weights differences of floats in [0, 640)).
+DVO_HD bool pixel_finish_flat_d(const LevelGeom& g, const float4 ref, const PixelProj& p, const PixelTaps& t, PixelTerms& o) {
+#pragma clang fp contract(off)
+  const float a1 = p.a1, a0 = 1.0f - a1, b1 = p.b1, b0 = 1.0f - b1;
+#define DVO_BILERP(f) (b0 * (a0 * t.A00.f + a1 * t.A10.f) + b1 * (a0 * t.A01.f + a1 * t.A11.f))
+  const float cI = DVO_BILERP(x), cZ = DVO_BILERP(y);
+#undef DVO_BILERP
+#define DVO_BILERP_FMA(v00, v10, v01, v11) fmaf(b1, fmaf(a1, v11, a0 * (v01)), b0 * fmaf(a1, v10, a0 * (v00)))
+  const float cIx = 0.5f * DVO_BILERP_FMA(t.A00.z, t.A10.z, t.A01.z, t.A11.z);
+  const float cIy = 0.5f * DVO_BILERP_FMA(t.A00.w, t.A10.w, t.A01.w, t.A11.w);
+  const float cZx = 0.5f * DVO_BILERP_FMA(t.B00.x, t.B10.x, t.B01.x, t.B11.x);
+  const float cZy = 0.5f * DVO_BILERP_FMA(t.B00.y, t.B10.y, t.B01.y, t.B11.y);
+#undef DVO_BILERP_FMA
+  const float inv255 = 1.0f / 255.0f;
+  o.r0 = inv255 * cI + (-inv255) * ref.y;
+  o.r1 = 1.0f * cZ + (-1.0f) * p.qz;
+  float sigma = p.Z - 0.4f;
+  sigma = 0.0012f + 0.0019f * sigma * sigma;
+  o.gix = g.wi_x * cIx + g.wi_x * ref.z;
+  o.giy = g.wi_y * cIy + g.wi_y * ref.w;
+  o.gzx = (1.0f * g.fx) * cZx;
+  o.gzy = (1.0f * g.fy) * cZy;
+  o.X = p.X; o.Y = p.Y; o.Z = p.Z;
+  // intensities are never NaN: the three depth channels carry every hole of the 12-pixel neighbourhood (Q9)
   return (cI == cI && cZ == cZ) && (cIx == cIx && cIy == cIy) && (cZx == cZx && cZy == cZy) && o.r1 > -20.0f * sigma;   // Q9, Q5
 }
 

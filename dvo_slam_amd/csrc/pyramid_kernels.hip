@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
           if (ROLE == 0) {
             f.A[0][at] = make_float4(i0, z0, idx, idy);
             f.B[0][at] = make_float2(zdx, zdy);
+            if (f.C[0]) f.C[0][at] = make_float2(i0, z0);   // what the window sweep stages in LDS (align_window.hip)
           } else {
             ok = z0 == z0 && zdx == zdx && zdy == zdy && (fabsf(idx) > ithr || fabsf(idy) > ithr || fabsf(zdx) > dthr || fabsf(zdy) > dthr);
             f.R[0][at] = make_float2(ok ? z0 : nanv, i0);
@@ -229,6 +230,7 @@ __global__ void k_derive_current(const FrameBuildPtrs* __restrict__ tbl, int lev
     const Derivs d = derive_at(f.I[level], f.Z[level], w, h, x, y);
     f.A[level][size_t(y) * w + x] = make_float4(d.i0, d.z0, d.idx, d.idy);
     f.B[level][size_t(y) * w + x] = make_float2(d.zdx, d.zdy);
+    if (f.C[level]) f.C[level][size_t(y) * w + x] = make_float2(d.i0, d.z0);
   });
 }
 
