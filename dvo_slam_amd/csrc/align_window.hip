@@ -37,12 +37,12 @@ constexpr int kWinRows = kWinRowGroups * kWinLoads;     // 30 window rows: 16 + 
 constexpr int kWinCells = kWinPitch * kWinRows;         // 2400 cells x 8 B = 19.2 KB
 constexpr int kNoProjection = 0x7fff7fff;               // WinRowState::uv of a lane without a usable projection
 
-// The operand slab of a wavefront.  f32 Gram: the layout of sweep_parts.h (4224 B).  f16 Gram: one 80-byte row per pixel --
-// 16 halfs "hi", 16 halfs "lo", 16 B of padding (conflict-free 16-byte stores: 80 i mod 128 are eight distinct 16-byte slots) --
-// read back with the LDS transpose read ds_read_b64_tr_b16 (5120 B).
+// The operand slab of a wavefront.  f32 Gram: the layout of sweep_parts.h (64 pixels, 4224 B).  f16 Gram: one 80-byte row per
+// pixel -- 16 halfs "hi", 16 halfs "lo", 16 B of padding (conflict-free 16-byte stores: 80 i mod 128 are eight distinct 16-byte
+// slots) -- for 32 pixels = one matrix instruction's worth (K = 32): the two half rows of a wavefront's row take turns (2560 B per
+// wavefront instead of 5120: with the window that is 29.4 KB per workgroup, five workgroups per compute unit instead of four).
 constexpr int kHalfRow = 40;                            // halfs per pixel row
-constexpr int kWinSlabFloats = 64 * kHalfRow / 2;       // 1280 floats = 5120 B >= kSlabFloats
-static_assert(kWinSlabFloats >= kSlabFloats, "the f32 layout must fit the slab");
+constexpr int kSlabFloatsF16 = 32 * kHalfRow / 2;       // 640 floats = 2560 B (>= the 512 floats the Gram matrices need at the end)
 constexpr float kResidualScale = 256.0f;                // the two residual components are lifted out of the f16 subnormal range
 
 typedef short __attribute__((ext_vector_type(2))) i16x2;
@@ -93,9 +93,12 @@ __device__ __forceinline__ f16x8 read_operand_f16(const _Float16* img, int lane,
 
 // F16: Gram accumulation on the f16 matrix pipe (variant 7)
 template <bool F16>
-__global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
+__global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count) {
+  // (Measured and dropped: a workgroup sweeping several vertically adjacent tiles in a loop, so that the pair's state, plane pointers
+  // and transform are fetched once per group of tiles -- inside a loop the compiler wants 155 vector registers for the same body and
+  // spills 59 of them at the five-wavefront budget.)
   constexpr int RPW = kWinRPW;
   const int tiles = g.tiles_x * g.tiles_y;
   const int total = tiles * n_pairs;
@@ -103,15 +106,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
   const int item = xcd * blocks_per_xcd + slot;
   if (item >= total) return;
   const int pair = item / tiles, tile = item - pair * tiles;
+  const int tile_x = tile % g.tiles_x, tile_y = tile / g.tiles_x;
   const PairState& st = states[pair];
+  // (Measured and dropped: requesting the pair's plane pointers together with its activity flag and pinning both above the branch,
+  // which helps the gathering sweep's short tiles -- here it cost 10 %.)
   if (!st.active) return;
   const PairPtrs pp = pairs[pair];
-  float KT[12], Pp[4];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) KT[i] = st.KT[i];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) Pp[i] = st.P_prev[i];
-  const bool first = st.first != 0;
   const int plane_bytes = g.w * g.h * 8;
   const __amdgpu_buffer_rsrc_t refR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.refR), 0, plane_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t curC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.curC), 0, plane_bytes, 0x00020000);
@@ -119,26 +119,31 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
   const __amdgpu_buffer_rsrc_t resid = __builtin_amdgcn_make_buffer_rsrc(scratch + size_t(pair) * size_t(g.w) * g.h, 0, plane_bytes, 0x00020000);
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int u_r = (tile % g.tiles_x) * kTileW + lane;          // < g.w: the level's width is a multiple of the tile's
-  const int row0 = (tile / g.tiles_x) * (kWavesPerBlock * RPW) + wave;
+  const int u_r = tile_x * kTileW + lane;                      // < g.w: the level's width is a multiple of the tile's
   const int row_bytes = g.w * 8;
   const float nanv = __builtin_nanf("");
   const float tx_u = g.tx[u_r];
   const float cx_u = fmaf(tx_u, tx_u, 1.0f);
-  const float P00 = Pp[0], P11 = Pp[3], P2x = Pp[1] + Pp[2];
 
-  __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kWinSlabFloats];
+  constexpr int kMySlabFloats = F16 ? kSlabFloatsF16 : kSlabFloats;
+  __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kMySlabFloats];
   __shared__ __attribute__((aligned(16))) float2 win[kWinCells];
   __shared__ __attribute__((aligned(16))) int bbox[kWavesPerBlock][2];
   __shared__ int counts[kWavesPerBlock];
   float* my = slab[wave];
+  const int off_px = u_r * 8;
+  const int off_edge = (lane == 0 ? max(u_r - 1, 0) : lane == 63 ? min(u_r + 1, g.w - 1) : u_r) * 8 + 4;
+  unsigned n_fallback = 0;
+
+  const int row0 = tile_y * (kWavesPerBlock * RPW) + wave;
+  float KT[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) KT[i] = st.KT[i];
 
   // ---- phase A: reference rows, projection, tap bounding box -------------------------------------------------------------------
   // Loads: the lane's byte offset in a row is a constant of the kernel, the row offset a scalar.  The horizontal neighbours of a
   // pixel come from the adjacent lanes; lanes 0 and 63 load the pixel beside the row segment (clamped at the image border like the
   // reference's derivative code, rgbd_image.cpp:419-489), the other lanes load their own pixel again: one unconditional load.
-  const int off_px = u_r * 8;
-  const int off_edge = (lane == 0 ? max(u_r - 1, 0) : lane == 63 ? min(u_r + 1, g.w - 1) : u_r) * 8 + 4;
   WinRowState rs[RPW];
   int uv_min = kNoProjection, uv_max = 0;                      // packed (u0, v0) extremes over the lanes with a projection
   {
@@ -233,11 +238,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
   __syncthreads();
 
   // ---- phase C: taps from LDS, residual, weight, Jacobian, Gram accumulation ----------------------------------------------------
-  f32x4* wr = reinterpret_cast<f32x4*>(my + lane * 4);
-  const float* rd = my + ((lane >> 2) & 3) * kQuadStride + (lane >> 4) * 4 + (lane & 3);
+  const float P00 = st.P_prev[0], P11 = st.P_prev[3], P2x = st.P_prev[1] + st.P_prev[2];
+  const bool first = st.first != 0;
+  const int lane_c = lane;
+  f32x4* wr = reinterpret_cast<f32x4*>(my + lane_c * 4);
+  const float* rd = my + ((lane_c >> 2) & 3) * kQuadStride + (lane_c >> 4) * 4 + (lane_c & 3);
   f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   int n_valid = 0;
-  unsigned n_fallback = 0;
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
     const int v_r = row0 + k * kWavesPerBlock;
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
     p.qz = r.qz; p.a1 = r.a1; p.b1 = r.b1; p.base = 0; p.ok = ok;
     const float4 ref = make_float4(r.z, r.i, r.gx, r.gy);
     PixelTerms o;
-    const bool valid = pixel_finish_flat_d(g, ref, p, t, o) && ok;
+    const bool valid = pixel_finish_flat_d<F16>(g, ref, p, t, o) && ok;   // (f32 Gram: bit-identical to the gathering sweep)
     n_valid += __popcll(__ballot(valid));
     if (v_r < g.h) {                                           // (uniform)
       const f32x2 rr2 = valid ? f32x2{o.r0, o.r1} : f32x2{nanv, nanv};
@@ -301,7 +308,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32v2, rr2), resid, off_px, v_r * row_bytes, 0);
     }
     if constexpr (F16) {
-      u32x4* hw = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(my) + lane * (kHalfRow * 2));
+      typedef volatile __attribute__((address_space(3))) u32x4* LdsQuadPtr;   // volatile: the stores stay where they are written
+      LdsQuadPtr hw = (LdsQuadPtr)(reinterpret_cast<char*>(my) + (lane_c & 31) * (kHalfRow * 2));
+      const bool low_half = lane_c < 32;
+      u32x4 h0, h1, l0, l1;
       if (valid) {
         const float sw = first ? 1.0f : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
         float J0[6], J1[6];
@@ -315,26 +325,41 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
         split_pair(J1[2], J1[3], hh[4], ll[4]);
         split_pair(J1[4], J1[5], hh[5], ll[5]);
         split_pair(sr * o.r0, sr * o.r1, hh[6], ll[6]);
-        hw[0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
-        hw[1] = u32x4{hh[4], hh[5], hh[6], 0u};
-        hw[2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
-        hw[3] = u32x4{ll[4], ll[5], ll[6], 0u};
-      } else {
-        // (volatile: keeps the compiler from merging these stores with the ones above behind fifteen register moves per row)
-        typedef volatile __attribute__((address_space(3))) u32x4* LdsQuadPtr;   // (still an LDS store, not a flat one)
-        LdsQuadPtr hz = (LdsQuadPtr)hw;
+        h0 = u32x4{hh[0], hh[1], hh[2], hh[3]};
+        h1 = u32x4{hh[4], hh[5], hh[6], 0u};
+        l0 = u32x4{ll[0], ll[1], ll[2], ll[3]};
+        l1 = u32x4{ll[4], ll[5], ll[6], 0u};
+        if (low_half) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }
+      } else if (low_half) {
         const u32x4 zero = {0u, 0u, 0u, 0u};
-        hz[0] = zero; hz[1] = zero; hz[2] = zero; hz[3] = zero;
+        hw[0] = zero; hw[1] = zero; hw[2] = zero; hw[3] = zero;
+      }
+      const _Float16* img = reinterpret_cast<const _Float16*>(my);
+      // pixels 0..31 of the row: the slab is private to the wavefront and LDS executes a wavefront's operations in order, so the
+      // reads below follow the stores above, and the stores of the second half follow the reads -- only the compiler is fenced
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      {
+        const f16x8 h = read_operand_f16(img, lane_c, 0), l = read_operand_f16(img + 16, lane_c, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, h, acc0, 0, 0, 0);      // H H^T
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, l, acc1, 0, 0, 0);      // S = H L^T ; G = H H^T + S + S^T
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (valid) {
+        if (!low_half) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }
+      } else if (!low_half) {
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        hw[0] = zero; hw[1] = zero; hw[2] = zero; hw[3] = zero;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const _Float16* img = reinterpret_cast<const _Float16*>(my);
-#pragma unroll
-      for (int chunk = 0; chunk < 2; ++chunk) {
-        const f16x8 h = read_operand_f16(img, lane, chunk), l = read_operand_f16(img + 16, lane, chunk);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, h, acc0, 0, 0, 0);      // H H^T
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, l, acc1, 0, 0, 0);      // S = H L^T ; G = H H^T + S + S^T
+      {
+        const f16x8 h = read_operand_f16(img, lane_c, 0), l = read_operand_f16(img + 16, lane_c, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, h, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, l, acc1, 0, 0, 0);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -390,14 +415,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
     for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
   }
   if (lane == 0) counts[wave] = n_valid;
-  if (fallback_count) {
-    const unsigned long long lanes = __ballot(n_fallback != 0);
-    if (lanes) {
-      unsigned t = n_fallback;
-      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-      if (lane == 0) atomicAdd(fallback_count, (unsigned long long)t);
-    }
-  }
   __syncthreads();
   const int kk = threadIdx.x;
   if (kk < kNumAcc) {
@@ -412,6 +429,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_window(
       if (e2 >= 0) v += G(e2);
     }
     partials[(size_t(pair) * tiles + tile) * kAccStride + kk] = v;
+  }
+  if (fallback_count) {
+    const unsigned long long lanes = __ballot(n_fallback != 0);
+    if (lanes) {
+      unsigned t = n_fallback;
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+      if (lane == 0) atomicAdd(fallback_count, (unsigned long long)t);
+    }
   }
 }
 
