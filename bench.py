@@ -9,9 +9,10 @@ records per step over RCCL when N > 1.
 A "step" is one pass of the hot path over the rank's whole shard, with the raw sensor planes already resident in HBM:
   re-ingest the raw planes of the shard's frames (u8 grey + u16 depth -> device pyramids, selection)   [SURVEY a11-a14]
   + dvo_hip_match_batch: the coarse-to-fine Gauss-Newton alignment of every pair                      [SURVEY a1-a10]
-`value` = pairs aligned per second of that loop (inputs resident in HBM when the timed region starts, as the bench contract
-prescribes).  The same loop fed from pinned HOST memory every step -- SURVEY.md 8d's "incl. H2D of 2 planes per frame" -- is
-measured right after it and reported beside it as `from_host` (PCIe-bound).  BASELINE config 2 (a single pair) is the same
+`value` = pairs aligned per second of that loop with the inputs resident in HBM when the timed region starts (the driver's bench
+contract: "inputs already resident in HBM").  SURVEY.md 8d config 4 and BASELINE.md word the same configuration "incl. H2D of 2
+planes per frame": that rate -- the same loop fed from pinned HOST memory every step -- is measured right after it in the same run
+and reported as `contract_value` / `from_host`, with its own roofline (the PCIe link).  BASELINE config 2 (a single pair) is the same
 call with a batch of one and is reported as `single_pair_ms` (latency): one 15 MB pair lives in the 256 MB Infinity Cache and
 cannot exercise HBM.
 
@@ -32,7 +33,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 W, H = 640, 480
-ALGO_BYTES_PER_PIXEL = 40.0          # ref {Z,I,Idx,Idy} 16 B + cur {I,Z,Idx,Idy,Zdx,Zdy} 24 B
+ALGO_BYTES_PER_PIXEL = 40.0          # SURVEY.md section 8d's ALGORITHMIC bytes: ref {Z,I,Idx,Idy} 16 B + cur {I,Z,Idx,Idy,Zdx,Zdy} 24 B.
+                                     # What the shipped sweep MOVES is less (reference {Zsel, I} 8 B + current {I, Z} 8 B x the staged
+                                     # window's halo, read; 8 B residual pair written): reported beside it as roofline.moved_bytes_per_pixel
+PCIE_PEAK_GBPS = 63.0                # PCIe Gen5 x16, spec (MI355X_MICROARCH.md "Host link")
 BACKGROUND_BUILD_WORKGROUPS = 0      # cap on the workgroups of background build kernels: measured, no gain (profiles/r01_i_overlap.txt)
 HBM_PEAK_GBPS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -103,6 +107,7 @@ def main():
     ap.add_argument("--build-workgroups", type=int, default=-1, help="cap on the workgroups of a background build kernel (library option build_workgroups; -1 = bench default)")
     ap.add_argument("--no-overlap", action="store_true", help="build each batch right before its match on one frame set (no build/match overlap)")
     ap.add_argument("--no-from-host", action="store_true", help="skip the PCIe-inclusive leg (raw planes handed over in pinned host memory)")
+    ap.add_argument("--no-scaling-model", action="store_true", help="skip the one-GPU step times at pairs/2, pairs/4, pairs/8 per step")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--resident-group", type=int, default=0, help="workgroups per pair in the resident match kernel (0 = as many as fit); "
                     "with --rows-per-wave: records that do not depend on the batch size")
@@ -258,15 +263,21 @@ def main():
     stream_w_ms = tracker.time_stream_mix(refs, curs, 0, reps=10, with_write=True)   # ... plus the 8-B residual pair the sweep writes
     algo_bytes = ALGO_BYTES_PER_PIXEL * W * H * B
     achieved = algo_bytes / (k_ms[0] * 1e-3) / 1e9
+    traffic = _pmc_traffic(B)
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                    traffic=_pmc_traffic(B), kernel="dvo_hip::k_residual_reduce_mfma<%d, true, false> (pyramid level 0, %d pairs per launch)" % (
-                        args.rows_per_wave or _rows_per_wave(B), B),
+                    traffic=traffic, kernel="dvo_hip::k_sweep_window<true> (pyramid level 0, %d pairs per launch; 64 x 16 tiles, the current "
+                                            "frame's {I, Z} window staged in LDS, Gram accumulation on the f16 matrix pipe)" % B,
                     kernel_ms=round(k_ms[0], 4), algorithmic_bytes_per_launch=algo_bytes,
+                    algorithmic_bytes_per_pixel=ALGO_BYTES_PER_PIXEL,
+                    moved_bytes_per_pixel=None if traffic is None else round(traffic / (W * H * B), 2),
+                    moved_GBps=None if traffic is None else round(traffic / (k_ms[0] * 1e-3) / 1e9, 1),
                     timed_at="converged transform, t-distribution weights on (3 warm-up Gauss-Newton steps on the level)",
                     bare_stream_ms=round(stream_ms, 4), bare_stream_frac=round(algo_bytes / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     bare_stream_with_write_ms=round(stream_w_ms, 4),
-                    bare_stream_note="kernels that only read the same planes in pixel order (no gather, arithmetic or reduction; the second "
-                                     "also writes the 8-B residual pair), timed the same way: what this part's memory system needs for the same bytes",
+                    bare_stream_note="kernels that only read the planes the sweep reads (reference {Zsel, I} 8 B + current {I, Z} 8 B per pixel) in "
+                                     "pixel order (no window, arithmetic or reduction; the second also writes the 8-B residual pair), timed the same "
+                                     "way: what this part's memory system needs for the bytes the sweep moves; bare_stream_frac is that time "
+                                     "priced at the 40 algorithmic bytes",
                     per_level_kernel_ms={str(k): round(v, 4) for k, v in k_ms.items()})
 
     # latency of BASELINE config 2: one 640x480 pair, 4 levels
@@ -295,6 +306,38 @@ def main():
     ctx.set_option("resident", 0)
     latency["pairs_1_launch_path"] = median_ms(lambda: tracker.match(refs[0], curs[0], one, with_stats=False))
     ctx.set_option("resident", -1)
+
+    # What the one-GPU measurements predict for N GPUs (strong scaling of the fixed 1024-pair total: every rank gets pairs / N): the
+    # same streaming loop timed on the first pairs / N pairs of this rank.  The driver measures the real curve; this is the prediction
+    # it can be checked against (it leaves out the record all-gather, which travels under the next step).
+    scaling_model = None
+    if world == 1 and n_sets > 1 and not args.no_scaling_model:
+        per_gpu = {}
+        for n_gpus in (1, 2, 4, 8):
+            b = B // n_gpus
+            if b < 1:
+                continue
+            if n_gpus == 1:
+                per_gpu[n_gpus] = elapsed / args.steps * 1e3
+                continue
+            sub = StreamPipeline(ctx, cfg, [d.FrameSet(fs[:b]) for fs in sets], [d.FrameSet(fs[B:B + b]) for fs in sets],
+                                 grey_ptrs[:b], depth_ptrs[:b], grey_ptrs[B:B + b], depth_ptrs[B:B + b])
+            sub.step(now=None, nxt=0)
+            for j in range(2):
+                sub.step(now=j % 2, nxt=(j + 1) % 2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = max(args.steps, 10)
+            for j in range(reps):
+                sub.step(now=j % 2, nxt=(j + 1) % 2)
+            torch.cuda.synchronize()
+            per_gpu[n_gpus] = (time.perf_counter() - t1) / reps * 1e3
+        scaling_model = {"ms_per_step_at_pairs_per_gpu": {str(B // n): round(ms, 3) for n, ms in per_gpu.items()},
+                         "predicted_alignments_per_s": {str(n): round(n_total / (ms * 1e-3), 1) for n, ms in per_gpu.items()},
+                         "predicted_efficiency": {str(n): round(per_gpu[1] / (n * ms), 3) for n, ms in per_gpu.items()},
+                         "note": "one GPU, HBM-resident loop on pairs/N pairs; N ranks run this independently (no data-path collective), so "
+                                 "alignments/s at N GPUs ~ total pairs / that step time"}
+        pipe.step(now=None, nxt=counter[0] % n_sets)      # (the sub-pipelines re-ingested some frames of the sets: restore the pipeline's state)
 
     # PCIe-inclusive leg (never `value`): the same pipeline, but every step's raw planes are handed over in pinned HOST memory
     # (SURVEY.md 8d config 4 "incl. H2D of 2 planes per frame") -- DMA on the upload stream, build on the build stream, match on
@@ -341,6 +384,10 @@ def main():
         from_host = {"value": round(n_total * args.steps / el_h, 2), "unit": "alignments/s", "ms_per_step": round(el_h / args.steps * 1e3, 3),
                      "h2d_bytes_per_step_per_gpu": bytes_step, "h2d_GBps_per_gpu": round(bytes_step * args.steps / el_h / 1e9, 2),
                      "same_results": bool(np.array_equal(out_h["T"], last["T"])),
+                     "roofline": {"bound": "pcie", "achieved": round(bytes_step * args.steps / el_h / 1e9, 2), "peak": PCIE_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": round(bytes_step * args.steps / el_h / 1e9 / PCIE_PEAK_GBPS, 4),
+                                  "note": "host-to-device bytes of the raw planes per second per GPU against the PCIe Gen5 x16 spec rate: this leg "
+                                          "is bound by the link, not by a kernel"},
                      "host_thread_ms_per_match_call": host_split,
                      "note": "raw planes (u8 grey + u16 depth of both frames of every pair, 1.84 MB per pair) DMA-ed from pinned host "
                              "memory every step; reported beside `value`, never as it"}
@@ -368,7 +415,11 @@ def main():
             "match_only_ms_per_batch": round(match_only_ms, 3),
             "single_pair_ms": round(single_pair_ms, 3),
             "latency_ms": latency,
+            "contract_value": None if from_host is None else from_host["value"],
+            "contract_value_note": "SURVEY.md 8d config 4 / BASELINE.md: alignments/s INCLUDING the host-to-device transfer of two raw planes per "
+                                   "frame (= from_host.value, PCIe-bound, see from_host.roofline); `value` has the raw planes resident in HBM",
             "from_host": from_host,
+            "scaling_model": scaling_model,
             "max_twist_error_vs_truth": twist_err, "nan_results": nan_results,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -380,26 +431,16 @@ def main():
         print(json.dumps(out))
 
 
-def _rows_per_wave(pairs):
-    """the tile height the library picks for the 640x480 level of a batch (capi.hip::pick_rows_per_wave), to name the kernel
-    instantiation the way rocprofv3 lists it"""
-    enough = 512 if pairs <= 8 else 1024 if pairs < 64 else 2048
-    for r in (8, 4, 2, 1):
-        if (W // 64) * -(-H // (4 * r)) * pairs >= enough:
-            return r
-    return 1
-
-
 def _pmc_traffic(pairs):
     """HBM bytes per launch of the finest-level kernel from the committed rocprofv3 --pmc passes (profiles/pmc_finest_kernel.json:
     FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes, see scripts/pmc.sh).  bench.py cannot run the profiler itself.  The
     number is reported only when it was collected for the same number of pairs per launch AND the record names the very source of
-    the sweep kernel that is compiled now (sha256 of align_mfma.hip + sweep_parts.h + pixel_math.h) -- a stale record reads as null."""
+    the sweep kernel that is compiled now (sha256 of align_window.hip + sweep_parts.h + pixel_math.h) -- a stale record reads as null."""
     import hashlib
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_finest_kernel.json")))
         h = hashlib.sha256()
-        for f in ("align_mfma.hip", "sweep_parts.h", "pixel_math.h"):
+        for f in ("align_window.hip", "sweep_parts.h", "pixel_math.h"):
             h.update(open(os.path.join(ROOT, "dvo_slam_amd", "csrc", f), "rb").read())
         if rec.get("kernel_source_sha256") != h.hexdigest() or rec["pairs_per_launch"] != pairs:
             return None

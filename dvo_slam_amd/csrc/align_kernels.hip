@@ -170,15 +170,25 @@ void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool 
 // pixel order and an 8-byte pair is written where the sweep writes its residuals.  No gather, no arithmetic, no reduction:
 // the time of this kernel is what the memory system needs for the sweep's algorithmic traffic (dvo_hip_time_stream_mix).
 // WRITE = false: the read side alone (what the default sweep moves since it keeps the residual pairs in registers).
-template <bool WRITE>
+// WINDOW: the planes of the window sweep (align_window.hip) -- reference {Zsel, I} 8 B + current {I, Z} 8 B -- instead of the
+// gathering sweep's 8 + 16 + 8 B.
+template <bool WRITE, bool WINDOW>
 __global__ __launch_bounds__(kBlock) void k_stream_mix(const PairPtrs* __restrict__ pairs, int n_px, float2* __restrict__ scratch, float* __restrict__ sink) {
   const PairPtrs pp = pairs[blockIdx.y];
   float2* out = scratch + size_t(blockIdx.y) * n_px;
   float fold = 0.0f;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_px; i += gridDim.x * kBlock) {
     const float2 r = pp.refR[i];
-    const float4 a = pp.curA[i];
-    const float2 b = pp.curB[i];
+    float4 a;
+    float2 b;
+    if constexpr (WINDOW) {
+      const float2 c = pp.curC[i];
+      a = make_float4(c.x, c.y, c.x, c.y);
+      b = c;
+    } else {
+      a = pp.curA[i];
+      b = pp.curB[i];
+    }
     if constexpr (WRITE) out[i] = make_float2(r.x + a.y + b.x, r.y + a.z + b.y);
     else fold += (r.x + a.y + b.x) + (r.y + a.z + b.y) + (a.x + a.w);
   }
@@ -189,10 +199,16 @@ __global__ __launch_bounds__(kBlock) void k_stream_mix(const PairPtrs* __restric
   }
 }
 
-void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch, float* sink) {
+void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch, float* sink, bool window_planes) {
   const int per_pair = (n_px + kBlock * 8 - 1) / (kBlock * 8);
-  if (scratch) k_stream_mix<true><<<dim3(per_pair, n_pairs), dim3(kBlock), 0, s>>>(pairs, n_px, scratch, sink);
-  else k_stream_mix<false><<<dim3(per_pair, n_pairs), dim3(kBlock), 0, s>>>(pairs, n_px, scratch, sink);
+  const dim3 grid(per_pair, n_pairs), block(kBlock);
+  if (window_planes) {
+    if (scratch) k_stream_mix<true, true><<<grid, block, 0, s>>>(pairs, n_px, scratch, sink);
+    else k_stream_mix<false, true><<<grid, block, 0, s>>>(pairs, n_px, scratch, sink);
+  } else {
+    if (scratch) k_stream_mix<true, false><<<grid, block, 0, s>>>(pairs, n_px, scratch, sink);
+    else k_stream_mix<false, false><<<grid, block, 0, s>>>(pairs, n_px, scratch, sink);
+  }
 }
 
 void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,

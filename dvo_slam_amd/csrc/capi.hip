@@ -85,7 +85,7 @@ struct FrameLevel {
   float2* B = nullptr;
   float2* R = nullptr;
   float2* C = nullptr;         // {I, Z} of a current frame for the window sweep (null: not kept at this level)
-  bool has_current = false;    // A, B built (current-frame role)
+  int cur_have = 0;            // flavours of the current-frame role that are built: kCurAB (A, B) | kCurC (C)
   bool selected = false;       // R / count built for (ithr, dthr) (reference role)
   float ithr = 0, dthr = 0;
 };
@@ -214,7 +214,8 @@ struct dvo_hip_context {
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
   int opt_fused_ll_pixels = 0;     // largest level (pixels) whose log-likelihood sweep runs inside the solver workgroup (0 = by batch size)
-  int opt_variant = 5;             // schedule of the reduce kernel: 5 = Gram accumulation on the matrix cores (default)
+  int opt_variant = 7;             // schedule of the sweep: 7 = current-frame window staged in LDS + f16 hi/lo Gram on the matrix pipe where the level allows
+                                   // (width a multiple of 64), else 5 = gathering sweep with the f32 Gram on the matrix cores
   // the resident match kernel (align_resident.hip): -1 = levels whose sweep is short enough for the groups that fit (default),
   // 0 = never (launches per iteration only), 1 = every level
   int opt_resident = -1;
@@ -544,6 +545,15 @@ bool aligned_to(const void* p, size_t a) { return reinterpret_cast<uintptr_t>(p)
 // (ensure_roles), like the reference's buildAccelerationStructure / PointSelection caches.  From raw planes: one fused pass
 // (k_build_from_raw) that also writes level 0 in role `role` (-1: not known yet, 0: current, 1: reference with the given
 // thresholds) and leaves a copy of the raw planes in the frame unless the current-role planes make it redundant.
+// flavours of the current role a consumer of `n_frames` freshly built frames will most likely ask for at `level`: where the window
+// sweep handles the level, a batch too large for the resident kernel only ever reads the 8-byte plane C (a third of the bytes to
+// write); a small one may run the level resident (taps A + B) or on the launch path (C): both.  Whatever is missing at match time is
+// derived then (ensure_roles).
+int eager_current_flavor(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_frames) {
+  if (!level_uses_window(ctx, cam->w[level], cam->h[level])) return kCurAB;
+  return n_frames > (ctx->compute_units > 0 ? ctx->compute_units : 256) ? kCurC : (kCurAB | kCurC);
+}
+
 int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, const void* const* grey, const void* const* raw,
                  float depth_scale, int role = -1, float ithr = 0.0f, float dthr = 0.0f) {
   Range range("build");
@@ -551,12 +561,13 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
   const int levels = frames[0]->levels;
   std::vector<FrameBuildPtrs> host(n);
   bool wide = cam->w[0] % 4 == 0;
+  const int flavor0 = eager_current_flavor(ctx, cam, 0, n);
   for (int i = 0; i < n; ++i) {
     dvo_hip_frame* f = frames[i];
     if (f->cam != cam || f->levels != levels) return fail(ctx, DVO_HIP_ERR_INVALID, "frames of one build batch must share camera and levels");
     fill_build_ptrs(f, host[i]);
     for (int l = 0; l < levels; ++l) {   // new pixels: every cached role plane is stale (PointSelection::setRgbdImagePyramid)
-      f->lv[l].has_current = false;
+      f->lv[l].cur_have = 0;
       f->lv[l].selected = false;
     }
     f->raw0 = grey != nullptr;
@@ -574,7 +585,7 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
       f->raw_copy = true;
     }
     wide = wide && aligned_to(host[i].grey, 4) && aligned_to(host[i].raw, 8) && aligned_to(staging_grey(f), 4);
-    if (role == 0) f->lv[0].has_current = true;
+    if (role == 0) f->lv[0].cur_have = flavor0;
     if (role == 1) { f->lv[0].selected = true; f->lv[0].ithr = ithr; f->lv[0].dthr = dthr; }
   }
   DVO_HIP_TRY(ctx, ctx->build_tbl.reserve(size_t(n) * sizeof(FrameBuildPtrs)));
@@ -584,7 +595,7 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
   ctx->build_tbl_frames.assign(frames, frames + n);
   int built = 1;                                       // float ingest: level 0 is already in place
   if (grey) {
-    launch_build_from_raw(bs, tbl, n, depth_scale, cam->w[0], cam->h[0], levels, role, wide, ithr, dthr, ctx->opt_build_workgroups);
+    launch_build_from_raw(bs, tbl, n, depth_scale, cam->w[0], cam->h[0], levels, role, wide, ithr, dthr, ctx->opt_build_workgroups, flavor0);
     built = levels < 4 ? levels : 4;
   }
   for (int l = built; l < levels; ++l) launch_pyr_down(bs, tbl, n, l, cam->w[l - 1], cam->h[l - 1]);
@@ -592,93 +603,115 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
   return stamp_build(ctx, n, frames);
 }
 
-// Build the missing role planes of a set of frames for levels [l0, l1]: role 0 = current (A, B), role 1 = reference
-// (R + selection count for the given thresholds).  One launch per level for all frames that need it.
+// Build the missing role planes of a set of frames for levels [l0, l1]: role 0 = current (flavours `cur_want[level]`, kCurAB | kCurC;
+// null: the taps A + B), role 1 = reference (R + selection count for the given thresholds).  One launch per level (and source) for
+// all frames that need it.
 // `eager`: on the build stream (dvo_hip_frames_prepare), otherwise on the main stream right before the planes are used.
-int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int role, int l0, int l1, float ithr, float dthr, bool eager = false) {
+int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int role, int l0, int l1, float ithr, float dthr, bool eager = false,
+                 const int* cur_want = nullptr) {
   const CameraGeom* cam = frames[0]->cam;
-  std::vector<FrameBuildPtrs> host;
   const size_t slice = size_t(n) * sizeof(FrameBuildPtrs);
   DevBuf& table = eager ? (role == 0 ? ctx->prep_tbl_cur : ctx->prep_tbl_ref) : (role == 0 ? ctx->role_tbl_cur : ctx->role_tbl_ref);
   hipStream_t stream = eager ? ctx->build_stream : ctx->stream;
+  const int cap = eager ? ctx->opt_build_workgroups : 0;   // planes needed right now are built at full width
   bool launched = false;
-  std::vector<FrameBuildPtrs> from_raw;      // level 0 of frames ingested from raw planes: derived from their raw copy
-  std::vector<dvo_hip_frame*> from_planes;   // ... or (reference role only) from their current-role planes
+  int uploads = 0;                                           // table slices used so far (each launch reads its own)
+  auto upload = [&](const std::vector<FrameBuildPtrs>& host, const FrameBuildPtrs** tbl, bool plane_pointers_only = true) -> int {
+    if (plane_pointers_only && eager && int(host.size()) == n && ctx->build_tbl_frames.size() == size_t(n) &&
+        std::equal(frames, frames + n, ctx->build_tbl_frames.begin())) {
+      *tbl = ctx->build_tbl.as<FrameBuildPtrs>();           // the ingest of these very frames left their table on this stream
+      return DVO_HIP_OK;
+    }
+    constexpr int kSlices = 4 * kMaxLevels;
+    if (uploads == kSlices) {                                // (never in practice: a slice per level and source)
+      DVO_HIP_TRY(ctx, hipStreamSynchronize(stream));
+      uploads = 0;
+    }
+    DVO_HIP_TRY(ctx, table.reserve(slice * kSlices));
+    FrameBuildPtrs* up = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * uploads++);
+    DVO_HIP_TRY(ctx, ctx->tables.upload(stream, up, host.data(), host.size() * sizeof(FrameBuildPtrs)));
+    *tbl = up;
+    return DVO_HIP_OK;
+  };
   for (int l = l0; l <= l1; ++l) {
-    host.clear();
-    from_raw.clear();
-    from_planes.clear();
+    const int want = role == 0 ? (cur_want ? cur_want[l] : kCurAB) & (frames[0]->lv[l].C ? (kCurAB | kCurC) : kCurAB) : 0;
+    // sources, per frame: float planes I / Z (levels >= 1, and level 0 of frames created from float planes); at level 0 of a frame
+    // ingested from raw planes: the other flavour of the current role, else the frame's copy of its raw planes
+    std::vector<FrameBuildPtrs> from_planes[4], from_raw[4], ab_from_c, c_from_a, ref_from_c;
+    std::vector<dvo_hip_frame*> ref_from_ab;
     float raw_scale = 0.0f;
+    bool deferred = false;                                   // frames of another depth scale than the launch gathered so far
     for (int i = 0; i < n; ++i) {
       dvo_hip_frame* f = frames[i];
       FrameLevel& L = f->lv[l];
-      const bool need = role == 0 ? !L.has_current : !(L.selected && L.ithr == ithr && L.dthr == dthr);
+      const int miss = role == 0 ? want & ~L.cur_have : 0;
+      const bool need = role == 0 ? miss != 0 : !(L.selected && L.ithr == ithr && L.dthr == dthr);
       if (!need) continue;   // also skips the second visit of a frame that is listed twice
       FrameBuildPtrs p;
       fill_build_ptrs(f, p);
       if (l == 0 && f->raw0) {
-        if (role == 1 && L.has_current) {
-          from_planes.push_back(f);
-        } else if (f->raw_copy && (from_raw.empty() || f->depth_scale == raw_scale)) {
+        if (role == 0 && (L.cur_have & kCurC)) {
+          ab_from_c.push_back(p);
+        } else if (role == 0 && (L.cur_have & kCurAB)) {
+          c_from_a.push_back(p);
+        } else if (role == 1 && (L.cur_have & kCurAB)) {
+          ref_from_ab.push_back(f);
+        } else if (role == 1 && (L.cur_have & kCurC)) {
+          ref_from_c.push_back(p);
+        } else if (f->raw_copy && (raw_scale == 0.0f || f->depth_scale == raw_scale)) {
           raw_scale = f->depth_scale;
           p.grey = staging_grey(f);
           p.raw = staging_depth(f);
-          from_raw.push_back(p);
+          from_raw[miss].push_back(p);
         } else if (f->raw_copy) {
-          continue;            // another depth scale than the frames gathered so far: picked up by the pass below
+          deferred = true;     // another depth scale than the frames gathered so far: picked up by the pass below
+          continue;
         } else {
           return fail(ctx, DVO_HIP_ERR_INVALID, "frame has neither sampling planes nor a raw copy at level 0");
         }
       } else {
-        host.push_back(p);
+        from_planes[miss].push_back(p);
       }
-      if (role == 0) L.has_current = true;
+      if (role == 0) L.cur_have |= miss;
       else { L.selected = true; L.ithr = ithr; L.dthr = dthr; }
     }
-    const int cap = eager ? ctx->opt_build_workgroups : 0;   // planes needed right now are built at full width
-    if (!host.empty()) {
-      const FrameBuildPtrs* tbl;
-      if (eager && int(host.size()) == n && ctx->build_tbl_frames.size() == size_t(n) &&
-          std::equal(frames, frames + n, ctx->build_tbl_frames.begin())) {
-        tbl = ctx->build_tbl.as<FrameBuildPtrs>();       // the ingest of these very frames left their table on this stream
-      } else {
-        // each level has its own slice of the table so that a copy never waits for the previous level's kernel
-        DVO_HIP_TRY(ctx, table.reserve(slice * (kMaxLevels + 1)));
-        FrameBuildPtrs* up = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * l);
-        DVO_HIP_TRY(ctx, ctx->tables.upload(stream, up, host.data(), host.size() * sizeof(FrameBuildPtrs)));
-        tbl = up;
+    const FrameBuildPtrs* tbl = nullptr;
+    for (int miss = 0; miss < 4; ++miss) {
+      if (!from_planes[miss].empty()) {
+        int rc = upload(from_planes[miss], &tbl);
+        if (rc != DVO_HIP_OK) return rc;
+        if (role == 0) launch_derive_current(stream, tbl, int(from_planes[miss].size()), l, cam->w[l], cam->h[l], cap, miss);
+        else launch_derive_reference(stream, tbl, int(from_planes[miss].size()), l, cam->w[l], cam->h[l], ithr, dthr, cap);
+        launched = true;
       }
-      if (role == 0) launch_derive_current(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], cap);
-      else launch_derive_reference(stream, tbl, int(host.size()), l, cam->w[l], cam->h[l], ithr, dthr, cap);
+      if (!from_raw[miss].empty()) {
+        int rc = upload(from_raw[miss], &tbl, /*plane_pointers_only=*/false);
+        if (rc != DVO_HIP_OK) return rc;
+        launch_build_from_raw(stream, tbl, int(from_raw[miss].size()), raw_scale, cam->w[0], cam->h[0], /*levels=*/1, role, cam->w[0] % 4 == 0, ithr, dthr, cap, miss);
+        launched = true;
+      }
+    }
+    const struct { std::vector<FrameBuildPtrs>* list; int mode; } conversions[3] = {{&ab_from_c, 0}, {&c_from_a, 1}, {&ref_from_c, 2}};
+    for (const auto& c : conversions) {
+      if (c.list->empty()) continue;
+      int rc = upload(*c.list, &tbl);
+      if (rc != DVO_HIP_OK) return rc;
+      launch_from_current_plane(stream, tbl, int(c.list->size()), l, cam->w[l], cam->h[l], c.mode, ithr, dthr, cap);
       launched = true;
     }
-    if (!from_raw.empty()) {
-      DVO_HIP_TRY(ctx, table.reserve(slice * (kMaxLevels + 1)));
-      FrameBuildPtrs* tbl = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * kMaxLevels);
-      DVO_HIP_TRY(ctx, ctx->tables.upload(stream, tbl, from_raw.data(), from_raw.size() * sizeof(FrameBuildPtrs)));
-      launch_build_from_raw(stream, tbl, int(from_raw.size()), raw_scale, cam->w[0], cam->h[0], /*levels=*/1, role, cam->w[0] % 4 == 0, ithr, dthr, cap);
-      launched = true;
-    }
-    for (dvo_hip_frame* f : from_planes) {   // PointSelection over a frame that has been a current frame so far
+    for (dvo_hip_frame* f : ref_from_ab) {   // PointSelection over a frame that has been a current frame so far
       FrameLevel& L = f->lv[0];
       DVO_HIP_TRY(ctx, hipMemsetAsync(f->sel_count, 0, sizeof(int), stream));
       launch_select_pack(stream, L.A, L.B, L.w * L.h, ithr, dthr, L.R, f->sel_count, nullptr);
       launched = true;
     }
-    if (l == 0) {   // frames of a second depth scale (one kernel launch takes one scale): rare, one more pass each
-      bool again = false;
-      for (int i = 0; i < n; ++i) {
-        const FrameLevel& L = frames[i]->lv[0];
-        again = again || (role == 0 ? !L.has_current : !(L.selected && L.ithr == ithr && L.dthr == dthr));
+    if (deferred) {   // frames of a second depth scale (one kernel launch takes one scale): rare, one more pass each
+      if (eager && launched) {
+        const int rc = stamp_build(ctx, n, frames);
+        if (rc != DVO_HIP_OK) return rc;
       }
-      if (again) {
-        if (eager && launched) {
-          const int rc = stamp_build(ctx, n, frames);
-          if (rc != DVO_HIP_OK) return rc;
-        }
-        DVO_HIP_TRY(ctx, hipStreamSynchronize(stream));   // the table slice is reused
-        return ensure_roles(ctx, n, frames, role, l0, l1, ithr, dthr, eager);
-      }
+      DVO_HIP_TRY(ctx, hipStreamSynchronize(stream));   // the table slices are reused
+      return ensure_roles(ctx, n, frames, role, l0, l1, ithr, dthr, eager, cur_want);
     }
   }
   if (eager && launched) {
@@ -743,12 +776,23 @@ void make_plan(const dvo_hip_context* ctx, const CameraGeom* cam, const dvo_hip_
 
 // buildAccelerationStructure for the current frames, PointSelection::select for the reference frames (both cached per
 // frame and level); enqueued on the context's main stream
-int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg) {
+// `launch_path_only`: the caller runs every level on the launch-per-step path (the parity / measurement entry points)
+int resident_levels_of(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const CameraGeom* cam, int n);
+
+int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
+                       bool launch_path_only = false) {
   Range range("build");
   int rc = wait_for_build(ctx, n, refs);
   if (rc == DVO_HIP_OK) rc = wait_for_build(ctx, n, curs);
   if (rc != DVO_HIP_OK) return rc;
-  rc = ensure_roles(ctx, n, curs, 0, cfg->last_level, cfg->first_level, 0.0f, 0.0f);
+  // the flavour of the current role each level is read in: the resident kernel and the gathering sweep read the taps A + B, the
+  // window sweep the 8-byte plane C
+  const CameraGeom* cam = curs[0]->cam;
+  const int resident = launch_path_only ? 0 : resident_levels_of(ctx, cfg, cam, n);
+  int want[kMaxLevels];
+  for (int l = 0; l < kMaxLevels; ++l)
+    want[l] = l > cfg->first_level - resident || l >= cam->levels || !level_uses_window(ctx, cam->w[l], cam->h[l]) ? kCurAB : kCurC;
+  rc = ensure_roles(ctx, n, curs, 0, cfg->last_level, cfg->first_level, 0.0f, 0.0f, /*eager=*/false, want);
   if (rc == DVO_HIP_OK)
     rc = ensure_roles(ctx, n, refs, 1, cfg->last_level, cfg->first_level, cfg->intensity_derivative_threshold, cfg->depth_derivative_threshold);
   return rc;
@@ -940,6 +984,12 @@ ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg
   rp.direct = rp.levels == cfg->first_level - cfg->last_level + 1 && bp.n <= kResidentDirectPairs &&
               size_t(bp.n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats) <= kResidentDirectStatsBytes;   // (pinned, if asked for)
   return rp;
+}
+
+int resident_levels_of(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const CameraGeom* cam, int n) {
+  BatchPlan bp;
+  make_plan(ctx, cam, cfg, n, bp);
+  return plan_resident(ctx, cfg, bp).levels;
 }
 
 int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, const BatchPlan& bp, const ResidentPlan& rp,
@@ -1154,7 +1204,8 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     const int keep = ctx->opt_resident;
     ctx->opt_resident = 0;
     w.needs_drain = true;
-    rc = run_batch(ctx, n, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
+    rc = ensure_batch_roles(ctx, n, refs, curs, cfg);          // (the launch path may read another flavour of the current planes)
+    if (rc == DVO_HIP_OK) rc = run_batch(ctx, n, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
     ctx->opt_resident = keep;
     return rc;
   }
@@ -1193,7 +1244,7 @@ int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_
   int rc = validate_batch(ctx, n, refs, curs, cfg);
   if (rc != DVO_HIP_OK) return rc;
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  rc = ensure_batch_roles(ctx, n, refs, curs, cfg);
+  rc = ensure_batch_roles(ctx, n, refs, curs, cfg, /*launch_path_only=*/true);
   if (rc != DVO_HIP_OK) return rc;
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
   rc = prepare_buffers(ctx->ws[0], cfg, refs, curs, bp);
@@ -1469,8 +1520,10 @@ int check_prepare_args(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const*
 // role planes of levels cfg->last_level .. cfg->first_level on the build stream (what is already there is skipped)
 int prepare_roles(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, int role, const dvo_hip_config* cfg) {
   const bool ref = role == DVO_HIP_ROLE_REFERENCE;
+  int want[kMaxLevels];
+  for (int l = 0; l < kMaxLevels; ++l) want[l] = l < frames[0]->cam->levels ? eager_current_flavor(ctx, frames[0]->cam, l, n_frames) : kCurAB;
   const int rc = ensure_roles(ctx, n_frames, frames, ref ? 1 : 0, cfg->last_level, cfg->first_level, ref ? cfg->intensity_derivative_threshold : 0.0f,
-                              ref ? cfg->depth_derivative_threshold : 0.0f, /*eager=*/true);
+                              ref ? cfg->depth_derivative_threshold : 0.0f, /*eager=*/true, want);
   if (rc != DVO_HIP_OK) return rc;
   DVO_HIP_TRY(ctx, hipGetLastError());
   return DVO_HIP_OK;
@@ -1856,9 +1909,10 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* co
   hipEvent_t e0, e1;
   DVO_HIP_TRY(ctx, hipEventCreate(&e0));
   DVO_HIP_TRY(ctx, hipEventCreate(&e1));
-  launch_stream_mix(s, pp, bp.n, g.w * g.h, scratch, sink);   // warm
+  const bool window_planes = level_uses_window(ctx, g.w, g.h);   // the planes the level's sweep really reads
+  launch_stream_mix(s, pp, bp.n, g.w * g.h, scratch, sink, window_planes);   // warm
   DVO_HIP_TRY(ctx, hipEventRecord(e0, s));
-  for (int r = 0; r < reps; ++r) launch_stream_mix(s, pp, bp.n, g.w * g.h, scratch, sink);
+  for (int r = 0; r < reps; ++r) launch_stream_mix(s, pp, bp.n, g.w * g.h, scratch, sink, window_planes);
   DVO_HIP_TRY(ctx, hipEventRecord(e1, s));
   DVO_HIP_TRY(ctx, hipEventSynchronize(e1));
   float ms = 0;

@@ -52,6 +52,11 @@ struct PairPtrs {                     // device planes of one pair at one level
                                       // (align_window.hip); null when the frame has none at this level (the sweep then reads A.xy)
 };
 
+// The current-frame role of a frame level comes in two flavours: the gathered taps A + B (gathering sweep, resident kernel, plane
+// downloads) and the 8-byte {I, Z} plane C the window sweep stages in LDS.  A level is built in the flavour(s) its consumer asks for;
+// either is derived from the other on demand, bit-identically.
+constexpr int kCurAB = 1, kCurC = 2;
+
 struct FrameBuildPtrs {                // one frame of a batched pyramid build
   const uint8_t* grey;                 // raw planes (device), may be null for the float ingest path
   const uint16_t* raw;

@@ -12,9 +12,13 @@ namespace dvo_hip {
 void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h);
 // max_workgroups > 0 caps the grid (the kernels walk the tiles with a grid stride): background build next to an alignment
 // level 0 in role `role` (-1 none, 0 current, 1 reference) + pyramid levels 1..3 straight from raw planes; `wide`: 4-pixel aligned rows
+// cur_flavor (role 0): which planes of the current role are written, kCurAB | kCurC (device_types.h)
 void launch_build_from_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int role, bool wide,
-                           float ithr, float dthr, int max_workgroups);
-void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int max_workgroups);
+                           float ithr, float dthr, int max_workgroups, int cur_flavor = kCurAB);
+void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int max_workgroups, int cur_flavor = kCurAB);
+// mode 0: A + B from C; 1: C from A; 2: R + selection count from C (the level's counters are zeroed first)
+void launch_from_current_plane(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int mode, float ithr, float dthr,
+                               int max_workgroups);
 void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr,
                              int max_workgroups);
 void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float2* R, int* count, uint8_t* mask);
@@ -34,7 +38,8 @@ bool window_sweep_supports(const LevelGeom& g);
 void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                          float* partials, float2* scratch, unsigned long long* fallback_count);
 // scratch == null: read-only (one float per workgroup goes to `sink`, which must hold a float per (8 * 256)-pixel block)
-void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch, float* sink);
+// window_planes: the planes the window sweep reads (reference 8 B + current {I, Z} 8 B) instead of the gathering sweep's 8 + 16 + 8 B
+void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch, float* sink, bool window_planes = false);
 void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,
                    const float2* scratch, double* ll_partials, int blocks_per_pair);
 

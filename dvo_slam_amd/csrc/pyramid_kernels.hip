@@ -47,7 +47,7 @@ constexpr int kB0W = 64, kB0H = 16, kB0Stride = 68;
 
 template <int ROLE, bool WIDE>
 __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __restrict__ tbl, float scale, int w0, int h0, int levels,
-                                                        float ithr, float dthr, int tiles_x, int tiles_y, int n_frames) {
+                                                        float ithr, float dthr, int tiles_x, int tiles_y, int n_frames, int cur_flavor) {
 #pragma clang fp contract(off)
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8 threads, one 2 x 2 quad each
   const int w1 = w0 >> 1, h1 = h0 >> 1;
@@ -135,9 +135,13 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
           const float zdx = (sZ[r][c + 1] - sZ[r][c - 1]) * 0.5f, zdy = (sZ[r + 1][c] - sZ[r - 1][c]) * 0.5f;
           const size_t at = size_t(y) * w0 + x;
           if (ROLE == 0) {
-            f.A[0][at] = make_float4(i0, z0, idx, idy);
-            f.B[0][at] = make_float2(zdx, zdy);
-            if (f.C[0]) f.C[0][at] = make_float2(i0, z0);   // what the window sweep stages in LDS (align_window.hip)
+            // the current role comes in two flavours (device_types.h kCurAB / kCurC): the gathered taps of the gathering sweep and
+            // the resident kernel, and / or the 8-byte {I, Z} plane the window sweep stages in LDS (align_window.hip)
+            if (cur_flavor & kCurAB) {
+              f.A[0][at] = make_float4(i0, z0, idx, idy);
+              f.B[0][at] = make_float2(zdx, zdy);
+            }
+            if (cur_flavor & kCurC) f.C[0][at] = make_float2(i0, z0);
           } else {
             ok = z0 == z0 && zdx == zdx && zdy == zdy && (fabsf(idx) > ithr || fabsf(idy) > ithr || fabsf(zdx) > dthr || fabsf(zdy) > dthr);
             f.R[0][at] = make_float2(ok ? z0 : nanv, i0);
@@ -221,16 +225,66 @@ __device__ __forceinline__ Derivs derive_at(const float* __restrict__ I, const f
 }
 
 // current-frame role: the two sampling planes
-__global__ void k_derive_current(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h, int tiles_x, int tiles_y, int n_frames) {
+__global__ void k_derive_current(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h, int tiles_x, int tiles_y, int n_frames, int cur_flavor) {
   for_each_tile(tiles_x, tiles_y, n_frames, [&](int bx, int by, int frame) {
     const FrameBuildPtrs& f = tbl[frame];
     const int x = bx * 64 + threadIdx.x;
     const int y = by * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
+    if (cur_flavor == kCurC) {                                  // (uniform) only the {I, Z} pair: no neighbours to read
+      f.C[level][size_t(y) * w + x] = make_float2(f.I[level][size_t(y) * w + x], f.Z[level][size_t(y) * w + x]);
+      return;
+    }
     const Derivs d = derive_at(f.I[level], f.Z[level], w, h, x, y);
     f.A[level][size_t(y) * w + x] = make_float4(d.i0, d.z0, d.idx, d.idy);
     f.B[level][size_t(y) * w + x] = make_float2(d.zdx, d.zdy);
-    if (f.C[level]) f.C[level][size_t(y) * w + x] = make_float2(d.i0, d.z0);
+    if (cur_flavor & kCurC) f.C[level][size_t(y) * w + x] = make_float2(d.i0, d.z0);
+  });
+}
+
+// A frame that holds only one flavour of the current role at a level gets the other: the taps A + B from the {I, Z} plane C (the
+// clamped central differences of derive_at, same operation order: bit-identical planes), or C from A.  MODE 2: the reference role
+// (R + selection count, counter zeroed before) from C -- PointSelection over a frame that has been a current frame of the window
+// sweep so far.
+template <int MODE>
+__global__ void k_from_current_plane(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h, float ithr, float dthr,
+                                     int tiles_x, int tiles_y, int n_frames) {
+#pragma clang fp contract(off)
+  __shared__ int wave_counts[4];
+  for_each_tile(tiles_x, tiles_y, n_frames, [&](int bx, int by, int frame) {
+    const FrameBuildPtrs& f = tbl[frame];
+    const int x = bx * 64 + threadIdx.x;
+    const int y = by * 4 + threadIdx.y;
+    bool ok = false;
+    if (x < w && y < h) {
+      const size_t at = size_t(y) * w + x;
+      if (MODE == 1) {
+        const float4 a = f.A[level][at];
+        f.C[level][at] = make_float2(a.x, a.y);
+      } else {
+        const float2* C = f.C[level];
+        const int xp = max(x - 1, 0), xn = min(x + 1, w - 1), yp = max(y - 1, 0), yn = min(y + 1, h - 1);
+        const float2 c = C[at], l = C[size_t(y) * w + xp], r = C[size_t(y) * w + xn], u = C[size_t(yp) * w + x], d = C[size_t(yn) * w + x];
+        const float idx = (r.x - l.x) * 0.5f, idy = (d.x - u.x) * 0.5f, zdx = (r.y - l.y) * 0.5f, zdy = (d.y - u.y) * 0.5f;
+        if (MODE == 0) {
+          f.A[level][at] = make_float4(c.x, c.y, idx, idy);
+          f.B[level][at] = make_float2(zdx, zdy);
+        } else {
+          ok = c.y == c.y && zdx == zdx && zdy == zdy && (fabsf(idx) > ithr || fabsf(idy) > ithr || fabsf(zdx) > dthr || fabsf(zdy) > dthr);
+          f.R[level][at] = make_float2(ok ? c.y : __builtin_nanf(""), c.x);
+        }
+      }
+    }
+    if (MODE == 2) {
+      const int count = __popcll(__ballot(ok));
+      if (threadIdx.x == 0) wave_counts[threadIdx.y] = count;
+      __syncthreads();
+      if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const int total = (wave_counts[0] + wave_counts[1]) + (wave_counts[2] + wave_counts[3]);
+        if (total) atomicAdd(f.sel_count + level, total);
+      }
+      __syncthreads();
+    }
   });
 }
 
@@ -310,12 +364,12 @@ static int capped_grid(int tiles_x, int tiles_y, int n_frames, int max_workgroup
 }
 
 void launch_build_from_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int role, bool wide,
-                           float ithr, float dthr, int max_workgroups) {
+                           float ithr, float dthr, int max_workgroups, int cur_flavor) {
   const int tx = (w0 + kB0W - 1) / kB0W, ty = (h0 + kB0H - 1) / kB0H;
   const dim3 grid(capped_grid(tx, ty, n_frames, max_workgroups)), block(256);
   const int lv = levels < 4 ? levels : 4;
   if (role == 1) k_zero_counts<<<dim3((n_frames + 63) / 64), dim3(64), 0, s>>>(tbl, n_frames, 0);
-#define DVO_LAUNCH_B0(ROLE, WIDE) k_build_from_raw<ROLE, WIDE><<<grid, block, 0, s>>>(tbl, scale, w0, h0, lv, ithr, dthr, tx, ty, n_frames)
+#define DVO_LAUNCH_B0(ROLE, WIDE) k_build_from_raw<ROLE, WIDE><<<grid, block, 0, s>>>(tbl, scale, w0, h0, lv, ithr, dthr, tx, ty, n_frames, cur_flavor)
   if (wide) {
     if (role == 0) DVO_LAUNCH_B0(0, true); else if (role == 1) DVO_LAUNCH_B0(1, true); else DVO_LAUNCH_B0(-1, true);
   } else {
@@ -329,9 +383,19 @@ void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int
   k_pyr_down<<<dim3((ow + 63) / 64, (oh + 3) / 4, n_frames), dim3(64, 4), 0, s>>>(tbl, level, w, h);
 }
 
-void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int max_workgroups) {
+void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int max_workgroups, int cur_flavor) {
   const int tx = (w + 63) / 64, ty = (h + 3) / 4;
-  k_derive_current<<<dim3(capped_grid(tx, ty, n_frames, max_workgroups)), dim3(64, 4), 0, s>>>(tbl, level, w, h, tx, ty, n_frames);
+  k_derive_current<<<dim3(capped_grid(tx, ty, n_frames, max_workgroups)), dim3(64, 4), 0, s>>>(tbl, level, w, h, tx, ty, n_frames, cur_flavor);
+}
+
+void launch_from_current_plane(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int mode, float ithr, float dthr,
+                               int max_workgroups) {
+  const int tx = (w + 63) / 64, ty = (h + 3) / 4;
+  const dim3 grid(capped_grid(tx, ty, n_frames, max_workgroups)), block(64, 4);
+  if (mode == 2) k_zero_counts<<<dim3((n_frames + 63) / 64), dim3(64), 0, s>>>(tbl, n_frames, level);
+  if (mode == 0) k_from_current_plane<0><<<grid, block, 0, s>>>(tbl, level, w, h, ithr, dthr, tx, ty, n_frames);
+  else if (mode == 1) k_from_current_plane<1><<<grid, block, 0, s>>>(tbl, level, w, h, ithr, dthr, tx, ty, n_frames);
+  else k_from_current_plane<2><<<grid, block, 0, s>>>(tbl, level, w, h, ithr, dthr, tx, ty, n_frames);
 }
 
 void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr,

@@ -593,7 +593,8 @@ class DenseTracker:
         return ms.value
 
     def time_stream_mix(self, references, currents, level, reps=20, with_write=False):
-        """Average duration (ms) of a kernel that only streams the sweep's planes (40 B read per pixel; with_write: + 8 B written)."""
+        """Average duration (ms) of a kernel that only streams the planes the level's sweep reads (window sweep: 16 B per pixel, gathering
+        sweep: 32 B; with_write: + 8 B written)."""
         n = len(references)
         vp = C.c_void_p
         refs = (vp * n)(*[p.ptr for p in references])

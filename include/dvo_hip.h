@@ -240,16 +240,19 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs,
                                  dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
                                  int level, int warm_iterations, int reps, float* avg_ms);
 
-/* The yardstick for that number: a kernel that only streams the same planes of the same pairs in pixel order (8 + 16 + 8 B
- * read per pixel; with_write != 0: plus the 8 B per pixel the sweep writes for the log-likelihood pass) -- no gather, no
- * arithmetic, no reduction.  What the memory system needs for the sweep's algorithmic traffic on this part. */
+/* The yardstick for that number: a kernel that only streams the planes the level's sweep reads, of the same pairs, in pixel order
+ * (window sweep, the default where the level's width is a multiple of 64: reference {Zsel, I} 8 B + current {I, Z} 8 B per pixel;
+ * gathering sweep: 8 + 16 + 8 B; with_write != 0: plus the 8 B per pixel the sweep writes for the log-likelihood pass) -- no
+ * gather, no arithmetic, no reduction.  What the memory system needs for the bytes the sweep moves on this part. */
 int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
                             dvo_hip_frame* const* references, dvo_hip_frame* const* currents,
                             int level, int with_write, int reps, float* avg_ms);
 
 /* Tunables (0 = library default).  key: "rows_per_wave" (1,2,4,8,16: tile height of the sweep kernel),
  * "iters_per_sync" (host polling cadence of the batched Gauss-Newton loop), "variant" (schedule of the sweep
- * kernel: 5 = Gram accumulation on the matrix cores (default), 0 = all-VALU with the DPP + LDS reduction),
+ * kernel: 7 = the current frame's {I, Z} window staged in LDS + Gram accumulation on the f16 matrix pipe, exact hi/lo split, on
+ * every level whose width is a multiple of 64 and variant 5 elsewhere (default); 6 = the same with the f32 Gram (bit-identical to
+ * 5); 5 = gathered taps, f32 Gram accumulation on the matrix cores; 0 = all-VALU with the DPP + LDS reduction),
  * "min_workgroups" (tile-height heuristic: smallest launch that counts as filling the chip; 0 = built-in table),
  * "fused_ll_pixels" (largest level, in pixels, whose log-likelihood sweep runs inside the solver
  * workgroup instead of a launch of its own; 0 = 160x120, and 320x240 for batches of 64 pairs and more),
@@ -265,6 +268,7 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 /* Event counters of a context.  key: "resident_launches" (matches, or coarse-level runs, done by the resident kernel),
  * "resident_timeouts" (batches repeated on the launch-per-step path because a workgroup group of the resident kernel waited
  * in vain for its peers -- the device was shared with another such kernel; the results are those of the repeat),
+ * "window_fallbacks" (lanes of the window sweep whose bilinear taps fell outside the staged window and were fetched from memory),
  * "host_batches" and "host_ns_prepare" / "host_ns_enqueue" / "host_ns_wait" / "host_ns_finish" (nanoseconds the calling thread spent
  * in dvo_hip_match_batch before its first launch, enqueueing, waiting for the device and afterwards; accumulated). */
 int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value);

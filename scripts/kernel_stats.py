@@ -17,6 +17,11 @@ def main():
     dur = defaultdict(list)
     for row in csv.DictReader(open(path)):
         name = row.get("Kernel_Name") or row.get("kernel_name")
+        # one kernel serves several pyramid levels (same name, another grid): told apart by the grid size, in workgroups
+        grid = row.get("Grid_Size") or row.get("Grid_Size_X") or ""
+        wg = row.get("Workgroup_Size") or row.get("Workgroup_Size_X") or ""
+        if grid and wg and int(wg) > 0:
+            name = "[%7d wg] %s" % (int(grid) // int(wg), name.replace("void ", "").replace("dvo_hip::", ""))
         dur[name].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)   # us
     total = sum(sum(v) for v in dur.values())
     print("%-100s %6s %6s %10s %10s %10s %7s" % ("kernel", "real", "no-op", "avg us", "min us", "max us", "% time"))
