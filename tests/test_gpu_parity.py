@@ -18,6 +18,7 @@ from dvo_slam_amd import datagen
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
+DEFAULT_VARIANT = 7     # the library's default sweep schedule (dvo_hip.h, option "variant")
 
 
 def gpu_pyramids(ctx, pair, levels):
@@ -73,7 +74,7 @@ def test_single_linearisation_against_oracle(gpu_ctx, w, h, level):
     trk = d.DenseTracker(d.Config(FirstLevel=level, LastLevel=level), gpu_ctx)
     T34 = po.se3_exp(np.array([0.004, -0.003, 0.002, 0.005, -0.004, 0.003]))[:3]
     # every tile height / schedule: same answer
-    for rows, variant in ((0, 0), (1, 0), (2, 0), (4, 0), (8, 0), (16, 0), (0, 5), (1, 5), (2, 5), (4, 5), (8, 5), (16, 5)):
+    for rows, variant in ((0, 0), (1, 0), (2, 0), (4, 0), (8, 0), (16, 0), (0, 5), (1, 5), (2, 5), (4, 5), (8, 5), (16, 5), (0, 6), (0, 7)):
         gpu_ctx.set_option("rows_per_wave", rows)
         gpu_ctx.set_option("variant", variant)
         o = po.level_iteration(oref, ocur, level, T34, first=True, mode=po.MATH, want_residuals=True)
@@ -95,7 +96,103 @@ def test_single_linearisation_against_oracle(gpu_ctx, w, h, level):
         assert np.abs(g2["A"] - o2["A"]).max() <= 1e-5 * np.abs(o2["A"]).max()
         assert np.abs(g2["b"] - o2["b"]).max() <= 1e-5 * np.abs(o2["b"]).max()
     gpu_ctx.set_option("rows_per_wave", 0)
-    gpu_ctx.set_option("variant", 5)
+    gpu_ctx.set_option("variant", DEFAULT_VARIANT)
+
+
+@pytest.mark.parametrize("w,h,xi", [(640, 480, [0.004, -0.003, 0.002, 0.006, -0.004, 0.003]), (320, 240, [0.02, 0.01, -0.015, -0.02, 0.025, 0.03]),
+                                    (640, 480, [0.05, -0.04, 0.03, 0.05, 0.04, -0.06]), (128, 96, [0, 0, 0, 0, 0, 0]), (64, 48, [0.01, 0, 0, 0, 0.01, 0]),
+                                    (640, 480, [0.3, -0.2, 0.1, 0.2, 0.3, -0.4]), (192, 80, [-0.05, 0.08, 0.02, 0.1, -0.1, 0.2])])
+def test_window_sweep_against_the_gathering_sweep(w, h, xi):
+    """The sweep that stages the current frame's {I, Z} window in LDS and derives the gradient channels itself (align_window.hip,
+    variants 6 / 7; the default on levels whose width is a multiple of 64) against the gathering sweep (variant 5) at the same tile
+    height.  Variant 6 (f32 Gram) is the gathering sweep BIT FOR BIT: residuals, valid count, every entry of A and b -- which pins
+    the staged window, the derived gradients (= the stored planes), the short division (= the IEEE division) and, for the large
+    motions, the lanes whose taps fall outside the window and are fetched from memory (counter window_fallbacks).  Variant 7
+    accumulates the Gram matrix on the f16 matrix pipe with an exact hi / lo split: residuals and counts identical, sums to 1e-6."""
+    pair = cm.synth(31, w, h)
+    T34 = po.se3_exp(np.array(xi, np.float64))[:3]
+    out = {}
+    for v in (5, 6, 7):
+        ctx = d.Context(0)
+        ctx.set_option("variant", v)
+        ctx.set_option("rows_per_wave", 4)
+        gref, gcur = gpu_pyramids(ctx, pair, 1)
+        trk = d.DenseTracker(d.Config(FirstLevel=0, LastLevel=0), ctx)
+        out[v] = [trk.level_iteration(gref, gcur, 0, T34, P_prev=[900.0, 3.0, 3.0, 400.0], first=f, want_residuals=True) for f in (True, False)]
+        out[v].append(ctx.counter("window_fallbacks"))
+    assert out[5][2] == 0
+    if max(abs(x) for x in xi) > 0.15:
+        assert out[6][2] > 0 and out[7][2] == out[6][2]              # the motion is large enough to leave the 80 x 30 window
+    for k in (0, 1):
+        a = out[5][k]
+        for v in (6, 7):
+            b = out[v][k]
+            assert a["n"] == b["n"] and a["n_selected"] == b["n_selected"]
+            assert np.array_equal(a["residuals"], b["residuals"], equal_nan=True)
+        assert np.array_equal(a["A"], out[6][k]["A"]) and np.array_equal(a["b"], out[6][k]["b"]) and a["neg_ll"] == out[6][k]["neg_ll"]
+        assert np.abs(a["A"] - out[7][k]["A"]).max() <= 1e-6 * np.abs(a["A"]).max()
+        assert np.abs(a["b"] - out[7][k]["b"]).max() <= 1e-6 * np.abs(a["b"]).max() + 1e-9 * np.abs(a["A"]).max()
+        assert abs(a["neg_ll"] - out[7][k]["neg_ll"]) <= 1e-5 * abs(a["neg_ll"])      # (through the inverse of the 2 x 2 scale matrix)
+
+
+def test_window_sweep_whole_matches_and_plane_flavours():
+    """Whole matches on the three schedules (5: gathered taps; 6: window, f32 Gram -- identical records; 7: window, f16 Gram -- the
+    same iteration structure, transforms within 1e-9), and the two flavours of the current role: frames ingested in a batch too large
+    for the resident kernel carry only the 8-byte plane C at the window levels; the taps A + B (a plane download, a small batch that
+    runs the level resident) and the reference role (point selection) are derived from it on demand, bit-identically."""
+    w, h, levels = 640, 480, 4
+    pair = cm.synth(1234, w, h)
+    res = {}
+    for v in (5, 6, 7):
+        ctx = d.Context(0)
+        ctx.set_option("variant", v)
+        ctx.set_option("rows_per_wave", 4)
+        ctx.set_option("resident", 0)
+        gref, gcur = gpu_pyramids(ctx, pair, levels)
+        r = d.Result()
+        d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0), ctx).match(gref, gcur, r)
+        res[v] = r
+    assert np.array_equal(res[5].Transformation, res[6].Transformation) and np.array_equal(res[5].Information, res[6].Information)
+    assert [len(L.Iterations) for L in res[5].Statistics.Levels] == [len(L.Iterations) for L in res[7].Statistics.Levels]
+    assert cm.twist_matrix_error(res[5].Transformation, res[7].Transformation) < 1e-9
+    # flavours: 300 frames ingested as current frames in ONE call (> compute units: plane C only at levels 0 and 1)
+    ctx = d.Context(0)
+    cfg = d.Config(FirstLevel=3, LastLevel=0)
+    K = pair["K"]
+    cam = d.RgbdCameraPyramid(w, h, K, ctx)
+    cam.build(levels)
+    n = 300
+    b = datagen.synth_batch(5, 3, w, h)
+    dummy = np.zeros((h, w), np.uint8), np.full((h, w), 5000, np.uint16)
+    frames = [cam.create_raw(*dummy) for _ in range(n)]
+    grey = [np.ascontiguousarray(b["grey_cur"][i % 3]) for i in range(n)]
+    depth = [np.ascontiguousarray(b["depth_cur"][i % 3]) for i in range(n)]
+    d.update_raw_host_batch(frames, grey, depth, role="current", config=cfg)
+    long_way = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(3)]
+    names = ("intensity", "depth", "intensity_dx", "intensity_dy", "depth_dx", "depth_dy")
+    for i in (0, 1, 2, 299):
+        for l in range(levels):
+            for k in names:                                             # (the download derives A + B from C at levels 0 and 1)
+                assert np.array_equal(getattr(frames[i].level(l), k), getattr(long_way[i % 3].level(l), k), equal_nan=True), (i, l, k)
+    d.update_raw_host_batch(frames, grey, depth, role="current", config=cfg)            # C only again
+    for l in range(levels):                                             # the reference role from a C-only current frame
+        assert d.PointSelection(frames[1]).select(l) == d.PointSelection(long_way[1]).select(l)
+        assert d.PointSelection(frames[2], 6.0, 0.03).select(l) == d.PointSelection(long_way[2], 6.0, 0.03).select(l)
+    # ... and alignments: the same records whichever way the planes came about, in both roles, on both paths
+    d.update_raw_host_batch(frames, grey, depth, role="current", config=cfg)
+    refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(3)]
+    trk = d.DenseTracker(cfg, ctx)
+
+    def raw(out):
+        return b"".join(np.ascontiguousarray(out[k]).tobytes() for k in ("T", "information", "loglik", "n_iterations"))
+    for resident in (0, -1):
+        ctx.set_option("resident", resident)
+        want = raw(trk.match_batch_arrays(refs, long_way))
+        d.update_raw_host_batch(frames, grey, depth, role="current", config=cfg)
+        assert raw(trk.match_batch_arrays(refs, frames[:3])) == want                    # current role: C (launch path) / A + B from C (resident)
+        want_back = raw(trk.match_batch_arrays(long_way, refs))
+        d.update_raw_host_batch(frames, grey, depth, role="current", config=cfg)
+        assert raw(trk.match_batch_arrays(frames[:3], refs)) == want_back               # reference role from C
 
 
 def test_golden_linearisation(gpu_ctx):
