@@ -85,7 +85,8 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce(
     scratch[pix_base + size_t(v_r) * g.w + u_r] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);
     if (!valid) return;
     // t-distribution weight with the PREVIOUS pass' precision (Q11); first pass on a level: w = 1
-    const float w = first ? 1.0f : tdist_weight(o.r0, o.r1, Pp);
+    const float w = first ? 1.0f : g.rcp_table ? 7.0f * rcp_like_the_host(g.rcp_table, g.rcp_shift, 5.0f + mahalanobis(o.r0, o.r1, Pp))   // (option "ref_compat")
+                                               : tdist_weight(o.r0, o.r1, Pp);
     accumulate_pixel(acc, o, w);
   };
 

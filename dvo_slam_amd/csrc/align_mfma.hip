@@ -176,7 +176,8 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
       ty_p = g.ty[min(v_r, g.h - 1)];
       cx = cx_u;
     }
-    const PixelProj p = pixel_project_flat(g, KT, in_image ? ref.x : nanv, tx_p, ty_p);
+    const PixelProj p = g.rcp_table ? pixel_project_flat<true>(g, KT, in_image ? ref.x : nanv, tx_p, ty_p)      // (uniform; option "ref_compat")
+                                    : pixel_project_flat<false>(g, KT, in_image ? ref.x : nanv, tx_p, ty_p);
     PixelTaps t;
     if (p.ok) taps.fetch(p.base, t);                          // lanes without a usable projection are masked out of `valid`
     PixelTerms o;
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     if (valid) {
       // t-distribution weight with the PREVIOUS pass' precision (Q11); first pass on a level: w = 1.  sqrt(w) is folded into
       // the four gradient factors of the Jacobian rows.
-      const float sw = first ? 1.0f : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
+      const float sw = first ? 1.0f : g.rcp_table ? tdist_weight_sqrt_compat(g.rcp_table, g.rcp_shift, o.r0, o.r1, Pp)   // (uniform; option "ref_compat")
+                                                  : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
       float J0[6], J1[6];
       jacobian_rows_fast(o, sw, tx_p, ty_p, cx, fmaf(ty_p, ty_p, 1.0f), J0, J1);
       wr[0] = f32x4{J0[0], J0[1], J0[2], J0[3]};

@@ -91,8 +91,9 @@ __device__ __forceinline__ f16x8 read_operand_f16(const _Float16* img, int lane,
   return f16x8{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
 }
 
-// F16: Gram accumulation on the f16 matrix pipe (variant 7)
-template <bool F16>
+// F16: Gram accumulation on the f16 matrix pipe (variant 7).  COMPAT: the reference's x * rcp(z) in projection and weights with the
+// host CPU's reciprocal table (option "ref_compat", LevelGeom::rcp_table).
+template <bool F16, bool COMPAT>
 __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count) {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
       const float z = v_r < g.h ? zv[k] : nanv;                // rows below the image: no depth
       const float ty_p = g.ty[min(v_r, g.h - 1)];
       int u0, v0;
-      const PixelProj p = pixel_project_uv_flat<true>(g, KT, z, tx_u, ty_p, u0, v0);
+      const PixelProj p = pixel_project_uv_flat<COMPAT ? 2 : 1>(g, KT, z, tx_u, ty_p, u0, v0);
       const int uv = u0 | (v0 << 16);
       rs[k].z = z;
       rs[k].i = iv[k];
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
       const bool low_half = lane_c < 32;
       u32x4 h0, h1, l0, l1;
       if (valid) {
-        const float sw = first ? 1.0f : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
+        const float sw = first ? 1.0f : COMPAT ? tdist_weight_sqrt_compat(g.rcp_table, g.rcp_shift, o.r0, o.r1, st.P_prev) : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
         float J0[6], J1[6];
         jacobian_rows_fast(o, sw, tx_u, ty_p, cx_u, fmaf(ty_p, ty_p, 1.0f), J0, J1);
         const float sr = sw * kResidualScale;
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
       continue;
     }
     if (valid) {
-      const float sw = first ? 1.0f : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
+      const float sw = first ? 1.0f : COMPAT ? tdist_weight_sqrt_compat(g.rcp_table, g.rcp_shift, o.r0, o.r1, st.P_prev) : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
       float J0[6], J1[6];
       jacobian_rows_fast(o, sw, tx_u, ty_p, cx_u, fmaf(ty_p, ty_p, 1.0f), J0, J1);
       wr[0] = f32x4{J0[0], J0[1], J0[2], J0[3]};
@@ -447,8 +448,13 @@ void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const Pair
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(kBlock);
-  if (f16) k_sweep_window<true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
-  else k_sweep_window<false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+  if (g.rcp_table) {
+    if (f16) k_sweep_window<true, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+    else k_sweep_window<false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+  } else {
+    if (f16) k_sweep_window<true, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+    else k_sweep_window<false, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+  }
 }
 
 }  // namespace dvo_hip

@@ -5,6 +5,7 @@
 // context's HIP stream and polls one integer ("pairs still iterating") every few iterations.
 #include <hip/hip_runtime.h>
 #include <rocprofiler-sdk-roctx/roctx.h>
+#include <xmmintrin.h>
 
 #include <algorithm>
 #include <cmath>
@@ -229,6 +230,9 @@ struct dvo_hip_context {
   long long host_batches = 0;
   std::chrono::steady_clock::time_point batch_entry;
   int opt_resident_flags = 0;      // kResidentFlag* (measurement and test hooks)
+  int opt_ref_compat = 0;          // projection and weights multiply with the HOST CPU's _mm_rcp_ps like the reference does
+  DevBuf rcp_table;                // ... from this table, dumped from the instruction itself when the option is first switched on
+  int rcp_shift = 0;
   int opt_resident_cooperative = 0; // launch groups through hipLaunchCooperativeKernel (a separate hardware queue: +0.1 ms per launch)
   int compute_units = 0;
   std::vector<CameraGeom*> cameras;
@@ -445,6 +449,8 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   g.tx = cam->tx[level]; g.ty = cam->ty[level];
   g.linear = level_is_linear(ctx, g.w) ? 1 : 0;
   level_tiles(g.w, g.h, rows_per_wave, g.linear != 0, &g.tiles_x, &g.tiles_y);
+  g.rcp_table = ctx->opt_ref_compat ? ctx->rcp_table.as<float>() : nullptr;
+  g.rcp_shift = ctx->rcp_shift;
   return g;
 }
 
@@ -962,7 +968,7 @@ constexpr size_t kResidentDirectStatsBytes = size_t(64) << 20;
 
 ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const BatchPlan& bp) {
   ResidentPlan rp;
-  if (ctx->opt_resident == 0) return rp;
+  if (ctx->opt_resident == 0 || ctx->opt_ref_compat) return rp;   // (the resident kernel does not carry the reference-compatible arithmetic)
   const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
   // more pairs than compute units: the workgroups would run in shifts, and the launch path, which gives every phase the whole chip,
   // is as fast (measured: 256 pairs -3 %, 512 pairs +1.6 % against it).  (Not with a pinned group size: the caller asks for
@@ -1281,6 +1287,40 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
 
 const char* dvo_hip_version(void) { return "dvo_hip 0.1 (gfx950)"; }
 
+namespace {
+// The host CPU's _mm_rcp_ps as a table (option "ref_compat").  The instruction's result is probed, not assumed: over all 2^23
+// mantissas of [1, 2) the smallest k is found for which the result depends on the leading k mantissa bits only (11 on the Intel
+// Xeon this was developed on, 12 on the EPYC 9575F of the MI355X box), and the exact scaling with the exponent is checked on a
+// sample.  A CPU whose instruction does not have that form (k > 16) is refused.
+int build_rcp_table(dvo_hip_context* ctx) {
+  auto rcp = [](float x) { return _mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(x))); };
+  auto at = [](unsigned m) { unsigned b = 0x3f800000u | m; float x; std::memcpy(&x, &b, 4); return x; };
+  // change points of the result along the mantissa: their common alignment gives k
+  unsigned all_changes = 0;
+  float prev = rcp(at(0));
+  for (unsigned m = 1; m < (1u << 23); ++m) {
+    const float r = rcp(at(m));
+    if (r != prev) { all_changes |= m; prev = r; }
+  }
+  int shift = 0;
+  while (shift < 23 && !((all_changes >> shift) & 1u)) ++shift;     // every change point is a multiple of 2^shift
+  const int k = 23 - shift;
+  if (k > 16) return fail(ctx, DVO_HIP_ERR_INVALID, "ref_compat: this CPU's _mm_rcp_ps is not a table on at most 16 mantissa bits");
+  for (unsigned m = 0; m < (1u << 23); m += 4099)
+    for (int e = -24; e <= 24; e += 3) {
+      const float s = std::ldexp(1.0f, e);
+      if (rcp(at(m) * s) != rcp(at(m)) / s) return fail(ctx, DVO_HIP_ERR_INVALID, "ref_compat: this CPU's _mm_rcp_ps does not scale exactly with the exponent");
+    }
+  std::vector<float> table(size_t(1) << k);
+  for (unsigned i = 0; i < table.size(); ++i) table[i] = rcp(at(i << shift));
+  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DVO_HIP_TRY(ctx, ctx->rcp_table.reserve(table.size() * sizeof(float)));
+  DVO_HIP_TRY(ctx, hipMemcpy(ctx->rcp_table.p, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
+  ctx->rcp_shift = shift;
+  return DVO_HIP_OK;
+}
+}  // namespace
+
 int dvo_hip_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1328,6 +1368,14 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
     dvo_hip_context_destroy(ctx);
     return DVO_HIP_ERR_HIP;
   }
+  // DVO_HIP_REF_COMPAT=1: the reference-compatible arithmetic for callers that cannot set options -- the reference's own, unmodified
+  // programs linked against the facade (tests/dropin)
+  if (const char* env = std::getenv("DVO_HIP_REF_COMPAT"))
+    if (env[0] == '1' && dvo_hip_set_option(ctx, "ref_compat", 1) != DVO_HIP_OK) {
+      g_create_error = ctx->err;
+      dvo_hip_context_destroy(ctx);
+      return DVO_HIP_ERR_INVALID;
+    }
   *out = ctx;
   return DVO_HIP_OK;
 }
@@ -1343,7 +1391,7 @@ void dvo_hip_context_destroy(dvo_hip_context* ctx) {
   for (hipEvent_t ev : ctx->build_events)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->build_stream) (void)hipStreamDestroy(ctx->build_stream);
-  for (DevBuf* b : {&ctx->misc, &ctx->build_tbl, &ctx->role_tbl_cur, &ctx->role_tbl_ref, &ctx->prep_tbl_cur, &ctx->prep_tbl_ref}) b->release();
+  for (DevBuf* b : {&ctx->misc, &ctx->build_tbl, &ctx->role_tbl_cur, &ctx->role_tbl_ref, &ctx->prep_tbl_cur, &ctx->prep_tbl_ref, &ctx->rcp_table}) b->release();
   for (DevBuf& b : ctx->upload_buf) b.release();
   for (const dvo_hip_context::PooledBlock& b : ctx->frame_pool) (void)hipFree(b.p);
   ctx->frame_pool.clear();
@@ -1378,6 +1426,15 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     if (value != 0 && value != 5 && value != 6 && value != 7)
       return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0 (all-VALU schedule), 5 (matrix-core schedule), 6 or 7 (current-frame window staged in LDS)");
     ctx->opt_variant = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "ref_compat") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "ref_compat must be 0 or 1");
+    if (value && !ctx->rcp_table.p) {
+      const int rc = build_rcp_table(ctx);
+      if (rc != DVO_HIP_OK) return rc;
+    }
+    ctx->opt_ref_compat = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "resident") == 0) {

@@ -40,6 +40,12 @@ struct LevelGeom {                    // identical for every pair of a batch (on
   // tiles.  Used when w is not a multiple of 64: an 80-pixel-wide level otherwise runs every second wavefront-row with 16
   // of its 64 lanes (37 % of the issue slots wasted), a 160-wide one with 32 (17 %).
   int linear;
+  // Reference-compatible arithmetic (option "ref_compat"; null = off): the reference's projection and weights multiply with
+  // _mm_rcp_ps (dense_tracking_impl.cpp:192, :700), an approximate reciprocal whose value is a lookup on the leading mantissa bits of
+  // its operand -- different on different CPUs.  The table is dumped from the host CPU's own instruction when the option is switched
+  // on: rcp(1.m x 2^e) = rcp_table[m >> rcp_shift] x 2^-e (pixel_math.h::rcp_like_the_host).
+  const float* rcp_table;
+  int rcp_shift;
 };
 
 struct PairPtrs {                     // device planes of one pair at one level

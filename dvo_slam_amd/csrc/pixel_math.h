@@ -32,6 +32,17 @@ DVO_HD float fast_rsqrt(float x) {
 #endif
 }
 
+// _mm_rcp_ps of the host CPU, from the table dumped at run time (LevelGeom::rcp_table): the instruction returns a value that depends
+// on the leading mantissa bits of its operand only (2^11 table entries on Intel, 2^12 on AMD Zen 5 -- probed, never assumed) and
+// scales exactly with its exponent.  Zero, subnormal, infinite and NaN operands are not reproduced (a depth is none of them).
+DVO_HD float rcp_like_the_host(const float* table, int shift, float x) {
+  union { float f; unsigned u; } in, t;
+  in.f = x;
+  t.f = table[(in.u & 0x7fffffu) >> shift];             // rcp(1.m), in (0.5, 1]
+  t.u = (t.u + ((127u - ((in.u >> 23) & 0xffu)) << 23)) | (in.u & 0x80000000u);   // x 2^-(e - 127), sign of x
+  return t.f;
+}
+
 struct PixelTerms {
   float r0, r1;       // intensity / depth residual
   float gix, giy;     // intensity gradient row  (0.5 fx (Icx + Irx)/255 , 0.5 fy (Icy + Iry)/255)
@@ -112,7 +123,15 @@ DVO_HD PixelProj pixel_project_at(const LevelGeom& g, const float* KT, const flo
   const float qz = (KT[8] * X + KT[9] * Y) + (KT[10] * Z + KT[11]);
   p.qz = qz;
   if (!(Z == Z)) return p;                          // not selected / no depth (Q19)
-  const float u = qx / qz, v = qy / qz;             // correctly rounded division (MATH semantics, Q1)
+  float u, v;
+  if (g.rcp_table) {                                // reference-compatible (option "ref_compat")
+    const float r = rcp_like_the_host(g.rcp_table, g.rcp_shift, qz);
+    u = qx * r;
+    v = qy * r;
+  } else {
+    u = qx / qz;                                    // correctly rounded division (MATH semantics, Q1)
+    v = qy / qz;
+  }
   if (!(u >= 0.0f && u <= float(g.w - 2) && v >= 0.0f && v <= float(g.h - 2))) return p;   // Q4
   const float uf = floorf(u), vf = floorf(v);
   p.a1 = u - uf;
@@ -211,6 +230,9 @@ DVO_HD void jacobian_rows(const PixelTerms& t, float* J0, float* J1) { jacobian_
 // two forms against each other.  (Measured and dropped: fused multiply-adds throughout, u = qx * rcp(qz), the blend as four
 // shared tap weights -- 35 fewer vector instructions per pixel, not a microsecond faster in the sweep, which is not bound by
 // vector-ALU issue)
+// COMPAT: the reference's u = x * rcp(z) with the host CPU's reciprocal table (option "ref_compat"; the resident kernel does not
+// carry it: with the option on every level runs on the launch path)
+template <bool COMPAT = false>
 DVO_HD PixelProj pixel_project_flat(const LevelGeom& g, const float* KT, float Z, float tx, float ty) {
 #pragma clang fp contract(off)
   PixelProj p;
@@ -221,7 +243,15 @@ DVO_HD PixelProj pixel_project_flat(const LevelGeom& g, const float* KT, float Z
   const float qy = (KT[4] * X + KT[5] * Y) + (KT[6] * Z + KT[7]);
   const float qz = (KT[8] * X + KT[9] * Y) + (KT[10] * Z + KT[11]);
   p.qz = qz;
-  const float u = qx / qz, v = qy / qz;             // correctly rounded division (MATH semantics, Q1)
+  float u, v;
+  if (COMPAT) {                                     // reference-compatible: u = x * rcp(z) (dense_tracking_impl.cpp:192, Q1)
+    const float r = rcp_like_the_host(g.rcp_table, g.rcp_shift, qz);
+    u = qx * r;
+    v = qy * r;
+  } else {
+    u = qx / qz;                                    // correctly rounded division (MATH semantics)
+    v = qy / qz;
+  }
   p.ok = u >= 0.0f && u <= float(g.w - 2) && v >= 0.0f && v <= float(g.h - 2);   // Q4; false for NaN
   const float uf = floorf(u), vf = floorf(v);
   p.a1 = u - uf;
@@ -256,7 +286,9 @@ DVO_HD void divide2_correctly_rounded(float nx, float ny, float d, float& u, flo
 
 // The same projection for the sweep that stages the current frame in LDS (align_window.hip): returns the tap corner as (u0, v0)
 // instead of a plane index, and leaves X / Y to the caller (it recomputes them where it needs them).
-template <bool SHORT_DIVISION = false>
+// DIVISION: 0 = the compiler's IEEE division, 1 = divide2_correctly_rounded (the same bits), 2 = the reference's x * rcp(z) with the
+// host CPU's reciprocal table (option "ref_compat")
+template <int DIVISION = 0>
 DVO_HD PixelProj pixel_project_uv_flat(const LevelGeom& g, const float* KT, float Z, float tx, float ty, int& u0, int& v0) {
 #pragma clang fp contract(off)
   PixelProj p;
@@ -268,7 +300,11 @@ DVO_HD PixelProj pixel_project_uv_flat(const LevelGeom& g, const float* KT, floa
   const float qz = (KT[8] * X + KT[9] * Y) + (KT[10] * Z + KT[11]);
   p.qz = qz;
   float u, v;
-  if (SHORT_DIVISION) {
+  if (DIVISION == 2) {
+    const float r = rcp_like_the_host(g.rcp_table, g.rcp_shift, qz);
+    u = qx * r;
+    v = qy * r;
+  } else if (DIVISION == 1) {
     divide2_correctly_rounded(qx, qy, qz, u, v);
   } else {
     u = qx / qz;
@@ -362,6 +398,11 @@ DVO_HD bool pixel_finish_flat_d(const LevelGeom& g, const float4 ref, const Pixe
 DVO_HD float tdist_weight_sqrt_fast(float r0, float r1, float P00, float P2x, float P11) {
   const float t = fmaf(P2x, r1, P00 * r0);
   return 2.6457513110645906f * fast_rsqrt(fmaf(t, r0, fmaf(P11 * r1, r1, 5.0f)));
+}
+
+// reference-compatible: the square root of w = 7 * rcp(5 + r^T P r) with the host CPU's reciprocal (dense_tracking_impl.cpp:700, Q1)
+DVO_HD float tdist_weight_sqrt_compat(const float* table, int shift, float r0, float r1, const float* P) {
+  return sqrtf(7.0f * rcp_like_the_host(table, shift, 5.0f + mahalanobis(r0, r1, P)));
 }
 
 // The scaled Jacobian rows in normalised coordinates: with x = tx z, y = ty z the warp Jacobian is
