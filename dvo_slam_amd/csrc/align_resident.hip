@@ -26,7 +26,7 @@
 // The exchange is the "LL" protocol of collective libraries: a row is 8-byte slots {value, sequence number}, written with relaxed
 // agent-scope stores and polled with relaxed agent-scope loads (sc1: through the non-coherent per-XCD L2s).  An aligned 8-byte
 // access is single-copy atomic, so a slot whose sequence number is current carries current data -- no flag, no fence and ONE round
-// trip when the data is there.  Rows are double-buffered by the parity of the exchange count; a workgroup can run at most one
+// trip when the data is there.  Rows travel in a ring of four buffers; heartbeat words keep a workgroup from running more than three
 // exchange ahead of its peers.  All workgroups of a launch with G > 1 must be on the device together (one per compute unit; the
 // host sizes G accordingly and lets such launches take turns); polling is bounded: a group that waits in vain raises the error
 // word and leaves, and the host repeats the batch on the launch path.  With G = 1 (large batches, coarse levels) there is no
@@ -77,7 +77,7 @@ __device__ __forceinline__ bool slot_gather(const unsigned long long* group_rows
     for (int r = 0; r < kGatherRows; ++r) {
       const int j = q + r * kGatherLanes;
       if (j < G) {
-        v[r] = __hip_atomic_load(group_rows + (size_t(j) * 2 + parity) * kResidentSlots + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[r] = __hip_atomic_load(group_rows + (size_t(j) * kResidentRing + parity) * kResidentSlots + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok &= unsigned(v[r] >> 32) == seq;
       }
     }
@@ -170,8 +170,10 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
   // while the other seven sum the log-likelihood of their residuals next to it
   const bool sweeper = wave > 0;
   const int gw = wg * kResidentSweepers + (wave - 1), W = G * kResidentSweepers;   // this sweeping wavefront among the group's
-  unsigned long long* group_rows = a.exchange + size_t(pair) * G * 2 * kResidentSlots;
-  unsigned long long* my_rows = group_rows + size_t(wg) * 2 * kResidentSlots;
+  unsigned long long* group_rows = a.exchange + size_t(pair) * G * kResidentRing * kResidentSlots;
+  unsigned long long* my_rows = group_rows + size_t(wg) * kResidentRing * kResidentSlots;
+  // one word per workgroup behind the rows of all pairs: the number of the exchange the workgroup has begun (flow control, below)
+  unsigned* group_beats = reinterpret_cast<unsigned*>(a.exchange + size_t(a.n_pairs) * G * kResidentRing * kResidentSlots) + size_t(pair) * G;
   unsigned seq = a.sequence_base;
 
 #ifdef DVO_RESIDENT_CLOCKS
@@ -350,8 +352,20 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
       // ---- the exchange: partial rows of this pass and log-likelihood sums of the pass before it, one round trip ----------------
       if (G > 1) {
         seq += 1;
-        const int parity = seq & 1;
+        const int parity = seq & (kResidentRing - 1);             // the ring buffer this exchange travels in
         unsigned long long* mine = my_rows + parity * kResidentSlots;
+        // Flow control: a workgroup without segments on this level (wg >= G_act) contributes no row, but it consumes every exchange
+        // like the others (all of them run the loop body redundantly).  Every workgroup announces the exchange it begins in its
+        // HEARTBEAT word (G consecutive 4-byte words per group: two cache lines, read by 64 otherwise idle lanes in the same round
+        // trip as the rows), and nobody completes exchange s before everybody has begun exchange s - 2.  The rows travel in a ring
+        // of kResidentRing = 4 buffers: the rows of exchange s overwrite those of s - 4, which everybody has finished reading --
+        // the writer completed s - 1, so all had begun s - 3.  The heartbeats asked for are two exchanges old: the check never
+        // waits unless a workgroup really lags (started late: the device shared with another launch).  (Without flow control the
+        // sweeping workgroups could run any number of exchanges ahead of an idle one, which then polled for a sequence number that
+        // had been overwritten, timed out after a quarter of a second and sent the batch to the launch path -- the "one launch in
+        // seven" of two launches sharing the device.  Measured on the way: a zero ROW per idle workgroup, waited for every pass:
+        // +17 % on a single pair's latency; heartbeat words waited for every pass with two buffers: +9 %.)
+        if (tid == kNumAcc + 1) __hip_atomic_store(group_beats + wg, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (wg < G_act && !((a.flags & kResidentFlagWithhold) && wg == 1)) {
           if (tid < kNumAcc) slot_store(mine + tid, __float_as_uint(row_value), seq);
           if (tid == kNumAcc) {                                // the log-likelihood sum of the pass before (its wavefronts' parts)
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
           // workgroups need.  One wavefront watches one slot per row until the rows have been started, then everybody reads.
           if (wave == 0 && lane < G_act) {
             int spins = 0;
-            while (unsigned(__hip_atomic_load(group_rows + (size_t(lane) * 2 + parity) * kResidentSlots + kAccN, __ATOMIC_RELAXED,
+            while (unsigned(__hip_atomic_load(group_rows + (size_t(lane) * kResidentRing + parity) * kResidentSlots + kAccN, __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_AGENT) >> 32) != seq) {
               if (++spins > kSpinLimit) { bail = 1; break; }
               __builtin_amdgcn_s_sleep(1);
@@ -381,10 +395,19 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
           double t = 0.0;
           if (!slot_gather(group_rows, G_act, q, parity, k, seq, [&](unsigned bits) { t += double(__uint_as_float(bits)); })) bail = 1;
           sums_q[q][k] = t;
+        } else if (k >= 96 && q >= 2) {                       // heartbeats: lane j waits until workgroup j has begun exchange seq - 2
+          const int j = (k - 96) + 32 * (q - 2);
+          if (j < G) {
+            int spins = 0;
+            while (int(__hip_atomic_load(group_beats + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < -2) {
+              if (++spins > kSpinLimit) { bail = 1; break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
         } else if (k >= 96 && q < 2) {                        // the log-likelihood sum of workgroup j: both halves
           const int j = (k - 96) + 32 * q;
           if (j < G_act) {
-            const unsigned long long* src = group_rows + (size_t(j) * 2 + parity) * kResidentSlots + kResidentSlotLl;
+            const unsigned long long* src = group_rows + (size_t(j) * kResidentRing + parity) * kResidentSlots + kResidentSlotLl;
             unsigned long long lo = 0, hi = 0;
             int spins = 0;
             for (;;) {
@@ -546,6 +569,13 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
     if (wg == 0 && have_level) coop_copy(lvl_global, &lvl);
   }
   if (uniform(bail)) {
+    // the batch is repeated on the launch path: leave the pair in a defined, inactive state for whatever is still enqueued behind
+    // this launch (the launch-path levels of a mixed run read it before the host has seen the error word)
+    if (wg == 0 && tid == 0) {
+      a.states[pair].active = 0;
+      a.states[pair].n_levels = 0;
+      a.states[pair].n_iters_total = 0;
+    }
     if (tid == 0) __hip_atomic_store(a.error_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }

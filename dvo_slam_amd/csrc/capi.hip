@@ -199,6 +199,8 @@ struct Workspace {
   // thread reads as soon as the kernel has counted the pairs done (no copy command, no stream synchronisation)
   PinnedBuf direct_results, direct_levels, direct_iters, direct_done;
   bool needs_drain = false;        // a batch ended early: the stream is drained before buffers are reused
+  int resident_error_word = 0;     // index of the current resident launch's error word in host_status (a ring, see kResidentErrorWords)
+  unsigned resident_launch_counter = 0;
 };
 
 struct dvo_hip_context {
@@ -364,6 +366,11 @@ int wait_for_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames) {
     if (frames[i] && frames[i]->built_seq > need) need = frames[i]->built_seq;
   return wait_for_ticket(ctx, need, /*upload=*/false);
 }
+
+// The error word of a resident launch: one of a ring of words of Workspace::host_status indexed by the launch counter (the per-step
+// words start behind the ring).  A workgroup of an EARLIER launch that gives up late -- the host returns from the direct path as soon
+// as every pair is done, not when every workgroup has left -- raises its own launch's word, not the one the next batch has just reset.
+constexpr int kResidentErrorWords = 8;
 
 const int kLlBlocksPerPair = 32;
 const int kFusedLoglikMaxPixels = 160 * 120;      // any batch
@@ -820,7 +827,7 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
   DVO_WS_TRY(w, w.it_stats.reserve(size_t(n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats)));
   DVO_WS_TRY(w, w.results.reserve(size_t(n) * sizeof(dvo_hip_result)));
   DVO_WS_TRY(w, w.t_init.reserve(size_t(n) * 16 * sizeof(double)));
-  DVO_WS_TRY(w, w.counters.reserve(size_t(bp.cap_iters + 8) * sizeof(unsigned long long)));
+  DVO_WS_TRY(w, w.counters.reserve(size_t(bp.cap_iters + 8 + kResidentErrorWords) * sizeof(unsigned long long)));
   if (!w.win_fallbacks.p) {
     DVO_WS_TRY(w, w.win_fallbacks.reserve(64));
     DVO_WS_TRY(w, hipMemsetAsync(w.win_fallbacks.p, 0, 64, w.stream));
@@ -874,14 +881,14 @@ int wait_for_step(Workspace& w, int step, int* active) {
 // are complete in pinned host memory; a group that timed out raises the error word instead (the caller repeats the batch).
 int wait_for_direct(Workspace& w, int n_pairs) {
   volatile int* done = w.direct_done.as<int>();
-  volatile int* error_word = w.host_status + 0;
+  volatile int* error_word = w.host_status + w.resident_error_word;
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 1;; ++spins) {
+    if (*error_word != 0) return DVO_HIP_OK;                 // (looked at first: an error raised in this launch is reported by this launch)
     if (*done >= n_pairs) {
       std::atomic_thread_fence(std::memory_order_acquire);
       return DVO_HIP_OK;
     }
-    if (*error_word != 0) return DVO_HIP_OK;
     if ((spins & 0xfffff) == 0) {
       const hipError_t q = hipStreamQuery(w.stream);
       if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();
@@ -916,11 +923,12 @@ int ensure_host_status(Workspace& w, size_t n_steps) {
 
 // ---- the resident kernel: which levels, how many workgroups per pair ------------------------------------------------------------
 // Workgroups of a group wait for each other, so all groups in flight on a device must be on it together.  Contexts of one process
-// (one per host thread, like the reference's one DenseTracker per TBB worker) therefore take turns: one launch with groups per
-// device at a time.  (Letting launches that fit next to each other run together was tried: on some boxes one launch in seven then
-// saw a group time out -- and the batch repeated on the launch path, with that path's rounding -- although the workgroups of
-// both fit the device; the cause was not found.  Another PROCESS on the same device is not seen here; there a group can time
-// out, and the batch is repeated on the launch path.)
+// (one per host thread, like the reference's one DenseTracker per TBB worker, keyframe_graph.cpp:576-593) share a per-device budget
+// of compute units: launches with groups run SIDE BY SIDE as long as their workgroups fit the device together (one 512-thread
+// workgroup per compute unit), and wait for each other beyond that.  (Round 2 let only one such launch run at a time: side by side,
+// one launch in seven had timed out.  The cause was the exchange's missing flow control towards idle workgroups -- fixed in
+// align_resident.hip, "Flow control" -- which a second launch on the device, delaying some workgroups' start, merely exposed.)
+// Another PROCESS on the same device is not seen here; there a group can time out, and the batch is repeated on the launch path.
 struct ResidentBudget {
   std::mutex m;
   std::condition_variable cv;
@@ -937,8 +945,7 @@ struct ResidentBudget {
     Hold& operator=(const Hold&) = delete;
     void take(ResidentBudget& budget, int workgroups, int capacity) {
       std::unique_lock<std::mutex> lock(budget.m);
-      (void)capacity;
-      budget.cv.wait(lock, [&] { return budget.in_flight == 0; });
+      budget.cv.wait(lock, [&] { return budget.in_flight == 0 || budget.in_flight + workgroups <= capacity; });
       budget.in_flight += workgroups;
       b = &budget;
       n = workgroups;
@@ -955,7 +962,7 @@ struct ResidentBudget {
 };
 
 constexpr int kResidentRowsDefault = 24;      // segments per wavefront and iteration up to which a level runs resident
-constexpr int kResidentErrorWord = 0;         // index into Workspace::host_status (the per-step words start behind it)
+
 
 struct ResidentPlan {
   int group = 1;                               // workgroups per pair
@@ -1010,7 +1017,7 @@ int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, 
   args.iters = w.it_stats.as<dvo_hip_iteration_stats>();
   args.T_init = w.t_init.as<double>();
   args.scratch = w.scratch.as<float2>();
-  args.error_word = w.host_status + kResidentErrorWord;
+  args.error_word = w.host_status + w.resident_error_word;
   args.prm = bp.prm;
   args.n_pairs = bp.n;
   args.group = rp.group;
@@ -1039,7 +1046,8 @@ int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, 
   }
   ctx->resident_launches += 1;
   if (rp.group > 1) {
-    const size_t bytes = size_t(bp.n) * rp.group * 2 * kResidentSlots * sizeof(unsigned long long);
+    // the rows of every group, and behind them one heartbeat word per workgroup (align_resident.hip, "Flow control")
+    const size_t bytes = size_t(bp.n) * rp.group * kResidentRing * kResidentSlots * sizeof(unsigned long long) + align_up(size_t(bp.n) * rp.group * sizeof(unsigned), 256);
     const bool grown = bytes > w.exchange.bytes;
     DVO_WS_TRY(w, w.exchange.reserve(bytes));
     // sequence numbers never repeat between launches; when they would wrap (or the rows are new / in doubt) the rows are cleared
@@ -1076,15 +1084,16 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   for (int i = 0; i < n; ++i) std::memcpy(&tinit[size_t(i) * 16], results[i].transformation, 16 * sizeof(double));
   if (!tables_inline) DVO_WS_TRY(w, w.tables->upload(s, w.t_init.p, tinit.data(), tinit.size() * sizeof(double)));
   // per-step tallies (device) and status words (pinned host memory the device writes, see publish_step)
-  const size_t n_steps = size_t(bp.cap_iters) + 8;
+  const size_t n_steps = size_t(bp.cap_iters) + 8 + kResidentErrorWords;
   // a batch that ended early (time-out, HIP error) may have left steps queued: nothing of it may still be running when the
   // status words and tallies are reset
   if (w.needs_drain) DVO_WS_TRY(w, hipStreamSynchronize(s));
   w.needs_drain = true;                                        // until this batch has come to its regular end
   rc = ensure_host_status(w, n_steps);
   if (rc != DVO_HIP_OK) return rc;
+  w.resident_error_word = int(w.resident_launch_counter++ % kResidentErrorWords);
   if (rp.direct) {
-    w.host_status[kResidentErrorWord] = 0;
+    w.host_status[w.resident_error_word] = 0;
   } else {
     // (the previous batch may have ended on the host's side before the device was through with the step words: the direct path)
     DVO_WS_TRY(w, hipStreamSynchronize(s));
@@ -1101,7 +1110,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   unsigned long long* tallies = w.counters.as<unsigned long long>();
   const int per_level = cfg->max_iterations_per_level;
   const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 1;
-  int step = kResidentErrorWord + 1;                        // status word 0 belongs to the resident kernel
+  int step = kResidentErrorWords;                           // the first status words belong to the resident kernel's launches
   const auto t_launch = std::chrono::steady_clock::now();
   int level_from = cfg->first_level;
   const bool want_stats = (levels && cap_levels > 0) || (iters && cap_iters > 0);
@@ -1174,7 +1183,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     rc = wait_for_direct(w, n);
     if (rc != DVO_HIP_OK) return rc;
     t_done = std::chrono::steady_clock::now();
-    if (w.host_status[kResidentErrorWord] == 0) {
+    if (w.host_status[w.resident_error_word] == 0) {
       std::memcpy(results, w.direct_results.p, size_t(n) * sizeof(dvo_hip_result));
       if (levels && cap_levels > 0) hl_src = w.direct_levels.as<dvo_hip_level_stats>();
       if (iters && cap_iters > 0) hi_src = w.direct_iters.as<dvo_hip_iteration_stats>();
@@ -1199,13 +1208,15 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     DVO_WS_TRY(w, hipGetLastError());
     t_done = std::chrono::steady_clock::now();
   }
-  if (resident_used && w.host_status[kResidentErrorWord] != 0) {
+  if (resident_used && w.host_status[w.resident_error_word] != 0) {
     // A group of the resident kernel gave up waiting for its peers: its workgroups were not all on the device at once (the
     // device is shared with another process that does the same, or a compute-unit mask shrank it).  Nothing is wrong with the
     // batch: it runs again, one launch per step, and the context stops using groups.
     w.resident_sequence = 0xffffffffu;                       // the exchange rows are in an unknown state: cleared before the next use
     ctx->resident_timeouts += 1;
-    ctx->opt_resident_group = 1;
+    // (not after a single incident: a launch that started late once -- the device busy with another process for a moment -- is no
+    // reason to give up the latency path for the rest of the context's life)
+    if (ctx->resident_timeouts >= 3) ctx->opt_resident_group = 1;
     for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, &tinit[size_t(i) * 16], 16 * sizeof(double));
     const int keep = ctx->opt_resident;
     ctx->opt_resident = 0;

@@ -123,6 +123,7 @@ constexpr int kResidentRowsLds = 3;                  // residual pairs of a wave
                                                      // passes are, give a wavefront one to three segments
 constexpr int kResidentBlock = kResidentWaves * 64;
 constexpr int kResidentMaxGroup = 64;                // workgroups per pair at most (power of two)
+constexpr int kResidentRing = 4;                     // exchange rows in flight per workgroup (a power of two; align_resident.hip, "Flow control")
 constexpr int kResidentSlots = 96;                   // 8-byte {value, sequence} slots of an exchange row: the 85 accumulators, ...
 constexpr int kResidentSlotLl = 88;                  // ... and the two halves of the workgroup's float64 log-likelihood sum
 
@@ -138,7 +139,7 @@ struct ResidentArgs {
   dvo_hip_iteration_stats* iters;
   const double* T_init;                               // non-null: the pairs are initialised here (the launch starts the match)
   float2* scratch;                                    // residual pairs, n_pairs x pixels of the level
-  unsigned long long* exchange;                       // [n_pairs][group][2][kResidentSlots], used when group > 1
+  unsigned long long* exchange;                       // [n_pairs][group][kResidentRing][kResidentSlots] + one heartbeat word per workgroup, used when group > 1
   int* error_word;                                    // pinned host word: set when a group timed out
   SolverParams prm;
   int n_pairs, group;                                 // group: workgroups per pair (power of two)

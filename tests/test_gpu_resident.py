@@ -178,3 +178,37 @@ def test_resident_groups_next_to_a_busy_build_stream(ctx):
             assert np.array_equal(out["T"], quiet[i]["T"]) and np.array_equal(out["information"], quiet[i]["information"])
     d.upload_wait(ctx)
     assert ctx.counter("resident_timeouts") == before[0] and ctx.counter("resident_launches") == before[1] + 24
+
+
+def test_contexts_of_two_host_threads_run_resident_side_by_side():
+    """The reference runs thread-local trackers concurrently (keyframe_graph.cpp:576-593: one validator per TBB worker).  Two host
+    threads, a context each, align pairs through the resident kernel at the same time: their launches share the device (64 + 64
+    workgroups), every result equals the idle device's bit for bit, no group ever times out.  (Round 2 had to serialise such launches:
+    one in seven timed out -- the exchange lacked flow control towards workgroups that are idle on a coarse level.)"""
+    import threading
+    b = datagen.synth_batch(3, 4, 640, 480)
+    cfg = d.Config(FirstLevel=3, LastLevel=1, MaxIterationsPerLevel=50, Precision=1e-4, Mu=0.05, UseInitialEstimate=True)
+    guess = np.eye(4)[None]
+    workers = []
+    for k in range(3):
+        c = d.Context(0)
+        cam = d.RgbdCameraPyramid(640, 480, b["K"], c)
+        cam.build(4)
+        ref, cur = cam.create_raw(b["grey_ref"][k], b["depth_ref"][k]), cam.create_raw(b["grey_cur"][k], b["depth_cur"][k])
+        trk = d.DenseTracker(cfg, c)
+        workers.append(dict(ctx=c, trk=trk, ref=ref, cur=cur, quiet=trk.match_batch_arrays([ref], [cur], T_init=guess), bad=0))
+    go = threading.Barrier(len(workers))
+
+    def run(wk):
+        go.wait()
+        for _ in range(400):
+            o = wk["trk"].match_batch_arrays([wk["ref"]], [wk["cur"]], T_init=guess)
+            wk["bad"] += not (np.array_equal(o["T"], wk["quiet"]["T"]) and np.array_equal(o["information"], wk["quiet"]["information"]))
+    ts = [threading.Thread(target=run, args=(wk,)) for wk in workers]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert sum(wk["bad"] for wk in workers) == 0
+    assert sum(wk["ctx"].counter("resident_timeouts") for wk in workers) == 0
+    assert all(wk["ctx"].counter("resident_launches") == 401 for wk in workers)
