@@ -151,6 +151,11 @@ def bind_public_api(L, prefix):
     f = getattr(L, prefix + "frontend")
     f.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.POINTER(fp), C.POINTER(fp), C.c_void_p, C.c_double, C.c_double, C.c_double,
                   C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    f = getattr(L, prefix + "set_engine_option")
+    f.argtypes = [C.c_char_p, C.c_int]
+    f = getattr(L, prefix + "api_members")
+    f.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, fp, C.POINTER(Config), C.POINTER(C.c_double), C.c_int, fp, C.c_char_p, C.c_int,
+                  C.POINTER(C.c_double)]
 
 
 def _api(api, name):
@@ -346,6 +351,21 @@ def ref_match(intensity_ref, depth_ref, intensity_cur, depth_cur, K, cfg, T_init
         raise RuntimeError("ref_match rc=%d" % rc)
     return dict(T=np.array(res.transformation).reshape(4, 4), information=np.array(res.information).reshape(6, 6),
                 loglik=res.loglik, levels=_unpack_stats(res, levels, iters))
+
+
+def ref_api_members(intensity_ref, depth_ref, intensity_cur, depth_cur, K, cfg, T, level, api=None):
+    """computeIntensityErrorImage, the printers of Config / Stats and the information eigenvalues of the REFERENCE's public API after
+    one match (oracle/ref_public_api.inc::api_members); api = (library, prefix) runs the same caller code on another build."""
+    I0, Z0, I1, Z1 = [np.ascontiguousarray(a, dtype=np.float32) for a in (intensity_ref, depth_ref, intensity_cur, depth_cur)]
+    h, w = I0.shape
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    err = np.zeros((h >> level, w >> level), np.float32)
+    text = C.create_string_buffer(1 << 16)
+    eig = (C.c_double * 7)()
+    rc = _api(api, "api_members")(w, h, _fp(K), _fp(I0), _fp(Z0), _fp(I1), _fp(Z1), C.byref(cfg), _dp(T), level, _fp(err), text, len(text), eig)
+    assert rc == err.shape[0] * 65536 + err.shape[1], (rc, err.shape)
+    return dict(error_image=err, text=text.value.decode(), eigenvalues=np.array(eig[:6]), condition_number=eig[6])
 
 
 def ref_level_planes(intensity, depth, K, level, want_points=False):

@@ -226,3 +226,63 @@ def test_benchmark_slam_built_target_on_the_engine(tum_folder, name):
           % (name, len(stamps), d, ate_hip, ate_ref))
     assert d < 3e-4, d                # measured 1.4e-4: 40 chained steps of <= 3e-5 each (rcpps) + 6-digit text
     assert abs(ate_hip - ate_ref) < 1e-4 and ate_hip < 1e-3
+
+
+@pytest.mark.gpu
+def test_remaining_public_members_against_the_reference():
+    """The members of the public API that callers OUTSIDE match() use -- DenseTracker::computeIntensityErrorImage
+    (dense_tracking.cpp:378-444; keyframe_graph.cpp:352-371), operator<< of Config and Stats (dense_tracking.h:218-291;
+    keyframe_graph.cpp logs them), IterationStats::InformationEigenValues / InformationConditionNumber
+    (dense_tracking_config.cpp:122-135; keyframe_tracker.cpp:170-196) -- through the facade on the MI355X engine against the
+    reference's own, same caller code on both sides (oracle/ref_public_api.inc::api_members)."""
+    import re
+    api = need_dropin()
+    L = api[0]
+    pair = cm.synth(7, 320, 240)
+    cfg = po.make_config(2, 1, 50, 1e-4, 0.05, False)
+    T = po.se3_exp(np.array([0.004, -0.003, 0.002, 0.005, -0.004, 0.003]))
+    level = 1
+    ref = po.ref_api_members(*planes_of(pair), pair["K"], cfg, T, level)
+    out = {}
+    for compat in (0, 1):
+        assert L.dropin_set_engine_option(b"ref_compat", compat) == 0
+        out[compat] = po.ref_api_members(*planes_of(pair), pair["K"], cfg, T, level, api=api)
+    assert L.dropin_set_engine_option(b"ref_compat", 0) == 0
+    # ---- the printers: the same text but for the digits of the floating-point values (Config: identical to the last character) ----
+    for compat in (0, 1):
+        got, want = out[compat]["text"].splitlines(), ref["text"].splitlines()
+        assert got[0] == want[0], (got[0], want[0])                        # operator<<(Config)
+        assert len(got) == len(want) or compat == 0, (len(got), len(want))
+        skeleton = lambda line: re.sub(r"-?\d+\.?\d*(e[-+]?\d+)?|nan|inf", "#", line)
+        for a, b in zip(got, want):
+            assert skeleton(a) == skeleton(b), (a, b)
+        pixels = lambda lines: [re.search(r"Pixel: (\d+)/(\d+)", x).groups() for x in lines if x.startswith("Level:")]
+        assert pixels(got) == pixels(want)                                 # selected / maximum pixels of every level: exact
+    print(out[1]["text"])
+    # with the reference's reciprocal the iteration structure and the valid-constraint counts agree line by line
+    counts = lambda text: [int(m) for m in re.findall(r"ValidConstraints: (\d+)", text)]
+    a, b = counts(out[1]["text"]), counts(ref["text"])
+    assert len(a) == len(b) and max(abs(x - y) for x, y in zip(a, b)) <= 3, (a, b)
+    # ---- eigenvalues / condition number of the information matrix: the facade's own solver against numpy on the same matrix ----
+    g = po.ref_match(*planes_of(pair), pair["K"], cfg, api=api)
+    info = g["levels"][-1]["iterations"][-1]["A"]
+    want_ev = np.linalg.eigvalsh(info)
+    assert np.allclose(out[0]["eigenvalues"], want_ev, rtol=1e-9), (out[0]["eigenvalues"], want_ev)
+    assert abs(out[0]["condition_number"] - abs(want_ev[-1] / want_ev[0])) <= 1e-9 * out[0]["condition_number"]
+    # (against the reference's values only loosely: its precision matrix comes from the pairing scale estimate, SURVEY.md Q6, and the
+    # information matrix scales with it -- a few per cent)
+    assert np.allclose(ref["eigenvalues"], out[1]["eigenvalues"], rtol=0.15)
+    # ---- computeIntensityErrorImage: |intensity residual| of every constraint, 0 elsewhere ----
+    e_ref = ref["error_image"]
+    # (ref_compat leaves the reference's round-toward-zero mode, SURVEY.md Q2, as the only per-pixel difference: a handful of pixels)
+    for compat, frac_tol, val_tol in ((0, 0.02, 5e-3), (1, 0.002, 1e-5)):
+        e = out[compat]["error_image"]
+        assert e.shape == e_ref.shape == (240 >> level, 320 >> level)
+        support_differs = ((e > 0) != (e_ref > 0)).mean()
+        both = (e > 0) & (e_ref > 0)
+        diff = np.abs(e - e_ref)[both]
+        worst = diff.max()
+        print("ref_compat %d: constraint masks differ on %.4f %% of the pixels, |difference| on the common ones: largest %.2e, 99.9th percentile %.2e, "
+              "median %.2e, above 1e-5: %d of %d (image max %.3f)"
+              % (compat, 100 * support_differs, worst, np.percentile(diff, 99.9), np.median(diff), (diff > 1e-5).sum(), diff.size, e_ref.max()))
+        assert support_differs <= frac_tol and np.percentile(diff, 99.9 if compat else 99.0) <= val_tol and (diff > 10 * val_tol).mean() <= 2e-3
