@@ -5,3 +5,4 @@ namespace boost { using std::bind; }
 using std::placeholders::_1;
 using std::placeholders::_2;
 using std::placeholders::_3;
+using std::placeholders::_4;

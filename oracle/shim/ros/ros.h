@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <fstream>   // (the real roscpp headers pull it in transitively; dvo_slam/serialization/map_serializer.h relies on that)
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -41,7 +42,20 @@ class Rate {
   double hz_;
 };
 
-class Publisher { public: template <typename M> void publish(const M&) const {} };
+// Publishing is a no-op but for a count and an optional tap: a test of the reference's live-camera front end
+// (dvo_ros/src/camera_dense_tracking.cpp) reads what the node published through it.
+class Publisher {
+ public:
+  template <typename M> void publish(const M& m) const {
+    published() += 1;
+    if (tap()) tap()(static_cast<const void*>(&m));
+  }
+  unsigned getNumSubscribers() const { return tap() ? 1u : 0u; }
+  static int& published() { static int n = 0; return n; }
+  typedef void (*Tap)(const void* message);
+  static Tap& tap() { static Tap t = nullptr; return t; }
+};
+class Subscriber {};
 
 class NodeHandle {
  public:
@@ -49,6 +63,7 @@ class NodeHandle {
   explicit NodeHandle(const std::string&) {}
   NodeHandle(const NodeHandle&, const std::string&) {}
   template <typename M> Publisher advertise(const std::string&, int) { return Publisher(); }
+  template <typename M, typename T> Subscriber subscribe(const std::string&, int, void (T::*)(const std::shared_ptr<const M>&), T*) { return Subscriber(); }
   bool getParam(const std::string& name, std::string& value) const {
     std::map<std::string, std::string>::const_iterator it = private_params().find(name);
     if (it == private_params().end()) return false;

@@ -19,6 +19,14 @@ class Time {
  private:
   double sec_;
 };
+class Duration {
+ public:
+  Duration() : sec_(0) {}
+  explicit Duration(double s) : sec_(s) {}
+  double toSec() const { return sec_; }
+ private:
+  double sec_;
+};
 // printed like roscpp prints it: seconds '.' nanoseconds on nine digits (the trajectory files of benchmark_slam.cpp:494 carry it)
 inline std::ostream& operator<<(std::ostream& o, const Time& t) {
   double sec = std::floor(t.toSec());

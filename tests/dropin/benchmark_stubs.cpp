@@ -51,7 +51,7 @@ Mat imread(const std::string& filename, int flags) {
   return m;
 }
 
-void cvtColor(const Mat& src, Mat& dst, int code) {
+void cvtColor(const Mat& src, Mat& dst, int code, int /*dst_channels*/) {
   if (code != CV_BGR2GRAY || src.type() != CV_8UC3) std::abort();
   Mat out(src.rows, src.cols, CV_8UC1);
   const size_t n = size_t(src.rows) * src.cols;

@@ -7,5 +7,5 @@
 #define CV_BGR2GRAY 6
 namespace cv {
 Mat imread(const std::string& filename, int flags = 1);   // flags 1: 8-bit BGR; -1: as stored (16-bit depth PNGs stay 16-bit)
-void cvtColor(const Mat& src, Mat& dst, int code);
+void cvtColor(const Mat& src, Mat& dst, int code, int dst_channels = 0);
 }  // namespace cv

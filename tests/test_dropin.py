@@ -286,3 +286,45 @@ def test_remaining_public_members_against_the_reference():
               "median %.2e, above 1e-5: %d of %d (image max %.3f)"
               % (compat, 100 * support_differs, worst, np.percentile(diff, 99.9), np.median(diff), (diff > 1e-5).sum(), diff.size, e_ref.max()))
         assert support_differs <= frac_tol and np.percentile(diff, 99.9 if compat else 99.0) <= val_tol and (diff > 10 * val_tol).mean() <= 2e-3
+
+
+@pytest.mark.gpu
+def test_reference_live_camera_front_end_on_the_engine():
+    """dvo_ros/src/camera_dense_tracking.cpp + camera_base.cpp -- the reference's live-camera node (the Affine3d&
+    overload of match(), RgbdCameraPyramid::create per frame, SurfacePyramid::convertRawDepthImageSse, configtools.h) -- compiled
+    UNMODIFIED against the facade (tests/dropin/Makefile: libdvo_camera_node.so; ROS is stand-ins) and fed eight frames as sensor
+    messages: the poses it broadcasts on tf equal the chain of matches made through the Python mirror of the C-ABI on the same planes."""
+    import ctypes as C
+    import dvo_slam_amd as d
+    from dvo_slam_amd import datagen
+    path = os.path.join(cm.HERE, "dropin", "_build", "libdvo_camera_node.so")
+    if not os.path.exists(path):
+        pytest.skip("tests/dropin/_build/libdvo_camera_node.so is not built (needs the reference tree at build time)")
+    L = C.CDLL(path)
+    n, w, h = 8, 320, 240
+    seq = datagen.synth_sequence(9, n, w, h)
+    grey = [np.ascontiguousarray(g) for g in seq["grey"]]
+    depth_mm = [np.ascontiguousarray(np.round(z.astype(np.float64) / 5.0).astype(np.uint16)) for z in seq["depth"]]      # 1/5000 m -> mm
+    K = np.ascontiguousarray(seq["K"], np.float32)
+    poses = np.zeros((n, 4, 4))
+    vp = C.c_void_p
+    L.dropin_camera_node.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int,
+                                     C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
+    sent = L.dropin_camera_node(n, w, h, K.ctypes.data_as(C.POINTER(C.c_float)), (vp * n)(*[vp(g.ctypes.data) for g in grey]),
+                                (vp * n)(*[vp(z.ctypes.data) for z in depth_mm]), 3, 1, 50, 1e-4, 0.05, 0, poses.ctypes.data_as(C.POINTER(C.c_double)))
+    assert sent == n - 1                                                 # one transform per frame after the first
+    ctx = d.Context(0)
+    cam = d.RgbdCameraPyramid(w, h, K, ctx)
+    cam.build(4)
+    trk = d.DenseTracker(d.Config(FirstLevel=3, LastLevel=1, MaxIterationsPerLevel=50, Precision=1e-4, Mu=0.05, UseInitialEstimate=False), ctx)
+    frames = [cam.create(g.astype(np.float32), po.convert_raw_depth(z, 0.001)) for g, z in zip(grey, depth_mm)]
+    acc = np.eye(4)
+    worst = 0.0
+    for k in range(1, n):
+        r = d.Result()
+        trk.match(frames[k - 1], frames[k], r)
+        acc = acc @ r.Transformation
+        worst = max(worst, np.abs(poses[k] - acc).max())
+    print("live-camera node on the engine, %d frames: largest pose difference to the chain of C-ABI matches %.2e" % (n, worst))
+    assert worst < 1e-9
+    assert np.abs(po.se3_log(np.linalg.inv(acc) @ np.linalg.inv(seq["poses"][0]) @ seq["poses"][-1])).max() < 5e-3   # ... and it is the motion
