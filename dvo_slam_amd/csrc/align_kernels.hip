@@ -213,10 +213,11 @@ void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_
 }
 
 void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,
-                   const float2* scratch, double* ll_partials, int blocks_per_pair) {
+                   const float2* scratch, double* ll_partials, int blocks_per_pair, bool one_schedule) {
   // few pairs: the sweep is a handful of dependent round trips per lane, more loads in flight shorten it (one pair 0.52 -> 0.50 ms);
   // a full batch is bandwidth-bound and runs 6 % slower with the larger chunks
-  if (n_pairs <= 16) k_loglik<8><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, blocks_per_pair);
+  // (one_schedule: the grouping of the partial sums must not follow the batch size -- option "deterministic")
+  if (n_pairs <= 16 && !one_schedule) k_loglik<8><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, blocks_per_pair);
   else k_loglik<4><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, blocks_per_pair);
 }
 

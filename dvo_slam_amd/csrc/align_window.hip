@@ -27,13 +27,11 @@
 
 namespace dvo_hip {
 
-constexpr int kWinRPW = 4;                              // rows per wavefront: a 64 x 16 tile per workgroup
+constexpr int kWinTileRows = 16;                        // a 64 x 16 tile per workgroup: WAVES wavefronts x 16 / WAVES rows each
 constexpr int kWinPitch = 80;                           // window columns: 64 + the taps' reach (3) + 13 of motion / parallax
 // phase B: a thread owns one PAIR of window columns (16 B: the window starts at an even image column) and every sixth row
 constexpr int kWinPairs = kWinPitch / 2;                // 40 column pairs
-constexpr int kWinRowGroups = kBlock / kWinPairs;       // 6 (240 of the 256 threads load)
-constexpr int kWinLoads = 5;                            // loads of 16 B per thread
-constexpr int kWinRows = kWinRowGroups * kWinLoads;     // 30 window rows: 16 + the taps' reach (3) + 11
+constexpr int kWinRows = 30;                            // window rows: 16 + the taps' reach (3) + 11
 constexpr int kWinCells = kWinPitch * kWinRows;         // 2400 cells x 8 B = 19.2 KB
 constexpr int kNoProjection = 0x7fff7fff;               // WinRowState::uv of a lane without a usable projection
 
@@ -76,9 +74,13 @@ typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
 // two components per call, packed as the two halves of a register
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
   const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-  const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - float(h.x), b - float(h.y));
   hi = __builtin_bit_cast(unsigned, h);
-  lo = __builtin_bit_cast(unsigned, l);
+  // a - float(h.lo), b - float(h.hi) in ONE instruction each: v_fma_mix_f32 reads the f16 half of `hi` directly (the compiler emits a
+  // conversion and a subtraction unless it can fold a multiplication in)
+  float ra, rb;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(hi));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(hi));
+  lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
 
 // matrix operand of 32 pixels (k index) x 16 components from the pixel-major f16 image: lane (i = l & 15, g = l >> 4) gets the
@@ -91,16 +93,20 @@ __device__ __forceinline__ f16x8 read_operand_f16(const _Float16* img, int lane,
   return f16x8{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
 }
 
+// WAVES: wavefronts per workgroup (4: four rows each, 8: two rows each -- less projection state per lane, one wavefront per SIMD more).
 // F16: Gram accumulation on the f16 matrix pipe (variant 7).  COMPAT: the reference's x * rcp(z) in projection and weights with the
 // host CPU's reciprocal table (option "ref_compat", LevelGeom::rcp_table).
-template <bool F16, bool COMPAT>
-__global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
+template <bool F16, bool COMPAT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_sweep_window(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count) {
   // (Measured and dropped: a workgroup sweeping several vertically adjacent tiles in a loop, so that the pair's state, plane pointers
   // and transform are fetched once per group of tiles -- inside a loop the compiler wants 155 vector registers for the same body and
   // spills 59 of them at the five-wavefront budget.)
-  constexpr int RPW = kWinRPW;
+  constexpr int RPW = kWinTileRows / WAVES;
+  constexpr int kThreads = WAVES * 64;
+  constexpr int kWinRowGroups = kThreads / kWinPairs;     // 6 (240 of 256 threads load) / 12 (480 of 512)
+  constexpr int kWinLoads = (kWinRows + kWinRowGroups - 1) / kWinRowGroups;   // loads of 16 B per thread: 5 / 3
   const int tiles = g.tiles_x * g.tiles_y;
   const int total = tiles * n_pairs;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -127,16 +133,16 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
   const float cx_u = fmaf(tx_u, tx_u, 1.0f);
 
   constexpr int kMySlabFloats = F16 ? kSlabFloatsF16 : kSlabFloats;
-  __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kMySlabFloats];
+  __shared__ __attribute__((aligned(16))) float slab[WAVES][kMySlabFloats];
   __shared__ __attribute__((aligned(16))) float2 win[kWinCells];
-  __shared__ __attribute__((aligned(16))) int bbox[kWavesPerBlock][2];
-  __shared__ int counts[kWavesPerBlock];
+  __shared__ __attribute__((aligned(16))) int bbox[WAVES][2];
+  __shared__ int counts[WAVES];
   float* my = slab[wave];
   const int off_px = u_r * 8;
   const int off_edge = (lane == 0 ? max(u_r - 1, 0) : lane == 63 ? min(u_r + 1, g.w - 1) : u_r) * 8 + 4;
   unsigned n_fallback = 0;
 
-  const int row0 = tile_y * (kWavesPerBlock * RPW) + wave;
+  const int row0 = tile_y * (WAVES * RPW) + wave;
   float KT[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) KT[i] = st.KT[i];
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
     float zv[RPW], iv[RPW], up[RPW], down[RPW], edge[RPW];
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {                            // all loads of the four rows first: one round trip
-      const int v = min(row0 + k * kWavesPerBlock, g.h - 1);
+      const int v = min(row0 + k * WAVES, g.h - 1);
       const int soff = v * row_bytes;
       const f32x2 zi = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(refR, off_px, soff, 0));
       zv[k] = zi.x;
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
     }
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
-      const int v_r = row0 + k * kWavesPerBlock;
+      const int v_r = row0 + k * WAVES;
       const int ic = __builtin_bit_cast(int, iv[k]), ie = __builtin_bit_cast(int, edge[k]);
       const float right = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ie, ic, 0x130, 0xf, 0xf, false));   // wave_shl:1
       const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ie, ic, 0x138, 0xf, 0xf, false));    // wave_shr:1
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
   {
     i16x2 lo = __builtin_bit_cast(i16x2, bbox[0][0]), hi = __builtin_bit_cast(i16x2, bbox[0][1]);
 #pragma unroll
-    for (int w4 = 1; w4 < kWavesPerBlock; ++w4) {
+    for (int w4 = 1; w4 < WAVES; ++w4) {
       lo = __builtin_elementwise_min(lo, __builtin_bit_cast(i16x2, bbox[w4][0]));
       hi = __builtin_elementwise_max(hi, __builtin_bit_cast(i16x2, bbox[w4][1]));
     }
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
       f32x4 cell[kWinLoads];
 #pragma unroll
       for (int j = 0; j < kWinLoads; ++j) {
-        const int cy = rg + j * kWinRowGroups;
+        const int cy = rg + j * kWinRowGroups;                  // (cy >= kWinRows, past the window: >= wh as well)
         const int y = min(max(y0 + cy, 0), g.h - 1);
         const int off = col_needed && cy < wh ? y * row_bytes + xl : 0x7ffffff0;
         cell[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(curC, off, 0, 0));
@@ -233,7 +239,8 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
       }
       f32x4* dst = reinterpret_cast<f32x4*>(win) + t;
 #pragma unroll
-      for (int j = 0; j < kWinLoads; ++j) dst[j * kWinRowGroups * kWinPairs] = cell[j];
+      for (int j = 0; j < kWinLoads; ++j)
+        if (kWinRowGroups * kWinLoads == kWinRows || rg + j * kWinRowGroups < kWinRows) dst[j * kWinRowGroups * kWinPairs] = cell[j];
     }
   }
   __syncthreads();
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
   int n_valid = 0;
 #pragma unroll
   for (int k = 0; k < RPW; ++k) {
-    const int v_r = row0 + k * kWavesPerBlock;
+    const int v_r = row0 + k * WAVES;
     const WinRowState& r = rs[k];
     const bool ok = r.uv != kNoProjection;
     const int u0 = r.uv & 0xffff, v0 = r.uv >> 16;
@@ -259,15 +266,14 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
     {
       // every lane reads (lanes without a neighbourhood in the window: cell 0; their values are never used): no divergent region
       // around the twelve reads, no uninitialised registers
-      const float2* q = win + (in_win ? cy * kWinPitch + cx : 0);
+      // (volatile: twelve ds_read_b64, two LDS cycles each; the compiler otherwise pairs them into ds_read2_b64, eight cycles a pair)
+      typedef const volatile __attribute__((address_space(3))) f32x2* LdsCellPtr;
+      LdsCellPtr q = (LdsCellPtr)(win + (in_win ? cy * kWinPitch + cx : 0));
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
-          if ((rr == 1 || rr == 2) || (cc == 1 || cc == 2)) {
-            const float2 t = q[rr * kWinPitch + cc];
-            P[rr][cc] = f32x2{t.x, t.y};
-          }
+          if ((rr == 1 || rr == 2) || (cc == 1 || cc == 2)) P[rr][cc] = q[rr * kWinPitch + cc];
     }
     if (ok && !in_win) {                                        // rare: the neighbourhood from memory, coordinates clamped like the window's
       n_fallback += 1;
@@ -419,10 +425,16 @@ __global__ __launch_bounds__(kBlock, F16 ? 5 : 4) void k_sweep_window(
   __syncthreads();
   const int kk = threadIdx.x;
   if (kk < kNumAcc) {
-    auto G = [&](int e) { return (slab[0][e] + slab[1][e]) + (slab[2][e] + slab[3][e]); };
+    auto G = [&](int e) {
+      float t = (slab[0][e] + slab[1][e]) + (slab[2][e] + slab[3][e]);
+      if (WAVES == 8) t += (slab[4][e] + slab[5][e]) + (slab[6][e] + slab[7][e]);
+      return t;
+    };
     float v;
     if (kk == kAccN) {
-      v = float((counts[0] + counts[1]) + (counts[2] + counts[3]));
+      int c = (counts[0] + counts[1]) + (counts[2] + counts[3]);
+      if (WAVES == 8) c += (counts[4] + counts[5]) + (counts[6] + counts[7]);
+      v = float(c);
     } else {
       int e1, e2;
       gram_entries_of_accumulator(kk, e1, e2);
@@ -447,13 +459,17 @@ void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const Pair
                          float* partials, float2* scratch, unsigned long long* fallback_count) {
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
-  const dim3 grid(per_xcd * 8), block(kBlock);
+  const dim3 grid(per_xcd * 8);
+  // (Measured and dropped: eight wavefronts of two rows each -- WAVES = 8, 69 registers, six wavefronts per SIMD instead of five:
+  // 3.10 instead of 2.57 ms per 1024-pair launch; the barriers of the three phases span twice the wavefronts and every wavefront's
+  // fixed work is spread over half the rows.)
+  const dim3 block(256);
   if (g.rcp_table) {
-    if (f16) k_sweep_window<true, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
-    else k_sweep_window<false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+    if (f16) k_sweep_window<true, true, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+    else k_sweep_window<false, true, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
   } else {
-    if (f16) k_sweep_window<true, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
-    else k_sweep_window<false, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+    if (f16) k_sweep_window<true, false, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+    else k_sweep_window<false, false, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
   }
 }
 

@@ -232,6 +232,7 @@ struct dvo_hip_context {
   long long host_batches = 0;
   std::chrono::steady_clock::time_point batch_entry;
   int opt_resident_flags = 0;      // kResidentFlag* (measurement and test hooks)
+  int opt_deterministic = 0;       // a pair's record does not depend on the batch it is aligned in (see dvo_hip.h, option "deterministic")
   int opt_ref_compat = 0;          // projection and weights multiply with the HOST CPU's _mm_rcp_ps like the reference does
   DevBuf rcp_table;                // ... from this table, dumped from the instruction itself when the option is first switched on
   int rcp_shift = 0;
@@ -465,6 +466,7 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
 // keep all 256 CUs busy when the batch is small
 int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_pairs) {
   if (level_uses_window(ctx, cam->w[level], cam->h[level])) return 4;
+  if (ctx->opt_deterministic) return ctx->opt_rows_per_wave > 0 ? ctx->opt_rows_per_wave : 4;   // one tile height whatever the batch
   if (ctx->opt_rows_per_wave > 0) return ctx->opt_rows_per_wave;
   const int candidates[4] = {8, 4, 2, 1};   // measured (profiles/r01_c_tile_sweep.txt): 8 rows is at or near the optimum on every level
   // The tallest tile that still yields this many workgroups.  Fewer, taller tiles also mean fewer partial rows for the
@@ -975,7 +977,7 @@ constexpr size_t kResidentDirectStatsBytes = size_t(64) << 20;
 
 ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const BatchPlan& bp) {
   ResidentPlan rp;
-  if (ctx->opt_resident == 0 || ctx->opt_ref_compat) return rp;   // (the resident kernel does not carry the reference-compatible arithmetic)
+  if (ctx->opt_resident == 0 || ctx->opt_ref_compat || ctx->opt_deterministic) return rp;   // (the resident kernel does not carry the reference-compatible arithmetic)
   const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
   // more pairs than compute units: the workgroups would run in shifts, and the launch path, which gives every phase the whole chip,
   // is as fast (measured: 256 pairs -3 %, 512 pairs +1.6 % against it).  (Not with a pinned group size: the caller asks for
@@ -1137,7 +1139,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // (measured, scripts/ab_match.py fused_ll_pixels: 128 pairs 2.152 -> 2.117 ms with level 1 fused; 16 pairs 0.756 -> 0.799, one
     // pair 0.524 -> 0.547: a lone workgroup per pair is slower than 32 blocks when the chip is empty)
     const int fuse_opt = ctx->opt_fused_ll_pixels;
-    const bool fused_ll = g.w * g.h <= (fuse_opt > 0 ? fuse_opt : (n >= 64 ? kFusedLoglikMaxPixelsBatch : kFusedLoglikMaxPixels));
+    const bool fused_ll = g.w * g.h <= (fuse_opt > 0 ? fuse_opt : (n >= 64 && !ctx->opt_deterministic ? kFusedLoglikMaxPixelsBatch : kFusedLoglikMaxPixels));
     // Chunks of `per_sync` iterations are enqueued ONE AHEAD of the poll: while the host waits for the status word of
     // chunk k, chunk k+1 is already queued, so the GPU never idles for a host round trip.  Iterations enqueued past the
     // end of the level are no-ops (workgroups exit on !active).
@@ -1146,7 +1148,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
         {
           Range range(kErr[level]);
           launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch, w.win_fallbacks.as<unsigned long long>());
-          if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, kLlBlocksPerPair);
+          if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, kLlBlocksPerPair, ctx->opt_deterministic != 0);
         }
         Range range(kLinsys[level]);
         launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, kLlBlocksPerPair, fused_ll ? scratch : nullptr, d_levels, d_iters,
@@ -1437,6 +1439,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     if (value != 0 && value != 5 && value != 6 && value != 7)
       return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0 (all-VALU schedule), 5 (matrix-core schedule), 6 or 7 (current-frame window staged in LDS)");
     ctx->opt_variant = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "deterministic") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "deterministic must be 0 or 1");
+    ctx->opt_deterministic = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "ref_compat") == 0) {

@@ -41,7 +41,7 @@ void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const Pair
 // window_planes: the planes the window sweep reads (reference 8 B + current {I, Z} 8 B) instead of the gathering sweep's 8 + 16 + 8 B
 void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch, float* sink, bool window_planes = false);
 void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, int n_pairs, const float* partials,
-                   const float2* scratch, double* ll_partials, int blocks_per_pair);
+                   const float2* scratch, double* ll_partials, int blocks_per_pair, bool one_schedule = false);
 
 // align_resident.hip: levels first_level..last_level of every pair in one launch.  The n_pairs * group workgroups must fit the
 // device at once when group > 1 (one per compute unit); `cooperative` launches them through hipLaunchCooperativeKernel.

@@ -258,6 +258,11 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * workgroup instead of a launch of its own; 0 = 160x120, and 320x240 for batches of 64 pairs and more),
  * "condition_number" (1: results carry the condition number of the information
  * matrix, ~20 us of extra serial work per batch; default 0),
+ * "deterministic" (1: a pair's record -- transform, information matrix, log-likelihood, every statistic -- is bit-identical whatever
+ * batch the pair is aligned in and however many GPUs the batch is spread over, like the reference's result for a pair never depends on
+ * its neighbours: one tile height on every level, one log-likelihood schedule, every level on the launch path.  By default the tile
+ * height and the latency path follow the batch size and records agree to the precision of the stopping rule (1e-8 per pass) instead.
+ * Price: a lone pair takes the launch path's 0.50 ms instead of 0.36 ms; large batches are unaffected; default 0),
  * "ref_compat" (1: the projection and the t-distribution weights multiply with the HOST CPU's approximate reciprocal _mm_rcp_ps, like
  * the reference's SSE path does (dvo_core/src/dense_tracking_impl.cpp:192, :700), instead of dividing exactly -- the one quirk of the
  * reference that separates its trajectories from the exact arithmetic's; the instruction is dumped into a table

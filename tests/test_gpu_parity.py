@@ -814,3 +814,38 @@ def test_config4_batch_of_1024_distinct_pairs(gpu_ctx):
     print("sample of %d: largest twist distance to the oracle (MATH) %.2e, to the reference's own match() %.2e" % (len(sample), worst_m, worst_r))
     assert worst_m < 2e-6
     assert worst_r < 5e-5
+
+
+def test_deterministic_mode_records_do_not_depend_on_the_batch():
+    """Option "deterministic": the record of a pair -- transform, information, log-likelihood, every iteration record -- is the same to
+    the last bit whether the pair is aligned alone, among 6 others or among 299 others (three classes of tile height, resident plan and
+    log-likelihood schedule in the default mode, whose records agree to the stopping rule's precision only)."""
+    w, h = 320, 240
+    ctx = d.Context(0)
+    ctx.set_option("deterministic", 1)
+    b = datagen.synth_batch(41, 12, w, h)
+    cam = d.RgbdCameraPyramid(w, h, b["K"], ctx)
+    cam.build(4)
+    refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(12)]
+    curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(12)]
+    trk = d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0), ctx)
+
+    def record(out, k):
+        return b"".join(np.ascontiguousarray(out[key][k]).tobytes() for key in ("T", "information", "loglik", "n_iterations", "entropy"))
+    alone = [record(trk.match_batch_arrays([refs[i]], [curs[i]]), 0) for i in range(12)]
+    seven = trk.match_batch_arrays(refs[:7], curs[:7])
+    assert [record(seven, i) for i in range(7)] == alone[:7]
+    order = [(5 * i + 3) % 12 for i in range(300)]
+    many = trk.match_batch_arrays([refs[i] for i in order], [curs[i] for i in order])
+    assert all(record(many, k) == alone[i] for k, i in enumerate(order))
+    # statistics as well (one pair, with and without company)
+    r1 = d.Result()
+    trk.match(refs[4], curs[4], r1)
+    res = [d.Result() for _ in range(9)]
+    trk.match_batch(refs[:9], curs[:9], res, with_stats=True)
+    r2 = res[4]
+    assert [len(L.Iterations) for L in r1.Statistics.Levels] == [len(L.Iterations) for L in r2.Statistics.Levels]
+    for La, Lb in zip(r1.Statistics.Levels, r2.Statistics.Levels):
+        for Ia, Ib in zip(La.Iterations, Lb.Iterations):
+            assert Ia.ValidConstraints == Ib.ValidConstraints and Ia.TDistributionLogLikelihood == Ib.TDistributionLogLikelihood
+            assert np.array_equal(Ia.EstimateIncrement, Ib.EstimateIncrement, equal_nan=True) and np.array_equal(Ia.EstimateInformation, Ib.EstimateInformation, equal_nan=True)
