@@ -213,6 +213,7 @@ struct dvo_hip_context {
   std::string err;
   int opt_rows_per_wave = 0;
   int opt_iters_per_sync = 0;
+  long long strip_ingests = 0;     // frames ingested by the strip kernel (ingest_strips.hip), counter "strip_ingests"
   int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
@@ -610,8 +611,19 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
   ctx->build_tbl_frames.assign(frames, frames + n);
   int built = 1;                                       // float ingest: level 0 is already in place
   if (grey) {
-    launch_build_from_raw(bs, tbl, n, depth_scale, cam->w[0], cam->h[0], levels, role, wide, ithr, dthr, ctx->opt_build_workgroups, flavor0);
+    // current frames: the {I, Z} plane of the pyramid levels the window sweep will read comes out of the same pass (no neighbours
+    // needed), where the strip ingest runs (ingest_strips.hip)
     built = levels < 4 ? levels : 4;
+    int c_levels = 0;
+    if (role == 0 && ingest_strips_supports(cam->w[0], wide)) {
+      for (int l = 1; l < built; ++l)
+        if (eager_current_flavor(ctx, cam, l, n) & kCurC) c_levels |= 1 << l;
+      for (int i = 0; i < n; ++i)
+        for (int l = 1; l < built; ++l)
+          if ((c_levels >> l & 1) && frames[i]->lv[l].C) frames[i]->lv[l].cur_have |= kCurC;
+    }
+    launch_build_from_raw(bs, tbl, n, depth_scale, cam->w[0], cam->h[0], levels, role, wide, ithr, dthr, ctx->opt_build_workgroups, flavor0, c_levels);
+    if (ingest_strips_supports(cam->w[0], wide)) ctx->strip_ingests += n;
   }
   for (int l = built; l < levels; ++l) launch_pyr_down(bs, tbl, n, l, cam->w[l - 1], cam->h[l - 1]);
   DVO_HIP_TRY(ctx, hipGetLastError());
@@ -1289,6 +1301,7 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
     }
     *value = (long long)v;
   }
+  else if (std::strcmp(key, "strip_ingests") == 0) *value = ctx->strip_ingests;
   else if (std::strcmp(key, "host_batches") == 0) *value = ctx->host_batches;
   else if (std::strcmp(key, "host_ns_prepare") == 0) *value = ctx->host_ns[0];
   else if (std::strcmp(key, "host_ns_enqueue") == 0) *value = ctx->host_ns[1];

@@ -13,8 +13,14 @@ void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int
 // max_workgroups > 0 caps the grid (the kernels walk the tiles with a grid stride): background build next to an alignment
 // level 0 in role `role` (-1 none, 0 current, 1 reference) + pyramid levels 1..3 straight from raw planes; `wide`: 4-pixel aligned rows
 // cur_flavor (role 0): which planes of the current role are written, kCurAB | kCurC (device_types.h)
+// c_levels: bit l set = pyramid level l (1..3) also gets the current role's {I, Z} plane C in the same pass (ingest_strips.hip only:
+// ingest_strips_supports tells the caller whether the pass will honour it)
 void launch_build_from_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int role, bool wide,
-                           float ithr, float dthr, int max_workgroups, int cur_flavor = kCurAB);
+                           float ithr, float dthr, int max_workgroups, int cur_flavor = kCurAB, int c_levels = 0);
+// ingest_strips.hip: the same pass with one 128 x 8 strip per wavefront, registers only (even widths, aligned planes)
+bool ingest_strips_supports(int w0, bool wide);
+void launch_ingest_strips(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int role,
+                          float ithr, float dthr, int max_workgroups, int cur_flavor, int c_levels);
 void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int max_workgroups, int cur_flavor = kCurAB);
 // mode 0: A + B from C; 1: C from A; 2: R + selection count from C (the level's counters are zeroed first)
 void launch_from_current_plane(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int mode, float ithr, float dthr,

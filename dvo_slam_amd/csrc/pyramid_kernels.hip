@@ -14,6 +14,7 @@
 //   R             float4 {Zsel, I, Idx, Idy} reference-side stream; Zsel = NaN where the selection
 //                 predicate rejects the pixel, so the reduce kernel needs no separate mask or list
 // These are bandwidth-trivial elementwise kernels; they are written for coalescing only.
+#include "global_ptr.h"
 #include "launch.h"
 
 namespace dvo_hip {
@@ -60,6 +61,17 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
   const float nanv = __builtin_nanf("");
   for_each_tile(tiles_x, tiles_y, n_frames, [&](int bx, int by, int frame) {
     const FrameBuildPtrs& f = tbl[frame];
+    // (global_ptr.h: every plane pointer read once, as a pointer into the global address space)
+    const auto grey = global_ptr(f.grey);
+    const auto raw = global_ptr(f.raw);
+    const auto keep_grey = global_ptr(f.keep_grey);
+    const auto keep_raw = global_ptr(f.keep_raw);
+    const auto A0 = global_ptr(f.A[0]);
+    const auto B0 = global_ptr(f.B[0]);
+    const auto C0 = global_ptr(f.C[0]);
+    const auto R0 = global_ptr(f.R[0]);
+    const auto I1 = global_ptr(f.I[1]), I2 = global_ptr(f.I[2]), I3 = global_ptr(f.I[3]);
+    const auto Z1 = global_ptr(f.Z[1]), Z2 = global_ptr(f.Z[2]), Z3 = global_ptr(f.Z[3]);
     const int x0 = bx * kB0W, y0 = by * kB0H;
     auto depth_of = [&](uint16_t d) { return d == 0 ? nanv : float(d) * scale; };
     // ---- tile + border into LDS (column c of the slab = image column x0 - 1 + c, row r = image row y0 - 1 + r, clamped) ----
@@ -70,26 +82,28 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
         const int x = x0 + 4 * qd;
         const size_t at = size_t(y) * w0 + x;
         if (x + 3 < w0) {
-          const uchar4 gq = *reinterpret_cast<const uchar4*>(f.grey + at);
-          const ushort4 dq = *reinterpret_cast<const ushort4*>(f.raw + at);
+          const unsigned gbits = *(Global<const unsigned>)(grey + at);
+          const GlobalU32x2 dbits = *(Global<const GlobalU32x2>)(raw + at);
+          const uchar4 gq = make_uchar4(gbits & 0xffu, gbits >> 8 & 0xffu, gbits >> 16 & 0xffu, gbits >> 24);
+          const ushort4 dq = make_ushort4(dbits.x & 0xffffu, dbits.x >> 16, dbits.y & 0xffffu, dbits.y >> 16);
           float* di = &sI[r][1 + 4 * qd];
           float* dz = &sZ[r][1 + 4 * qd];
           di[0] = float(gq.x); di[1] = float(gq.y); di[2] = float(gq.z); di[3] = float(gq.w);
           dz[0] = depth_of(dq.x); dz[1] = depth_of(dq.y); dz[2] = depth_of(dq.z); dz[3] = depth_of(dq.w);
-          if (f.keep_grey && yy == y && r >= 1 && r <= kB0H) {
-            *reinterpret_cast<uchar4*>(f.keep_grey + at) = gq;
-            *reinterpret_cast<ushort4*>(f.keep_raw + at) = dq;
+          if (keep_grey && yy == y && r >= 1 && r <= kB0H) {
+            *(Global<unsigned>)(keep_grey + at) = gbits;
+            *(Global<GlobalU32x2>)(keep_raw + at) = dbits;
           }
         } else {
           for (int k = 0; k < 4; ++k) {
             const int xc = min(x + k, w0 - 1);
-            const uint8_t gv = f.grey[size_t(y) * w0 + xc];
-            const uint16_t dv = f.raw[size_t(y) * w0 + xc];
+            const uint8_t gv = grey[size_t(y) * w0 + xc];
+            const uint16_t dv = raw[size_t(y) * w0 + xc];
             sI[r][1 + 4 * qd + k] = float(gv);
             sZ[r][1 + 4 * qd + k] = depth_of(dv);
-            if (f.keep_grey && yy == y && r >= 1 && r <= kB0H && x + k < w0) {
-              f.keep_grey[size_t(y) * w0 + xc] = gv;
-              f.keep_raw[size_t(y) * w0 + xc] = dv;
+            if (keep_grey && yy == y && r >= 1 && r <= kB0H && x + k < w0) {
+              keep_grey[size_t(y) * w0 + xc] = gv;
+              keep_raw[size_t(y) * w0 + xc] = dv;
             }
           }
         }
@@ -98,21 +112,21 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
         const int r = threadIdx.x >> 1, side = threadIdx.x & 1;
         const int y = min(max(y0 - 1 + r, 0), h0 - 1);
         const int x = side ? min(x0 + kB0W, w0 - 1) : max(x0 - 1, 0);
-        sI[r][side ? kB0W + 1 : 0] = float(f.grey[size_t(y) * w0 + x]);
-        sZ[r][side ? kB0W + 1 : 0] = depth_of(f.raw[size_t(y) * w0 + x]);
+        sI[r][side ? kB0W + 1 : 0] = float(grey[size_t(y) * w0 + x]);
+        sZ[r][side ? kB0W + 1 : 0] = depth_of(raw[size_t(y) * w0 + x]);
       }
     } else {
       for (int i = threadIdx.x; i < (kB0H + 2) * (kB0W + 2); i += 256) {
         const int r = i / (kB0W + 2), c = i - r * (kB0W + 2);
         const int yy = y0 - 1 + r, xx = x0 - 1 + c;
         const int y = min(max(yy, 0), h0 - 1), x = min(max(xx, 0), w0 - 1);
-        const uint8_t gv = f.grey[size_t(y) * w0 + x];
-        const uint16_t dv = f.raw[size_t(y) * w0 + x];
+        const uint8_t gv = grey[size_t(y) * w0 + x];
+        const uint16_t dv = raw[size_t(y) * w0 + x];
         sI[r][c] = float(gv);
         sZ[r][c] = depth_of(dv);
-        if (f.keep_grey && yy == y && xx == x && r >= 1 && r <= kB0H && c >= 1 && c <= kB0W) {
-          f.keep_grey[size_t(y) * w0 + x] = gv;
-          f.keep_raw[size_t(y) * w0 + x] = dv;
+        if (keep_grey && yy == y && xx == x && r >= 1 && r <= kB0H && c >= 1 && c <= kB0W) {
+          keep_grey[size_t(y) * w0 + x] = gv;
+          keep_raw[size_t(y) * w0 + x] = dv;
         }
       }
     }
@@ -138,13 +152,13 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
             // the current role comes in two flavours (device_types.h kCurAB / kCurC): the gathered taps of the gathering sweep and
             // the resident kernel, and / or the 8-byte {I, Z} plane the window sweep stages in LDS (align_window.hip)
             if (cur_flavor & kCurAB) {
-              f.A[0][at] = make_float4(i0, z0, idx, idy);
-              f.B[0][at] = make_float2(zdx, zdy);
+              gstore(A0 + at, make_float4(i0, z0, idx, idy));
+              gstore(B0 + at, make_float2(zdx, zdy));
             }
-            if (cur_flavor & kCurC) f.C[0][at] = make_float2(i0, z0);
+            if (cur_flavor & kCurC) gstore(C0 + at, make_float2(i0, z0));
           } else {
             ok = z0 == z0 && zdx == zdx && zdy == zdy && (fabsf(idx) > ithr || fabsf(idy) > ithr || fabsf(zdx) > dthr || fabsf(zdy) > dthr);
-            f.R[0][at] = make_float2(ok ? z0 : nanv, i0);
+            gstore(R0 + at, make_float2(ok ? z0 : nanv, i0));
           }
         }
         if (ROLE == 1) count += __popcll(__ballot(ok));         // wave-uniform
@@ -156,8 +170,8 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
     const float i1 = (sI[r][c] + sI[r][c + 1] + sI[r + 1][c] + sI[r + 1][c + 1]) / 4.0f;   // same summation order as the reference
     const float z00 = sZ[r][c];
     if (levels >= 2 && x1 < w1 && y1 < h1) {
-      f.I[1][size_t(y1) * w1 + x1] = i1;
-      f.Z[1][size_t(y1) * w1 + x1] = z00;                       // top-left sample, NaN holes kept (Q18)
+      I1[size_t(y1) * w1 + x1] = i1;
+      Z1[size_t(y1) * w1 + x1] = z00;                       // top-left sample, NaN holes kept (Q18)
     }
     s1[ty][tx] = i1;
     __syncthreads();                                             // s1 and wave_counts complete; sI / sZ free for the next tile
@@ -169,8 +183,8 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
     if ((tx & 1) == 0 && (ty & 1) == 0) {
       const float i2 = (s1[ty][tx] + s1[ty][tx + 1] + s1[ty + 1][tx] + s1[ty + 1][tx + 1]) / 4.0f;
       if (levels >= 3 && x2 < w2 && y2 < h2) {
-        f.I[2][size_t(y2) * w2 + x2] = i2;
-        f.Z[2][size_t(y2) * w2 + x2] = z00;
+        I2[size_t(y2) * w2 + x2] = i2;
+        Z2[size_t(y2) * w2 + x2] = z00;
       }
       s2[ty >> 1][tx >> 1] = i2;
     }
@@ -178,8 +192,8 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
     if (levels >= 4 && (tx & 3) == 0 && (ty & 3) == 0) {
       const int x3 = x1 >> 2, y3 = y1 >> 2, cx = tx >> 1, cy = ty >> 1;
       if (x3 < w3 && y3 < h3) {
-        f.I[3][size_t(y3) * w3 + x3] = (s2[cy][cx] + s2[cy][cx + 1] + s2[cy + 1][cx] + s2[cy + 1][cx + 1]) / 4.0f;
-        f.Z[3][size_t(y3) * w3 + x3] = z00;
+        I3[size_t(y3) * w3 + x3] = (s2[cy][cx] + s2[cy][cx + 1] + s2[cy + 1][cx] + s2[cy + 1][cx + 1]) / 4.0f;
+        Z3[size_t(y3) * w3 + x3] = z00;
       }
     }
     __syncthreads();                                             // s1, s2, wave_counts free for the next tile of this workgroup
@@ -189,16 +203,18 @@ __global__ __launch_bounds__(256) void k_build_from_raw(const FrameBuildPtrs* __
 __global__ void k_pyr_down(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h) {
 #pragma clang fp contract(off)
   const FrameBuildPtrs& f = tbl[blockIdx.z];
-  const float* __restrict__ I = f.I[level - 1];
-  const float* __restrict__ Z = f.Z[level - 1];
+  const auto I = global_ptr<const float>(f.I[level - 1]);       // (global_ptr.h: read once, global address space)
+  const auto Z = global_ptr<const float>(f.Z[level - 1]);
+  const auto outI = global_ptr(f.I[level]);
+  const auto outZ = global_ptr(f.Z[level]);
   const int ow = w >> 1, oh = h >> 1;
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= ow || y >= oh) return;
-  const float* r0 = I + size_t(2 * y) * w + 2 * x;
-  const float* r1 = r0 + w;
-  f.I[level][size_t(y) * ow + x] = (r0[0] + r0[1] + r1[0] + r1[1]) / 4.0f;   // same summation order as the reference
-  f.Z[level][size_t(y) * ow + x] = Z[size_t(2 * y) * w + 2 * x];             // top-left sample, NaN holes kept (Q18)
+  const auto r0 = I + size_t(2 * y) * w + 2 * x;
+  const auto r1 = r0 + w;
+  outI[size_t(y) * ow + x] = (r0[0] + r0[1] + r1[0] + r1[1]) / 4.0f;   // same summation order as the reference
+  outZ[size_t(y) * ow + x] = Z[size_t(2 * y) * w + 2 * x];             // top-left sample, NaN holes kept (Q18)
 }
 
 // Central differences with clamped borders (rgbd_image.cpp:419-489).  The derived planes are built per ROLE, like the
@@ -209,7 +225,7 @@ struct Derivs {
   float i0, z0, idx, idy, zdx, zdy;
 };
 
-__device__ __forceinline__ Derivs derive_at(const float* __restrict__ I, const float* __restrict__ Z, int w, int h, int x, int y) {
+__device__ __forceinline__ Derivs derive_at(Global<const float> I, Global<const float> Z, int w, int h, int x, int y) {
 #pragma clang fp contract(off)
   const int xp = max(x - 1, 0), xn = min(x + 1, w - 1);
   const int yp = max(y - 1, 0), yn = min(y + 1, h - 1);
@@ -228,17 +244,22 @@ __device__ __forceinline__ Derivs derive_at(const float* __restrict__ I, const f
 __global__ void k_derive_current(const FrameBuildPtrs* __restrict__ tbl, int level, int w, int h, int tiles_x, int tiles_y, int n_frames, int cur_flavor) {
   for_each_tile(tiles_x, tiles_y, n_frames, [&](int bx, int by, int frame) {
     const FrameBuildPtrs& f = tbl[frame];
+    const auto I = global_ptr<const float>(f.I[level]);         // (global_ptr.h: read once, global address space)
+    const auto Z = global_ptr<const float>(f.Z[level]);
+    const auto A = global_ptr(f.A[level]);
+    const auto B = global_ptr(f.B[level]);
+    const auto C = global_ptr(f.C[level]);
     const int x = bx * 64 + threadIdx.x;
     const int y = by * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
     if (cur_flavor == kCurC) {                                  // (uniform) only the {I, Z} pair: no neighbours to read
-      f.C[level][size_t(y) * w + x] = make_float2(f.I[level][size_t(y) * w + x], f.Z[level][size_t(y) * w + x]);
+      gstore(C + size_t(y) * w + x, make_float2(I[size_t(y) * w + x], Z[size_t(y) * w + x]));
       return;
     }
-    const Derivs d = derive_at(f.I[level], f.Z[level], w, h, x, y);
-    f.A[level][size_t(y) * w + x] = make_float4(d.i0, d.z0, d.idx, d.idy);
-    f.B[level][size_t(y) * w + x] = make_float2(d.zdx, d.zdy);
-    if (cur_flavor & kCurC) f.C[level][size_t(y) * w + x] = make_float2(d.i0, d.z0);
+    const Derivs d = derive_at(I, Z, w, h, x, y);
+    gstore(A + size_t(y) * w + x, make_float4(d.i0, d.z0, d.idx, d.idy));
+    gstore(B + size_t(y) * w + x, make_float2(d.zdx, d.zdy));
+    if (cur_flavor & kCurC) gstore(C + size_t(y) * w + x, make_float2(d.i0, d.z0));
   });
 }
 
@@ -253,25 +274,29 @@ __global__ void k_from_current_plane(const FrameBuildPtrs* __restrict__ tbl, int
   __shared__ int wave_counts[4];
   for_each_tile(tiles_x, tiles_y, n_frames, [&](int bx, int by, int frame) {
     const FrameBuildPtrs& f = tbl[frame];
+    const auto A = global_ptr(f.A[level]);                      // (global_ptr.h: read once, global address space)
+    const auto B = global_ptr(f.B[level]);
+    const auto R = global_ptr(f.R[level]);
+    const auto Cw = global_ptr(f.C[level]);
     const int x = bx * 64 + threadIdx.x;
     const int y = by * 4 + threadIdx.y;
     bool ok = false;
     if (x < w && y < h) {
       const size_t at = size_t(y) * w + x;
       if (MODE == 1) {
-        const float4 a = f.A[level][at];
-        f.C[level][at] = make_float2(a.x, a.y);
+        const float4 a = gload((Global<const float4>)(A + at));
+        gstore(Cw + at, make_float2(a.x, a.y));
       } else {
-        const float2* C = f.C[level];
+        const auto C = global_ptr<const float2>(f.C[level]);
         const int xp = max(x - 1, 0), xn = min(x + 1, w - 1), yp = max(y - 1, 0), yn = min(y + 1, h - 1);
-        const float2 c = C[at], l = C[size_t(y) * w + xp], r = C[size_t(y) * w + xn], u = C[size_t(yp) * w + x], d = C[size_t(yn) * w + x];
+        const float2 c = gload(C + at), l = gload(C + size_t(y) * w + xp), r = gload(C + size_t(y) * w + xn), u = gload(C + size_t(yp) * w + x), d = gload(C + size_t(yn) * w + x);
         const float idx = (r.x - l.x) * 0.5f, idy = (d.x - u.x) * 0.5f, zdx = (r.y - l.y) * 0.5f, zdy = (d.y - u.y) * 0.5f;
         if (MODE == 0) {
-          f.A[level][at] = make_float4(c.x, c.y, idx, idy);
-          f.B[level][at] = make_float2(zdx, zdy);
+          gstore(A + at, make_float4(c.x, c.y, idx, idy));
+          gstore(B + at, make_float2(zdx, zdy));
         } else {
           ok = c.y == c.y && zdx == zdx && zdy == zdy && (fabsf(idx) > ithr || fabsf(idy) > ithr || fabsf(zdx) > dthr || fabsf(zdy) > dthr);
-          f.R[level][at] = make_float2(ok ? c.y : __builtin_nanf(""), c.x);
+          gstore(R + at, make_float2(ok ? c.y : __builtin_nanf(""), c.x));
         }
       }
     }
@@ -296,6 +321,9 @@ __global__ void k_derive_reference(const FrameBuildPtrs* __restrict__ tbl, int l
   __shared__ int wave_counts[4];
   for_each_tile(tiles_x, tiles_y, n_frames, [&](int bx, int by, int frame) {
     const FrameBuildPtrs& f = tbl[frame];
+    const auto I = global_ptr<const float>(f.I[level]);         // (global_ptr.h: read once, global address space)
+    const auto Z = global_ptr<const float>(f.Z[level]);
+    const auto R = global_ptr(f.R[level]);
     const int x = bx * 64 + threadIdx.x;
     int count = 0;
 #pragma unroll
@@ -303,10 +331,10 @@ __global__ void k_derive_reference(const FrameBuildPtrs* __restrict__ tbl, int l
       const int y = (by * 4 + r) * 4 + threadIdx.y;
       bool ok = false;
       if (x < w && y < h) {
-        const Derivs d = derive_at(f.I[level], f.Z[level], w, h, x, y);
+        const Derivs d = derive_at(I, Z, w, h, x, y);
         ok = d.z0 == d.z0 && d.zdx == d.zdx && d.zdy == d.zdy &&
              (fabsf(d.idx) > ithr || fabsf(d.idy) > ithr || fabsf(d.zdx) > dthr || fabsf(d.zdy) > dthr);
-        f.R[level][size_t(y) * w + x] = make_float2(ok ? d.z0 : __builtin_nanf(""), d.i0);
+        gstore(R + size_t(y) * w + x, make_float2(ok ? d.z0 : __builtin_nanf(""), d.i0));
       }
       count += __popcll(__ballot(ok));      // wave-uniform
     }
@@ -364,7 +392,12 @@ static int capped_grid(int tiles_x, int tiles_y, int n_frames, int max_workgroup
 }
 
 void launch_build_from_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int role, bool wide,
-                           float ithr, float dthr, int max_workgroups, int cur_flavor) {
+                           float ithr, float dthr, int max_workgroups, int cur_flavor, int c_levels) {
+  if (ingest_strips_supports(w0, wide)) {
+    if (role == 1) k_zero_counts<<<dim3((n_frames + 63) / 64), dim3(64), 0, s>>>(tbl, n_frames, 0);
+    launch_ingest_strips(s, tbl, n_frames, scale, w0, h0, levels, role, ithr, dthr, max_workgroups, cur_flavor, c_levels);
+    return;
+  }
   const int tx = (w0 + kB0W - 1) / kB0W, ty = (h0 + kB0H - 1) / kB0H;
   const dim3 grid(capped_grid(tx, ty, n_frames, max_workgroups)), block(256);
   const int lv = levels < 4 ? levels : 4;

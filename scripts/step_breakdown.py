@@ -14,7 +14,7 @@ for r in rows:
     grid, wg = int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0), int(r.get("Workgroup_Size") or r.get("Workgroup_Size_X") or 1)
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, grid // max(wg, 1), r.get("Queue_Id") or r.get("Stream_Id") or ""))
 ev.sort()
-marks = [s for s, e, n, g, q in ev if n.startswith("k_build_from_raw<0")]
+marks = [s for s, e, n, g, q in ev if n.startswith("k_build_from_raw<0") or n.startswith("k_ingest_strips<0")]
 # the bench builds once per step; the measurement legs after the timed loop build nothing in that role
 t0, t1 = marks[-steps - 1], marks[-1]
 win = [x for x in ev if t0 <= x[0] < t1]

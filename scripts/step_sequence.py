@@ -11,7 +11,7 @@ for r in rows:
     grid, wg = int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0), int(r.get("Workgroup_Size") or r.get("Workgroup_Size_X") or 1)
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, grid // max(wg, 1)))
 ev.sort()
-marks = [s for s, e, n, g in ev if n.startswith("k_build_from_raw<0")]
+marks = [s for s, e, n, g in ev if n.startswith("k_build_from_raw<0") or n.startswith("k_ingest_strips<0")]
 t0, t1 = marks[-2], marks[-1]
 for s, e, n, g in ev:
     if t0 <= s < t1:

@@ -33,7 +33,10 @@ def test_library_loaded_and_device_present(gpu_ctx):
     assert gpu_ctx.ptr
 
 
-@pytest.mark.parametrize("w,h,levels", [(640, 480, 4), (160, 120, 3), (100, 76, 2)])
+@pytest.mark.parametrize("w,h,levels", [(640, 480, 4), (160, 120, 3), (100, 76, 2),
+                                        # the strip ingest (even rows of 4-pixel groups): ragged last strip, heights that are no multiple of
+                                        # the 8-row strip or of the 32-row group, odd coarser levels; a one-strip image
+                                        (140, 62, 3), (388, 122, 4), (128, 8, 2), (132, 34, 4)])
 def test_pyramid_planes_bit_exact(gpu_ctx, w, h, levels):
     pair = cm.synth(17, w, h)
     oref, _ = cm.oracle_pyramids(pair, levels)
@@ -526,7 +529,7 @@ def test_streaming_upload_from_host_memory(gpu_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,levels", [(320, 240, 3), (102, 78, 3), (640, 480, 4)])
+@pytest.mark.parametrize("w,h,levels", [(320, 240, 3), (102, 78, 3), (640, 480, 4), (140, 62, 3), (388, 122, 4)])
 def test_role_aware_ingest_is_bit_identical(gpu_ctx, w, h, levels):
     """dvo_hip_frames_update_raw_as: level 0 written straight from the raw planes into the role's planes (no float planes at
     level 0, 4-pixel-wide loads when the rows allow it).  Same planes, same selection, same alignment results as frames built
@@ -596,6 +599,41 @@ def test_role_aware_ingest_is_bit_identical(gpu_ctx, w, h, levels):
     d.update_raw_host_batch(R, gr, zr, role="reference", config=coarse)
     d.update_raw_host_batch(Cu, gc, zc, role="current", config=coarse)
     assert raw(trk.match_batch_arrays(R, Cu)) == forward
+
+
+@pytest.mark.gpu
+def test_strip_ingest_of_a_batch_that_only_needs_the_window_plane(gpu_ctx):
+    """More current frames than the device has compute units: the role-aware ingest writes only the {I, Z} plane of the levels the
+    window sweep reads (level 0 without neighbours, level 1 out of the same pass) -- ingest_strips.hip ROLE 0 / TAPS false and
+    c_levels.  Same matches and same planes as frames built one by one the long way; the counter shows that the strips ran."""
+    n, w, h, levels = 260, 128, 48, 2
+    cfg = d.Config(FirstLevel=levels - 1, LastLevel=0)
+    trk = d.DenseTracker(cfg, gpu_ctx)
+    cam = d.RgbdCameraPyramid(w, h, po.FR1_K * (w / 640.0), gpu_ctx)
+    cam.build(levels)
+    b = datagen.synth_batch(303, 4, w, h)
+    pick = lambda arrs, i: np.ascontiguousarray(arrs[i % 4] if i < 4 else np.roll(arrs[i % 4], i, axis=1))   # 260 distinct frames from 4 scenes
+    gr, zr = [pick(b["grey_ref"], i) for i in range(n)], [pick(b["depth_ref"], i) for i in range(n)]
+    gc, zc = [pick(b["grey_cur"], i) for i in range(n)], [pick(b["depth_cur"], i) for i in range(n)]
+    refs = [cam.create_raw(gr[i], zr[i]) for i in range(n)]
+    curs = [cam.create_raw(gc[i], zc[i]) for i in range(n)]
+    want = trk.match_batch_arrays(refs, curs)
+    dummy = np.zeros((h, w), np.uint8), np.full((h, w), 5000, np.uint16)
+    R = [cam.create_raw(*dummy) for _ in range(n)]
+    Cu = [cam.create_raw(*dummy) for _ in range(n)]
+    before = gpu_ctx.counter("strip_ingests")
+    d.update_raw_host_batch(R, gr, zr, role="reference", config=cfg)
+    d.update_raw_host_batch(Cu, gc, zc, role="current", config=cfg)
+    assert gpu_ctx.counter("strip_ingests") == before + 2 * n
+    got = trk.match_batch_arrays(R, Cu)
+    for k in ("T", "information", "loglik", "n_iterations", "entropy"):
+        assert np.array_equal(want[k], got[k], equal_nan=True), k
+    names = ("intensity", "depth", "intensity_dx", "intensity_dy", "depth_dx", "depth_dy")
+    for i in (0, 5, n - 1):
+        for a, c in ((refs[i], R[i]), (curs[i], Cu[i])):
+            for l in range(levels):
+                for k in names:
+                    assert np.array_equal(np.array(getattr(a.level(l), k)), np.array(getattr(c.level(l), k)), equal_nan=True), (i, l, k)
 
 
 @pytest.mark.gpu
