@@ -96,6 +96,35 @@ __device__ __forceinline__ f16x8 read_operand_f16(const _Float16* img, int lane,
 // WAVES: wavefronts per workgroup (4: four rows each, 8: two rows each -- less projection state per lane, one wavefront per SIMD more).
 // F16: Gram accumulation on the f16 matrix pipe (variant 7).  COMPAT: the reference's x * rcp(z) in projection and weights with the
 // host CPU's reciprocal table (option "ref_compat", LevelGeom::rcp_table).
+// v_mul_legacy_f32: the multiply with 0 x anything = 0 (NaN and infinity included); the ordinary product otherwise
+__device__ __forceinline__ float mul_legacy(float a, float b) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// jacobian_rows_fast (pixel_math.h) for a lane that may be invalid: s = 0 there, and every product in which a term of that lane (NaN
+// where the reference point or a tap is a hole) meets a zero is v_mul_legacy_f32 -- 0 x anything = 0.  For a valid lane the legacy
+// multiply is the ordinary one.
+__device__ __forceinline__ void jacobian_rows_masked(const PixelTerms& t, float s, float tx, float ty, float cx, float cy, float* J0, float* J1) {
+  const float iz = fast_rcp(t.Z);
+  const float txy = tx * ty;
+  const float gix = mul_legacy(s, t.gix), giy = mul_legacy(s, t.giy);
+  const float gzx = mul_legacy(s, t.gzx), gzy = mul_legacy(s, t.gzy);
+  J0[0] = mul_legacy(gix, iz);
+  J0[1] = mul_legacy(giy, iz);
+  J0[2] = fmaf(-ty, J0[1], -tx * J0[0]);
+  J0[3] = fmaf(-giy, cy, -gix * txy);
+  J0[4] = fmaf(gix, cx, giy * txy);
+  J0[5] = fmaf(giy, tx, -gix * ty);
+  J1[0] = mul_legacy(gzx, iz);
+  J1[1] = mul_legacy(gzy, iz);
+  J1[2] = fmaf(-ty, J1[1], fmaf(-tx, J1[0], -s));
+  J1[3] = fmaf(-gzy, cy, fmaf(-gzx, txy, -mul_legacy(s, t.Y)));
+  J1[4] = fmaf(gzx, cx, fmaf(gzy, txy, mul_legacy(s, t.X)));
+  J1[5] = fmaf(gzy, tx, -gzx * ty);
+}
+
 template <bool F16, bool COMPAT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_sweep_window(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
@@ -318,29 +347,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
       typedef volatile __attribute__((address_space(3))) u32x4* LdsQuadPtr;   // volatile: the stores stay where they are written
       LdsQuadPtr hw = (LdsQuadPtr)(reinterpret_cast<char*>(my) + (lane_c & 31) * (kHalfRow * 2));
       const bool low_half = lane_c < 32;
-      u32x4 h0, h1, l0, l1;
-      if (valid) {
-        const float sw = first ? 1.0f : COMPAT ? tdist_weight_sqrt_compat(g.rcp_table, g.rcp_shift, o.r0, o.r1, st.P_prev) : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
-        float J0[6], J1[6];
-        jacobian_rows_fast(o, sw, tx_u, ty_p, cx_u, fmaf(ty_p, ty_p, 1.0f), J0, J1);
-        const float sr = sw * kResidualScale;
-        unsigned hh[7], ll[7];
-        split_pair(J0[0], J0[1], hh[0], ll[0]);
-        split_pair(J0[2], J0[3], hh[1], ll[1]);
-        split_pair(J0[4], J0[5], hh[2], ll[2]);
-        split_pair(J1[0], J1[1], hh[3], ll[3]);
-        split_pair(J1[2], J1[3], hh[4], ll[4]);
-        split_pair(J1[4], J1[5], hh[5], ll[5]);
-        split_pair(sr * o.r0, sr * o.r1, hh[6], ll[6]);
-        h0 = u32x4{hh[0], hh[1], hh[2], hh[3]};
-        h1 = u32x4{hh[4], hh[5], hh[6], 0u};
-        l0 = u32x4{ll[0], ll[1], ll[2], ll[3]};
-        l1 = u32x4{ll[4], ll[5], ll[6], 0u};
-        if (low_half) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }
-      } else if (low_half) {
-        const u32x4 zero = {0u, 0u, 0u, 0u};
-        hw[0] = zero; hw[1] = zero; hw[2] = zero; hw[3] = zero;
-      }
+      // No branch on `valid`: an invalid lane's weight is zero and every product that could meet one of its NaN terms is a LEGACY
+      // multiply (0 x anything = 0), so its operand rows are zeros without a second control-flow path (14 zero moves, the exec
+      // juggling and the register shuffles where the two paths met: about 30 instructions per row)
+      const float sw_any = first ? 1.0f : COMPAT ? tdist_weight_sqrt_compat(g.rcp_table, g.rcp_shift, o.r0, o.r1, st.P_prev) : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
+      const float sw = valid ? sw_any : 0.0f;
+      float J0[6], J1[6];
+      jacobian_rows_masked(o, sw, tx_u, ty_p, cx_u, fmaf(ty_p, ty_p, 1.0f), J0, J1);
+      const float sr = sw * kResidualScale;
+      unsigned hh[7], ll[7];
+      split_pair(J0[0], J0[1], hh[0], ll[0]);
+      split_pair(J0[2], J0[3], hh[1], ll[1]);
+      split_pair(J0[4], J0[5], hh[2], ll[2]);
+      split_pair(J1[0], J1[1], hh[3], ll[3]);
+      split_pair(J1[2], J1[3], hh[4], ll[4]);
+      split_pair(J1[4], J1[5], hh[5], ll[5]);
+      split_pair(mul_legacy(sr, o.r0), mul_legacy(sr, o.r1), hh[6], ll[6]);
+      const u32x4 h0 = {hh[0], hh[1], hh[2], hh[3]}, h1 = {hh[4], hh[5], hh[6], 0u};
+      const u32x4 l0 = {ll[0], ll[1], ll[2], ll[3]}, l1 = {ll[4], ll[5], ll[6], 0u};
+      if (low_half) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }
       const _Float16* img = reinterpret_cast<const _Float16*>(my);
       // pixels 0..31 of the row: the slab is private to the wavefront and LDS executes a wavefront's operations in order, so the
       // reads below follow the stores above, and the stores of the second half follow the reads -- only the compiler is fenced
@@ -354,12 +379,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (valid) {
-        if (!low_half) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }
-      } else if (!low_half) {
-        const u32x4 zero = {0u, 0u, 0u, 0u};
-        hw[0] = zero; hw[1] = zero; hw[2] = zero; hw[3] = zero;
-      }
+      if (!low_half) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
