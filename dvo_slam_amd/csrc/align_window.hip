@@ -70,18 +70,27 @@ typedef __fp16 __attribute__((__vector_size__(4 * sizeof(__fp16)))) fp16x4;
 typedef __fp16 __attribute__((ext_vector_type(2))) fp16x2;
 typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
 
-// v = hi + lo with hi, lo in f16 (round toward zero: hi never exceeds the f16 range, it saturates; lo = v - hi is exact in f32);
-// two components per call, packed as the two halves of a register
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
-  const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-  hi = __builtin_bit_cast(unsigned, h);
-  // a - float(h.lo), b - float(h.hi) in ONE instruction each: v_fma_mix_f32 reads the f16 half of `hi` directly (the compiler emits a
-  // conversion and a subtraction unless it can fold a multiplication in)
-  float ra, rb;
-  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(hi));
-  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(hi));
-  lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+// v = hi + lo with hi, lo in f16; two components per call, packed as the two halves of a register.  hi is rounded toward zero (it
+// saturates at the largest f16 instead of becoming infinite), lo = f16(v - hi) with the subtraction exact in f32:
+// v_fma_mix_f32 reads the f16 half of `hi` directly and subtracts in f32 (the compiler emits a conversion and a subtraction
+// unless it can fold a multiplication in); the two differences are packed with round toward zero as well.
+// Range: a component beyond +-65504 saturates hi and the sum no longer represents it; the epilogue detects that from the diagonal
+// of H H^T (kF16RangeSquared) and the batch is repeated with the f32 Gram (capi.hip, counter "f16_range_repeats").
+// (seven pairs at a time, each step for all pairs before the next: an instruction never waits for the one right before it)
+__device__ __forceinline__ void split_pairs(const float (&v)[14], unsigned (&hi)[7], unsigned (&lo)[7]) {
+#pragma unroll
+  for (int k = 0; k < 7; ++k) hi[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * k], v[2 * k + 1]));
+  // (measured: v_fma_mixlo_f16 / v_fma_mixhi_f16 would write the rounded low parts straight into the halves of one register -- 14
+  // instructions instead of 21 -- but the sweep runs 1.7 % SLOWER with them than with v_fma_mix_f32 + v_cvt_pkrtz: scripts/ab_sweep.py)
+  float ra[7], rb[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(ra[k]) : "v"(v[2 * k]), "v"(hi[k]));
+#pragma unroll
+  for (int k = 0; k < 7; ++k) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb[k]) : "v"(v[2 * k + 1]), "v"(hi[k]));
+#pragma unroll
+  for (int k = 0; k < 7; ++k) lo[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra[k], rb[k]));
 }
+constexpr float kF16RangeSquared = 65504.0f * 65504.0f;
 
 // matrix operand of 32 pixels (k index) x 16 components from the pixel-major f16 image: lane (i = l & 15, g = l >> 4) gets the
 // eight k-values 8 g .. 8 g + 7 of component i (scripts/ubench/gram_f16.hip)
@@ -128,7 +137,7 @@ __device__ __forceinline__ void jacobian_rows_masked(const PixelTerms& t, float 
 template <bool F16, bool COMPAT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_sweep_window(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
-    float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count) {
+    float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count, int* __restrict__ f16_range_flag) {
   // (Measured and dropped: a workgroup sweeping several vertically adjacent tiles in a loop, so that the pair's state, plane pointers
   // and transform are fetched once per group of tiles -- inside a loop the compiler wants 155 vector registers for the same body and
   // spills 59 of them at the five-wavefront budget.)
@@ -155,6 +164,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
   const __amdgpu_buffer_rsrc_t resid = __builtin_amdgcn_make_buffer_rsrc(scratch + size_t(pair) * size_t(g.w) * g.h, 0, plane_bytes, 0x00020000);
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned gram_entries = kGramEntryTable.e[min(int(threadIdx.x), kNumAcc - 1)];   // (for the epilogue; loaded here, used there)
   const int u_r = tile_x * kTileW + lane;                      // < g.w: the level's width is a multiple of the tile's
   const int row_bytes = g.w * 8;
   const float nanv = __builtin_nanf("");
@@ -356,13 +366,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
       jacobian_rows_masked(o, sw, tx_u, ty_p, cx_u, fmaf(ty_p, ty_p, 1.0f), J0, J1);
       const float sr = sw * kResidualScale;
       unsigned hh[7], ll[7];
-      split_pair(J0[0], J0[1], hh[0], ll[0]);
-      split_pair(J0[2], J0[3], hh[1], ll[1]);
-      split_pair(J0[4], J0[5], hh[2], ll[2]);
-      split_pair(J1[0], J1[1], hh[3], ll[3]);
-      split_pair(J1[2], J1[3], hh[4], ll[4]);
-      split_pair(J1[4], J1[5], hh[5], ll[5]);
-      split_pair(mul_legacy(sr, o.r0), mul_legacy(sr, o.r1), hh[6], ll[6]);
+      const float comps[14] = {J0[0], J0[1], J0[2], J0[3], J0[4], J0[5], J1[0], J1[1], J1[2], J1[3], J1[4], J1[5], mul_legacy(sr, o.r0), mul_legacy(sr, o.r1)};
+      split_pairs(comps, hh, ll);
       const u32x4 h0 = {hh[0], hh[1], hh[2], hh[3]}, h1 = {hh[4], hh[5], hh[6], 0u};
       const u32x4 l0 = {ll[0], ll[1], ll[2], ll[3]}, l1 = {ll[4], ll[5], ll[6], 0u};
       if (low_half) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }
@@ -429,6 +434,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int col = lane & 15;
+    if (f16_range_flag) {
+      // a component beyond the f16 range saturated its high part at +-65504: that pixel alone puts 65504^2 on the diagonal of H H^T
+      // (sums of squares: nothing cancels), and no entry of a Gram matrix exceeds its largest diagonal entry -- so the largest
+      // magnitude of ANY entry tells.  Not-a-number counts as out of range.
+      const float largest = fmaxf(fmaxf(fabsf(acc0[0]), fabsf(acc0[1])), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
+      const bool out_of_range = !(largest < kF16RangeSquared) || acc0[0] != acc0[0] || acc0[1] != acc0[1] || acc0[2] != acc0[2] || acc0[3] != acc0[3];
+      if (__ballot(out_of_range) != 0 && lane == 0) __hip_atomic_store(f16_range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const float cs = col >= 12 ? 1.0f / kResidualScale : 1.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -456,10 +469,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
       if (WAVES == 8) c += (counts[4] + counts[5]) + (counts[6] + counts[7]);
       v = float(c);
     } else {
-      int e1, e2;
-      gram_entries_of_accumulator(kk, e1, e2);
+      const int e1 = gram_entries & 0xff, e2 = gram_entries >> 8;   // gram_entries_of_accumulator(kk), from its table
       v = G(e1);
-      if (e2 >= 0) v += G(e2);
+      if (e2 != 0xff) v += G(e2);
     }
     partials[(size_t(pair) * tiles + tile) * kAccStride + kk] = v;
   }
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
 bool window_sweep_supports(const LevelGeom& g) { return !g.linear && g.w % kTileW == 0 && g.w < 32768 && g.h < 32768; }
 
 void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
-                         float* partials, float2* scratch, unsigned long long* fallback_count) {
+                         float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag) {
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8);
@@ -485,11 +497,11 @@ void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const Pair
   // fixed work is spread over half the rows.)
   const dim3 block(256);
   if (g.rcp_table) {
-    if (f16) k_sweep_window<true, true, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
-    else k_sweep_window<false, true, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+    if (f16) k_sweep_window<true, true, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+    else k_sweep_window<false, true, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
   } else {
-    if (f16) k_sweep_window<true, false, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
-    else k_sweep_window<false, false, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count);
+    if (f16) k_sweep_window<true, false, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+    else k_sweep_window<false, false, 4><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
   }
 }
 

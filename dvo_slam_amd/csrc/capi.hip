@@ -187,6 +187,7 @@ struct Workspace {
   hipStream_t stream = nullptr;
   DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters;
   DevBuf win_fallbacks;          // one 64-bit counter: lanes of the window sweep whose taps were fetched from memory (align_window.hip)
+  int* f16_range_flag = nullptr; // pinned: raised by a workgroup of the f16 Gram schedule whose Jacobian left the f16 range (align_window.hip)
   PinnedRing* tables = nullptr;  // the context's ring for small uploads
   int* host_status = nullptr;    // pinned: one word per Gauss-Newton step of a batch, written by the device (k_solver_step)
   size_t host_status_words = 0;
@@ -213,6 +214,7 @@ struct dvo_hip_context {
   std::string err;
   int opt_rows_per_wave = 0;
   int opt_iters_per_sync = 0;
+  long long f16_range_repeats = 0; // batches repeated with the f32 Gram because a Jacobian left the f16 range (counter "f16_range_repeats")
   long long strip_ingests = 0;     // frames ingested by the strip kernel (ingest_strips.hip), counter "strip_ingests"
   int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
@@ -329,6 +331,8 @@ void workspace_destroy(Workspace& w) {
   if (w.host_status) (void)hipHostFree(w.host_status);
   w.host_status = nullptr;
   w.host_status_words = 0;
+  if (w.f16_range_flag) (void)hipHostFree(w.f16_range_flag);
+  w.f16_range_flag = nullptr;
   for (PinnedBuf* b : {&w.direct_results, &w.direct_levels, &w.direct_iters, &w.direct_done}) b->release();
   (void)hipStreamDestroy(w.stream);
   w.created = false;
@@ -846,6 +850,10 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
     DVO_WS_TRY(w, w.win_fallbacks.reserve(64));
     DVO_WS_TRY(w, hipMemsetAsync(w.win_fallbacks.p, 0, 64, w.stream));
   }
+  if (!w.f16_range_flag) {
+    DVO_WS_TRY(w, hipHostMalloc(reinterpret_cast<void**>(&w.f16_range_flag), 64, hipHostMallocCoherent | hipHostMallocMapped));
+    *w.f16_range_flag = 0;
+  }
   std::vector<PairPtrs>& host = bp.host_ptrs;
   host.assign(size_t(n) * need_levels, PairPtrs());
   for (int l = cfg->last_level; l <= cfg->first_level; ++l)
@@ -1159,7 +1167,8 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       for (int c = 0; c < count; ++c, ++step) {
         {
           Range range(kErr[level]);
-          launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch, w.win_fallbacks.as<unsigned long long>());
+          launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch, w.win_fallbacks.as<unsigned long long>(),
+                                 w.f16_range_flag);
           if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, kLlBlocksPerPair, ctx->opt_deterministic != 0);
         }
         Range range(kLinsys[level]);
@@ -1240,6 +1249,18 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     ctx->opt_resident = keep;
     return rc;
   }
+  if (*static_cast<volatile int*>(w.f16_range_flag) != 0) {
+    // A Jacobian component of some pixel was beyond +-65504: the f16 high / low split of the Gram operands (variant 7) does not
+    // represent it.  The batch runs again with the f32 Gram of the same sweep (variant 6: same planes, same tiles).
+    *static_cast<volatile int*>(w.f16_range_flag) = 0;
+    ctx->f16_range_repeats += 1;
+    for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, &tinit[size_t(i) * 16], 16 * sizeof(double));
+    const int keep = ctx->opt_variant;
+    ctx->opt_variant = 6;
+    rc = run_batch(ctx, n, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
+    ctx->opt_variant = keep;
+    return rc;
+  }
   bool truncated = false;
   for (int i = 0; i < n; ++i) {
     if (hl_src) {
@@ -1302,6 +1323,7 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
     *value = (long long)v;
   }
   else if (std::strcmp(key, "strip_ingests") == 0) *value = ctx->strip_ingests;
+  else if (std::strcmp(key, "f16_range_repeats") == 0) *value = ctx->f16_range_repeats;
   else if (std::strcmp(key, "host_batches") == 0) *value = ctx->host_batches;
   else if (std::strcmp(key, "host_ns_prepare") == 0) *value = ctx->host_ns[0];
   else if (std::strcmp(key, "host_ns_enqueue") == 0) *value = ctx->host_ns[1];
@@ -1902,11 +1924,19 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
   launch_set_fixed_state(s, states, g, d_T, d_P, first_iteration_on_level ? 1 : 0);
   const PairPtrs* pp = bp.pair_ptrs + size_t(level);
   launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>(),
-                         ctx->ws[0].win_fallbacks.as<unsigned long long>());
+                         ctx->ws[0].win_fallbacks.as<unsigned long long>(), ctx->ws[0].f16_range_flag);
   launch_loglik(s, g, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>(), ctx->ws[0].ll_partials.as<double>(), kLlBlocksPerPair);
   int n_sel = 0;
   DVO_HIP_TRY(ctx, hipMemcpyAsync(&n_sel, reference->sel_count + level, sizeof(int), hipMemcpyDeviceToHost, s));
   DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (*static_cast<volatile int*>(ctx->ws[0].f16_range_flag) != 0) {   // (see run_batch: beyond the f16 range, again with the f32 Gram)
+    *static_cast<volatile int*>(ctx->ws[0].f16_range_flag) = 0;
+    ctx->f16_range_repeats += 1;
+    launch_residual_reduce(s, 6, bp.rpw[level], level == 0, g, pp, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>(),
+                           ctx->ws[0].win_fallbacks.as<unsigned long long>());
+    launch_loglik(s, g, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>(), ctx->ws[0].ll_partials.as<double>(), kLlBlocksPerPair);
+    DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
+  }
   launch_single_shot_out(s, g, ctx->ws[0].partials.as<float>(), ctx->ws[0].ll_partials.as<double>(), kLlBlocksPerPair, n_sel, d_out);
   DVO_HIP_TRY(ctx, hipMemcpyAsync(out, d_out, sizeof(dvo_hip_iteration_out), hipMemcpyDeviceToHost, s));
   if (residuals_or_null) DVO_HIP_TRY(ctx, hipMemcpyAsync(residuals_or_null, ctx->ws[0].scratch.p, npx * sizeof(float2), hipMemcpyDeviceToHost, s));

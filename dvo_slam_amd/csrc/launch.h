@@ -34,15 +34,17 @@ void launch_unpack_plane(hipStream_t s, const float4* A, const float2* B, int n,
 // variant 5 (default): Gram accumulation on the matrix cores (align_mfma.hip); variant 0: the all-VALU schedule with the DPP + LDS
 // two-stage reduction (align_kernels.hip).  Same outputs.
 void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
-                            const PairState* states, int n_pairs, float* partials, float2* scratch, unsigned long long* window_fallbacks = nullptr);
+                            const PairState* states, int n_pairs, float* partials, float2* scratch, unsigned long long* window_fallbacks = nullptr,
+                            int* f16_range_flag = nullptr);
 void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
                                  const PairState* states, int n_pairs, float* partials, float2* scratch);
 // align_window.hip: variants 6 (f32 Gram) and 7 (f16 hi/lo Gram) -- the current frame's {I, Z} window staged in LDS; tiled levels whose
 // width is a multiple of 64 only (window_sweep_supports), tile height 16 (rows_per_wave 4).  fallback_count (may be null): lanes
-// whose taps fell outside the staged window and were fetched from memory.
+// whose taps fell outside the staged window and were fetched from memory.  f16_range_flag (may be null; pinned host memory): set
+// to 1 by a workgroup of variant 7 whose Jacobian components left the f16 range -- the caller repeats the work with variant 6.
 bool window_sweep_supports(const LevelGeom& g);
 void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
-                         float* partials, float2* scratch, unsigned long long* fallback_count);
+                         float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag = nullptr);
 // scratch == null: read-only (one float per workgroup goes to `sink`, which must hold a float per (8 * 256)-pixel block)
 // window_planes: the planes the window sweep reads (reference 8 B + current {I, Z} 8 B) instead of the gathering sweep's 8 + 16 + 8 B
 void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch, float* sink, bool window_planes = false);

@@ -61,4 +61,35 @@ __device__ __forceinline__ void gram_entries_of_accumulator(int k, int& e1, int&
   else e1 = E(6 + (k - kAccB11), 13);
 }
 
+// The same map as a table built at compile time (entry k: e1 | e2 << 8, e2 = 0xff for none): one load per thread at the top of a
+// kernel instead of the index arithmetic in its epilogue.
+struct GramEntryTable {
+  unsigned short e[kNumAcc];
+};
+constexpr GramEntryTable make_gram_entry_table() {
+  GramEntryTable t{};
+  auto E = [](int r, int c) { return r * 16 + c; };
+  for (int k = 0; k < kNumAcc; ++k) {
+    int e1 = 0, e2 = 0xff;
+    if (k == kAccN) e1 = 0;
+    else if (k == kAccS) e1 = E(12, 12);
+    else if (k == kAccS + 1) e1 = E(12, 13);
+    else if (k == kAccS + 2) e1 = E(13, 13);
+    else if (k < kAccB00) {
+      const int blockId = (k - kAccJ00) / 21;
+      int o = (k - kAccJ00) % 21, i = 0;
+      while (o >= 6 - i) { o -= 6 - i; ++i; }
+      const int j = i + o;
+      if (blockId == 0) e1 = E(i, j);
+      else if (blockId == 1) e1 = E(6 + i, 6 + j);
+      else { e1 = E(i, 6 + j); e2 = E(j, 6 + i); }
+    } else if (k < kAccB01) e1 = E(k - kAccB00, 12);
+    else if (k < kAccB11) { e1 = E(k - kAccB01, 13); e2 = E(6 + (k - kAccB01), 12); }
+    else e1 = E(6 + (k - kAccB11), 13);
+    t.e[k] = (unsigned short)(e1 | e2 << 8);
+  }
+  return t;
+}
+__device__ __constant__ const GramEntryTable kGramEntryTable = make_gram_entry_table();
+
 }  // namespace dvo_hip

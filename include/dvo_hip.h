@@ -279,6 +279,8 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
  * "resident_timeouts" (batches repeated on the launch-per-step path because a workgroup group of the resident kernel waited
  * in vain for its peers -- the device was shared with another such kernel; the results are those of the repeat),
  * "window_fallbacks" (lanes of the window sweep whose bilinear taps fell outside the staged window and were fetched from memory),
+ * "f16_range_repeats" (batches that ran a second time with the f32 Gram because a Jacobian component of some pixel was beyond the f16
+ * range of the default schedule's matrix operands, +-65504: depth steps of metres right in front of the camera),
  * "strip_ingests" (frames whose raw planes went through the strip ingest, one 128 x 8 strip per wavefront -- even-width rows and
  * 4 / 8-byte aligned planes; the others take the tile kernel),
  * "host_batches" and "host_ns_prepare" / "host_ns_enqueue" / "host_ns_wait" / "host_ns_finish" (nanoseconds the calling thread spent

@@ -138,6 +138,36 @@ def test_window_sweep_against_the_gathering_sweep(w, h, xi):
         assert abs(a["neg_ll"] - out[7][k]["neg_ll"]) <= 1e-5 * abs(a["neg_ll"])      # (through the inverse of the 2 x 2 scale matrix)
 
 
+def test_f16_gram_range_guard_repeats_with_the_f32_gram():
+    """The default schedule forms its Gram operands as f16 high + low parts: a Jacobian component beyond +-65504 (a depth step of
+    ten metres one centimetre in front of the camera: fx * 5 m/px / 0.01 m) is not representable.  The sweep notices (the diagonal of
+    H H^T reaches 65504^2), the batch runs again with the f32 Gram: same record as the f32 schedule, the counter shows the repeat.
+    An ordinary scene on the same context does not repeat."""
+    w, h = 128, 96
+    pair = cm.synth(4, w, h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    depth = np.where(((xx // 8) + (yy // 8)) % 2 == 0, 0.002, 10.0).astype(np.float32)
+    grey = pair["grey_ref"].astype(np.float32)
+    recs = {}
+    for v in (6, 7):
+        ctx = d.Context(0)
+        ctx.set_option("variant", v)
+        ctx.set_option("resident", 0)
+        cam = d.RgbdCameraPyramid(w, h, pair["K"], ctx)
+        cam.build(1)
+        trk = d.DenseTracker(d.Config(FirstLevel=0, LastLevel=0, MaxIterationsPerLevel=3), ctx)
+        ref, cur = cam.create(grey, depth), cam.create(grey, depth)
+        out = trk.match_batch_arrays([ref], [cur])
+        recs[v] = (out, ctx.counter("f16_range_repeats"))
+        if v == 7:
+            gref, gcur = gpu_pyramids(ctx, pair, 1)
+            trk.match_batch_arrays([gref], [gcur])
+            assert ctx.counter("f16_range_repeats") == recs[7][1]
+    assert recs[6][1] == 0 and recs[7][1] == 1
+    for k in ("T", "information", "loglik", "n_iterations"):
+        assert np.array_equal(recs[6][0][k], recs[7][0][k], equal_nan=True), k
+
+
 def test_window_sweep_whole_matches_and_plane_flavours():
     """Whole matches on the three schedules (5: gathered taps; 6: window, f32 Gram -- identical records; 7: window, f16 Gram -- the
     same iteration structure, transforms within 1e-9), and the two flavours of the current role: frames ingested in a batch too large
