@@ -17,7 +17,7 @@
 // conflict-free ds_write_b128; the MFMA operand for pixel group g (lane l <- component l&15 of pixel 4g + l>>4)
 // is one conflict-free ds_read_b32 at a constant offset.  A == B (the sqrt(w)-scaled vector on both sides).
 // The LDS slab is private to the wavefront, so the row loop contains no barrier.
-#include "sweep_parts.h"
+#include "gram_f16.h"
 
 namespace dvo_hip {
 
@@ -32,10 +32,11 @@ struct RefRow {
 
 // LINEAR: the level is walked as one row of w*h pixels in 64-pixel segments (LevelGeom::linear) -- same per-pixel arithmetic,
 // the pixel coordinates come from a division instead of the tile position.
-template <int RPW, bool FINEST, bool LINEAR>
+// F16: the Gram accumulation on the f16 matrix pipe (gram_f16.h, schedule variant 7) instead of the f32 matrix instruction.
+template <int RPW, bool FINEST, bool LINEAR, bool F16>
 __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
-    float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd) {
+    float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, int* __restrict__ f16_range_flag) {
   // XCD-aware (pair, tile) -> workgroup mapping, see k_residual_reduce
   const int tiles = g.tiles_x * g.tiles_y;
   const int total = tiles * n_pairs;
@@ -88,7 +89,8 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   const float cx_u = fmaf(tx_u, tx_u, 1.0f);
   const float P2x = Pp[1] + Pp[2];
 
-  __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kSlabFloats];
+  constexpr int kMySlabFloats = F16 ? kSlabFloatsF16 : kSlabFloats;
+  __shared__ __attribute__((aligned(16))) float slab[kWavesPerBlock][kMySlabFloats];
   __shared__ int counts[kWavesPerBlock];
   float* my = slab[wave];
   // write side: component quad q of pixel `lane` at my[q*kQuadStride + lane*4 .. +3]
@@ -184,6 +186,13 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     const bool valid = pixel_finish_flat(g, ref, p, t, o) && p.ok;
     n_valid += __popcll(__ballot(valid));                     // exact count on the scalar unit
     if (in_image) scratch[pix_base + pix] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);   // one full-width store
+    if constexpr (F16) {
+      // (no branch on `valid`: zero weight and legacy multiplies, gram_f16.h)
+      const float sw_any = first ? 1.0f : g.rcp_table ? tdist_weight_sqrt_compat(g.rcp_table, g.rcp_shift, o.r0, o.r1, Pp)
+                                                      : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
+      gram_f16_row(my, lane, o, valid ? sw_any : 0.0f, tx_p, ty_p, cx, acc0, acc1);
+      return;
+    }
     if (valid) {
       // t-distribution weight with the PREVIOUS pass' precision (Q11); first pass on a level: w = 1.  sqrt(w) is folded into
       // the four gradient factors of the Jacobian rows.
@@ -233,7 +242,9 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   // lane l, register i holds G[row (l>>4)*4 + i][col l&15] of this wavefront's rows
 #pragma unroll
   // (the wavefront is done with its slab: its Gram matrix goes into the first 256 floats)
-  for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
+  for (int i = 0; i < 4; ++i)
+    if (!F16) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
+  if constexpr (F16) gram_f16_finish(my, lane, acc0, acc1, f16_range_flag);
   if (lane == 0) counts[wave] = n_valid;
   __syncthreads();
   // fold the four wavefront Gram matrices into the canonical partial row (device_types.h); vector layout:
@@ -254,30 +265,37 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   }
 }
 
-template <int RPW>
+template <int RPW, bool F16>
 static void launch_m(hipStream_t s, bool finest, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
-                     float* partials, float2* scratch) {
+                     float* partials, float2* scratch, int* f16_range_flag) {
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(kBlock);
   if (g.linear) {
-    if (finest) k_residual_reduce_mfma<RPW, true, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
-    else k_residual_reduce_mfma<RPW, false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+    if (finest) k_residual_reduce_mfma<RPW, true, true, F16><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag);
+    else k_residual_reduce_mfma<RPW, false, true, F16><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag);
   } else {
-    if (finest) k_residual_reduce_mfma<RPW, true, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
-    else k_residual_reduce_mfma<RPW, false, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
+    if (finest) k_residual_reduce_mfma<RPW, true, false, F16><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag);
+    else k_residual_reduce_mfma<RPW, false, false, F16><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag);
+  }
+}
+
+template <bool F16>
+static void launch_rpw(hipStream_t s, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs, const PairState* states,
+                       int n_pairs, float* partials, float2* scratch, int* f16_range_flag) {
+  switch (rows_per_wave) {
+    case 1: launch_m<1, F16>(s, finest, g, pairs, states, n_pairs, partials, scratch, f16_range_flag); break;
+    case 2: launch_m<2, F16>(s, finest, g, pairs, states, n_pairs, partials, scratch, f16_range_flag); break;
+    case 4: launch_m<4, F16>(s, finest, g, pairs, states, n_pairs, partials, scratch, f16_range_flag); break;
+    case 16: launch_m<16, F16>(s, finest, g, pairs, states, n_pairs, partials, scratch, f16_range_flag); break;
+    default: launch_m<8, F16>(s, finest, g, pairs, states, n_pairs, partials, scratch, f16_range_flag); break;
   }
 }
 
 void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
-                                 const PairState* states, int n_pairs, float* partials, float2* scratch) {
-  switch (rows_per_wave) {
-    case 1: launch_m<1>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 2: launch_m<2>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 4: launch_m<4>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    case 16: launch_m<16>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-    default: launch_m<8>(s, finest, g, pairs, states, n_pairs, partials, scratch); break;
-  }
+                                 const PairState* states, int n_pairs, float* partials, float2* scratch, bool f16, int* f16_range_flag) {
+  if (f16) launch_rpw<true>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, f16_range_flag);
+  else launch_rpw<false>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, nullptr);
 }
 
 }  // namespace dvo_hip

@@ -23,7 +23,7 @@
 // Variant 7 additionally accumulates the Gram matrix on the f16 matrix pipe: every component is split exactly into hi + lo
 // (two f16), G = H H^T + H L^T + L H^T through v_mfma_f32_16x16x32_f16 (4 instead of 16 matrix instructions per row; the f32
 // matrix instruction shares the vector ALU's issue time, the f16 one does not).  f32-class accuracy (scripts/ubench/gram_f16.hip).
-#include "sweep_parts.h"
+#include "gram_f16.h"
 
 namespace dvo_hip {
 
@@ -34,14 +34,6 @@ constexpr int kWinPairs = kWinPitch / 2;                // 40 column pairs
 constexpr int kWinRows = 30;                            // window rows: 16 + the taps' reach (3) + 11
 constexpr int kWinCells = kWinPitch * kWinRows;         // 2400 cells x 8 B = 19.2 KB
 constexpr int kNoProjection = 0x7fff7fff;               // WinRowState::uv of a lane without a usable projection
-
-// The operand slab of a wavefront.  f32 Gram: the layout of sweep_parts.h (64 pixels, 4224 B).  f16 Gram: one 80-byte row per
-// pixel -- 16 halfs "hi", 16 halfs "lo", 16 B of padding (conflict-free 16-byte stores: 80 i mod 128 are eight distinct 16-byte
-// slots) -- for 32 pixels = one matrix instruction's worth (K = 32): the two half rows of a wavefront's row take turns (2560 B per
-// wavefront instead of 5120: with the window that is 29.4 KB per workgroup, five workgroups per compute unit instead of four).
-constexpr int kHalfRow = 40;                            // halfs per pixel row
-constexpr int kSlabFloatsF16 = 32 * kHalfRow / 2;       // 640 floats = 2560 B (>= the 512 floats the Gram matrices need at the end)
-constexpr float kResidualScale = 256.0f;                // the two residual components are lifted out of the f16 subnormal range
 
 typedef short __attribute__((ext_vector_type(2))) i16x2;
 
@@ -65,75 +57,9 @@ struct WinRowState {                                    // what phase A leaves f
   int uv;                                               // u0 | v0 << 16 of tap (u0, v0); kNoProjection: no usable projection
 };
 
-typedef _Float16 __attribute__((ext_vector_type(8))) f16x8;
-typedef __fp16 __attribute__((__vector_size__(4 * sizeof(__fp16)))) fp16x4;
-typedef __fp16 __attribute__((ext_vector_type(2))) fp16x2;
-typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
-
-// v = hi + lo with hi, lo in f16; two components per call, packed as the two halves of a register.  hi is rounded toward zero (it
-// saturates at the largest f16 instead of becoming infinite), lo = f16(v - hi) with the subtraction exact in f32:
-// v_fma_mix_f32 reads the f16 half of `hi` directly and subtracts in f32 (the compiler emits a conversion and a subtraction
-// unless it can fold a multiplication in); the two differences are packed with round toward zero as well.
-// Range: a component beyond +-65504 saturates hi and the sum no longer represents it; the epilogue detects that from the diagonal
-// of H H^T (kF16RangeSquared) and the batch is repeated with the f32 Gram (capi.hip, counter "f16_range_repeats").
-// (seven pairs at a time, each step for all pairs before the next: an instruction never waits for the one right before it)
-__device__ __forceinline__ void split_pairs(const float (&v)[14], unsigned (&hi)[7], unsigned (&lo)[7]) {
-#pragma unroll
-  for (int k = 0; k < 7; ++k) hi[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * k], v[2 * k + 1]));
-  // (measured: v_fma_mixlo_f16 / v_fma_mixhi_f16 would write the rounded low parts straight into the halves of one register -- 14
-  // instructions instead of 21 -- but the sweep runs 1.7 % SLOWER with them than with v_fma_mix_f32 + v_cvt_pkrtz: scripts/ab_sweep.py)
-  float ra[7], rb[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(ra[k]) : "v"(v[2 * k]), "v"(hi[k]));
-#pragma unroll
-  for (int k = 0; k < 7; ++k) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb[k]) : "v"(v[2 * k + 1]), "v"(hi[k]));
-#pragma unroll
-  for (int k = 0; k < 7; ++k) lo[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra[k], rb[k]));
-}
-constexpr float kF16RangeSquared = 65504.0f * 65504.0f;
-
-// matrix operand of 32 pixels (k index) x 16 components from the pixel-major f16 image: lane (i = l & 15, g = l >> 4) gets the
-// eight k-values 8 g .. 8 g + 7 of component i (scripts/ubench/gram_f16.hip)
-__device__ __forceinline__ f16x8 read_operand_f16(const _Float16* img, int lane, int chunk32) {
-  const int i = lane & 15, gq = lane >> 4;
-  const _Float16* p0 = img + (chunk32 * 32 + 8 * gq + (i >> 2)) * kHalfRow + (i & 3) * 4;
-  const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p0);
-  const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p0 + 4 * kHalfRow));
-  return f16x8{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
-}
-
 // WAVES: wavefronts per workgroup (4: four rows each, 8: two rows each -- less projection state per lane, one wavefront per SIMD more).
 // F16: Gram accumulation on the f16 matrix pipe (variant 7).  COMPAT: the reference's x * rcp(z) in projection and weights with the
 // host CPU's reciprocal table (option "ref_compat", LevelGeom::rcp_table).
-// v_mul_legacy_f32: the multiply with 0 x anything = 0 (NaN and infinity included); the ordinary product otherwise
-__device__ __forceinline__ float mul_legacy(float a, float b) {
-  float r;
-  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// jacobian_rows_fast (pixel_math.h) for a lane that may be invalid: s = 0 there, and every product in which a term of that lane (NaN
-// where the reference point or a tap is a hole) meets a zero is v_mul_legacy_f32 -- 0 x anything = 0.  For a valid lane the legacy
-// multiply is the ordinary one.
-__device__ __forceinline__ void jacobian_rows_masked(const PixelTerms& t, float s, float tx, float ty, float cx, float cy, float* J0, float* J1) {
-  const float iz = fast_rcp(t.Z);
-  const float txy = tx * ty;
-  const float gix = mul_legacy(s, t.gix), giy = mul_legacy(s, t.giy);
-  const float gzx = mul_legacy(s, t.gzx), gzy = mul_legacy(s, t.gzy);
-  J0[0] = mul_legacy(gix, iz);
-  J0[1] = mul_legacy(giy, iz);
-  J0[2] = fmaf(-ty, J0[1], -tx * J0[0]);
-  J0[3] = fmaf(-giy, cy, -gix * txy);
-  J0[4] = fmaf(gix, cx, giy * txy);
-  J0[5] = fmaf(giy, tx, -gix * ty);
-  J1[0] = mul_legacy(gzx, iz);
-  J1[1] = mul_legacy(gzy, iz);
-  J1[2] = fmaf(-ty, J1[1], fmaf(-tx, J1[0], -s));
-  J1[3] = fmaf(-gzy, cy, fmaf(-gzx, txy, -mul_legacy(s, t.Y)));
-  J1[4] = fmaf(gzx, cx, fmaf(gzy, txy, mul_legacy(s, t.X)));
-  J1[5] = fmaf(gzy, tx, -gzx * ty);
-}
-
 template <bool F16, bool COMPAT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_sweep_window(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
@@ -354,47 +280,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32v2, rr2), resid, off_px, v_r * row_bytes, 0);
     }
     if constexpr (F16) {
-      typedef volatile __attribute__((address_space(3))) u32x4* LdsQuadPtr;   // volatile: the stores stay where they are written
-      LdsQuadPtr hw = (LdsQuadPtr)(reinterpret_cast<char*>(my) + (lane_c & 31) * (kHalfRow * 2));
-      const bool low_half = lane_c < 32;
       // No branch on `valid`: an invalid lane's weight is zero and every product that could meet one of its NaN terms is a LEGACY
       // multiply (0 x anything = 0), so its operand rows are zeros without a second control-flow path (14 zero moves, the exec
       // juggling and the register shuffles where the two paths met: about 30 instructions per row)
       const float sw_any = first ? 1.0f : COMPAT ? tdist_weight_sqrt_compat(g.rcp_table, g.rcp_shift, o.r0, o.r1, st.P_prev) : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
-      const float sw = valid ? sw_any : 0.0f;
-      float J0[6], J1[6];
-      jacobian_rows_masked(o, sw, tx_u, ty_p, cx_u, fmaf(ty_p, ty_p, 1.0f), J0, J1);
-      const float sr = sw * kResidualScale;
-      unsigned hh[7], ll[7];
-      const float comps[14] = {J0[0], J0[1], J0[2], J0[3], J0[4], J0[5], J1[0], J1[1], J1[2], J1[3], J1[4], J1[5], mul_legacy(sr, o.r0), mul_legacy(sr, o.r1)};
-      split_pairs(comps, hh, ll);
-      const u32x4 h0 = {hh[0], hh[1], hh[2], hh[3]}, h1 = {hh[4], hh[5], hh[6], 0u};
-      const u32x4 l0 = {ll[0], ll[1], ll[2], ll[3]}, l1 = {ll[4], ll[5], ll[6], 0u};
-      if (low_half) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }
-      const _Float16* img = reinterpret_cast<const _Float16*>(my);
-      // pixels 0..31 of the row: the slab is private to the wavefront and LDS executes a wavefront's operations in order, so the
-      // reads below follow the stores above, and the stores of the second half follow the reads -- only the compiler is fenced
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      {
-        const f16x8 h = read_operand_f16(img, lane_c, 0), l = read_operand_f16(img + 16, lane_c, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, h, acc0, 0, 0, 0);      // H H^T
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, l, acc1, 0, 0, 0);      // S = H L^T ; G = H H^T + S + S^T
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (!low_half) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      {
-        const f16x8 h = read_operand_f16(img, lane_c, 0), l = read_operand_f16(img + 16, lane_c, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, h, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, l, acc1, 0, 0, 0);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      gram_f16_row(my, lane_c, o, valid ? sw_any : 0.0f, tx_u, ty_p, cx_u, acc0, acc1);
       continue;
     }
     if (valid) {
@@ -426,30 +316,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
   }
 
   if constexpr (F16) {
-    // G = H H^T + S + S^T, entry (row, col) of lane l, register i: row = (l >> 4) * 4 + i, col = l & 15; S^T through the slab.
-    // The two residual components (12, 13) carry the factor kResidualScale.
-#pragma unroll
-    for (int i = 0; i < 4; ++i) my[256 + ((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc1[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int col = lane & 15;
-    if (f16_range_flag) {
-      // a component beyond the f16 range saturated its high part at +-65504: that pixel alone puts 65504^2 on the diagonal of H H^T
-      // (sums of squares: nothing cancels), and no entry of a Gram matrix exceeds its largest diagonal entry -- so the largest
-      // magnitude of ANY entry tells.  Not-a-number counts as out of range.
-      const float largest = fmaxf(fmaxf(fabsf(acc0[0]), fabsf(acc0[1])), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
-      const bool out_of_range = !(largest < kF16RangeSquared) || acc0[0] != acc0[0] || acc0[1] != acc0[1] || acc0[2] != acc0[2] || acc0[3] != acc0[3];
-      if (__ballot(out_of_range) != 0 && lane == 0) __hip_atomic_store(f16_range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    const float cs = col >= 12 ? 1.0f / kResidualScale : 1.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (lane >> 4) * 4 + i;
-      const float rsc = row >= 12 ? 1.0f / kResidualScale : 1.0f;
-      const float st = my[256 + col * 16 + row];
-      my[row * 16 + col] = ((acc0[i] + acc1[i]) + st) * (cs * rsc);
-    }
+    gram_f16_finish(my, lane, acc0, acc1, f16_range_flag);
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];

@@ -169,8 +169,8 @@ def test_f16_gram_range_guard_repeats_with_the_f32_gram():
 
 
 def test_window_sweep_whole_matches_and_plane_flavours():
-    """Whole matches on the three schedules (5: gathered taps; 6: window, f32 Gram -- identical records; 7: window, f16 Gram -- the
-    same iteration structure, transforms within 1e-9), and the two flavours of the current role: frames ingested in a batch too large
+    """Whole matches on the three schedules (5: gathered taps; 6: window, f32 Gram -- identical records; 7: f16 Gram on every level --
+    the same iteration structure up to one step on a level, transforms within 2e-7), and the two flavours of the current role: frames ingested in a batch too large
     for the resident kernel carry only the 8-byte plane C at the window levels; the taps A + B (a plane download, a small batch that
     runs the level resident) and the reference role (point selection) are derived from it on demand, bit-identically."""
     w, h, levels = 640, 480, 4
@@ -186,8 +186,12 @@ def test_window_sweep_whole_matches_and_plane_flavours():
         d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0), ctx).match(gref, gcur, r)
         res[v] = r
     assert np.array_equal(res[5].Transformation, res[6].Transformation) and np.array_equal(res[5].Information, res[6].Information)
-    assert [len(L.Iterations) for L in res[5].Statistics.Levels] == [len(L.Iterations) for L in res[7].Statistics.Levels]
-    assert cm.twist_matrix_error(res[5].Transformation, res[7].Transformation) < 1e-9
+    # (the f16 Gram differs from the f32 one in the 7th digit of the normal equations: a termination test on the edge may fall the
+    # other way on some level, the transforms agree far below the tracker's precision)
+    its5, its7 = ([len(L.Iterations) for L in res[v].Statistics.Levels] for v in (5, 7))
+    print("iterations per level: variant 5 %s, variant 7 %s; twist distance %.2e" % (its5, its7, cm.twist_matrix_error(res[5].Transformation, res[7].Transformation)))
+    assert all(abs(a - b) <= 1 for a, b in zip(its5, its7))
+    assert cm.twist_matrix_error(res[5].Transformation, res[7].Transformation) < 2e-7
     # flavours: 300 frames ingested as current frames in ONE call (> compute units: plane C only at levels 0 and 1)
     ctx = d.Context(0)
     cfg = d.Config(FirstLevel=3, LastLevel=0)
