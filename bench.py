@@ -37,7 +37,8 @@ ALGO_BYTES_PER_PIXEL = 40.0          # SURVEY.md section 8d's ALGORITHMIC bytes:
                                      # What the shipped sweep MOVES is less (reference {Zsel, I} 8 B + current {I, Z} 8 B x the staged
                                      # window's halo, read; 8 B residual pair written): reported beside it as roofline.moved_bytes_per_pixel
 PCIE_PEAK_GBPS = 63.0                # PCIe Gen5 x16, spec (MI355X_MICROARCH.md "Host link")
-BACKGROUND_BUILD_WORKGROUPS = 0      # cap on the workgroups of background build kernels: measured, no gain (profiles/r01_i_overlap.txt)
+BACKGROUND_BUILD_WORKGROUPS = 256    # cap on the workgroups of background build kernels (library option build_workgroups): one per compute unit --
+                                     # with the strip ingest the alignment's short kernels get through beside it (r03: 14.23 -> 13.77 ms per step)
 HBM_PEAK_GBPS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 

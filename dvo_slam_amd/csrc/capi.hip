@@ -473,6 +473,10 @@ int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int le
   if (level_uses_window(ctx, cam->w[level], cam->h[level])) return 4;
   if (ctx->opt_deterministic) return ctx->opt_rows_per_wave > 0 ? ctx->opt_rows_per_wave : 4;   // one tile height whatever the batch
   if (ctx->opt_rows_per_wave > 0) return ctx->opt_rows_per_wave;
+  // A large batch fills the device whatever the tile: short tiles (2 rows per wavefront: the schedule with the pinned prologue) run the
+  // coarse levels' sweeps 6-11 % faster than tall ones since the f16 Gram (scripts/ab_sweep.py: 1024 pairs, 160x120 0.200 -> 0.187 ms,
+  // 80x60 0.056 -> 0.050 ms; bench step 14.22 -> 13.89 ms)
+  if (n_pairs >= 256 && ctx->opt_variant == 7) return 2;
   const int candidates[4] = {8, 4, 2, 1};   // measured (profiles/r01_c_tile_sweep.txt): 8 rows is at or near the optimum on every level
   // The tallest tile that still yields this many workgroups.  Fewer, taller tiles also mean fewer partial rows for the
   // bookkeeping kernel, which matters most when there are few pairs (whole-match timings: profiles/r01_f_tile_heuristic.txt).
