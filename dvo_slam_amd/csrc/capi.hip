@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -121,6 +122,19 @@ __global__ void k_copy_table(unsigned long long* __restrict__ dst, const unsigne
   if (i < n8) dst[i] = src[i];
 }
 
+// Waiting for a stream on the paths where the wait is part of a match's or a frame's latency: polling keeps the thread on its core
+// instead of parking it in the driver; a wait that lasts longer than 20 ms falls back to the sleeping kind.
+hipError_t sync_stream(hipStream_t s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1;; ++spins) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return hipSuccess;
+    if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();   // "still running" is not an error to keep
+    if (q != hipErrorNotReady) return q;
+    if ((spins & 0xff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipStreamSynchronize(s);
+  }
+}
+
 struct PinnedRing {
   static const int kSlots = 48;
   char* base = nullptr;
@@ -200,6 +214,7 @@ struct Workspace {
   // thread reads as soon as the kernel has counted the pairs done (no copy command, no stream synchronisation)
   PinnedBuf direct_results, direct_levels, direct_iters, direct_done;
   bool needs_drain = false;        // a batch ended early: the stream is drained before buffers are reused
+  bool device_may_lag = true;      // the last batch returned without waiting for the stream (the resident kernel's direct path)
   int resident_error_word = 0;     // index of the current resident launch's error word in host_status (a ring, see kResidentErrorWords)
   unsigned resident_launch_counter = 0;
 };
@@ -214,6 +229,22 @@ struct dvo_hip_context {
   std::string err;
   int opt_rows_per_wave = 0;
   int opt_iters_per_sync = 0;
+  // Rendezvous of single-pair matches (dvo_hip_match): the reference's LocalTracker aligns every new image against two reference
+  // frames from two threads at once (tbb::parallel_invoke, dvo_slam/src/local_tracker.cpp:180-184).  Two such calls with the same
+  // current frame and the same configuration leave as ONE two-pair batch (one resident launch: 0.19 ms for both instead of 2 x 0.18
+  // one after the other).  A caller waits for a partner only on a context where concurrent callers have been seen.
+  struct MatchRequest {
+    dvo_hip_frame* reference; dvo_hip_frame* current; const dvo_hip_config* cfg; dvo_hip_result* result;
+    dvo_hip_level_stats* levels; int cap_levels; dvo_hip_iteration_stats* iters; int cap_iters;
+    std::atomic<int> state{0};       // 0: waiting for a partner, 1: taken by one, 2: done (rc valid)
+    int rc = 0;
+  };
+  std::mutex rendezvous_mutex;
+  MatchRequest* rendezvous_waiting = nullptr;
+  dvo_hip_frame* rendezvous_busy_current = nullptr;   // the current frame of the single-pair match that is running right now (null: none)
+  int rendezvous_expect = 0;          // > 0: a lone caller waits (briefly) for a partner; refreshed whenever two callers met or collided
+  int opt_rendezvous = 1;
+  long long rendezvous_pairs = 0;     // two-pair batches formed (counter "rendezvous_pairs")
   long long f16_range_repeats = 0; // batches repeated with the f32 Gram because a Jacobian left the f16 range (counter "f16_range_repeats")
   long long strip_ingests = 0;     // frames ingested by the strip kernel (ingest_strips.hip), counter "strip_ingests"
   int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
@@ -668,6 +699,54 @@ int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int 
     *tbl = up;
     return DVO_HIP_OK;
   };
+  // Several levels, every frame missing the same planes on each of them, all to be derived from the float planes I / Z (a camera
+  // frame that has just been built): ONE launch for all levels (k_derive_levels) instead of a table upload, a counter reset and a
+  // launch per level.
+  if (l1 > l0) {
+    LevelSpan span;
+    span.l0 = l0; span.l1 = l1;
+    bool uniform = true;
+    for (int i = 0; i < n && uniform; ++i)
+      for (int j = 0; j < i && uniform; ++j) uniform = frames[i] != frames[j];        // (a frame listed twice: the general path skips its second visit)
+    if (n > 64) uniform = false;                                                        // (the check above is quadratic; large batches come through the ingest)
+    int tiles = 0;
+    for (int l = l0; l <= l1 && uniform; ++l) {
+      const int want = role == 0 ? (cur_want ? cur_want[l] : kCurAB) & (frames[0]->lv[l].C ? (kCurAB | kCurC) : kCurAB) : 0;
+      int miss_all = -1;
+      for (int i = 0; i < n && uniform; ++i) {
+        dvo_hip_frame* f = frames[i];
+        const FrameLevel& L = f->lv[l];
+        const int miss = role == 0 ? want & ~L.cur_have : 0;
+        const bool need = role == 0 ? miss != 0 : !(L.selected && L.ithr == ithr && L.dthr == dthr);
+        uniform = need && !(l == 0 && f->raw0) && (role == 1 || L.cur_have == 0) && (miss_all < 0 || miss == miss_all);
+        miss_all = miss;
+      }
+      span.w[l] = cam->w[l]; span.h[l] = cam->h[l]; span.flavor[l] = miss_all;
+      span.tile0[l] = tiles;
+      tiles += ((cam->w[l] + 63) / 64) * ((cam->h[l] + 15) / 16);
+    }
+    span.tile0[l1 + 1] = tiles;
+    if (uniform) {
+      std::vector<FrameBuildPtrs> host(n);
+      for (int i = 0; i < n; ++i) fill_build_ptrs(frames[i], host[i]);
+      const FrameBuildPtrs* tbl = nullptr;
+      const int rc = upload(host, &tbl);
+      if (rc != DVO_HIP_OK) return rc;
+      launch_derive_levels(stream, tbl, n, span, role, ithr, dthr, cap);
+      for (int i = 0; i < n; ++i)
+        for (int l = l0; l <= l1; ++l) {
+          FrameLevel& L = frames[i]->lv[l];
+          if (role == 0) L.cur_have |= span.flavor[l];
+          else { L.selected = true; L.ithr = ithr; L.dthr = dthr; }
+        }
+      if (eager) {
+        const int rc2 = stamp_build(ctx, n, frames);
+        if (rc2 != DVO_HIP_OK) return rc2;
+      }
+      DVO_HIP_TRY(ctx, hipGetLastError());
+      return DVO_HIP_OK;
+    }
+  }
   for (int l = l0; l <= l1; ++l) {
     const int want = role == 0 ? (cur_want ? cur_want[l] : kCurAB) & (frames[0]->lv[l].C ? (kCurAB | kCurC) : kCurAB) : 0;
     // sources, per frame: float planes I / Z (levels >= 1, and level 0 of frames created from float planes); at level 0 of a frame
@@ -1091,11 +1170,22 @@ int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, 
   return DVO_HIP_OK;
 }
 
+hipEvent_t g_trace_ev[2] = {nullptr, nullptr};   // DVO_HIP_TRACE_SLOW: device time stamps around a batch's preparation
+
 // The coarse-to-fine Gauss-Newton driver of a batch (dense_tracking.cpp:131-376 for every pair at once).
 int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
               dvo_hip_result* results, dvo_hip_level_stats* levels, int cap_levels, dvo_hip_iteration_stats* iters, int cap_iters) {
   Workspace& w = ctx->ws[0];
   hipStream_t s = w.stream;
+  // DVO_HIP_TRACE_SLOW=<ms>: where the host thread spent the time before the first launch of a batch whose preparation took longer
+  static const double trace_slow_ms = std::getenv("DVO_HIP_TRACE_SLOW") ? std::atof(std::getenv("DVO_HIP_TRACE_SLOW")) : 0.0;
+  double mark_ms[5] = {0, 0, 0, 0, 0};
+  auto mark = [&](int k) { if (trace_slow_ms > 0.0) mark_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->batch_entry).count(); };
+  mark(0);                                                     // roles ensured (dvo_hip_match_batch)
+  if (trace_slow_ms > 0.0) {
+    if (!g_trace_ev[0]) { (void)hipEventCreate(&g_trace_ev[0]); (void)hipEventCreate(&g_trace_ev[1]); }
+    (void)hipEventRecord(g_trace_ev[0], s);
+  }
   BatchPlan bp;
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
   // The coarse levels -- for a small batch every level -- run inside ONE launch (align_resident.hip): no launch per iteration, no
@@ -1104,6 +1194,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   const bool tables_inline = rp.direct && n <= kResidentInline;   // plane pointers and initial guesses travel as kernel arguments
   int rc = prepare_buffers(w, cfg, refs, curs, bp, !tables_inline);
   if (rc != DVO_HIP_OK) return rc;
+  mark(1);
 
   // initial guesses (Result.Transformation is in/out, dense_tracking.cpp:137-147)
   std::vector<double> tinit(size_t(n) * 16);
@@ -1113,16 +1204,30 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   const size_t n_steps = size_t(bp.cap_iters) + 8 + kResidentErrorWords;
   // a batch that ended early (time-out, HIP error) may have left steps queued: nothing of it may still be running when the
   // status words and tallies are reset
-  if (w.needs_drain) DVO_WS_TRY(w, hipStreamSynchronize(s));
+  if (w.needs_drain) DVO_WS_TRY(w, sync_stream(s));
   w.needs_drain = true;                                        // until this batch has come to its regular end
+  mark(2);
   rc = ensure_host_status(w, n_steps);
   if (rc != DVO_HIP_OK) return rc;
+  mark(3);
   w.resident_error_word = int(w.resident_launch_counter++ % kResidentErrorWords);
   if (rp.direct) {
     w.host_status[w.resident_error_word] = 0;
   } else {
     // (the previous batch may have ended on the host's side before the device was through with the step words: the direct path)
-    DVO_WS_TRY(w, hipStreamSynchronize(s));
+    // (only then: a batch that ended with a stream wait left nothing behind, and a wait for the table uploads just enqueued has been
+    // seen to return 14-24 ms after the device was done with them -- 19 microseconds by its own time stamps: r03, the validator's
+    // 128-pair batches in the first process on a box, never under the profiler)
+    if (trace_slow_ms > 0.0) (void)hipEventRecord(g_trace_ev[1], s);
+    if (w.device_may_lag) DVO_WS_TRY(w, sync_stream(s));
+    w.device_may_lag = false;
+    if (trace_slow_ms > 0.0) {
+      mark(4);
+      float gpu_ms = -1.0f;
+      if (mark_ms[4] - mark_ms[3] > trace_slow_ms && hipEventElapsedTime(&gpu_ms, g_trace_ev[0], g_trace_ev[1]) == hipSuccess)
+        std::fprintf(stderr, "dvo_hip: the stream wait took %.3f ms on the host; on the device %.3f ms passed between the batch's first and last command so far\n",
+                     mark_ms[4] - mark_ms[3], gpu_ms);
+    }
     std::memset(w.host_status, 0, n_steps * sizeof(int));
     DVO_WS_TRY(w, hipMemsetAsync(w.counters.p, 0, n_steps * sizeof(unsigned long long), s));
   }
@@ -1137,6 +1242,10 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   const int per_level = cfg->max_iterations_per_level;
   const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 1;
   int step = kResidentErrorWords;                           // the first status words belong to the resident kernel's launches
+  mark(4);
+  if (trace_slow_ms > 0.0 && mark_ms[4] > trace_slow_ms)
+    std::fprintf(stderr, "dvo_hip: slow preparation of a %d-pair batch: roles %.3f, plan + buffers + tables %.3f, initial guesses + drain %.3f, status words %.3f, "
+                 "stream wait + reset %.3f ms\n", n, mark_ms[0], mark_ms[1] - mark_ms[0], mark_ms[2] - mark_ms[1], mark_ms[3] - mark_ms[2], mark_ms[4] - mark_ms[3]);
   const auto t_launch = std::chrono::steady_clock::now();
   int level_from = cfg->first_level;
   const bool want_stats = (levels && cap_levels > 0) || (iters && cap_iters > 0);
@@ -1208,6 +1317,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // word -- no copy command, no stream synchronisation on the way out
     t_enqueued = std::chrono::steady_clock::now();
     rc = wait_for_direct(w, n);
+    w.device_may_lag = true;
     if (rc != DVO_HIP_OK) return rc;
     t_done = std::chrono::steady_clock::now();
     if (w.host_status[w.resident_error_word] == 0) {
@@ -1215,7 +1325,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       if (levels && cap_levels > 0) hl_src = w.direct_levels.as<dvo_hip_level_stats>();
       if (iters && cap_iters > 0) hi_src = w.direct_iters.as<dvo_hip_iteration_stats>();
     } else {
-      DVO_WS_TRY(w, hipStreamSynchronize(s));                  // every group has to be gone before the batch is repeated
+      DVO_WS_TRY(w, sync_stream(s));                           // every group has to be gone before the batch is repeated
     }
   } else {
     if (level_from >= cfg->last_level) launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());   // else: done by the resident launch
@@ -1231,7 +1341,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       hi_src = hi.data();
     }
     t_enqueued = std::chrono::steady_clock::now();
-    DVO_WS_TRY(w, hipStreamSynchronize(s));
+    DVO_WS_TRY(w, sync_stream(s));
     DVO_WS_TRY(w, hipGetLastError());
     t_done = std::chrono::steady_clock::now();
   }
@@ -1304,7 +1414,7 @@ int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_
   if (rc != DVO_HIP_OK) return rc;
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
   rc = prepare_buffers(ctx->ws[0], cfg, refs, curs, bp);
-  if (rc == DVO_HIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = DVO_HIP_ERR_HIP;
+  if (rc == DVO_HIP_OK && sync_stream(ctx->stream) != hipSuccess) rc = DVO_HIP_ERR_HIP;
   if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
   return rc;
 }
@@ -1327,6 +1437,10 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
     *value = (long long)v;
   }
   else if (std::strcmp(key, "strip_ingests") == 0) *value = ctx->strip_ingests;
+  else if (std::strcmp(key, "rendezvous_pairs") == 0) {
+    std::lock_guard<std::mutex> lock(ctx->rendezvous_mutex);
+    *value = ctx->rendezvous_pairs;
+  }
   else if (std::strcmp(key, "f16_range_repeats") == 0) *value = ctx->f16_range_repeats;
   else if (std::strcmp(key, "host_batches") == 0) *value = ctx->host_batches;
   else if (std::strcmp(key, "host_ns_prepare") == 0) *value = ctx->host_ns[0];
@@ -1480,6 +1594,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     ctx->opt_variant = value;
     return DVO_HIP_OK;
   }
+  if (std::strcmp(key, "rendezvous") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "rendezvous must be 0 or 1");
+    ctx->opt_rendezvous = value;
+    return DVO_HIP_OK;
+  }
   if (std::strcmp(key, "deterministic") == 0) {
     if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "deterministic must be 0 or 1");
     ctx->opt_deterministic = value;
@@ -1555,7 +1674,7 @@ int dvo_hip_frame_create_f32(dvo_hip_context* ctx, int width, int height, const 
   if (e == hipSuccess) e = hipMemsetAsync(f->sel_count, 0, sizeof(int) * kMaxLevels, ctx->build_stream);
   if (e == hipSuccess) {
     rc = frames_build(ctx, 1, &f, nullptr, nullptr, 0.0f);
-    if (rc == DVO_HIP_OK) e = hipStreamSynchronize(ctx->build_stream);   // the caller's host buffers may go away
+    if (rc == DVO_HIP_OK) e = sync_stream(ctx->build_stream);   // the caller's host buffers may go away
   }
   if (e != hipSuccess) ctx->err = std::string("frame_create_f32: ") + hipGetErrorString(e);
   if (e != hipSuccess || rc != DVO_HIP_OK) {
@@ -1585,7 +1704,7 @@ int dvo_hip_frame_create_raw(dvo_hip_context* ctx, int width, int height, const 
     const void* g[1] = {d_grey};
     const void* r[1] = {d_raw};
     rc = frames_build(ctx, 1, &f, g, r, depth_scale);
-    if (rc == DVO_HIP_OK) e = hipStreamSynchronize(ctx->build_stream);
+    if (rc == DVO_HIP_OK) e = sync_stream(ctx->build_stream);
   }
   if (e != hipSuccess) ctx->err = std::string("frame_create_raw: ") + hipGetErrorString(e);
   if (e != hipSuccess || rc != DVO_HIP_OK) {
@@ -1890,9 +2009,101 @@ int dvo_hip_match_batch(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const*
 
 int dvo_hip_match(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame* current, const dvo_hip_config* cfg,
                   dvo_hip_result* result, dvo_hip_level_stats* levels, int cap_levels, dvo_hip_iteration_stats* iters, int cap_iters) {
-  dvo_hip_frame* r[1] = {reference};
-  dvo_hip_frame* c[1] = {current};
-  return dvo_hip_match_batch(ctx, 1, r, c, cfg, result, levels, cap_levels, iters, cap_iters);
+  auto alone = [&]() {
+    dvo_hip_frame* r[1] = {reference};
+    dvo_hip_frame* c[1] = {current};
+    return dvo_hip_match_batch(ctx, 1, r, c, cfg, result, levels, cap_levels, iters, cap_iters);
+  };
+  if (!ctx || !reference || !current || !cfg || !result || !ctx->opt_rendezvous) return alone();
+  typedef dvo_hip_context::MatchRequest Request;
+  constexpr int kExpectCalls = 64;                             // lone calls that still wait after the last meeting / collision
+  constexpr auto kPartnerWait = std::chrono::microseconds(60);
+  Request me;
+  me.reference = reference; me.current = current; me.cfg = cfg; me.result = result;
+  me.levels = levels; me.cap_levels = cap_levels; me.iters = iters; me.cap_iters = cap_iters;
+  Request* partner = nullptr;
+  bool waiting = false;
+  {
+    std::lock_guard<std::mutex> lock(ctx->rendezvous_mutex);
+    Request* w = ctx->rendezvous_waiting;
+    if (w && w->current == current && std::memcmp(w->cfg, cfg, sizeof(*cfg)) == 0) {
+      partner = w;
+      ctx->rendezvous_waiting = nullptr;
+      w->state.store(1, std::memory_order_release);
+      ctx->rendezvous_expect = kExpectCalls;
+    } else if (ctx->rendezvous_busy_current == current) {
+      ctx->rendezvous_expect = kExpectCalls;                   // a collision: the other caller of this frame is already on the device
+    } else if (!w && ctx->rendezvous_expect > 0) {
+      ctx->rendezvous_expect -= 1;
+      ctx->rendezvous_waiting = &me;
+      waiting = true;
+    }
+  }
+  if (partner) {
+    // this thread runs both: the partner's pair first (it arrived first), one batch, statistics through a common stride
+    dvo_hip_frame* r[2] = {partner->reference, reference};
+    dvo_hip_frame* c[2] = {partner->current, current};
+    dvo_hip_result res[2] = {*partner->result, *result};
+    const bool want_levels = (partner->levels && partner->cap_levels > 0) || (levels && cap_levels > 0);
+    const bool want_iters = (partner->iters && partner->cap_iters > 0) || (iters && cap_iters > 0);
+    const int cl = want_levels ? cfg->first_level - cfg->last_level + 1 : 0;
+    const int ci = want_iters ? cl * std::max(cfg->max_iterations_per_level, 1) : 0;
+    std::vector<dvo_hip_level_stats> lv(size_t(2) * std::max(cl, 0));
+    std::vector<dvo_hip_iteration_stats> it(size_t(2) * std::max(ci, 0));
+    int rc = dvo_hip_match_batch(ctx, 2, r, c, cfg, res, want_levels ? lv.data() : nullptr, cl, want_iters ? it.data() : nullptr, ci);
+    Request* both[2] = {partner, &me};
+    int rcs[2] = {rc, rc};
+    for (int k = 0; k < 2; ++k) {
+      Request* q = both[k];
+      if (rc != DVO_HIP_OK && rc != DVO_HIP_ERR_CAPACITY) continue;
+      *q->result = res[k];
+      rcs[k] = DVO_HIP_OK;
+      if (q->levels && q->cap_levels > 0) {
+        const int nl = std::min(res[k].n_levels, std::min(q->cap_levels, cl));
+        std::memcpy(q->levels, lv.data() + size_t(k) * cl, size_t(std::max(nl, 0)) * sizeof(dvo_hip_level_stats));
+        if (res[k].n_levels > q->cap_levels) rcs[k] = DVO_HIP_ERR_CAPACITY;
+      }
+      if (q->iters && q->cap_iters > 0) {
+        const int ni = std::min(res[k].n_iterations_total, std::min(q->cap_iters, ci));
+        std::memcpy(q->iters, it.data() + size_t(k) * ci, size_t(std::max(ni, 0)) * sizeof(dvo_hip_iteration_stats));
+        if (res[k].n_iterations_total > q->cap_iters) rcs[k] = DVO_HIP_ERR_CAPACITY;
+      }
+    }
+    {
+      std::lock_guard<std::mutex> lock(ctx->rendezvous_mutex);
+      ctx->rendezvous_pairs += 1;
+    }
+    partner->rc = rcs[0];
+    partner->state.store(2, std::memory_order_release);
+    return rcs[1];
+  }
+  if (waiting) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (me.state.load(std::memory_order_acquire) == 0) {
+      if (std::chrono::steady_clock::now() - t0 > kPartnerWait) {
+        std::lock_guard<std::mutex> lock(ctx->rendezvous_mutex);
+        if (ctx->rendezvous_waiting == &me) {
+          ctx->rendezvous_waiting = nullptr;
+          waiting = false;                                     // nobody came: alone after all
+        }
+        break;                                                 // (else: taken in this very moment)
+      }
+    }
+    if (waiting) {
+      while (me.state.load(std::memory_order_acquire) != 2) std::this_thread::yield();   // the partner's thread runs the batch
+      return me.rc;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lock(ctx->rendezvous_mutex);
+    ctx->rendezvous_busy_current = current;
+  }
+  const int rc = alone();
+  {
+    std::lock_guard<std::mutex> lock(ctx->rendezvous_mutex);
+    if (ctx->rendezvous_busy_current == current) ctx->rendezvous_busy_current = nullptr;
+  }
+  return rc;
 }
 
 int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame* current, int level, float ithr,

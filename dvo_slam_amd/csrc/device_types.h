@@ -77,6 +77,14 @@ struct FrameBuildPtrs {                // one frame of a batched pyramid build
   int* sel_count;                      // one counter per level
 };
 
+// several pyramid levels of one camera for a launch that covers them all (k_derive_levels): 64 x 16 tiles, level l's tiles of a frame
+// are tile0[l] .. tile0[l + 1] - 1
+struct LevelSpan {
+  int l0, l1;
+  int w[kMaxLevels], h[kMaxLevels], flavor[kMaxLevels];
+  int tile0[kMaxLevels + 1];
+};
+
 struct SE3d {
   double R[9];
   double t[3];

@@ -27,6 +27,9 @@ void launch_from_current_plane(hipStream_t s, const FrameBuildPtrs* tbl, int n_f
                                int max_workgroups);
 void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr,
                              int max_workgroups);
+// the role planes (role 0: current, flavours per level in span.flavor; role 1: reference) of the levels span.l0 .. span.l1 in one launch
+void launch_derive_levels(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, const LevelSpan& span, int role, float ithr, float dthr,
+                          int max_workgroups);
 void launch_select_pack(hipStream_t s, const float4* A, const float2* B, int n, float ithr, float dthr, float2* R, int* count, uint8_t* mask);
 void launch_unpack_plane(hipStream_t s, const float4* A, const float2* B, int n, int plane, float* out);
 

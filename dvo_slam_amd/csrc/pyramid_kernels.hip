@@ -348,6 +348,72 @@ __global__ void k_derive_reference(const FrameBuildPtrs* __restrict__ tbl, int l
   });
 }
 
+// The role planes of SEVERAL pyramid levels of a set of frames in one launch (a single camera frame: levels 1-3 are 6000 pixels
+// together; one launch per level, each with its table upload and counter reset, is 9-12 launches of 4 microseconds of work and 8 of
+// launch latency each -- the largest item of a tracking front end's frame after the match itself).  Same arithmetic as
+// k_derive_current / k_derive_reference (derive_at): bit-identical planes.  A workgroup takes a 64 x 16 tile of one level of one frame.
+// ROLE 0: current (flavour per level: LevelSpan::flavor), ROLE 1: reference (counters of the levels zeroed before).
+template <int ROLE>
+__global__ __launch_bounds__(256) void k_derive_levels(const FrameBuildPtrs* __restrict__ tbl, const LevelSpan span, int n_frames, float ithr, float dthr) {
+  __shared__ int wave_counts[4];
+  const int per_frame = span.tile0[span.l1 + 1], total = per_frame * n_frames;
+  for (int gi = blockIdx.x; gi < total; gi += gridDim.x) {
+    const int frame = gi / per_frame, t = gi - frame * per_frame;
+    int level = span.l0;
+    while (level < span.l1 && t >= span.tile0[level + 1]) ++level;
+    const int w = span.w[level], h = span.h[level], tiles_x = (w + 63) / 64;
+    const int tile = t - span.tile0[level], bx = tile % tiles_x, by = tile / tiles_x;
+    const FrameBuildPtrs& f = tbl[frame];
+    const auto I = global_ptr<const float>(f.I[level]);
+    const auto Z = global_ptr<const float>(f.Z[level]);
+    const auto A = global_ptr(f.A[level]);
+    const auto B = global_ptr(f.B[level]);
+    const auto C = global_ptr(f.C[level]);
+    const auto R = global_ptr(f.R[level]);
+    const int flavor = span.flavor[level];
+    const int x = bx * 64 + threadIdx.x;
+    int count = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = (by * 4 + r) * 4 + threadIdx.y;
+      bool ok = false;
+      if (x < w && y < h) {
+        const size_t at = size_t(y) * w + x;
+        if (ROLE == 0 && flavor == kCurC) {                     // (uniform) only the {I, Z} pair: no neighbours to read
+          gstore(C + at, make_float2(I[at], Z[at]));
+        } else {
+          const Derivs d = derive_at(I, Z, w, h, x, y);
+          if (ROLE == 0) {
+            gstore(A + at, make_float4(d.i0, d.z0, d.idx, d.idy));
+            gstore(B + at, make_float2(d.zdx, d.zdy));
+            if (flavor & kCurC) gstore(C + at, make_float2(d.i0, d.z0));
+          } else {
+            ok = d.z0 == d.z0 && d.zdx == d.zdx && d.zdy == d.zdy &&
+                 (fabsf(d.idx) > ithr || fabsf(d.idy) > ithr || fabsf(d.zdx) > dthr || fabsf(d.zdy) > dthr);
+            gstore(R + at, make_float2(ok ? d.z0 : __builtin_nanf(""), d.i0));
+          }
+        }
+      }
+      if (ROLE == 1) count += __popcll(__ballot(ok));           // wave-uniform
+    }
+    if (ROLE == 1) {
+      if (threadIdx.x == 0) wave_counts[threadIdx.y] = count;
+      __syncthreads();
+      if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const int sum = (wave_counts[0] + wave_counts[1]) + (wave_counts[2] + wave_counts[3]);
+        if (sum) atomicAdd(f.sel_count + level, sum);
+      }
+      __syncthreads();                                          // wave_counts is rewritten by the next tile
+    }
+  }
+}
+
+__global__ void k_zero_counts_levels(const FrameBuildPtrs* __restrict__ tbl, int n_frames, int l0, int l1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_frames)
+    for (int l = l0; l <= l1; ++l) tbl[i].sel_count[l] = 0;
+}
+
 __global__ void k_zero_counts(const FrameBuildPtrs* __restrict__ tbl, int n_frames, int level) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_frames) tbl[i].sel_count[level] = 0;
@@ -429,6 +495,18 @@ void launch_from_current_plane(hipStream_t s, const FrameBuildPtrs* tbl, int n_f
   if (mode == 0) k_from_current_plane<0><<<grid, block, 0, s>>>(tbl, level, w, h, ithr, dthr, tx, ty, n_frames);
   else if (mode == 1) k_from_current_plane<1><<<grid, block, 0, s>>>(tbl, level, w, h, ithr, dthr, tx, ty, n_frames);
   else k_from_current_plane<2><<<grid, block, 0, s>>>(tbl, level, w, h, ithr, dthr, tx, ty, n_frames);
+}
+
+void launch_derive_levels(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, const LevelSpan& span, int role, float ithr, float dthr,
+                          int max_workgroups) {
+  const int total = span.tile0[span.l1 + 1] * n_frames;
+  const dim3 grid(max_workgroups > 0 && total > max_workgroups ? max_workgroups : total), block(64, 4);
+  if (role == 1) {
+    k_zero_counts_levels<<<dim3((n_frames + 63) / 64), dim3(64), 0, s>>>(tbl, n_frames, span.l0, span.l1);
+    k_derive_levels<1><<<grid, block, 0, s>>>(tbl, span, n_frames, ithr, dthr);
+  } else {
+    k_derive_levels<0><<<grid, block, 0, s>>>(tbl, span, n_frames, ithr, dthr);
+  }
 }
 
 void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr,

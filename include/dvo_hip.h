@@ -272,7 +272,12 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * workgroups -- the latency path; 0: one to three launches per Gauss-Newton step always; 1: every level
  * resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
  * pass; default 24), "resident_group" (workgroups per pair, a power of two <= 64; 0 = as many as fit the device),
- * "resident_cooperative" (1: groups are launched with hipLaunchCooperativeKernel), "resident_flags" (measurement / test hooks). */
+ * "resident_cooperative" (1: groups are launched with hipLaunchCooperativeKernel), "resident_flags" (measurement / test hooks). 
+ * "rendezvous" (default 1): two dvo_hip_match calls from two host threads with the SAME current frame and configuration -- the
+ * reference's LocalTracker, dvo_slam/src/local_tracker.cpp:180-184 -- leave as one two-pair batch: the second caller's thread runs
+ * it, the first waits at most 60 microseconds for a partner, and only on a context where concurrent callers have been seen
+ * (counter "rendezvous_pairs").  A pair's record in a two-pair batch can differ from the single match's in the last bits (another
+ * split of the sweep over workgroups), unless "deterministic" or a pinned "resident_group" makes records independent of the batch. */
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 
 /* Event counters of a context.  key: "resident_launches" (matches, or coarse-level runs, done by the resident kernel),
@@ -281,6 +286,7 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
  * "window_fallbacks" (lanes of the window sweep whose bilinear taps fell outside the staged window and were fetched from memory),
  * "f16_range_repeats" (batches that ran a second time with the f32 Gram because a Jacobian component of some pixel was beyond the f16
  * range of the default schedule's matrix operands, +-65504: depth steps of metres right in front of the camera),
+ * "rendezvous_pairs" (two-pair batches formed from concurrent single matches, see option "rendezvous"),
  * "strip_ingests" (frames whose raw planes went through the strip ingest, one 128 x 8 strip per wavefront -- even-width rows and
  * 4 / 8-byte aligned planes; the others take the tile kernel),
  * "host_batches" and "host_ns_prepare" / "host_ns_enqueue" / "host_ns_wait" / "host_ns_finish" (nanoseconds the calling thread spent

@@ -215,3 +215,70 @@ def test_contexts_of_two_host_threads_run_resident_side_by_side():
     assert sum(wk["bad"] for wk in workers) == 0
     assert sum(wk["ctx"].counter("resident_timeouts") for wk in workers) == 0
     assert all(wk["ctx"].counter("resident_launches") == 401 for wk in workers)
+
+
+def test_rendezvous_of_two_threads_on_one_current_frame(ctx):
+    """dvo_hip_match from two host threads with the SAME current frame -- the reference's LocalTracker (local_tracker.cpp:180-184:
+    tbb::parallel_invoke of the keyframe tracker's and the odometry tracker's match): once the context has seen the two collide, the
+    calls leave as one two-pair batch.  With a pinned group size a pair's record does not depend on the batch it is in: every result
+    equals the single-threaded one bit for bit, statistics included; the counter shows that pairs were formed."""
+    import ctypes as C
+    import threading
+    from dvo_slam_amd import _lib as L
+    lib = ctx._lib
+    b = datagen.synth_batch(21, 2, 640, 480)
+    cam = d.RgbdCameraPyramid(640, 480, b["K"], ctx)
+    cam.build(4)
+    refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(2)]
+    cur = cam.create_raw(b["grey_cur"][0], b["depth_cur"][0])
+    cfg_py = d.Config(FirstLevel=3, LastLevel=1, MaxIterationsPerLevel=50, Precision=1e-4, Mu=0.05, UseInitialEstimate=True)   # the front end's
+    for f in refs + [cur]:
+        f.build(cfg_py.getNumLevels())
+    cfg = cfg_py.to_c()
+    nl, cap = 3, 150
+    ctx.set_option("variant", 7)
+    ctx.set_option("resident_group", 4)
+
+    def one(k, res, lv, it):
+        for r in range(16):
+            res.transformation[r] = 1.0 if r % 5 == 0 else 0.0
+        return lib.dvo_hip_match(ctx.ptr, refs[k].ptr, cur.ptr, C.byref(cfg), C.byref(res), lv, nl, it, cap)
+
+    def snapshot(res, lv, it):
+        return (bytes(res), bytes(lv)[:C.sizeof(L.LevelStats) * res.n_levels], bytes(it)[:C.sizeof(L.IterationStats) * res.n_iterations_total])
+    want = []
+    for k in range(2):
+        res, lv, it = L.Result(), (L.LevelStats * nl)(), (L.IterationStats * cap)()
+        assert one(k, res, lv, it) == 0
+        want.append(snapshot(res, lv, it))
+    assert want[0] != want[1]
+    before = ctx.counter("rendezvous_pairs")
+    rounds, bad = 300, []
+    go = threading.Barrier(2)
+
+    def worker(k):
+        res, lv, it = L.Result(), (L.LevelStats * nl)(), (L.IterationStats * cap)()
+        for _ in range(rounds):
+            go.wait()
+            if one(k, res, lv, it) != 0 or snapshot(res, lv, it) != want[k]:
+                bad.append(k)
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    pairs = ctx.counter("rendezvous_pairs") - before
+    print("rendezvous: %d of %d concurrent call pairs left as one two-pair batch" % (pairs, rounds))
+    assert not bad
+    assert pairs >= 1
+    ctx.set_option("rendezvous", 0)
+    try:
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        rounds = 20
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert ctx.counter("rendezvous_pairs") - before == pairs and not bad
+    finally:
+        ctx.set_option("rendezvous", 1)
