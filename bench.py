@@ -210,7 +210,7 @@ def main():
         last["loglik"] = res["loglik"]
         if world > 1:
             # the records of this batch travel (one all-gather, RCCL) while the next batch is aligned; buffers allocated once
-            rec = parallel.pack_records(parallel.twists_of(last["T"]), last["information"], last["loglik"])
+            rec = pipe.records()                                        # packed by the pipeline object (stream_pipeline.cpp)
             if pending[0] is not None:
                 gathered[0] = pending[0].result()
             pending[0] = gatherer.start(rec)

@@ -6,6 +6,7 @@
 // Reference call pattern it stands for: dvo_benchmark/src/benchmark_slam.cpp:327-383 (load pair -> create pyramid -> track),
 // with the proposals of dvo_slam/src/keyframe_graph.cpp:576-593 as the source of independent pairs.
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,6 +32,47 @@ int dvo_stream_step(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next_refs
   static const double identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, identity, sizeof(identity));   // Result is in/out
   return dvo_hip_match_batch(ctx, n, now_refs, now_curs, cfg, results, nullptr, 0, nullptr, 0);
+}
+
+// The fixed-size record of an alignment that travels between the ranks of a multi-GPU job (dvo_slam_amd/parallel.py: RECORD = 32
+// doubles): twist (v, omega) of the transform (closed-form log, small-angle safe) | upper triangle of the information matrix (21) |
+// log-likelihood | flag (0) | padding (3).  Same formulas as parallel.twists_of / pack_records (tests/test_parallel.py compares them);
+// here so that a step of the streaming loop hands its records to the all-gather without per-step array work in the host language.
+void dvo_stream_pack_records(int n, const dvo_hip_result* results, double* records) {
+  for (int i = 0; i < n; ++i) {
+    const double* T = results[i].transformation;               // row-major 4 x 4
+    double* rec = records + size_t(i) * 32;
+    for (int k = 0; k < 32; ++k) rec[k] = 0.0;
+    const double R[3][3] = {{T[0], T[1], T[2]}, {T[4], T[5], T[6]}, {T[8], T[9], T[10]}};
+    const double t[3] = {T[3], T[7], T[11]};
+    double c = ((R[0][0] + R[1][1] + R[2][2]) - 1.0) * 0.5;
+    c = c < -1.0 ? -1.0 : c > 1.0 ? 1.0 : c;
+    const double th = std::acos(c);
+    const double axis[3] = {0.5 * (R[2][1] - R[1][2]), 0.5 * (R[0][2] - R[2][0]), 0.5 * (R[1][0] - R[0][1])};
+    const double scale = th < 1e-6 ? 1.0 + th * th / 6.0 : th / std::sin(th);
+    const double w[3] = {axis[0] * scale, axis[1] * scale, axis[2] * scale};
+    const double O[3][3] = {{0.0, -w[2], w[1]}, {w[2], 0.0, -w[0]}, {-w[1], w[0], 0.0}};
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double cc = 1.0 / 12.0;
+    if (!(th2 < 1e-10)) {
+      const double a = std::sqrt(th2);
+      cc = (1.0 - a * std::cos(a / 2) / (2 * std::sin(a / 2))) / th2;
+    }
+    for (int r = 0; r < 3; ++r) {
+      double v = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        double oo = 0.0;
+        for (int m = 0; m < 3; ++m) oo += O[r][m] * O[m][k];
+        v += ((r == k ? 1.0 : 0.0) - 0.5 * O[r][k] + cc * oo) * t[k];
+      }
+      rec[r] = v;
+      rec[3 + r] = w[r];
+    }
+    int o = 6;
+    for (int r = 0; r < 6; ++r)
+      for (int k = r; k < 6; ++k) rec[o++] = results[i].information[r * 6 + k];
+    rec[27] = results[i].loglik;
+  }
 }
 
 // The same step fed from HOST memory (SURVEY.md 8d config 4 "incl. H2D of 2 planes per frame"): the raw planes of `next` are DMA-ed

@@ -24,6 +24,8 @@ def _load():
         pp = C.POINTER(vp)
         L.dvo_stream_step.argtypes = [vp, C.c_int, pp, pp, pp, pp, pp, pp, C.c_float, pp, pp, C.POINTER(_lib.Config), C.POINTER(_lib.Result)]
         L.dvo_stream_step_host.argtypes = L.dvo_stream_step.argtypes
+        L.dvo_stream_pack_records.argtypes = [C.c_int, C.POINTER(_lib.Result), C.POINTER(C.c_double)]
+        L.dvo_stream_pack_records.restype = None
         _pipe = L
     return _pipe
 
@@ -42,6 +44,13 @@ class StreamPipeline:
         self.cres = (_lib.Result * self.n)()
         self.results = np.frombuffer(self.cres, dtype=_RESULT_DTYPE)      # view: fields of the last aligned batch
         self.L = _load()
+        self._records = np.zeros((self.n, 32), np.float64)
+
+    def records(self):
+        """The records of the batch aligned last (dvo_slam_amd/parallel.py layout: twist | information triangle | log-likelihood |
+        flag), packed by the pipeline object; the array is reused by the next call."""
+        self.L.dvo_stream_pack_records(self.n, self.cres, self._records.ctypes.data_as(C.POINTER(C.c_double)))
+        return self._records
 
     def set_host_planes(self, grey_ref, depth_ref, grey_cur, depth_cur):
         """Host arrays (pinned, uint8 / uint16, C-contiguous, n each) the raw planes of every batch are DMA-ed from by step_host."""

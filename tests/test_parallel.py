@@ -115,3 +115,32 @@ def test_two_ranks_gather_the_records_of_one_rank(tmp_path):
     assert ra.shape == rb.shape == (12, par.RECORD)
     assert np.array_equal(ra, rb)
     assert ja["nan_results"] == 0 and ja["max_twist_error_vs_truth"] < 1e-4
+
+
+def test_pipeline_object_packs_the_same_records():
+    from oracle import pyoracle as po
+    """dvo_stream_pack_records (dvo_slam_amd/apps/stream_pipeline.cpp) -- the per-step record packing of a multi-GPU job done by the
+    pipeline object -- against parallel.pack_records(parallel.twists_of(.)): rotations from tiny to near pi, the identity included."""
+    import ctypes as C
+    from dvo_slam_amd import _lib, stream
+    L = stream._load()
+    rng = np.random.default_rng(5)
+    n = 64
+    xi = rng.uniform(-1.0, 1.0, (n, 6))
+    xi[0] = 0.0
+    xi[1, 3:] *= 1e-9
+    xi[2, 3:] *= 3.1 / np.linalg.norm(xi[2, 3:])
+    T = np.stack([po.se3_exp(x) for x in xi])
+    info = rng.normal(size=(n, 6, 6))
+    info = info @ info.transpose(0, 2, 1)
+    ll = rng.normal(size=n)
+    res = (_lib.Result * n)()
+    for i in range(n):
+        res[i].transformation[:] = list(T[i].reshape(-1))
+        res[i].information[:] = list(info[i].reshape(-1))
+        res[i].loglik = ll[i]
+    out = np.full((n, par.RECORD), -7.0)
+    L.dvo_stream_pack_records(n, res, out.ctypes.data_as(C.POINTER(C.c_double)))
+    want = par.pack_records(par.twists_of(T), info, ll)
+    assert np.allclose(out, want, rtol=1e-12, atol=1e-13)
+    assert np.allclose(out[:, :6], xi, atol=1e-9)
