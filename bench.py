@@ -436,12 +436,12 @@ def _pmc_traffic(pairs):
     """HBM bytes per launch of the finest-level kernel from the committed rocprofv3 --pmc passes (profiles/pmc_finest_kernel.json:
     FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes, see scripts/pmc.sh).  bench.py cannot run the profiler itself.  The
     number is reported only when it was collected for the same number of pairs per launch AND the record names the very source of
-    the sweep kernel that is compiled now (sha256 of align_window.hip + sweep_parts.h + pixel_math.h) -- a stale record reads as null."""
+    the sweep kernel that is compiled now (sha256 of align_window.hip + gram_f16.h + sweep_parts.h + pixel_math.h) -- a stale record reads as null."""
     import hashlib
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_finest_kernel.json")))
         h = hashlib.sha256()
-        for f in ("align_window.hip", "sweep_parts.h", "pixel_math.h"):
+        for f in ("align_window.hip", "gram_f16.h", "sweep_parts.h", "pixel_math.h"):
             h.update(open(os.path.join(ROOT, "dvo_slam_amd", "csrc", f), "rb").read())
         if rec.get("kernel_source_sha256") != h.hexdigest() or rec["pairs_per_launch"] != pairs:
             return None

@@ -606,7 +606,7 @@ bool aligned_to(const void* p, size_t a) { return reinterpret_cast<uintptr_t>(p)
 // derived then (ensure_roles).
 int eager_current_flavor(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_frames) {
   if (!level_uses_window(ctx, cam->w[level], cam->h[level])) return kCurAB;
-  return n_frames > (ctx->compute_units > 0 ? ctx->compute_units : 256) ? kCurC : (kCurAB | kCurC);
+  return n_frames * 2 > (ctx->compute_units > 0 ? ctx->compute_units : 256) ? kCurC : (kCurAB | kCurC);   // (plan_resident's limit)
 }
 
 int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, const void* const* grey, const void* const* raw,
@@ -1085,7 +1085,10 @@ ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg
   // more pairs than compute units: the workgroups would run in shifts, and the launch path, which gives every phase the whole chip,
   // is as fast (measured: 256 pairs -3 %, 512 pairs +1.6 % against it).  (Not with a pinned group size: the caller asks for
   // records that do not depend on the batch size, so the choice of path must not either.)
-  if (ctx->opt_resident < 0 && ctx->opt_resident_group == 0 && bp.n > cus) return rp;
+  // (round 3: with the f16 Gram and the short tiles the launch path is level with or ahead of ONE workgroup per pair as well -- 192 / 256
+  // pairs: screening stage 0.278 / 0.306 vs 0.293 / 0.341 ms, levels 3 -> 1 0.82 / 0.95 vs 0.87 / 1.01, full match equal; the resident
+  // kernel is kept for batches that get at least two workgroups per pair)
+  if (ctx->opt_resident < 0 && ctx->opt_resident_group == 0 && bp.n * 2 > cus) return rp;
   // all workgroups of a launch with groups must be resident at once: one workgroup (8 wavefronts, up to 256 registers) per compute unit
   int group = 1;
   while (group * 2 <= kResidentMaxGroup && bp.n * group * 2 <= cus) group *= 2;

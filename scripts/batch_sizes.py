@@ -15,6 +15,8 @@ from dvo_slam_amd import datagen    # noqa: E402
 sizes = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,4,8,16,32,64,128,256".split(","))]
 b = datagen.synth_batch(7, 64, 640, 480)
 ctx = d.Context(0)
+if os.environ.get("DVO_RESIDENT"):
+    ctx.set_option("resident", int(os.environ["DVO_RESIDENT"]))       # 0: every level on the launch path
 cam = d.RgbdCameraPyramid(640, 480, b["K"], ctx)
 cam.build(4)
 nmax = max(sizes)

@@ -35,7 +35,7 @@ for f in glob.glob('gpurun_out/pmc/*/*counter_collection.csv'):
         vals[c] = sum(big) / len(big)
 import hashlib, os
 h = hashlib.sha256()
-for f in ("align_window.hip", "sweep_parts.h", "pixel_math.h"):
+for f in ("align_window.hip", "gram_f16.h", "sweep_parts.h", "pixel_math.h"):
     h.update(open(os.path.join("dvo_slam_amd", "csrc", f), "rb").read())
 pairs = int(os.environ.get("PMC_PAIRS", "1024"))
 if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
