@@ -41,6 +41,58 @@ __device__ __forceinline__ float row_shifted(float v) {   // within a row of 16 
 
 }  // namespace
 
+// The role planes of a strip's 8 rows from its register rows: I / Z[j] = image row y0 + kFirst + j (clamped), kFirst = -1 with TAPS;
+// eI / eZ[r]: the strip's edge columns (lane 0: the column left of the strip, lane 63: the column right of it).  Returns the number of
+// selected pixels of the wavefront (ROLE 1).
+template <int ROLE, bool TAPS>
+__device__ __forceinline__ int strip_role_planes(const float (&I)[TAPS ? kStripH + 2 : kStripH][2], const float (&Z)[TAPS ? kStripH + 2 : kStripH][2],
+                                                 const float (&eI)[kStripH], const float (&eZ)[kStripH], int x, int y0, int w0, int h0, bool in_x,
+                                                 Global<float2> R0, Global<float4> A0, Global<float2> B0, Global<float2> C0, int cur_flavor,
+                                                 float ithr, float dthr) {
+#pragma clang fp contract(off)
+  constexpr int kFirst = TAPS ? -1 : 0;
+  const float nanv = __builtin_nanf("");
+  int count = 0;
+#pragma unroll
+      for (int r = 0; r < kStripH; ++r) {
+        const int j = r - kFirst, y = y0 + r;
+        const bool inside = in_x && y < h0;
+        const size_t at = size_t(y) * w0 + x;
+        const float i0 = I[j][0], i1 = I[j][1], z0 = Z[j][0], z1 = Z[j][1];
+        if (TAPS) {
+          // column x - 1 of the pair's first pixel: the previous lane's second pixel (lane 0: the edge column), clamped at the image
+          // border like the reference's derivative code; column x + 2 of the second pixel likewise
+          const float ie = eI[r], ze = eZ[r];
+          const float il_n = from_previous_lane(i1, ie), zl_n = from_previous_lane(z1, ze);
+          const float ir_n = from_next_lane(i0, ie), zr_n = from_next_lane(z0, ze);
+          const float il = x > 0 ? il_n : i0, zl = x > 0 ? zl_n : z0;
+          const float ir = x + 2 < w0 ? ir_n : i1, zr = x + 2 < w0 ? zr_n : z1;
+          const float idx0 = (i1 - il) * 0.5f, idx1 = (ir - i0) * 0.5f;
+          const float zdx0 = (z1 - zl) * 0.5f, zdx1 = (zr - z0) * 0.5f;
+          const float idy0 = (I[j + 1][0] - I[j - 1][0]) * 0.5f, idy1 = (I[j + 1][1] - I[j - 1][1]) * 0.5f;
+          const float zdy0 = (Z[j + 1][0] - Z[j - 1][0]) * 0.5f, zdy1 = (Z[j + 1][1] - Z[j - 1][1]) * 0.5f;
+          if (ROLE == 1) {
+            const bool ok0 = inside && z0 == z0 && zdx0 == zdx0 && zdy0 == zdy0 &&
+                             (fabsf(idx0) > ithr || fabsf(idy0) > ithr || fabsf(zdx0) > dthr || fabsf(zdy0) > dthr);
+            const bool ok1 = inside && z1 == z1 && zdx1 == zdx1 && zdy1 == zdy1 &&
+                             (fabsf(idx1) > ithr || fabsf(idy1) > ithr || fabsf(zdx1) > dthr || fabsf(zdy1) > dthr);
+            if (inside) gstore_pair(R0 + at, make_float4(ok0 ? z0 : nanv, i0, ok1 ? z1 : nanv, i1));
+            count += __popcll(__ballot(ok0)) + __popcll(__ballot(ok1));   // wave-uniform
+          } else if (inside) {
+            if (cur_flavor & kCurAB) {
+              gstore(A0 + at, make_float4(i0, z0, idx0, idy0));
+              gstore(A0 + at + 1, make_float4(i1, z1, idx1, idy1));
+              gstore_pair(B0 + at, make_float4(zdx0, zdy0, zdx1, zdy1));
+            }
+            if (cur_flavor & kCurC) gstore_pair(C0 + at, make_float4(i0, z0, i1, z1));
+          }
+        } else if (inside) {
+          gstore_pair(C0 + at, make_float4(i0, z0, i1, z1));
+        }
+      }
+  return count;
+}
+
 // ROLE: -1 = none (raw copy + pyramid only), 0 = current, 1 = reference (R + selection count, counter zeroed before).
 // TAPS: level 0 needs the central differences (reference role; current role with the gathered taps A + B).
 // c_levels: bit l set = pyramid level l (1-3) also gets the current role's {I, Z} plane C.
@@ -121,46 +173,12 @@ __global__ __launch_bounds__(256) void k_ingest_strips(const FrameBuildPtrs* __r
     }
 
     // ---- level 0 in the frame's role ----
-    int count = 0;
-    if (ROLE >= 0) {
+    float eI[kStripH], eZ[kStripH];
+    if (TAPS) {
 #pragma unroll
-      for (int r = 0; r < kStripH; ++r) {
-        const int j = r - kFirst, y = y0 + r;
-        const bool inside = in_x && y < h0;
-        const size_t at = size_t(y) * w0 + x;
-        const float i0 = I[j][0], i1 = I[j][1], z0 = Z[j][0], z1 = Z[j][1];
-        if (TAPS) {
-          // column x - 1 of the pair's first pixel: the previous lane's second pixel (lane 0: the edge column), clamped at the image
-          // border like the reference's derivative code; column x + 2 of the second pixel likewise
-          const float ie = float(ge[r]), ze = depth_of(de[r]);
-          const float il_n = from_previous_lane(i1, ie), zl_n = from_previous_lane(z1, ze);
-          const float ir_n = from_next_lane(i0, ie), zr_n = from_next_lane(z0, ze);
-          const float il = x > 0 ? il_n : i0, zl = x > 0 ? zl_n : z0;
-          const float ir = x + 2 < w0 ? ir_n : i1, zr = x + 2 < w0 ? zr_n : z1;
-          const float idx0 = (i1 - il) * 0.5f, idx1 = (ir - i0) * 0.5f;
-          const float zdx0 = (z1 - zl) * 0.5f, zdx1 = (zr - z0) * 0.5f;
-          const float idy0 = (I[j + 1][0] - I[j - 1][0]) * 0.5f, idy1 = (I[j + 1][1] - I[j - 1][1]) * 0.5f;
-          const float zdy0 = (Z[j + 1][0] - Z[j - 1][0]) * 0.5f, zdy1 = (Z[j + 1][1] - Z[j - 1][1]) * 0.5f;
-          if (ROLE == 1) {
-            const bool ok0 = inside && z0 == z0 && zdx0 == zdx0 && zdy0 == zdy0 &&
-                             (fabsf(idx0) > ithr || fabsf(idy0) > ithr || fabsf(zdx0) > dthr || fabsf(zdy0) > dthr);
-            const bool ok1 = inside && z1 == z1 && zdx1 == zdx1 && zdy1 == zdy1 &&
-                             (fabsf(idx1) > ithr || fabsf(idy1) > ithr || fabsf(zdx1) > dthr || fabsf(zdy1) > dthr);
-            if (inside) gstore_pair(R0 + at, make_float4(ok0 ? z0 : nanv, i0, ok1 ? z1 : nanv, i1));
-            count += __popcll(__ballot(ok0)) + __popcll(__ballot(ok1));   // wave-uniform
-          } else if (inside) {
-            if (cur_flavor & kCurAB) {
-              gstore(A0 + at, make_float4(i0, z0, idx0, idy0));
-              gstore(A0 + at + 1, make_float4(i1, z1, idx1, idy1));
-              gstore_pair(B0 + at, make_float4(zdx0, zdy0, zdx1, zdy1));
-            }
-            if (cur_flavor & kCurC) gstore_pair(C0 + at, make_float4(i0, z0, i1, z1));
-          }
-        } else if (inside) {
-          gstore_pair(C0 + at, make_float4(i0, z0, i1, z1));
-        }
-      }
+      for (int r = 0; r < kStripH; ++r) { eI[r] = float(ge[r]); eZ[r] = depth_of(de[r]); }
     }
+    const int count = ROLE >= 0 ? strip_role_planes<ROLE, TAPS>(I, Z, eI, eZ, x, y0, w0, h0, in_x, R0, A0, B0, C0, cur_flavor, ithr, dthr) : 0;
     if (ROLE == 1 && lane == 0 && count) atomicAdd((int*)sel_count, count);
 
     // ---- pyramid levels 1-3: 64 x 4, 32 x 2 and 16 x 1 pixels per strip; an out-of-image quad is never written ----
@@ -203,6 +221,77 @@ __global__ __launch_bounds__(256) void k_ingest_strips(const FrameBuildPtrs* __r
       if (want_c3) gstore(C3 + at, make_float2(m3, z1v[0]));
     }
   }
+}
+
+// The role planes of ONE pyramid level from the float planes I / Z (levels >= 1, and level 0 of frames created from float planes): the
+// same strips, the same role code, 8-byte loads of pixel pairs instead of the raw planes' 2 + 4 bytes.  Replaces k_derive_current /
+// k_derive_reference (one pixel per thread, ten scattered 4-byte loads each: 3 TB/s) for batches; a single camera frame's levels go
+// through k_derive_levels (one launch for all of them).
+template <int ROLE, bool TAPS>
+__global__ __launch_bounds__(256) void k_derive_strips(const FrameBuildPtrs* __restrict__ tbl, int level, int w0, int h0, float ithr, float dthr,
+                                                       int groups_x, int groups_y, int n_frames, int cur_flavor) {
+#pragma clang fp contract(off)
+  static_assert(ROLE == 0 || ROLE == 1, "current or reference");
+  static_assert(ROLE != 1 || TAPS, "the selection predicate needs the differences");
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int per_frame = groups_x * groups_y, total = per_frame * n_frames;
+  for (int gi = blockIdx.x; gi < total; gi += gridDim.x) {
+    const int frame = gi / per_frame, t = gi - frame * per_frame;
+    const int sx = t % groups_x, sy = (t / groups_x) * kStripsPerGroup + wave;
+    const int y0 = sy * kStripH;
+    if (y0 >= h0) continue;
+    const FrameBuildPtrs& f = tbl[frame];
+    const auto Ip = global_ptr<const float>(f.I[level]);
+    const auto Zp = global_ptr<const float>(f.Z[level]);
+    const auto Rl = global_ptr(f.R[level]);
+    const auto Al = global_ptr(f.A[level]);
+    const auto Bl = global_ptr(f.B[level]);
+    const auto Cl = global_ptr(f.C[level]);
+    const auto sel_count = global_ptr(f.sel_count);
+    const int x = sx * kStripW + 2 * lane;
+    const bool in_x = x < w0;
+    const int xl = in_x ? x : w0 - 2;
+    constexpr int kFirst = TAPS ? -1 : 0, kRows = TAPS ? kStripH + 2 : kStripH;
+    float I[kRows][2], Z[kRows][2];
+#pragma unroll
+    for (int j = 0; j < kRows; ++j) {
+      const int y = min(max(y0 + kFirst + j, 0), h0 - 1);
+      const size_t row = size_t(y) * w0;
+      const GlobalF32x2 iv = *(Global<const GlobalF32x2>)(Ip + row + xl);
+      const GlobalF32x2 zv = *(Global<const GlobalF32x2>)(Zp + row + xl);
+      I[j][0] = iv.x; I[j][1] = iv.y;
+      Z[j][0] = zv.x; Z[j][1] = zv.y;
+    }
+    float eI[kStripH], eZ[kStripH];
+    if (TAPS) {
+      const int xe = lane == 0 ? max(sx * kStripW - 1, 0) : min(sx * kStripW + kStripW, w0 - 1);
+      const bool edge_lane = lane == 0 || lane == 63;
+#pragma unroll
+      for (int r = 0; r < kStripH; ++r) {
+        const size_t row = size_t(min(y0 + r, h0 - 1)) * w0;
+        eI[r] = 0.0f; eZ[r] = 0.0f;
+        if (edge_lane) {
+          eI[r] = Ip[row + xe];
+          eZ[r] = Zp[row + xe];
+        }
+      }
+    }
+    const int count = strip_role_planes<ROLE, TAPS>(I, Z, eI, eZ, x, y0, w0, h0, in_x, Rl, Al, Bl, Cl, cur_flavor, ithr, dthr);
+    if (ROLE == 1 && lane == 0 && count) atomicAdd((int*)sel_count + level, count);
+  }
+}
+
+bool derive_strips_supports(int w) { return w % 2 == 0 && w >= 4; }
+
+// role 0: current (flavours cur_flavor), role 1: reference (the level's counters zeroed before by the caller's k_zero_counts)
+void launch_derive_strips(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int role, float ithr, float dthr,
+                          int max_workgroups, int cur_flavor) {
+  const int gx = (w + kStripW - 1) / kStripW, gy = (h + kStripH * kStripsPerGroup - 1) / (kStripH * kStripsPerGroup);
+  const long long total = (long long)gx * gy * n_frames;
+  const dim3 grid(int(max_workgroups > 0 && total > max_workgroups ? max_workgroups : total)), block(256);
+  if (role == 1) k_derive_strips<1, true><<<grid, block, 0, s>>>(tbl, level, w, h, ithr, dthr, gx, gy, n_frames, cur_flavor);
+  else if (cur_flavor & kCurAB) k_derive_strips<0, true><<<grid, block, 0, s>>>(tbl, level, w, h, ithr, dthr, gx, gy, n_frames, cur_flavor);
+  else k_derive_strips<0, false><<<grid, block, 0, s>>>(tbl, level, w, h, ithr, dthr, gx, gy, n_frames, cur_flavor);
 }
 
 bool ingest_strips_supports(int w0, bool wide) { return wide && w0 % 4 == 0; }

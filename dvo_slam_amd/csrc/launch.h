@@ -17,6 +17,10 @@ void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int
 // ingest_strips_supports tells the caller whether the pass will honour it)
 void launch_build_from_raw(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int role, bool wide,
                            float ithr, float dthr, int max_workgroups, int cur_flavor = kCurAB, int c_levels = 0);
+// ingest_strips.hip: the role planes of one level from the float planes I / Z in strips (even widths); role 1: counters zeroed before
+bool derive_strips_supports(int w);
+void launch_derive_strips(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int role, float ithr, float dthr,
+                          int max_workgroups, int cur_flavor);
 // ingest_strips.hip: the same pass with one 128 x 8 strip per wavefront, registers only (even widths, aligned planes)
 bool ingest_strips_supports(int w0, bool wide);
 void launch_ingest_strips(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, float scale, int w0, int h0, int levels, int role,

@@ -482,7 +482,12 @@ void launch_pyr_down(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int
   k_pyr_down<<<dim3((ow + 63) / 64, (oh + 3) / 4, n_frames), dim3(64, 4), 0, s>>>(tbl, level, w, h);
 }
 
+// (even widths: the strip form, ingest_strips.hip)
 void launch_derive_current(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, int max_workgroups, int cur_flavor) {
+  if (derive_strips_supports(w)) {
+    launch_derive_strips(s, tbl, n_frames, level, w, h, 0, 0.0f, 0.0f, max_workgroups, cur_flavor);
+    return;
+  }
   const int tx = (w + 63) / 64, ty = (h + 3) / 4;
   k_derive_current<<<dim3(capped_grid(tx, ty, n_frames, max_workgroups)), dim3(64, 4), 0, s>>>(tbl, level, w, h, tx, ty, n_frames, cur_flavor);
 }
@@ -512,6 +517,10 @@ void launch_derive_levels(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames
 void launch_derive_reference(hipStream_t s, const FrameBuildPtrs* tbl, int n_frames, int level, int w, int h, float ithr, float dthr,
                              int max_workgroups) {
   k_zero_counts<<<dim3((n_frames + 63) / 64), dim3(64), 0, s>>>(tbl, n_frames, level);
+  if (derive_strips_supports(w)) {
+    launch_derive_strips(s, tbl, n_frames, level, w, h, 1, ithr, dthr, max_workgroups, 0);
+    return;
+  }
   const int tx = (w + 63) / 64, ty = (h + 15) / 16;
   k_derive_reference<<<dim3(capped_grid(tx, ty, n_frames, max_workgroups)), dim3(64, 4), 0, s>>>(tbl, level, w, h, ithr, dthr, tx, ty, n_frames);
 }
