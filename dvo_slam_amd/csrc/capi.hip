@@ -4,7 +4,9 @@
 // The host never touches pixels or poses: it uploads two raw planes per frame, enqueues kernels on the
 // context's HIP stream and polls one integer ("pairs still iterating") every few iterations.
 #include <hip/hip_runtime.h>
+#ifdef DVO_WITH_ROCTX
 #include <rocprofiler-sdk-roctx/roctx.h>
+#endif
 #include <xmmintrin.h>
 
 #include <algorithm>
@@ -316,9 +318,14 @@ namespace {
 // (dvo_core/src/dense_tracking.cpp:154-158, 222, 246, 309, 325, 349): "prep" = per-level set-up, "err" = passes 1-4 (the sweep and
 // the log-likelihood pass), "linsys" = pass 5 + solve (the solver step); plus "build" for the frame construction.  They bracket
 // the ENQUEUE of a phase on the host (rocprofv3 --marker-trace shows them next to the kernel trace); free when no tool listens.
+// (marker ranges are a profiling aid: a ROCm installation without rocprofiler-sdk builds the library with WITH_ROCTX=0, Makefile)
 struct Range {
+#ifdef DVO_WITH_ROCTX
   explicit Range(const char* name) { roctxRangePushA(name); }
   ~Range() { roctxRangePop(); }
+#else
+  explicit Range(const char*) {}
+#endif
 };
 
 #define DVO_HIP_TRY(ctx, expr)                                                                   \
