@@ -144,8 +144,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
       const int uv = u0 | (v0 << 16);
       rs[k].z = z;
       rs[k].i = iv[k];
-      rs[k].gx = (right - left) * 0.5f;
-      rs[k].gy = (down[k] - up[k]) * 0.5f;
+      // (f16 schedule: plain differences, the 0.5 rides on a level constant -- pixel_finish_flat_d<true>)
+      rs[k].gx = F16 ? right - left : (right - left) * 0.5f;
+      rs[k].gy = F16 ? down[k] - up[k] : (down[k] - up[k]) * 0.5f;
       rs[k].qz = p.qz;
       rs[k].a1 = p.a1;
       rs[k].b1 = p.b1;

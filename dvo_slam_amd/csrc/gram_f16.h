@@ -31,8 +31,12 @@ typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
 // of H H^T (kF16RangeSquared) and the batch is repeated with the f32 Gram (capi.hip, counter "f16_range_repeats").
 // (seven pairs at a time, each step for all pairs before the next: an instruction never waits for the one right before it)
 __device__ __forceinline__ void split_pairs(const float (&v)[14], unsigned (&hi)[7], unsigned (&lo)[7]) {
+  // (round to nearest even -- v_cvt_pk_f16_f32, gfx950 -- for both parts: |v - hi - lo| <= 2^-22 |v|, four times closer than with
+  // round toward zero, which matters where the stopping precision of a level is near the noise of the normal equations)
+  typedef float __attribute__((ext_vector_type(2))) f32pair;
+  typedef _Float16 __attribute__((ext_vector_type(2))) f16pair;
 #pragma unroll
-  for (int k = 0; k < 7; ++k) hi[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * k], v[2 * k + 1]));
+  for (int k = 0; k < 7; ++k) hi[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32pair{v[2 * k], v[2 * k + 1]}, f16pair));
   // (measured: v_fma_mixlo_f16 / v_fma_mixhi_f16 would write the rounded low parts straight into the halves of one register -- 14
   // instructions instead of 21 -- but the sweep runs 1.7 % SLOWER with them than with v_fma_mix_f32 + v_cvt_pkrtz: scripts/ab_sweep.py)
   float ra[7], rb[7];
@@ -41,7 +45,7 @@ __device__ __forceinline__ void split_pairs(const float (&v)[14], unsigned (&hi)
 #pragma unroll
   for (int k = 0; k < 7; ++k) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb[k]) : "v"(v[2 * k + 1]), "v"(hi[k]));
 #pragma unroll
-  for (int k = 0; k < 7; ++k) lo[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra[k], rb[k]));
+  for (int k = 0; k < 7; ++k) lo[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32pair{ra[k], rb[k]}, f16pair));
 }
 constexpr float kF16RangeSquared = 65504.0f * 65504.0f;
 
@@ -97,6 +101,8 @@ __device__ __forceinline__ void gram_f16_row(float* my, int lane_c, const PixelT
       unsigned hh[7], ll[7];
       const float comps[14] = {J0[0], J0[1], J0[2], J0[3], J0[4], J0[5], J1[0], J1[1], J1[2], J1[3], J1[4], J1[5], mul_legacy(sr, o.r0), mul_legacy(sr, o.r1)};
       split_pairs(comps, hh, ll);
+      // (measured and dropped: 12-byte stores for the second quads over padding zeroed once per tile -- two register moves per row
+      // less, -0.3 % in the window sweep, and WRONG sums in the gathering sweep on the device for a reason not found)
       const u32x4 h0 = {hh[0], hh[1], hh[2], hh[3]}, h1 = {hh[4], hh[5], hh[6], 0u};
       const u32x4 l0 = {ll[0], ll[1], ll[2], ll[3]}, l1 = {ll[4], ll[5], ll[6], 0u};
       if (low_half) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }

@@ -352,8 +352,10 @@ DVO_HD bool pixel_finish_flat(const LevelGeom& g, const float4 ref, const PixelP
 // channels.  Bit-identical to blending the halved differences: a multiplication by 0.5 is exact and commutes with the rounding of
 // every product and fused multiply-add of the blend (no value here comes near the subnormal range: intensities are multiples of
 // 2^-8 at the finest level a sweep of this kind handles, depths of 2e-4, weights differences of floats in [0, 640)).
-// TAP_WEIGHTS: the four gradient channels (which only feed the Jacobian) are blended with four tap weights 0.5 b a formed once -- six
-// vector instructions fewer per pixel, last-bit differences in those channels; intensity and depth keep the reference's order.
+// TAP_WEIGHTS: the four gradient channels (which only feed the Jacobian) are blended with four tap weights b a formed once, and every
+// factor 0.5 of the central differences (taps and reference gradient: the caller passes ref.z / ref.w as plain differences) rides on the
+// level constants -- twelve vector instructions fewer per pixel, last-bit differences in those channels; intensity and depth keep
+// the reference's order.
 template <bool TAP_WEIGHTS = false>
 DVO_HD bool pixel_finish_flat_d(const LevelGeom& g, const float4 ref, const PixelProj& p, const PixelTaps& t, PixelTerms& o) {
 #pragma clang fp contract(off)
@@ -363,8 +365,9 @@ DVO_HD bool pixel_finish_flat_d(const LevelGeom& g, const float4 ref, const Pixe
 #undef DVO_BILERP
   float cIx, cIy, cZx, cZy;
   if (TAP_WEIGHTS) {
-    const float hb0 = 0.5f * b0, hb1 = 0.5f * b1;
-    const float w00 = hb0 * a0, w10 = hb0 * a1, w01 = hb1 * a0, w11 = hb1 * a1;
+    // TWICE the gradient channels: the taps are differences without the central difference's 0.5, and so is the reference
+    // gradient the caller hands over in ref.z / ref.w; the factor rides on the level constants below (0.5 wi, 0.5 f)
+    const float w00 = b0 * a0, w10 = b0 * a1, w01 = b1 * a0, w11 = b1 * a1;
 #define DVO_BLEND4(v00, v10, v01, v11) fmaf(w11, v11, fmaf(w01, v01, fmaf(w10, v10, w00 * (v00))))
     cIx = DVO_BLEND4(t.A00.z, t.A10.z, t.A01.z, t.A11.z);
     cIy = DVO_BLEND4(t.A00.w, t.A10.w, t.A01.w, t.A11.w);
@@ -384,10 +387,17 @@ DVO_HD bool pixel_finish_flat_d(const LevelGeom& g, const float4 ref, const Pixe
   o.r1 = 1.0f * cZ + (-1.0f) * p.qz;
   float sigma = p.Z - 0.4f;
   sigma = 0.0012f + 0.0019f * sigma * sigma;
-  o.gix = g.wi_x * cIx + g.wi_x * ref.z;
-  o.giy = g.wi_y * cIy + g.wi_y * ref.w;
-  o.gzx = (1.0f * g.fx) * cZx;
-  o.gzy = (1.0f * g.fy) * cZy;
+  if (TAP_WEIGHTS) {
+    o.gix = (0.5f * g.wi_x) * (cIx + ref.z);                  // (these rows only feed the Jacobian: one rounding fewer, not the reference's order)
+    o.giy = (0.5f * g.wi_y) * (cIy + ref.w);
+    o.gzx = (0.5f * g.fx) * cZx;
+    o.gzy = (0.5f * g.fy) * cZy;
+  } else {
+    o.gix = g.wi_x * cIx + g.wi_x * ref.z;
+    o.giy = g.wi_y * cIy + g.wi_y * ref.w;
+    o.gzx = (1.0f * g.fx) * cZx;
+    o.gzy = (1.0f * g.fy) * cZy;
+  }
   o.X = p.X; o.Y = p.Y; o.Z = p.Z;
   // intensities are never NaN: the three depth channels carry every hole of the 12-pixel neighbourhood (Q9)
   return (cI == cI && cZ == cZ) && (cIx == cIx && cIy == cIy) && (cZx == cZx && cZy == cZy) && o.r1 > -20.0f * sigma;   // Q9, Q5

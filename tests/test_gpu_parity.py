@@ -138,6 +138,31 @@ def test_window_sweep_against_the_gathering_sweep(w, h, xi):
         assert abs(a["neg_ll"] - out[7][k]["neg_ll"]) <= 1e-5 * abs(a["neg_ll"])      # (through the inverse of the 2 x 2 scale matrix)
 
 
+def test_f16_gram_does_not_lengthen_the_levels():
+    """The f16 high / low Gram (default schedule) carries a little more rounding noise than the f32 one; a noise floor of the normal
+    equations close to the stopping precision would show as levels that miss "increment too small" and run on until the log-likelihood
+    stops improving.  Over 96 pairs at BASELINE precision (5e-7), every level on the launch path: the same mean iteration counts per
+    level as the f32 schedule (within 0.25), no level more than three passes longer."""
+    n = 96
+    b = datagen.synth_batch(0, n, 640, 480)
+    its = {}
+    for v in (5, 7):
+        ctx = d.Context(0)
+        ctx.set_option("variant", v)
+        ctx.set_option("resident", 0)
+        cam = d.RgbdCameraPyramid(640, 480, b["K"], ctx)
+        cam.build(4)
+        refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)]
+        curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)]
+        results = [d.Result() for _ in range(n)]
+        d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0), ctx).match_batch(refs, curs, results, with_stats=True)
+        its[v] = np.array([[len(L.Iterations) for L in r.Statistics.Levels] for r in results])
+        del refs, curs, cam, ctx
+    print("mean iterations per level (3..0): f32 Gram %s, f16 Gram %s; longest levels %s / %s" % (its[5].mean(0), its[7].mean(0), its[5].max(0), its[7].max(0)))
+    assert np.abs(its[7].mean(0) - its[5].mean(0)).max() <= 0.25
+    assert (its[7].max(0) <= its[5].max(0) + 3).all()
+
+
 def test_f16_gram_range_guard_repeats_with_the_f32_gram():
     """The default schedule forms its Gram operands as f16 high + low parts: a Jacobian component beyond +-65504 (a depth step of
     ten metres one centimetre in front of the camera: fx * 5 m/px / 0.01 m) is not representable.  The sweep notices (the diagonal of
