@@ -4,7 +4,7 @@ schedule of the level sweep with its tile shape, LDS per workgroup and wavefront
 hipcc -Rpass-analysis=kernel-resource-usage), timed per level at the converged transform, and whole-match times for 1 / 8 / 32 pairs.
   variant 5: gathered taps, f32 Gram on the matrix cores      tile 64 x (4 rows_per_wave), 16.9 KB LDS, 64 VGPRs -> 7 wavefronts / SIMD
   variant 6: {I,Z} window staged in LDS, f32 Gram              tile 64 x 16, window 80 x 30 x 8 B = 19.2 KB + 16.9 KB, 84 VGPRs -> 4 / SIMD
-  variant 7: window + f16 hi/lo Gram on the matrix pipe        tile 64 x 16, 19.2 KB + 10.2 KB half-row slabs = 29.5 KB, 95 VGPRs -> 5 / SIMD (default)
+  variant 7: window + f16 hi/lo Gram on the matrix pipe        tile 64 x 16, 19.2 KB + 10.2 KB half-row slabs = 29.5 KB, 88-94 VGPRs -> 5 / SIMD (default)
 (levels narrower than 64 pixels x k walk the level as one row of pixels with variant 5 whatever the option says)"""
 import os
 import sys
