@@ -38,12 +38,17 @@ def hip_backend(width, height, K, cfg=None, ctx=None):
     return make_frame, match
 
 
-def replay(assoc_file, backend, groundtruth_file=None, K=None):
-    """-> dict(stamps, poses [n,4,4], failures).  backend(width, height, K) -> (make_frame, match)."""
-    entries = tum.read_associations(assoc_file)
+def replay(assoc_file, backend, groundtruth_file=None, K=None, max_frames=None):
+    """-> dict(stamps, poses [n,4,4], failures).  backend(width, height, K) -> (make_frame, match).  `assoc_file` is an association file,
+    or a sequence FOLDER (tum.sequence_entries: its association file, or rgb.txt + depth.txt matched by stamp)."""
+    if os.path.isdir(assoc_file):
+        folder, entries = os.path.abspath(assoc_file), tum.sequence_entries(assoc_file)
+    else:
+        folder, entries = os.path.dirname(os.path.abspath(assoc_file)), tum.read_associations(assoc_file)
     if not entries:
         raise ValueError("%s: no association entries" % assoc_file)
-    folder = os.path.dirname(os.path.abspath(assoc_file))
+    if max_frames:
+        entries = entries[:max_frames]
     trajectory = np.eye(4)
     if groundtruth_file:
         gs, gp = tum.read_trajectory(groundtruth_file)
@@ -51,7 +56,7 @@ def replay(assoc_file, backend, groundtruth_file=None, K=None):
     relative = np.eye(4)
     make_frame = match = None
     reference = current = None
-    stamps, poses, failures = [], [], 0
+    stamps, poses, rel, failures = [], [], [], 0
     for rgb_stamp, rgb_file, _, depth_file in entries:
         grey, depth = tum.load_frame(os.path.join(folder, rgb_file), os.path.join(folder, depth_file))
         if make_frame is None:
@@ -66,10 +71,11 @@ def replay(assoc_file, backend, groundtruth_file=None, K=None):
                 relative = np.eye(4)
             else:
                 relative = T
+            rel.append(relative.copy())
             trajectory = trajectory @ relative   # benchmark.cpp:463
         stamps.append(rgb_stamp)
         poses.append(trajectory.copy())
-    return dict(stamps=np.asarray(stamps), poses=np.asarray(poses), failures=failures)
+    return dict(stamps=np.asarray(stamps), poses=np.asarray(poses), relative=np.asarray(rel), failures=failures)
 
 
 def replay_arrays(grey, depth, backend, K, stamps=None):

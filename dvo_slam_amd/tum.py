@@ -155,6 +155,66 @@ def read_associations(path):
     return out
 
 
+def read_file_list(path):
+    """rgb.txt / depth.txt of a TUM RGB-D folder -> list of (stamp, file); '#' lines skipped."""
+    out = []
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if len(t) >= 2 and not t[0].startswith("#"):
+                out.append((float(t[0]), t[1]))
+    return out
+
+
+def sequence_entries(folder, max_difference=0.02):
+    """The association entries of a TUM RGB-D sequence folder: `assoc.txt` / `associations.txt` / `associate.txt` when the folder holds
+    one (the file the reference's benchmark reads, benchmark.cpp:402), otherwise rgb.txt and depth.txt matched by closest stamp like the
+    data set's associate.py does.  -> list of (rgb_stamp, rgb_file, depth_stamp, depth_file) in time order."""
+    for name in ("assoc.txt", "associations.txt", "associate.txt"):
+        path = os.path.join(folder, name)
+        if os.path.isfile(path):
+            return read_associations(path)
+    rgb, depth = read_file_list(os.path.join(folder, "rgb.txt")), read_file_list(os.path.join(folder, "depth.txt"))
+    ds = np.asarray([s for s, _ in depth])
+    cand = []
+    for i, (s, _) in enumerate(rgb):                          # the candidates of associate.py, found by bisection instead of n x m
+        lo, hi = np.searchsorted(ds, s - max_difference, "left"), np.searchsorted(ds, s + max_difference, "right")
+        cand += [(abs(s - ds[j]), i, j) for j in range(lo, hi) if abs(s - ds[j]) < max_difference]
+    cand.sort()
+    used_rgb, used_depth, out = set(), set(), []
+    for _, i, j in cand:
+        if i not in used_rgb and j not in used_depth:
+            used_rgb.add(i)
+            used_depth.add(j)
+            out.append((rgb[i][0], rgb[i][1], depth[j][0], depth[j][1]))
+    out.sort()
+    return out
+
+
+def find_sequences(root):
+    """The sequence folders under `root` (or `root` itself): every folder with a groundtruth.txt and either an association file or
+    rgb.txt + depth.txt."""
+    def is_sequence(d):
+        has = lambda n: os.path.isfile(os.path.join(d, n))
+        return has("groundtruth.txt") and (has("assoc.txt") or has("associations.txt") or has("associate.txt") or (has("rgb.txt") and has("depth.txt")))
+    if is_sequence(root):
+        return [root]
+    return sorted(os.path.join(root, d) for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)) and is_sequence(os.path.join(root, d)))
+
+
+# ROS default calibration of the three Kinect / Xtion sensors of the data set (fx, fy, cx, cy at 640 x 480), keyed by the folder name's
+# "freiburg<k>"; the reference's benchmark hard-codes the first (benchmark_slam.cpp:384)
+INTRINSICS = {"freiburg1": (517.3, 516.5, 318.6, 255.3), "freiburg2": (520.9, 521.0, 325.1, 249.7), "freiburg3": (535.4, 539.2, 320.1, 247.6)}
+
+
+def intrinsics_for(folder):
+    name = os.path.basename(os.path.normpath(folder))
+    for key, K in INTRINSICS.items():
+        if key in name:
+            return np.asarray(K, np.float32)
+    return np.asarray(INTRINSICS["freiburg1"], np.float32)
+
+
 def read_trajectory(path):
     """groundtruth.txt / estimated trajectory -> (stamps [n], poses [n,4,4])."""
     stamps, poses = [], []

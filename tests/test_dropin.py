@@ -68,6 +68,7 @@ def test_whole_match_every_iteration_against_the_reference(seed, w, h, first, la
     g = po.ref_match(*planes_of(pair), pair["K"], cfg, api=api)
     dT = np.abs(po.se3_log(np.linalg.inv(g["T"]) @ r["T"])).max()
     worst_n = worst_x = 0.0
+    worst_ll = {}
     assert len(r["levels"]) == len(g["levels"])
     for Lr, Lg in zip(r["levels"], g["levels"]):
         assert Lr["id"] == Lg["id"] and Lr["valid_pixels"] == Lg["valid_pixels"]      # the point selection is exact
@@ -79,8 +80,12 @@ def test_whole_match_every_iteration_against_the_reference(seed, w, h, first, la
             if np.isfinite(a["x"]).all() and np.isfinite(b["x"]).all():
                 worst_x = max(worst_x, np.abs(a["x"] - b["x"]).max())
             # the reference's log-likelihood drops n mod 50 terms and uses the paired scale (Q6, Q7): a few per cent apart
-            assert abs(a["neg_ll"] - b["neg_ll"]) <= 0.1 * abs(a["neg_ll"])
-    print("seed %d %dx%d levels %d..%d: |twist(T_gpu^-1 T_ref)| %.2e, worst |dn|/n %.2e, worst |dx| %.2e" % (seed, w, h, first, last, dT, worst_n, worst_x))
+            worst_ll[Lr["id"]] = max(worst_ll.get(Lr["id"], 0.0), abs(a["neg_ll"] - b["neg_ll"]) / abs(a["neg_ll"]))
+    print("seed %d %dx%d levels %d..%d: |twist(T_gpu^-1 T_ref)| %.2e, worst |dn|/n %.2e, worst |dx| %.2e, worst relative -ll difference per level %s"
+          % (seed, w, h, first, last, dT, worst_n, worst_x, {k: "%.3f" % v for k, v in sorted(worst_ll.items())}))
+    # measured: 0.061 / 0.057 / 0.030 / 0.053 on levels 0 / 1 / 2 / 3 (the engine's own restatement, oracle MATH, is held to 1e-6 in
+    # test_gpu_parity.py; what is bounded here is the reference's Q6 + Q7 against the exact sum)
+    assert all(v <= 0.075 for v in worst_ll.values())
     assert dT < 5e-5 if last < first else dT < 2e-3       # one coarse level alone stops at the coarse level's resolution
     assert worst_n < 0.08                                 # rcpps moves a few of the 100..500 constraints of the 80x60 level across a boundary
     assert worst_x < 5e-3                                 # measured 1e-3 .. 3e-3 on the coarsest level, 1e-5 .. 3e-4 below

@@ -214,3 +214,80 @@ def test_reference_compatible_mode_long_replay(long_sequence, name):
     assert abs(ate["compat"] - ate["ref"]) <= 0.10 * ate["ref"]                  # the default mode: 0.47 / 0.73
     assert abs(ate["compat"] - ate["ref"]) < 0.3 * abs(ate["default"] - ate["ref"])
     assert step[1].mean() < 0.75 * step[0].mean()
+
+
+# ---- real sequences of the TUM RGB-D benchmark, when a copy is on disk (DVO_TUM_ROOT) ----------------------------------------------------
+def replay_sequence_folder(folder, frames):
+    """One sequence folder (association file, or rgb.txt + depth.txt) through the engine in both arithmetic modes and through the CPU
+    oracle in MATH and REF_SSE mode, dvo_benchmark's launch/benchmark.yaml settings; -> the report line and the numbers asserted."""
+    import dvo_slam_amd as d
+    from dvo_slam_amd import replay, tum
+    from oracle import pyoracle as po
+    kw = CONFIGS["benchmark_yaml"]
+    cfg = d.Config(FirstLevel=kw["first_level"], LastLevel=kw["last_level"], MaxIterationsPerLevel=kw["max_iterations"],
+                   Precision=kw["precision"], Mu=kw["mu"], UseInitialEstimate=kw["use_initial_estimate"])
+    entries = tum.sequence_entries(folder)
+    grey, _ = tum.load_frame(os.path.join(folder, entries[0][1]), os.path.join(folder, entries[0][3]))
+    K = tum.intrinsics_for(folder) * np.float32(grey.shape[1] / 640.0)
+    gt = os.path.join(folder, "groundtruth.txt")
+    runs = {}
+    for compat in (0, 1):
+        ctx = d.Context(0)
+        ctx.set_option("ref_compat", compat)
+        runs["gpu" if compat == 0 else "compat"] = replay.replay(folder, lambda w, h, k: replay.hip_backend(w, h, k, cfg, ctx), gt, K=K, max_frames=frames)
+    runs["math"] = replay.replay(folder, oracle_backend(po.MATH, kw), gt, K=K, max_frames=frames)
+    runs["ref"] = replay.replay(folder, oracle_backend(po.REF_SSE, kw), gt, K=K, max_frames=frames)
+    gts, gtp = tum.read_trajectory(gt)
+    ate = {k: tum.evaluate_ate(gts, gtp, v["stamps"], v["poses"])["rmse"] for k, v in runs.items()}
+    dist = lambda a, b: np.array([np.abs(po.se3_log(np.linalg.inv(x) @ y)).max() for x, y in zip(runs[a]["relative"], runs[b]["relative"])])
+    out = dict(n=len(runs["gpu"]["poses"]), ate=ate, failures={k: v["failures"] for k, v in runs.items()},
+               gpu_math=dist("gpu", "math"), gpu_ref=dist("gpu", "ref"), compat_ref=dist("compat", "ref"))
+    line = ("%s, %d frames: ATE rmse engine %.4f mm, oracle MATH %.4f mm, engine ref_compat %.4f mm, reference arithmetic (REF_SSE) %.4f mm; "
+            "failures %s; per-step twist distance engine-MATH mean %.2e max %.2e, engine-REF_SSE mean %.2e, ref_compat-REF_SSE mean %.2e"
+            % (os.path.basename(os.path.normpath(folder)), out["n"], ate["gpu"] * 1e3, ate["math"] * 1e3, ate["compat"] * 1e3, ate["ref"] * 1e3, out["failures"],
+               out["gpu_math"].mean(), out["gpu_math"].max(), out["gpu_ref"].mean(), out["compat_ref"].mean()))
+    return line, out
+
+
+def check_sequence_report(out):
+    assert out["failures"]["gpu"] == out["failures"]["math"] and out["failures"]["compat"] == out["failures"]["ref"]
+    assert abs(out["ate"]["gpu"] - out["ate"]["math"]) <= 0.01 * out["ate"]["math"]          # config 3 against the semantics implemented
+    assert out["gpu_math"].max() < 2e-4                                                       # a match stopped at Precision 1e-4 (as the long replay)
+    assert abs(out["ate"]["compat"] - out["ate"]["ref"]) <= 0.10 * out["ate"]["ref"]          # and on the reference's own terms
+    assert out["compat_ref"].mean() <= out["gpu_ref"].mean()
+
+
+def test_real_tum_sequences_when_a_copy_is_on_disk():
+    """DVO_TUM_ROOT = a TUM RGB-D sequence folder (rgbd_dataset_freiburg1_xyz, ...) or a folder of them: the first DVO_TUM_FRAMES (120)
+    frames of each are replayed like the 300-frame synthetic sequence above.  Skipped when the variable is unset (no data set travels
+    with the repository; the driver's GPU box has none)."""
+    from dvo_slam_amd import tum
+    root = os.environ.get("DVO_TUM_ROOT")
+    if not root or not os.path.isdir(root):
+        pytest.skip("DVO_TUM_ROOT is not set")
+    folders = tum.find_sequences(root)
+    assert folders, "no sequence folder (groundtruth.txt + assoc.txt or rgb.txt/depth.txt) under " + root
+    for folder in folders:
+        line, out = replay_sequence_folder(folder, int(os.environ.get("DVO_TUM_FRAMES", "120")))
+        print(line)
+        check_sequence_report(out)
+
+
+def test_the_real_sequence_path_on_a_synthetic_folder(dataset, tmp_path):
+    """The same code path on the 10-frame synthetic folder, laid out like the data set ships (rgb.txt + depth.txt, no association file)."""
+    import shutil
+    from dvo_slam_amd import tum
+    root, _ = dataset
+    folder = tmp_path / "rgbd_dataset_freiburg1_synthetic"
+    shutil.copytree(root, folder)
+    entries = tum.read_associations(str(folder / "assoc.txt"))
+    os.remove(folder / "assoc.txt")
+    with open(folder / "rgb.txt", "w") as f:
+        f.writelines("%.6f %s\n" % (e[0], e[1]) for e in entries)
+    with open(folder / "depth.txt", "w") as f:
+        f.writelines("%.6f %s\n" % (e[2] + 0.004, e[3]) for e in entries)
+    assert tum.find_sequences(str(tmp_path)) == [str(folder)]
+    line, out = replay_sequence_folder(str(folder), 8)
+    print(line)
+    assert out["n"] == 8
+    check_sequence_report(out)

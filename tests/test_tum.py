@@ -154,6 +154,34 @@ def test_dataset_layout_and_readers(tmp_path):
     assert io_check("gt", tmp_path / "groundtruth.txt", "%.6f" % (gts[-1] + 10)).split()[0] == "0"
 
 
+def test_sequence_folder_without_an_association_file(tmp_path):
+    """A sequence as the data set ships it -- rgb.txt, depth.txt with their own stamps, groundtruth.txt, no assoc.txt: the entries are the
+    closest-stamp matches (associate.py's greedy rule, checked against the n x m version), and the folder is found under a root."""
+    from oracle import pyoracle as po
+    root = tmp_path / "rgbd_dataset_freiburg2_synthetic"
+    seq, _ = _write_small_dataset(root, n=6)
+    entries = tum.read_associations(str(root / "assoc.txt"))
+    os.remove(root / "assoc.txt")
+    rng = np.random.default_rng(3)
+    depth_stamps = [e[2] + rng.uniform(-0.012, 0.012) for e in entries]
+    depth_stamps[4] = entries[4][2] + 0.5                         # a depth frame with no colour frame within 20 ms: dropped
+    with open(root / "rgb.txt", "w") as f:
+        f.write("# color images\n# file\n# timestamp filename\n")
+        f.writelines("%.6f %s\n" % (e[0], e[1]) for e in entries)
+    with open(root / "depth.txt", "w") as f:
+        f.write("# depth maps\n")
+        f.writelines("%.6f %s\n" % (s, e[3]) for s, e in zip(depth_stamps, entries))
+    got = tum.sequence_entries(str(root))
+    want = tum.associate([e[0] for e in entries], [round(s, 6) for s in depth_stamps])
+    assert [(entries[i][1], entries[j][3]) for i, j in want] == [(g[1], g[3]) for g in got] and len(got) == 5
+    assert all(abs(g[0] - g[2]) < 0.02 for g in got)
+    assert tum.find_sequences(str(tmp_path)) == [str(root)] and tum.find_sequences(str(root)) == [str(root)]
+    assert tuple(tum.intrinsics_for(str(root))) == tuple(np.float32(tum.INTRINSICS["freiburg2"]))
+    from dvo_slam_amd import replay
+    run = replay.replay(str(root), oracle_backend(po.MATH, YAML), str(root / "groundtruth.txt"), K=seq["K"], max_frames=4)
+    assert run["failures"] == 0 and len(run["poses"]) == 4 and len(run["relative"]) == 3
+
+
 def test_quaternion_conventions():
     rng = np.random.default_rng(3)
     for _ in range(50):
