@@ -108,6 +108,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
   unsigned n_fallback = 0;
 
   const int row0 = tile_y * (WAVES * RPW) + wave;
+  float ty_rows[RPW];                                          // (wave-uniform: scalar loads, once for both phases)
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) ty_rows[k] = g.ty[min(row0 + k * WAVES, g.h - 1)];
   float KT[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) KT[i] = st.KT[i];
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
       const float right = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ie, ic, 0x130, 0xf, 0xf, false));   // wave_shl:1
       const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ie, ic, 0x138, 0xf, 0xf, false));    // wave_shr:1
       const float z = v_r < g.h ? zv[k] : nanv;                // rows below the image: no depth
-      const float ty_p = g.ty[min(v_r, g.h - 1)];
+      const float ty_p = ty_rows[k];
       int u0, v0;
       const PixelProj p = pixel_project_uv_flat<COMPAT ? 2 : 1>(g, KT, z, tx_u, ty_p, u0, v0);
       const int uv = u0 | (v0 << 16);
@@ -267,14 +270,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
       DVO_TAP(1, 1, t.A11, t.B11)
 #undef DVO_TAP
     }
-    const float ty_p = g.ty[min(v_r, g.h - 1)];
+    const float ty_p = ty_rows[k];
     PixelProj p;
     p.Z = r.z; p.X = tx_u * r.z; p.Y = ty_p * r.z;            // rgbd_image.cpp:258 (the products pixel_project_flat forms)
     p.qz = r.qz; p.a1 = r.a1; p.b1 = r.b1; p.base = 0; p.ok = ok;
     const float4 ref = make_float4(r.z, r.i, r.gx, r.gy);
     PixelTerms o;
     const bool valid = pixel_finish_flat_d<F16>(g, ref, p, t, o) && ok;   // (f32 Gram: bit-identical to the gathering sweep)
-    n_valid += __popcll(__ballot(valid));
+    if constexpr (!F16) n_valid += __popcll(__ballot(valid));
     if (v_r < g.h) {                                           // (uniform)
       const f32x2 rr2 = valid ? f32x2{o.r0, o.r1} : f32x2{nanv, nanv};
       typedef unsigned __attribute__((__vector_size__(2 * sizeof(unsigned)))) u32v2;
@@ -285,7 +288,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
       // multiply (0 x anything = 0), so its operand rows are zeros without a second control-flow path (14 zero moves, the exec
       // juggling and the register shuffles where the two paths met: about 30 instructions per row)
       const float sw_any = first ? 1.0f : COMPAT ? tdist_weight_sqrt_compat(g.rcp_table, g.rcp_shift, o.r0, o.r1, st.P_prev) : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);
-      gram_f16_row(my, lane_c, o, valid ? sw_any : 0.0f, tx_u, ty_p, cx_u, acc0, acc1);
+      const float sw_lane = valid ? sw_any : 0.0f;
+      n_valid += __popcll(__builtin_amdgcn_ballot_w64(sw_lane > 0.0f));   // (a weight is positive; counted off one compare instead of the flag's round trip through a register)
+      gram_f16_row(my, lane_c, o, sw_lane, tx_u, ty_p, cx_u, acc0, acc1);
       continue;
     }
     if (valid) {

@@ -497,6 +497,7 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   g.w = cam->w[level]; g.h = cam->h[level];
   g.fx = cam->K[level][0]; g.fy = cam->K[level][1]; g.ox = cam->K[level][2]; g.oy = cam->K[level][3];
   g.wi_x = 0.5f * g.fx / 255.0f; g.wi_y = 0.5f * g.fy / 255.0f;
+  g.half_wi_x = 0.5f * g.wi_x; g.half_wi_y = 0.5f * g.wi_y; g.half_fx = 0.5f * g.fx; g.half_fy = 0.5f * g.fy;
   g.tx = cam->tx[level]; g.ty = cam->ty[level];
   g.linear = level_is_linear(ctx, g.w) ? 1 : 0;
   level_tiles(g.w, g.h, rows_per_wave, g.linear != 0, &g.tiles_x, &g.tiles_y);

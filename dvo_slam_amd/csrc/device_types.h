@@ -33,6 +33,9 @@ struct LevelGeom {                    // identical for every pair of a batch (on
   int w, h;
   float fx, fy, ox, oy;
   float wi_x, wi_y;                   // 0.5f * fx / 255.0f, 0.5f * fy / 255.0f (intensity-gradient weights)
+  // half of wi_x, wi_y, fx, fy: the f16 schedule's gradient channels are plain differences (no central difference's 0.5) and the factor
+  // rides here (there is no scalar float multiply on this part: formed in the kernel it is four vector instructions per pixel row)
+  float half_wi_x, half_wi_y, half_fx, half_fy;
   const float* tx;                    // (u - ox)/fx per column, the reference's pointcloud_template_
   const float* ty;                    // (v - oy)/fy per row
   int tiles_x, tiles_y;

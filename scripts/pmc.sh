@@ -10,6 +10,9 @@ run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ
 run fetch FETCH_SIZE
 run write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+# LDS array cycles and bank conflicts, scalar and matrix pipes (SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT are cycles summed over the CUs)
+run lds1 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE
+run lds2 SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CU_CYCLES
 cd $R
 python - <<'PY'
 import csv, glob, collections
