@@ -49,13 +49,17 @@ __device__ __forceinline__ void split_pairs(const float (&v)[14], unsigned (&hi)
 }
 constexpr float kF16RangeSquared = 65504.0f * 65504.0f;
 
-// matrix operand of 32 pixels (k index) x 16 components from the pixel-major f16 image: lane (i = l & 15, g = l >> 4) gets the
-// eight k-values 8 g .. 8 g + 7 of component i (scripts/ubench/gram_f16.hip)
+// matrix operand of 32 pixels (k index) x 16 components from the pixel-major f16 image: lane (i = l & 15, g = l >> 4) gets eight
+// k-values of component i (scripts/ubench/gram_f16.hip).  WHICH eight pixels is free -- the Gram sum runs over all of them, and both
+// operands of a product are read with the same pattern: lane group g takes the pixel rows 8 g .. 8 g + 7 as (even rows, odd rows)
+// rather than (first four, last four).  With 80-byte rows the eight 32-byte chunks a 32-lane group reads per instruction then tile the
+// 64 banks exactly (rows 0, 2, 4, 6 and 8, 10, 12, 14 start at banks 0, 40, 16, 56 and 32, 8, 48, 24); rows 0..3 and 8..11 did not
+// (the fourth row's chunk wraps onto the first's: SQ_LDS_BANK_CONFLICT, profiles/r03_pmc_utilisation.md).
 __device__ __forceinline__ f16x8 read_operand_f16(const _Float16* img, int lane, int chunk32) {
   const int i = lane & 15, gq = lane >> 4;
-  const _Float16* p0 = img + (chunk32 * 32 + 8 * gq + (i >> 2)) * kHalfRow + (i & 3) * 4;
+  const _Float16* p0 = img + (chunk32 * 32 + 8 * gq + 2 * (i >> 2)) * kHalfRow + (i & 3) * 4;
   const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p0);
-  const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p0 + 4 * kHalfRow));
+  const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p0 + kHalfRow));
   return f16x8{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
 }
 
