@@ -2,7 +2,8 @@
 //
 // The reference's tracking front end (dvo_slam/src/keyframe_tracker.cpp, compiled unmodified) owns a KeyframeGraph, the pose-graph
 // back end (dvo_slam/src/keyframe_graph.cpp: g2o optimisation, TBB worker thread, RViz markers).  The back end is outside this
-// engine's scope and is not compiled; this file defines the members of the class DECLARED in
+// engine's scope; for the builds that do not link it (tests/dropin: benchmark_slam_graph does) this file defines the
+// members of the class DECLARED in
 // dvo_slam/include/dvo_slam/keyframe_graph.h:45-80 that the front end links against, as a sink that counts the completed local maps.
 #include <cstdlib>
 

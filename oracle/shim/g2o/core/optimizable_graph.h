@@ -1,20 +1,18 @@
-// oracle/shim/g2o/core/optimizable_graph.h -- TEST INFRASTRUCTURE, see oracle/shim/Eigen/Core.  g2o is an un-vendored dependency of
-// the reference (g2o/Makefile:5-8) and not installed here.  The reference's LocalMap (dvo_slam/src/local_map.cpp) uses it as the
-// container of its frame vertices and relative-pose edges; graph OPTIMISATION is outside this engine's scope, so the stand-in
-// stores vertices / edges and aborts on optimize().
+// oracle/shim/g2o/core/optimizable_graph.h -- TEST INFRASTRUCTURE, see hyper_graph.h.
 #pragma once
 
 #include <cstdlib>
 #include <iostream>
-#include <set>
-#include <vector>
 
 #include <Eigen/Core>
 #include <Eigen/Geometry>
 
+#include "hyper_graph.h"
+#include "robust_kernel.h"
+
 namespace g2o {
 
-class OptimizableGraph {
+class OptimizableGraph : public HyperGraph {
  public:
   class Data {
    public:
@@ -22,52 +20,38 @@ class OptimizableGraph {
     virtual bool read(std::istream&) = 0;
     virtual bool write(std::ostream&) const = 0;
   };
-  class Edge;
-  typedef std::set<Edge*> EdgeSet;
-  class Vertex {
+  class Vertex : public HyperGraph::Vertex {
    public:
-    Vertex() : id_(-1), fixed_(false), data_(0) {}
+    Vertex() : fixed_(false), marginalized_(false), hessian_index_(-1), data_(0) {}
     virtual ~Vertex() { delete data_; }
-    void setId(int id) { id_ = id; }
-    int id() const { return id_; }
     void setFixed(bool f) { fixed_ = f; }
     bool fixed() const { return fixed_; }
-    void setUserData(Data* d) { data_ = d; }
+    void setMarginalized(bool m) { marginalized_ = m; }
+    bool marginalized() const { return marginalized_; }
+    void setHessianIndex(int i) { hessian_index_ = i; }
+    int hessianIndex() const { return hessian_index_; }
+    void setUserData(Data* d) { data_ = d; }               // (the vertex owns it; callers hand it over with setUserData(0) on the donor)
     Data* userData() const { return data_; }
-    EdgeSet& edges() { return edges_; }
    private:
-    int id_;
-    bool fixed_;
+    bool fixed_, marginalized_;
+    int hessian_index_;
     Data* data_;
-    EdgeSet edges_;
   };
-  class Edge {
+  class Edge : public HyperGraph::Edge {
    public:
-    Edge() : id_(-1) {}
-    virtual ~Edge() {}
-    void setId(int id) { id_ = id; }
-    int id() const { return id_; }
-    void resize(size_t n) { vertices_.resize(n); }
-    void setVertex(size_t i, Vertex* v) { vertices_[i] = v; }
-    Vertex* vertex(size_t i) const { return vertices_[i]; }
-    const std::vector<Vertex*>& vertices() const { return vertices_; }
+    Edge() : level_(0), kernel_(0) {}
+    virtual ~Edge() { delete kernel_; }
+    int level() const { return level_; }
+    void setLevel(int l) { level_ = l; }
+    RobustKernel* robustKernel() const { return kernel_; }
+    void setRobustKernel(RobustKernel* k) { delete kernel_; kernel_ = k; }
+    virtual double chi2() const { return 0.0; }
    private:
-    int id_;
-    std::vector<Vertex*> vertices_;
+    int level_;
+    RobustKernel* kernel_;
   };
-  virtual ~OptimizableGraph() {
-    for (size_t i = 0; i < edges_.size(); ++i) delete edges_[i];
-    for (size_t i = 0; i < vertices_.size(); ++i) delete vertices_[i];
-  }
-  bool addVertex(Vertex* v) { vertices_.push_back(v); return true; }
-  bool addEdge(Edge* e) {
-    edges_.push_back(e);
-    for (size_t i = 0; i < e->vertices().size(); ++i) e->vertex(i)->edges().insert(e);
-    return true;
-  }
- protected:
-  std::vector<Vertex*> vertices_;
-  std::vector<Edge*> edges_;
+  Vertex* vertex(int id) { return static_cast<Vertex*>(HyperGraph::vertex(id)); }
+  const Vertex* vertex(int id) const { return static_cast<const Vertex*>(HyperGraph::vertex(id)); }
 };
 
 }  // namespace g2o

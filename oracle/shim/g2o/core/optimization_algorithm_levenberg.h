@@ -1,3 +1,4 @@
+// oracle/shim/g2o/core/optimization_algorithm_levenberg.h -- TEST INFRASTRUCTURE, see sparse_optimizer.h: constructed, never run.
 #pragma once
 #include "block_solver.h"
 namespace g2o {

@@ -1,4 +1,4 @@
-// oracle/shim/g2o/types/slam3d/vertex_se3.h -- TEST INFRASTRUCTURE, see optimizable_graph.h.
+// oracle/shim/g2o/types/slam3d/vertex_se3.h -- TEST INFRASTRUCTURE, see ../../core/hyper_graph.h.
 #pragma once
 #include "../../core/optimizable_graph.h"
 namespace g2o {

@@ -333,3 +333,123 @@ def test_reference_live_camera_front_end_on_the_engine():
     print("live-camera node on the engine, %d frames: largest pose difference to the chain of C-ABI matches %.2e" % (n, worst))
     assert worst < 1e-9
     assert np.abs(po.se3_log(np.linalg.inv(acc) @ np.linalg.inv(seq["poses"][0]) @ seq["poses"][-1])).max() < 5e-3   # ... and it is the motion
+
+
+# ---- the reference's pose-graph back end, dvo_slam/src/keyframe_graph.cpp, unmodified, inside the reference's executable -------------------
+LOOP_SEQ = dict(seed=91, n=24, depth_noise=1.0, grey_noise=3.0, exposure=0.01)
+# private parameters of the node (dvo_slam/cfg/dvo_slam.cfg names): keyframes every few centimetres of the 0.1 m sweep, and validation
+# thresholds under which some of the loop closures of this short synthetic sweep pass (with the defaults -- tuned for room-sized
+# trajectories -- every proposal is voted down on either tracker, which exercises less)
+LOOP_ARGS = ["_max_translational_distance:=0.03", "_max_rotational_distance:=0.05", "_constraint_min_entropy_ratio_coarse:=0.005",
+             "_constraint_min_entropy_ratio_fine:=0.2", "_constraint_min_eq_sys_constraint_ratio:=0.1", "_graph_opt_robust:=true"]
+
+
+def _loop_folder(root):
+    """A there-and-back camera sweep in TUM layout: 24 frames out, the same 23 frames back (every place is visited twice)."""
+    from dvo_slam_amd import datagen, tum
+    seq = datagen.synth_sequence(LOOP_SEQ["seed"], LOOP_SEQ["n"], 640, 480, depth_noise=LOOP_SEQ["depth_noise"], grey_noise=LOOP_SEQ["grey_noise"],
+                                 exposure=LOOP_SEQ["exposure"])
+    idx = list(range(LOOP_SEQ["n"])) + list(range(LOOP_SEQ["n"] - 2, -1, -1))
+    tum.write_dataset(root, seq["grey"][idx], seq["depth"][idx], seq["poses"][idx])
+    return len(idx)
+
+
+def _run_graph_target(exe, root, tag, env=None, extra=()):
+    """-> (trajectory poses, vertices {id: (stamp, pose7)}, edges {id: (v0, v1, level, chi2, weight, measurement7)}, stderr)"""
+    import subprocess
+    from dvo_slam_amd import tum
+    out = os.path.join(root, "traj_%s.txt" % tag)
+    p = subprocess.run([exe, "_rgbdpair_file:=%s/assoc.txt" % root, "_groundtruth_file:=%s/groundtruth.txt" % root, "_estimate_trajectory:=true",
+                        "_trajectory_file:=%s" % out] + LOOP_ARGS + list(extra), cwd=root, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stderr[-2000:]
+    vertices, edges = {}, {}
+    for line in open(os.path.join(root, "assoc_opt_traj_final.txt")):
+        t = line.split()
+        if t and not t[0].startswith("#"):
+            vertices[int(t[8])] = (float(t[0]), np.array([float(x) for x in t[1:8]]))
+    for line in open(os.path.join(root, "assoc_error.txt")):
+        t = line.split()
+        if t and not t[0].startswith("#"):
+            edges[int(t[0])] = (int(t[1]), int(t[2]), int(t[3]), float(t[4]), float(t[5]), np.array([float(x) for x in t[6:13]]))
+    return tum.read_trajectory(out)[1], vertices, edges, p.stderr
+
+
+def _keyframes(vertices):
+    return sorted(i for i in vertices if i > 0)
+
+
+def _loop_closures(edges):
+    return {i for i, x in edges.items() if x[0] > 0 and x[1] > 0 and abs(x[0] - x[1]) > 1}
+
+
+def test_keyframe_graph_binaries_are_the_reference_source():
+    """CPU tier.  _build/benchmark_slam_graph links dvo_slam/src/keyframe_graph.cpp (KeyframeGraphImpl, its TBB reduction body) and the
+    engine; _build/benchmark_slam_graph_ref the same file and the reference's own tracker."""
+    import subprocess
+    need_dropin()
+    exe, ref = _target("benchmark_slam_graph"), _target("benchmark_slam_graph_ref")
+    for path in (exe, ref):
+        syms = subprocess.check_output(["nm", "-C", path], text=True)
+        assert "dvo_slam::internal::KeyframeGraphImpl::execOptimization()" in syms or "KeyframeGraphImpl" in syms
+        assert "ValidateConstraintProposalReduction" in syms and "NearestNeighborConstraintSearch::findPossibleConstraints" in syms
+    assert " U dvo_hip_match" in subprocess.check_output(["nm", "-C", exe], text=True)
+    assert "dvo_hip" not in subprocess.check_output(["nm", "-C", ref], text=True)
+
+
+@pytest.mark.gpu
+def test_reference_keyframe_graph_on_the_engine(tmp_path):
+    """The reference's executable with its REAL back end -- dvo_slam/src/keyframe_graph.cpp and keyframe_constraint_search.cpp compiled
+    unmodified (SURVEY.md 8b: proposal generation and the validator pool under tbb::parallel_reduce, keyframe_graph.cpp:500-593, the
+    tracker configurations :819-838) -- on a there-and-back sweep, on the MI355X engine against the same executable on the reference's
+    CPU tracker, run here.  g2o is a container stand-in whose optimize() is a no-op (oracle/shim/g2o), so the two graphs are compared as
+    built: keyframes, odometry edges, and the loop closures the validators let through.
+
+    (1) `use_multithreading` off: the reference is deterministic then, and the graphs must coincide.  (2) on (the node's default): the
+    graph thread moves keyframe poses under the tracking thread and the reference's OWN graph changes from run to run (15 or 16
+    keyframes, 78 or 91 loop closures on its CPU tracker here), so the engine run -- four validator threads calling
+    DenseTracker::match concurrently beside the two of the tracking front end -- is held to what holds for every schedule."""
+    need_dropin()
+    exe, ref = _target("benchmark_slam_graph"), _target("benchmark_slam_graph_ref")
+    root_ref, root_hip = str(tmp_path / "ref"), str(tmp_path / "hip")
+    n = _loop_folder(root_ref)
+    _loop_folder(root_hip)
+    single = ["_use_multithreading:=false"]
+    traj_r, vert_r, edge_r, _ = _run_graph_target(ref, root_ref, "ref", extra=single)
+    print("reference tracker, one thread: %d frames, %d keyframes, %d graph edges, %d loop closures"
+          % (n, len(_keyframes(vert_r)), len(edge_r), len(_loop_closures(edge_r))))
+    assert len(_keyframes(vert_r)) >= 8 and len(_loop_closures(edge_r)) >= 10
+    for compat in ("0", "1"):
+        traj, vert, edge, _ = _run_graph_target(exe, root_hip, "hip" + compat, env={"DVO_HIP_REF_COMPAT": compat}, extra=single)
+        common = _loop_closures(edge) & _loop_closures(edge_r)
+        def apart(a, b):                                            # twist distance of two edges of one keyframe pair, either direction
+            from dvo_slam_amd import tum
+            Ta, Tb = tum.pose_from_tq(a[5][:3], a[5][3:]), tum.pose_from_tq(b[5][:3], b[5][3:])
+            if (a[0], a[1]) != (b[0], b[1]):                        # the validators kept the twin proposal (current -> reference)
+                Tb = np.linalg.inv(Tb)
+            return np.abs(po.se3_log(np.linalg.inv(Ta) @ Tb)).max()
+        diffs = np.array(sorted(apart(edge[i], edge_r[i]) for i in common))
+        worst = diffs[-1]
+        print("    measurement differences of the common loop closures: median %.2e, 95 %% %.2e, 99 %% %.2e, the five largest %s"
+              % (np.median(diffs), diffs[int(0.95 * len(diffs))], diffs[int(0.99 * len(diffs))], ["%.1e" % x for x in diffs[-5:]]))
+        worst_kf = max(np.abs(vert[i][1] - vert_r[i][1]).max() for i in _keyframes(vert_r) if i in vert)
+        print("engine, one thread (ref_compat %s): %d keyframes, %d graph edges, %d loop closures, %d in common with the reference's %d; largest "
+              "difference of a common loop closure's measurement %.2e, of a keyframe pose %.2e"
+              % (compat, len(_keyframes(vert)), len(edge), len(_loop_closures(edge)), len(common), len(_loop_closures(edge_r)), worst, worst_kf))
+        assert _keyframes(vert) == _keyframes(vert_r)                 # the front end took the same keyframes
+        assert len(common) >= 0.9 * max(len(_loop_closures(edge)), len(_loop_closures(edge_r)))
+        assert diffs[int(0.95 * len(diffs))] < 2e-3 and (diffs > 2e-3).mean() < 0.03 and worst_kf < 2e-3
+    # (2) the node's default threading on the engine, three times
+    for rep in range(3):
+        traj, vert, edge, log = _run_graph_target(exe, root_hip, "hipmt%d" % rep)
+        loops = _loop_closures(edge)
+        assert len(traj) >= n and np.isfinite(traj).all()
+        assert 8 <= len(_keyframes(vert)) <= n and len(loops) >= 10
+        # every loop closure the validators accepted agrees with the (odometry-chained) vertex estimates to centimetres: chi2 is the
+        # information-weighted distance between the measurement and the estimates' relative pose
+        off = []
+        for i in loops:
+            v0, v1 = vert[edge[i][0]][1], vert[edge[i][1]][1]
+            off.append(np.linalg.norm(edge[i][5][:3]) - np.linalg.norm(v1[:3] - v0[:3]))
+        print("engine, threaded run %d: %d keyframes, %d loop closures; |translation of the measurement| - |distance of its keyframes|: "
+              "median %.2e, worst %.2e" % (rep, len(_keyframes(vert)), len(loops), float(np.median(np.abs(off))), float(np.abs(off).max())))
+        assert np.abs(off).max() < 0.02
