@@ -33,6 +33,7 @@ struct RefRow {
 // LINEAR: the level is walked as one row of w*h pixels in 64-pixel segments (LevelGeom::linear) -- same per-pixel arithmetic,
 // the pixel coordinates come from a division instead of the tile position.
 // F16: the Gram accumulation on the f16 matrix pipe (gram_f16.h, schedule variant 7) instead of the f32 matrix instruction.
+// FINEST: not used in the body -- it only gives the launches of pyramid level 0 a kernel name of their own in profiler traces.
 template <int RPW, bool FINEST, bool LINEAR, bool F16>
 __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
