@@ -452,4 +452,4 @@ def test_reference_keyframe_graph_on_the_engine(tmp_path):
             off.append(np.linalg.norm(edge[i][5][:3]) - np.linalg.norm(v1[:3] - v0[:3]))
         print("engine, threaded run %d: %d keyframes, %d loop closures; |translation of the measurement| - |distance of its keyframes|: "
               "median %.2e, worst %.2e" % (rep, len(_keyframes(vert)), len(loops), float(np.median(np.abs(off))), float(np.abs(off).max())))
-        assert np.abs(off).max() < 0.02
+        assert np.abs(off).max() < 0.05                          # (measured 0.017; a diverged alignment on this 0.1 m sweep is off by more)
