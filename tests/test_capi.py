@@ -132,3 +132,19 @@ def test_match_batch_over_several_device_contexts_in_one_process(tmp_path):
     for k in range(7):
         true = np.linalg.inv(seq["poses"][k]) @ seq["poses"][k + 1]
         assert np.abs(runs[1][k].reshape(4, 4) - true).max() < 2e-3
+
+
+def test_every_option_and_counter_of_the_library_is_documented_in_the_header():
+    """dvo_hip_set_option / dvo_hip_get_counter dispatch on strings; include/dvo_hip.h is where an integrator reads what exists."""
+    import re
+    src = open(os.path.join(ROOT, "dvo_slam_amd", "csrc", "capi.hip")).read()
+    header = open(os.path.join(ROOT, "include", "dvo_hip.h")).read()
+
+    def body(signature):
+        a = src.index(signature)
+        return src[a:src.index("\n}\n", a)]
+    options = set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', body("int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value)")))
+    counters = set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', body("int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)")))
+    assert len(options) >= 10 and len(counters) >= 10, (options, counters)
+    missing = sorted(k for k in options | counters if not re.search(r"\b%s\b" % re.escape(k), header))
+    assert not missing, "not mentioned in include/dvo_hip.h: %s" % missing
