@@ -1,5 +1,5 @@
 // dvo/util/stopwatch.h -- dvo::util::stopwatch / stopwatch_collection with the interface of
-// dvo_core/include/dvo/util/stopwatch.h:37-120 (start / stop / print / stopAndPrint; the mean of `interval` samples goes to
+// dvo_core/include/dvo/util/stopwatch.h:37-119 (start / stop / print / stopAndPrint; the mean of `interval` samples goes to
 // stderr), on std::chrono instead of cv::getTickCount + boost.accumulators.  The reference's callers keep their live
 // instances ("prepare", "m", "match", "online", ...: SURVEY.md section 5).
 #pragma once

@@ -1,6 +1,6 @@
 // dvo_slam/constraints/constraint_proposal.h -- one loop-closure hypothesis: "keyframe Current is visible from keyframe
 // Reference under InitialTransformation", its tracking result and the voters' verdicts
-// (reference: dvo_slam/include/dvo_slam/constraints/constraint_proposal.h:37-91, src/constraints/constraint_proposal.cpp:30-123).
+// (reference: dvo_slam/include/dvo_slam/constraints/constraint_proposal.h:37-88, src/constraints/constraint_proposal.cpp:30-112).
 #pragma once
 
 #include <cstdlib>

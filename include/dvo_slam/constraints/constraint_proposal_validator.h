@@ -1,7 +1,7 @@
 // dvo_slam/constraints/constraint_proposal_validator.h -- staged validation of loop-closure proposals.
 //
 // Interface and decision logic of the reference's ConstraintProposalValidator
-// (dvo_slam/include/dvo_slam/constraints/constraint_proposal_validator.h:36-82,
+// (dvo_slam/include/dvo_slam/constraints/constraint_proposal_validator.h:36-80,
 // src/constraints/constraint_proposal_validator.cpp:30-165): every stage re-tracks the surviving proposals with its own
 // tracker configuration (typically a coarse level-3-only screening, then a 3->1 refinement), lets its voters decide,
 // drops the rejected ones and hands the inverse of each tracked transform to the next stage as initial guess.

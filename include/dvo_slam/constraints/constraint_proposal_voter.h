@@ -1,6 +1,6 @@
 // dvo_slam/constraints/constraint_proposal_voter.h -- the acceptance tests applied to a tracked loop-closure proposal
-// (reference: dvo_slam/include/dvo_slam/constraints/constraint_proposal_voter.h:37-118,
-// src/constraints/constraint_proposal_voter.cpp:30-211).  Pure host logic over DenseTracker::Result.
+// (reference: dvo_slam/include/dvo_slam/constraints/constraint_proposal_voter.h:37-110,
+// src/constraints/constraint_proposal_voter.cpp:30-186).  Pure host logic over DenseTracker::Result.
 #pragma once
 
 #include <cassert>

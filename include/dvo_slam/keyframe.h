@@ -1,5 +1,5 @@
 // dvo_slam/keyframe.h -- a keyframe as the loop-closure code sees it: id, device-resident image pyramid, pose in the
-// map and the tracking-quality baseline of its own odometry (reference: dvo_slam/include/dvo_slam/keyframe.h:39-62).
+// map and the tracking-quality baseline of its own odometry (reference: dvo_slam/include/dvo_slam/keyframe.h:39-58).
 #pragma once
 
 #include <memory>

@@ -1,6 +1,6 @@
 // dvo_slam/local_map.h -- the frames tracked against one keyframe, with the relative-pose measurements between them.
 //
-// Interface of the reference's LocalMap (dvo_slam/include/dvo_slam/local_map.h:44-98) as the tracking front-end uses
+// Interface of the reference's LocalMap (dvo_slam/include/dvo_slam/local_map.h:44-88) as the tracking front-end uses
 // it (local_tracker.cpp:141-216): keyframe, active frame, pose of the active frame = keyframe pose * last keyframe
 // measurement (local_map.cpp:196-200).  The reference stores the measurements as a g2o pose graph and can optimise it;
 // graph optimisation is outside this engine's scope, so the measurements are kept as a plain edge

@@ -1,7 +1,7 @@
 // dvo_slam/local_tracker.h -- the tracking front-end: every new frame is aligned against the current KEYFRAME and
 // against the PREVIOUS frame; callbacks decide whether the keyframe is still good or a new local map starts.
 //
-// Interface and control flow of the reference's LocalTracker (dvo_slam/include/dvo_slam/local_tracker.h:41-107,
+// Interface and control flow of the reference's LocalTracker (dvo_slam/include/dvo_slam/local_tracker.h:41-106,
 // src/local_tracker.cpp:59-221).  The reference runs the two alignments on two DenseTracker instances under
 // tbb::parallel_invoke (local_tracker.cpp:176-184); both read the same current frame.  Here they are ONE device batch of
 // two pairs (DenseTracker::matchBatch): the current frame's pyramid and sampling planes are built once and swept by both.

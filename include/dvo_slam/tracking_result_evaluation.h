@@ -1,7 +1,7 @@
 // dvo_slam/tracking_result_evaluation.h -- scalar quality measures of a DenseTracker::Result relative to the first /
 // average result seen for a keyframe: entropy (log det Information), negative log-likelihood, and the latter per
 // constraint.  The keyframe front-end polls these every frame and the loop-closure voters use them as acceptance
-// ratios.  Same interface as the reference (dvo_slam/include/dvo_slam/tracking_result_evaluation.h:31-83,
+// ratios.  Same interface as the reference (dvo_slam/include/dvo_slam/tracking_result_evaluation.h:31-80,
 // dvo_slam/src/tracking_result_evaluation.cpp:27-62); the Information matrix is a by-product of the device reduce.
 #pragma once
 

@@ -4,7 +4,7 @@
 // back end (dvo_slam/src/keyframe_graph.cpp: g2o optimisation, TBB worker thread, RViz markers).  The back end is outside this
 // engine's scope; for the builds that do not link it (tests/dropin: benchmark_slam_graph does) this file defines the
 // members of the class DECLARED in
-// dvo_slam/include/dvo_slam/keyframe_graph.h:45-80 that the front end links against, as a sink that counts the completed local maps.
+// dvo_slam/include/dvo_slam/keyframe_graph.h:45-78 that the front end links against, as a sink that counts the completed local maps.
 #include <cstdlib>
 
 #include <dvo_slam/keyframe_graph.h>

@@ -1,7 +1,7 @@
 """CPU restatement of the reference's loop-closure proposal validation -- TEST INFRASTRUCTURE ONLY (like everything under oracle/: only tests/ may import it).
 
 Follows dvo_slam/src/constraints/constraint_proposal_validator.cpp:69-165 (stage loop, vote collection with early
-abort, rejected-proposal removal, keepBest, initial-transformation hand-over), constraint_proposal_voter.cpp:34-211 (the
+abort, rejected-proposal removal, keepBest, initial-transformation hand-over), constraint_proposal_voter.cpp:34-186 (the
 five voters), constraint_proposal.cpp:30-110 and tracking_result_evaluation.cpp:27-62, one proposal at a time in list
 order exactly like the reference; `track` is injected (the oracle's sequential match(), or a table in the logic tests).
 Pinned: tests/test_oracle_ref.py::test_proposal_validation_restatement_is_the_references runs the reference's own validator,

@@ -26,3 +26,16 @@ def test_cited_repository_paths_exist():
             if not os.path.exists(os.path.join(ROOT, path)):
                 missing.append("%s: %s" % (doc, p))
     assert not missing, "\n".join(missing)
+
+
+def test_reference_citations_stay_within_the_cited_files():
+    """`file:line` citations of reference sources (headers, kernels, oracle, tests, documents) against the reference tree, when it is
+    there (the build container; the GPU box has no /root/reference)."""
+    import subprocess
+    import sys
+    import pytest
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("no reference tree on this machine")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "check_citations.py")], text=True)
+    head = out.splitlines()[0]
+    assert int(head.split()[0]) > 300 and "; 0 out of range" in head, out
