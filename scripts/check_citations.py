@@ -2,7 +2,7 @@
 """Build-container check (needs /root/reference): every `file:line` citation of a reference file in the headers, kernels, oracle,
 tests and documents resolves to a file of the reference tree and stays within its length.  tests/test_docs.py runs it when the tree is present."""
 import os, re, glob, collections
-ROOT='/root/repo'; REF='/root/reference'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); REF = '/root/reference'
 ref_files = collections.defaultdict(list)
 for d,_,fs in os.walk(REF):
     for f in fs:
