@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--resident-group", type=int, default=0, help="workgroups per pair in the resident match kernel (0 = as many as fit); "
                     "with --rows-per-wave: records that do not depend on the batch size")
     ap.add_argument("--iters-per-sync", type=int, default=0)
+    ap.add_argument("--resident", type=int, default=-1, help="library option resident (-1 default policy, 0 launch path only, 1 every level resident)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses GPU 0 (with --backend gloo)")
     args = ap.parse_args()
@@ -167,6 +168,8 @@ def main():
         ctx.set_option("rows_per_wave", args.rows_per_wave)
     if args.resident_group:
         ctx.set_option("resident_group", args.resident_group)
+    if args.resident != -1:
+        ctx.set_option("resident", args.resident)
     if args.iters_per_sync:
         ctx.set_option("iters_per_sync", args.iters_per_sync)
     if not args.no_overlap:

@@ -614,7 +614,7 @@ bool aligned_to(const void* p, size_t a) { return reinterpret_cast<uintptr_t>(p)
 // derived then (ensure_roles).
 int eager_current_flavor(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_frames) {
   if (!level_uses_window(ctx, cam->w[level], cam->h[level])) return kCurAB;
-  return n_frames * 2 > (ctx->compute_units > 0 ? ctx->compute_units : 256) ? kCurC : (kCurAB | kCurC);   // (plan_resident's limit)
+  return n_frames * 4 > (ctx->compute_units > 0 ? ctx->compute_units : 256) ? kCurC : (kCurAB | kCurC);   // (plan_resident's limit)
 }
 
 int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, const void* const* grey, const void* const* raw,
@@ -1095,8 +1095,11 @@ ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg
   // records that do not depend on the batch size, so the choice of path must not either.)
   // (round 3: with the f16 Gram and the short tiles the launch path is level with or ahead of ONE workgroup per pair as well -- 192 / 256
   // pairs: screening stage 0.278 / 0.306 vs 0.293 / 0.341 ms, levels 3 -> 1 0.82 / 0.95 vs 0.87 / 1.01, full match equal; the resident
-  // kernel is kept for batches that get at least two workgroups per pair)
-  if (ctx->opt_resident < 0 && ctx->opt_resident_group == 0 && bp.n * 2 > cus) return rp;
+  // kernel is kept for batches that get at least two workgroups per pair -- with launches limited to half the chip that is
+  // pairs <= compute units / 4.  Measured at the end of round 3, 96 / 128 pairs with ONE workgroup each: full match 1.63 / 1.93 ms
+  // resident against 1.61 / 1.90 on the launch path, levels 3 -> 1 0.60 / 0.67 against 0.57 / 0.65, and a streaming step of 128 pairs
+  // beside its background ingest 2.50 against 2.41 ms; at 64 pairs (two workgroups each) resident still wins, 1.19 against 1.26.)
+  if (ctx->opt_resident < 0 && ctx->opt_resident_group == 0 && bp.n * 4 > cus) return rp;
   // all workgroups of a launch with groups must be resident at once: one workgroup (8 wavefronts, up to 256 registers) per compute unit
   int group = 1;
   while (group * 2 <= kResidentMaxGroup && bp.n * group * 2 <= cus) group *= 2;
