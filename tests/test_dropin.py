@@ -453,3 +453,59 @@ def test_reference_keyframe_graph_on_the_engine(tmp_path):
         print("engine, threaded run %d: %d keyframes, %d loop closures; |translation of the measurement| - |distance of its keyframes|: "
               "median %.2e, worst %.2e" % (rep, len(_keyframes(vert)), len(loops), float(np.median(np.abs(off))), float(np.abs(off).max())))
         assert np.abs(off).max() < 0.05                          # (measured 0.017; a diverged alignment on this 0.1 m sweep is off by more)
+
+
+@pytest.mark.gpu
+def test_reference_live_slam_node_on_the_engine(tmp_path):
+    """dvo_slam/src/camera_keyframe_tracking.cpp -- the reference's live SLAM node: sensor messages -> KeyframeTracker -> KeyframeGraph,
+    reconfigure callbacks, graph publication on every map change, finalOptimization on request -- compiled UNMODIFIED against the facade
+    (tests/dropin/Makefile: libdvo_slam_node.so) and fed the there-and-back sweep as messages (mono8 + 32FC1 metres): it tracks and maps
+    like the reference's executable benchmark_slam does on the same frames read from PNG files (same engine, same front and back end),
+    and its last reconfigure call runs the final optimisation pass over all keyframes."""
+    import ctypes as C
+    from dvo_slam_amd import datagen, tum
+    need_dropin()
+    path = os.path.join(cm.HERE, "dropin", "_build", "libdvo_slam_node.so")
+    if not os.path.exists(path):
+        pytest.skip("tests/dropin/_build/libdvo_slam_node.so is not built (needs the reference tree at build time)")
+    exe = _target("benchmark_slam_graph")
+    root = str(tmp_path / "loop")
+    n = _loop_folder(root)
+    # the node hands its FIRST frame to nobody (camera_keyframe_tracking.cpp:252-258: init and return), so the executable gets the folder
+    # without it: the same 46 frames then reach the same front end
+    with open(os.path.join(root, "assoc.txt")) as f:
+        lines = f.readlines()
+    with open(os.path.join(root, "assoc.txt"), "w") as f:
+        f.writelines(lines[1:])
+    stamps_all = [float(l.split()[0]) for l in lines]
+    traj_b, vert_b, edge_b, _ = _run_graph_target(exe, root, "bench", extra=["_use_multithreading:=false"])
+    seq = datagen.synth_sequence(LOOP_SEQ["seed"], LOOP_SEQ["n"], 640, 480, depth_noise=LOOP_SEQ["depth_noise"], grey_noise=LOOP_SEQ["grey_noise"],
+                                 exposure=LOOP_SEQ["exposure"])
+    idx = list(range(LOOP_SEQ["n"])) + list(range(LOOP_SEQ["n"] - 2, -1, -1))
+    grey = [np.ascontiguousarray(seq["grey"][k]) for k in idx]
+    depth = [np.ascontiguousarray(po.convert_raw_depth(seq["depth"][k]), np.float32) for k in idx]
+    stamps = np.array(stamps_all)
+    K = np.ascontiguousarray(seq["K"], np.float32)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.dropin_slam_node.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_double),
+                                   C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    poses = np.zeros((n, 4, 4))
+    counts = np.zeros(8, np.int32)
+    sent = L.dropin_slam_node(n, 640, 480, K.ctypes.data_as(C.POINTER(C.c_float)), (vp * n)(*[vp(g.ctypes.data) for g in grey]),
+                              (vp * n)(*[vp(z.ctypes.data) for z in depth]), stamps.ctypes.data_as(C.POINTER(C.c_double)),
+                              3, 1, 50, 1e-4, 0.0, 1, 0.03, 0.05, 0.005, 0.2, 0.1, 1, 0, 1,
+                              poses.ctypes.data_as(C.POINTER(C.c_double)), counts.ctypes.data_as(C.POINTER(C.c_int)))
+    assert sent == n - 1
+    worst = max(np.abs(po.se3_log(np.linalg.inv(a) @ b)).max() for a, b in zip(poses[1:], traj_b[:n - 1]))
+    kf_b, loops_b = len(_keyframes(vert_b)), len(_loop_closures(edge_b))
+    print("live SLAM node on the engine, %d frames: largest pose distance to benchmark_slam's trajectory file %.2e; map changes %d, keyframes %d, "
+          "graph edges %d, loop closures %d (benchmark_slam, which forces a last keyframe: %d keyframes, %d loop closures); after the final "
+          "optimisation pass: %d map changes, %d keyframes, %d edges, %d loop closures"
+          % (n, worst, counts[0], counts[1], counts[2], counts[3], kf_b, loops_b, counts[4], counts[5], counts[6], counts[7]))
+    assert worst < 2e-5                                              # (the file holds six significant digits)
+    assert counts[1] in (kf_b, kf_b - 1) and counts[0] >= counts[1] - 1
+    assert 0.8 * loops_b <= counts[3] <= loops_b
+    assert counts[4] == counts[0] + 1 and counts[5] == counts[1] and counts[7] >= counts[3]
