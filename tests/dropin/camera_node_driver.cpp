@@ -14,6 +14,7 @@
 extern "C" int dropin_camera_node(int n, int w, int h, const float K[4], const unsigned char* const* grey, const unsigned short* const* depth_mm,
                                   int coarsest, int finest, int max_iterations, double precision, double mu, int use_initial_estimate,
                                   double* out_pose /* n x 16, row-major, pose after each frame */) {
+  const int sent_before = tf::TransformBroadcaster::count();      // (the counter is shared by every library of the process that holds this stand-in)
   ros::NodeHandle nh, nh_private("~");
   dvo_ros::CameraDenseTracker node(nh, nh_private);
   dvo_ros::CameraDenseTrackerConfig cfg = dvo_ros::CameraDenseTrackerConfig::__getDefault__();
@@ -43,9 +44,9 @@ extern "C" int dropin_camera_node(int n, int w, int h, const float K[4], const u
     node.handleImages(rgb, depth, info, info);
     Eigen::Affine3d pose;
     pose.setIdentity();
-    if (tf::TransformBroadcaster::count() > 0) tf::TransformTFToEigen(tf::TransformBroadcaster::last(), pose);
+    if (tf::TransformBroadcaster::count() > sent_before) tf::TransformTFToEigen(tf::TransformBroadcaster::last(), pose);
     for (int a = 0; a < 4; ++a)
       for (int b = 0; b < 4; ++b) out_pose[size_t(k) * 16 + a * 4 + b] = pose.matrix()(a, b);
   }
-  return tf::TransformBroadcaster::count();
+  return tf::TransformBroadcaster::count() - sent_before;
 }
