@@ -463,7 +463,7 @@ def test_reference_live_slam_node_on_the_engine(tmp_path):
     like the reference's executable benchmark_slam does on the same frames read from PNG files (same engine, same front and back end),
     and its last reconfigure call runs the final optimisation pass over all keyframes."""
     import ctypes as C
-    from dvo_slam_amd import datagen, tum
+    from dvo_slam_amd import datagen
     need_dropin()
     path = os.path.join(cm.HERE, "dropin", "_build", "libdvo_slam_node.so")
     if not os.path.exists(path):
