@@ -253,7 +253,7 @@ struct dvo_hip_context {
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
   int opt_fused_ll_pixels = 0;     // largest level (pixels) whose log-likelihood sweep runs inside the solver workgroup (0 = by batch size)
-  int opt_variant = 7;             // schedule of the sweep: 7 = current-frame window staged in LDS + f16 hi/lo Gram on the matrix pipe where the level allows
+  int opt_variant = 8;             // schedule of the sweep: 8 = current-frame window staged in LDS, contracted arithmetic + f16 hi/lo Gram on the matrix pipe where the level allows (7: residuals bit-identical to the oracle's)
                                    // (width a multiple of 64), else 5 = gathering sweep with the f32 Gram on the matrix cores
   // the resident match kernel (align_resident.hip): -1 = levels whose sweep is short enough for the groups that fit (default),
   // 0 = never (launches per iteration only), 1 = every level
@@ -515,7 +515,7 @@ int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int le
   // A large batch fills the device whatever the tile: short tiles (2 rows per wavefront: the schedule with the pinned prologue) run the
   // coarse levels' sweeps 6-11 % faster than tall ones since the f16 Gram (scripts/ab_sweep.py: 1024 pairs, 160x120 0.200 -> 0.187 ms,
   // 80x60 0.056 -> 0.050 ms; bench step 14.22 -> 13.89 ms)
-  if (n_pairs >= 256 && ctx->opt_variant == 7) return 2;
+  if (n_pairs >= 256 && ctx->opt_variant >= 7) return 2;
   const int candidates[4] = {8, 4, 2, 1};   // measured (profiles/r01_c_tile_sweep.txt): 8 rows is at or near the optimum on every level
   // The tallest tile that still yields this many workgroups.  Fewer, taller tiles also mean fewer partial rows for the
   // bookkeeping kernel, which matters most when there are few pairs (whole-match timings: profiles/r01_f_tile_heuristic.txt).
@@ -1603,8 +1603,8 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "variant") == 0) {
-    if (value != 0 && value != 5 && value != 6 && value != 7)
-      return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0 (all-VALU schedule), 5 (matrix-core schedule), 6 or 7 (current-frame window staged in LDS)");
+    if (value != 0 && (value < 5 || value > 9))
+      return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0 (all-VALU schedule), 5 (matrix-core schedule), 6 or 7 (current-frame window staged in LDS, residuals bit-identical to the oracle's), 8 or 9 (the same with contracted arithmetic)");
     ctx->opt_variant = value;
     return DVO_HIP_OK;
   }
@@ -2171,6 +2171,13 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
   if (residuals_or_null) DVO_HIP_TRY(ctx, hipMemcpyAsync(residuals_or_null, ctx->ws[0].scratch.p, npx * sizeof(float2), hipMemcpyDeviceToHost, s));
   DVO_HIP_TRY(ctx, hipStreamSynchronize(s));
   DVO_HIP_TRY(ctx, hipGetLastError());
+  if (residuals_or_null) {
+    // a pixel without a constraint is a NaN PAIR on this boundary; the contracted sweep marks it in the first component only (which
+    // is what the log-likelihood pass tests)
+    float* r = reinterpret_cast<float*>(residuals_or_null);
+    for (size_t i = 0; i < npx; ++i)
+      if (r[2 * i] != r[2 * i]) r[2 * i + 1] = r[2 * i];
+  }
   return DVO_HIP_OK;
 }
 

@@ -250,9 +250,13 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
 
 /* Tunables (0 = library default).  key: "rows_per_wave" (1,2,4,8,16: tile height of the sweep kernel),
  * "iters_per_sync" (host polling cadence of the batched Gauss-Newton loop), "variant" (schedule of the sweep
- * kernel: 7 = the current frame's {I, Z} window staged in LDS + Gram accumulation on the f16 matrix pipe, exact hi/lo split, on
- * every level whose width is a multiple of 64 and variant 5 elsewhere (default); 6 = the same with the f32 Gram (bit-identical to
- * 5); 5 = gathered taps, f32 Gram accumulation on the matrix cores; 0 = all-VALU with the DPP + LDS reduction),
+ * kernel: 8 (default) = the current frame's {I, Z} window staged in LDS, contracted per-pixel arithmetic (fused multiply-adds,
+ * v_rcp_f32 in the projection, separable blends: the same function as 7 to a few ulp of the tap coordinate -- residuals within 2e-5,
+ * constraint counts equal except at pixels on a bound) + Gram accumulation on the f16 matrix pipe, on every level whose width is a
+ * multiple of 64 and the schedule of 7 elsewhere; 9 = 8 without the full-wavefront operand stores (measurement); 7 = the window sweep
+ * whose residuals and constraint counts equal the oracle's MATH mode BIT FOR BIT (no contraction, correctly rounded divisions), f16
+ * Gram; 6 = the same with the f32 Gram (bit-identical to 5); 5 = gathered taps, f32 Gram accumulation on the matrix cores; 0 =
+ * all-VALU with the DPP + LDS reduction),
  * "min_workgroups" (tile-height heuristic: smallest launch that counts as filling the chip; 0 = built-in table),
  * "fused_ll_pixels" (largest level, in pixels, whose log-likelihood sweep runs inside the solver
  * workgroup instead of a launch of its own; 0 = 160x120, and 320x240 for batches of 64 pairs and more),

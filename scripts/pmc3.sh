@@ -25,7 +25,7 @@ for f in sorted(glob.glob(O + '/*/*counter_collection.csv')):
     for row in csv.DictReader(open(f)):
         agg[row['Kernel_Name'][:70]][row['Counter_Name']].append(float(row['Counter_Value']))
     for k in agg:
-        if 'residual_reduce' in k or 'sweep_window' in k:
+        if 'residual_reduce' in k or 'sweep_window' in k or 'sweep_fast' in k:
             for c, v in agg[k].items():
                 big = [x for x in v if x > 0.5 * max(v)] if max(v) > 0 else v          # (the speculative no-op launches of the warm-up steps excluded)
                 print("%-4s %-40s %-34s per-dispatch %.5g  (n=%d of %d)" % (f.split('/')[-2], k[9:49], c, sum(big) / len(big), len(big), len(v)))

@@ -22,7 +22,7 @@ def ctx(gpu_ctx):
     # (variant 6; the default's f16 Gram differs in the 7th digit, which moves a termination test on the edge now and then)
     gpu_ctx.set_option("variant", 6)
     yield gpu_ctx
-    for key, value in (("variant", 7), ("resident", -1), ("resident_group", 0), ("resident_rows", 0), ("resident_flags", 0), ("resident_cooperative", 0)):
+    for key, value in (("variant", 8), ("resident", -1), ("resident_group", 0), ("resident_rows", 0), ("resident_flags", 0), ("resident_cooperative", 0)):
         gpu_ctx.set_option(key, value)
 
 
