@@ -262,16 +262,35 @@ def main():
     # roofline of the dominant kernel: finest-level fused warp/residual/Jacobian/reduce sweep, HIP events on the context stream
     # (timed where the sweeps of a match run: after three Gauss-Newton steps on the level, i.e. at the converged transform with the
     # t-distribution weights on -- not at the identity with unit weights)
-    k_ms = {lvl: min(tracker.time_residual_kernel(refs, curs, lvl, reps=10, warm_iterations=3) for _ in range(2)) for lvl in (0, 1, 2, 3)}
+    # (round 4: the MEAN of 24 back-to-back launches per level -- the closest a run without the profiler gets to the in-situ average of
+    # profiles/r04_bench_kernel_stats_insitu.txt; rounds 1-3 reported the smaller of two means of 10)
+    ROOFLINE_REPS = 24
+    k_ms = {lvl: tracker.time_residual_kernel(refs, curs, lvl, reps=ROOFLINE_REPS, warm_iterations=3) for lvl in (0, 1, 2, 3)}
+    # the same launch on the other schedules of the finest level (library option "variant"): 7 = the window sweep whose residuals equal the
+    # oracle's bit for bit (no contraction, correctly rounded divisions), 6 = 7 with the f32 Gram (no f16 operands anywhere)
+    k_ms_variants = {}
+    for v in (7, 6):
+        ctx.set_option("variant", v)
+        k_ms_variants[v] = tracker.time_residual_kernel(refs, curs, 0, reps=ROOFLINE_REPS, warm_iterations=3)
+    ctx.set_option("variant", 8)
     stream_ms = tracker.time_stream_mix(refs, curs, 0, reps=10)                       # the same planes streamed in pixel order, read only
     stream_w_ms = tracker.time_stream_mix(refs, curs, 0, reps=10, with_write=True)   # ... plus the 8-B residual pair the sweep writes
     algo_bytes = ALGO_BYTES_PER_PIXEL * W * H * B
     achieved = algo_bytes / (k_ms[0] * 1e-3) / 1e9
     traffic = _pmc_traffic(B)
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                    traffic=traffic, kernel="dvo_hip::k_sweep_window<true> (pyramid level 0, %d pairs per launch; 64 x 16 tiles, the current "
-                                            "frame's {I, Z} window staged in LDS, Gram accumulation on the f16 matrix pipe)" % B,
-                    kernel_ms=round(k_ms[0], 4), algorithmic_bytes_per_launch=algo_bytes,
+                    traffic=traffic, kernel="dvo_hip::k_sweep_fast<true> (pyramid level 0, %d pairs per launch; 64 x 16 tiles, the current "
+                                            "frame's {I, Z} window staged in LDS, contracted f32 pixel arithmetic, Gram accumulation on the f16 "
+                                            "matrix pipe from exact hi + lo operand pairs)" % B,
+                    kernel_ms=round(k_ms[0], 4), kernel_ms_is="mean of %d back-to-back launches (HIP events on the context stream)" % ROOFLINE_REPS,
+                    kernel_ms_exact_arithmetic=round(k_ms_variants[7], 4), kernel_ms_f32_gram=round(k_ms_variants[6], 4),
+                    frac_exact_arithmetic=round(algo_bytes / (k_ms_variants[7] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    frac_f32_gram=round(algo_bytes / (k_ms_variants[6] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    schedules_note="kernel_ms: the shipped schedule (variant 8: fused multiply-adds, v_rcp_f32 in the projection; residuals within "
+                                   "2e-5 of the oracle's, tests/test_gpu_parity.py::test_contracted_sweep_against_the_exact_one); "
+                                   "kernel_ms_exact_arithmetic: variant 7, residuals and constraint counts bit-identical to the oracle's MATH mode, "
+                                   "f16 hi + lo Gram operands; kernel_ms_f32_gram: variant 6, the same with the f32 matrix instruction (no f16 anywhere)",
+                    algorithmic_bytes_per_launch=algo_bytes,
                     algorithmic_bytes_per_pixel=ALGO_BYTES_PER_PIXEL,
                     moved_bytes_per_pixel=None if traffic is None else round(traffic / (W * H * B), 2),
                     moved_GBps=None if traffic is None else round(traffic / (k_ms[0] * 1e-3) / 1e9, 1),
@@ -343,6 +362,27 @@ def main():
                                  "alignments/s at N GPUs ~ total pairs / that step time"}
         pipe.step(now=None, nxt=counter[0] % n_sets)      # (the sub-pipelines re-ingested some frames of the sets: restore the pipeline's state)
 
+    # The reference-compatible mode (option "ref_compat": projection and weights multiply with the host CPU's _mm_rcp_ps like the reference's
+    # SSE path) on the same streaming loop: every level on the launch path, a table lookup per pixel
+    ref_compat = None
+    if world == 1:
+        ctx.set_option("ref_compat", 1)
+        pipe.step(now=None, nxt=counter[0] % n_sets)
+        for j in range(2):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for j in range(args.steps):
+            step()
+        barrier()
+        el_c = time.perf_counter() - t1
+        ref_compat = {"value": round(n_total * args.steps / el_c, 2), "unit": "alignments/s", "ms_per_step": round(el_c / args.steps * 1e3, 3),
+                      "max_twist_error_vs_truth": float(np.abs(parallel.twists_of(last["T"]) - pairs_np["xi_true"]).max()),
+                      "note": "the same HBM-resident loop with option ref_compat on (the opt-in mode whose trajectories follow the reference's own, "
+                              "DESIGN.md section 2); the finest-level sweep is then dvo_hip::k_sweep_window<true, true, 4>"}
+        ctx.set_option("ref_compat", 0)
+        pipe.step(now=None, nxt=counter[0] % n_sets)
+
     # PCIe-inclusive leg (never `value`): the same pipeline, but every step's raw planes are handed over in pinned HOST memory
     # (SURVEY.md 8d config 4 "incl. H2D of 2 planes per frame") -- DMA on the upload stream, build on the build stream, match on
     # the main stream, three batches in flight
@@ -405,7 +445,7 @@ def main():
             "metric": "frame-pair alignments/s (640x480, 4-level pyramid) + finest-level HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (Gram operands f16 hi+lo, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "%d pairs (BASELINE config 4): independent 640x480 RGB-D frame pairs, seeds 0..%d, pair i on rank i mod %d, "
                                    "4-level pyramid, FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0; "
                                    "step = every rank re-ingests the raw planes of its shard from HBM (pyramids, sampling planes, point "
@@ -423,6 +463,7 @@ def main():
             "contract_value_note": "SURVEY.md 8d config 4 / BASELINE.md: alignments/s INCLUDING the host-to-device transfer of two raw planes per "
                                    "frame (= from_host.value, PCIe-bound, see from_host.roofline); `value` has the raw planes resident in HBM",
             "from_host": from_host,
+            "ref_compat": ref_compat,
             "scaling_model": scaling_model,
             "max_twist_error_vs_truth": twist_err, "nan_results": nan_results,
         }
@@ -439,12 +480,12 @@ def _pmc_traffic(pairs):
     """HBM bytes per launch of the finest-level kernel from the committed rocprofv3 --pmc passes (profiles/pmc_finest_kernel.json:
     FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes, see scripts/pmc.sh).  bench.py cannot run the profiler itself.  The
     number is reported only when it was collected for the same number of pairs per launch AND the record names the very source of
-    the sweep kernel that is compiled now (sha256 of align_window.hip + gram_f16.h + sweep_parts.h + pixel_math.h) -- a stale record reads as null."""
+    the sweep kernel that is compiled now (sha256 of align_fast.hip + gram_f16.h + sweep_parts.h + pixel_math.h) -- a stale record reads as null."""
     import hashlib
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_finest_kernel.json")))
         h = hashlib.sha256()
-        for f in ("align_window.hip", "gram_f16.h", "sweep_parts.h", "pixel_math.h"):
+        for f in ("align_fast.hip", "gram_f16.h", "sweep_parts.h", "pixel_math.h"):
             h.update(open(os.path.join(ROOT, "dvo_slam_amd", "csrc", f), "rb").read())
         if rec.get("kernel_source_sha256") != h.hexdigest() or rec["pairs_per_launch"] != pairs:
             return None

@@ -1,11 +1,11 @@
-// align_fast.hip -- schedule variant 8 of the sweep: the window sweep of align_window.hip (current frame's {I, Z} window staged in
-// LDS, Gram accumulation on the f16 matrix pipe) with CONTRACTED per-pixel arithmetic.
+// align_fast.hip -- schedule variants 8 / 9 of the sweep: the window sweep of align_window.hip (current frame's {I, Z} window
+// staged in LDS, Gram accumulation on the f16 matrix pipe) with CONTRACTED per-pixel arithmetic.
 //
 // Variants 6 / 7 spend about a third of their vector instructions on reproducing the residuals of the oracle's MATH mode bit for bit
 // (dense_tracking_impl.cpp:148-281 without fused multiply-adds, the reference's operation order, correctly rounded divisions) -- a
 // stricter bar than the float tolerance the alignment is specified to, and stricter than what MATH itself keeps against the
-// reference (3e-5 in the final twist).  The kernel is bound by vector-instruction issue (profiles/r03_pmc_utilisation.md), so this
-// variant computes THE SAME FUNCTION with the fewest instructions instead:
+// reference (3e-5 in the final twist).  The kernel is bound by vector-instruction issue (profiles/r03_pmc_utilisation.md), so these
+// variants compute THE SAME FUNCTION with the fewest instructions instead:
 //
 //   * projection  q = K T (tx z, ty z, z, 1) factored as  z (KT.col0 tx + KT.col1 ty + KT.col2) + KT.col3  -- the bracket is a
 //     constant of the column plus a constant of the row: 6 fused multiply-adds per pixel instead of 23 operations
@@ -20,6 +20,12 @@
 //   * the window fill of a tile whose window lies inside the image needs no clamping: one address per thread, scalar row offsets
 //   * the epilogue leaves H H^T and S to the 85 reducing threads instead of symmetrising per wavefront
 //
+// (Measured and dropped, round 4: packing the tile's SELECTED reference pixels -- Zsel not NaN -- into a list in LDS first and sweeping
+// ceil(n / 64) instead of 16 wavefront rows, what the reference's PointSelection does once per key frame.  Correct, same residuals;
+// 2.45 ms instead of 2.18 per 1024-pair launch: 81 % of the bench's reference pixels are selected -- the constraints that are lost
+// are lost to holes of the CURRENT frame, known only after the taps -- so a tile keeps 13-14 of its 16 rows and the list costs more
+// than they save.)
+//
 // What is NOT changed: which pixels are tested, the NaN / occlusion semantics (Q4, Q5, Q9, Q19), the weights, the Jacobian at the
 // untransformed point (Q10), the accumulator layout, the deterministic reduction order.  Differences to variant 7 are rounding
 // differences of a few ulp in u, v and the blends (tests/test_gpu_parity.py::test_contracted_sweep_against_the_exact_one states and
@@ -27,6 +33,10 @@
 #include <type_traits>
 
 #include "gram_f16.h"
+
+#ifndef DVO_FAST_SKIP
+#define DVO_FAST_SKIP 0
+#endif
 
 namespace dvo_hip {
 
@@ -41,6 +51,8 @@ constexpr int kFastCells = kFastPitch * kFastRows;      // 2688 cells x 8 B = 21
 
 typedef short __attribute__((ext_vector_type(2))) fast_i16x2;
 typedef unsigned __attribute__((ext_vector_type(2))) fast_u32x2;
+typedef unsigned __attribute__((__vector_size__(2 * sizeof(unsigned)))) fast_u32v2;
+typedef const volatile __attribute__((address_space(3))) f32x2* FastLdsCellPtr;
 
 // wavefront-wide minima (a, b) and maxima (c, d) of four integers through DPP, fused into the min / max instruction (row_shr 1, 2,
 // 4, 8; row_bcast 15, 31): valid in lane 63.  A lane without a source does not execute and keeps its own value, which is neutral.
@@ -83,7 +95,122 @@ __device__ __forceinline__ void fast_project(const float* KT, float c0, float c1
   v = qy * r;
 }
 
-// The operand rows of a pixel row, 32 pixels at a time.  SWAP: see the header.
+// ---- the window ------------------------------------------------------------------------------------------------------------------
+struct FastWindow {
+  int x0, y0, ww, wh;                                   // origin (image coordinates, may be -1 / -2) and the extent in use
+  bool all_in;                                          // every projected neighbourhood of the tile lies inside the window
+};
+
+// from the four wavefronts' tap bounding boxes (packed u | v << 16: minima in [w][0], maxima in [w][1]; 0x7fff = no projection)
+__device__ __forceinline__ FastWindow fast_window_of(const int (*bbox)[2]) {
+  fast_i16x2 lo = __builtin_bit_cast(fast_i16x2, bbox[0][0]), hi = __builtin_bit_cast(fast_i16x2, bbox[0][1]);
+#pragma unroll
+  for (int w4 = 1; w4 < 4; ++w4) {
+    lo = __builtin_elementwise_min(lo, __builtin_bit_cast(fast_i16x2, bbox[w4][0]));
+    hi = __builtin_elementwise_max(hi, __builtin_bit_cast(fast_i16x2, bbox[w4][1]));
+  }
+  const int lo_s = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lo)), hi_s = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi));
+  const int bu0 = lo_s & 0xffff, bv0 = (lo_s >> 16) & 0xffff, bu1 = hi_s & 0xffff, bv1 = (hi_s >> 16) & 0xffff;
+  FastWindow wnd;
+  wnd.x0 = (bu0 - 1) & ~1; wnd.y0 = bv0 - 1;            // even: a 16-byte load holds two window cells
+  const bool any = bu0 != 0x7fff;
+  wnd.ww = any ? min(bu1 + 3 - wnd.x0, kFastCols) : 0;  // columns x0 .. umax + 2
+  wnd.wh = any ? min(bv1 + 3 - wnd.y0, kFastRows) : 0;
+  wnd.all_in = !any || (bu1 + 3 - wnd.x0 <= kFastCols && bv1 + 3 - wnd.y0 <= kFastRows);
+  return wnd;
+}
+
+// phase B: thread t loads column pair t % 42 of rows t / 42, t / 42 + 6, ...  Cells outside the extent in use are not loaded at all.
+__device__ __forceinline__ void fast_fill_window(const LevelGeom& g, __amdgpu_buffer_rsrc_t curC, float2* win, const FastWindow& wnd, int row_bytes) {
+  const int t = threadIdx.x;
+  const int rg = t / kFastPairs, cxp = t - rg * kFastPairs;
+  f32x4* dst = reinterpret_cast<f32x4*>(win) + rg * (kFastPitch / 2) + cxp;
+  const int x0 = wnd.x0, y0 = wnd.y0, wh = wnd.wh;
+  const bool interior = x0 >= 0 && x0 + kFastCols <= g.w && y0 >= 0 && y0 + kFastRows <= g.h;   // (uniform)
+  if (rg < kFastRowGroups && 2 * cxp < wnd.ww) {
+    if (interior) {
+      // no clamping anywhere: one vector offset per thread, the row group's offset is a scalar
+      const int voff = (y0 + rg) * row_bytes + (x0 + 2 * cxp) * 8;
+      f32x4 cell[kFastLoads];
+#pragma unroll
+      for (int j = 0; j < kFastLoads; ++j)
+        if (j * kFastRowGroups < wh)                                                              // (uniform)
+          cell[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(curC, voff, j * kFastRowGroups * row_bytes, 0));
+#pragma unroll
+      for (int j = 0; j < kFastLoads; ++j)
+        if (j * kFastRowGroups < wh && rg + j * kFastRowGroups < kFastRows) dst[j * kFastRowGroups * (kFastPitch / 2)] = cell[j];
+    } else {
+      // a window that reaches over the image border: coordinates clamped like the frame build's border code (rgbd_image.cpp:419-489),
+      // so that the clamped central differences come out of the same subtraction.  Image width and window origin are even: a pair
+      // lies entirely inside the image, entirely left of it (both cells = column 0) or entirely right of it (both = column w - 1).
+      const int x = x0 + 2 * cxp;
+      const int xl = min(max(x, 0), g.w - 2) * 8;
+      f32x4 cell[kFastLoads];
+#pragma unroll
+      for (int j = 0; j < kFastLoads; ++j) {
+        const int cy = rg + j * kFastRowGroups;
+        const int y = min(max(y0 + cy, 0), g.h - 1);
+        cell[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(curC, cy < wh ? y * row_bytes + xl : 0x7ffffff0, 0, 0));
+      }
+      if (x < 0) {
+#pragma unroll
+        for (int j = 0; j < kFastLoads; ++j) { cell[j].z = cell[j].x; cell[j].w = cell[j].y; }
+      }
+      if (x >= g.w) {
+#pragma unroll
+        for (int j = 0; j < kFastLoads; ++j) { cell[j].x = cell[j].z; cell[j].y = cell[j].w; }
+      }
+#pragma unroll
+      for (int j = 0; j < kFastLoads; ++j)
+        if (rg + j * kFastRowGroups < kFastRows) dst[j * kFastRowGroups * (kFastPitch / 2)] = cell[j];
+    }
+  }
+}
+
+// the twelve cells of a lane's 4 x 4 tap neighbourhood (corners left out).  CHECKED = false: every neighbourhood of the tile lies
+// inside the window -- no per-lane test, no second source, and no vector-memory load whose counter the row would have to wait for.
+// CHECKED: a tile whose projections spread beyond the window (a depth discontinuity under a large motion): lanes inside read the
+// window, the others fetch their cells from memory, coordinates clamped like the window's -- correct for any motion.  The tap corner
+// is not kept apart from the window index: it is projected again (tx, ty), the same instructions as in phase A.
+template <bool CHECKED>
+__device__ __forceinline__ void fast_fetch_cells(const LevelGeom& g, const float* KT, __amdgpu_buffer_rsrc_t curC, const float2* win, const FastWindow& wnd,
+                                                 int neg_base, const FastRow& r, bool ok, float tx, float ty, f32x2 (&P)[4][4], unsigned& n_fallback) {
+  // (volatile: twelve ds_read_b64, two LDS cycles each; the compiler otherwise pairs them into ds_read2_b64, eight cycles a pair)
+  if constexpr (!CHECKED) {
+    const int addr = (r.idx << 3) + neg_base;
+    FastLdsCellPtr q = (FastLdsCellPtr)(reinterpret_cast<const char*>(win) + (ok ? addr : 0));
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        if ((rr == 1 || rr == 2) || (cc == 1 || cc == 2)) P[rr][cc] = q[rr * kFastPitch + cc];
+  } else {
+    float pu, pv, pqz;
+    fast_project(KT, fmaf(KT[0], tx, KT[2]), fmaf(KT[4], tx, KT[6]), fmaf(KT[8], tx, KT[10]), r.z, ty, pu, pv, pqz);
+    const int u0 = int(pu), v0 = int(pv);
+    const int cx = u0 - wnd.x0 - 1, cy = v0 - wnd.y0 - 1;
+    const bool in_win = ok && unsigned(cx) <= unsigned(kFastCols - 4) && unsigned(cy) <= unsigned(kFastRows - 4);
+    FastLdsCellPtr q = (FastLdsCellPtr)(win + (in_win ? cy * kFastPitch + cx : 0));
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        if ((rr == 1 || rr == 2) || (cc == 1 || cc == 2)) P[rr][cc] = q[rr * kFastPitch + cc];
+    if (ok && !in_win) {
+      n_fallback += 1;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          if ((rr == 1 || rr == 2) || (cc == 1 || cc == 2)) {
+            const int x = min(max(u0 - 1 + cc, 0), g.w - 1), y = min(max(v0 - 1 + rr, 0), g.h - 1);
+            P[rr][cc] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(curC, (y * g.w + x) * 8, 0, 0));
+          }
+    }
+  }
+}
+
+// ---- the operand rows of a pixel row on the f16 matrix pipe, 32 pixels at a time.  SWAP: see the header ------------------------------
 template <bool SWAP>
 __device__ __forceinline__ void fast_gram_row(float* my, int lane, const float (&comps)[14], f32x4& acc0, f32x4& acc1) {
   typedef volatile __attribute__((address_space(3))) u32x4* LdsQuadPtr;
@@ -150,6 +277,125 @@ __device__ __forceinline__ void fast_gram_row(float* my, int lane, const float (
   __builtin_amdgcn_wave_barrier();
 }
 
+// weights: sqrt(7 / (5 + r^T P r)) = c rsq(k + r^T P r); the first pass of a level (unit weights) rides the same code as 2 rsq(4 + 0)
+struct FastWeights {
+  float P00, P11, P2x, wk, wc;
+  __device__ __forceinline__ explicit FastWeights(const PairState& st) {
+    const bool first = st.first != 0;
+    P00 = first ? 0.0f : st.P_prev[0]; P11 = first ? 0.0f : st.P_prev[3]; P2x = first ? 0.0f : st.P_prev[1] + st.P_prev[2];
+    wk = first ? 4.0f : 5.0f; wc = first ? 2.0f : 2.6457513110645906f;
+  }
+};
+
+// Everything of a pixel row behind its twelve cells: blend, residual pair (stored for the log-likelihood pass: `resid` at vector offset
+// off_v + scalar offset off_s), validity, weight, Jacobian at the untransformed point, Gram accumulation.  tx, ty, cx = 1 + tx^2:
+// normalised coordinates of the lane's reference pixel.
+template <bool SWAP>
+__device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const f32x2 (&P)[4][4], const FastRow& r, unsigned long long ok_mask, float tx, float ty,
+                                              float cx, const FastWeights& wt, __amdgpu_buffer_rsrc_t resid, int off_v, int off_s, float* my, int lane,
+                                              f32x4& acc0, f32x4& acc1, int& n_valid) {
+  // separable blend (rows first): E_j = row j of the neighbourhood at the tap's column position; intensity / depth, TWICE the
+  // vertical and TWICE the horizontal central difference, each blended between rows 1 and 2
+  const float a1 = r.a1, b1 = r.b1;
+  float cI, cZ, cIx, cIy, cZx, cZy;
+#define DVO_BLEND(f, cV, cVx, cVy)                                                                                 \
+  {                                                                                                                \
+    const float e0 = fast_lerp(P[0][1].f, P[0][2].f, a1), e1 = fast_lerp(P[1][1].f, P[1][2].f, a1);                \
+    const float e2 = fast_lerp(P[2][1].f, P[2][2].f, a1), e3 = fast_lerp(P[3][1].f, P[3][2].f, a1);                \
+    cV = fast_lerp(e1, e2, b1);                                                                                    \
+    cVy = fast_lerp(e2 - e0, e3 - e1, b1);                                                                         \
+    const float d1 = fast_lerp(P[1][2].f - P[1][0].f, P[1][3].f - P[1][1].f, a1);                                  \
+    const float d2 = fast_lerp(P[2][2].f - P[2][0].f, P[2][3].f - P[2][1].f, a1);                                  \
+    cVx = fast_lerp(d1, d2, b1);                                                                                   \
+  }
+  DVO_BLEND(x, cI, cIx, cIy)
+  DVO_BLEND(y, cZ, cZx, cZy)
+#undef DVO_BLEND
+  const float r0 = (cI - r.i) * (1.0f / 255.0f);             // dense_tracking.cpp:217-220
+  const float r1 = cZ - r.qz;                                // reference depth := transformed z (dense_tracking_impl.cpp:269)
+  const float dz = r.z - 0.4f;                               // occlusion threshold -20 (0.0012 + 0.0019 (z - 0.4)^2) (:122-128, Q5)
+  const float thr = fmaf(dz * -0.038f, dz, -0.024f);
+  // Q9: a hole in any of the twelve cells makes cZ (hence r1), cZx or cZy not-a-number; intensities are never holes
+  const unsigned long long valid_mask = ok_mask & __builtin_amdgcn_ballot_w64(r1 > thr) & __builtin_amdgcn_ballot_w64(!__builtin_isunordered(cZx, cZy));
+  const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_mask);
+  n_valid += __popcll(valid_mask);
+  {
+    const f32x2 rr2 = {valid ? r0 : __builtin_nanf(""), r1};  // (the log-likelihood pass tests the first component)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fast_u32v2, rr2), resid, off_v, off_s, 0);
+  }
+#if DVO_FAST_SKIP
+  if (valid_mask == 0ull) return;                            // (uniform) a row without a constraint adds nothing to the sums
+#endif
+  const float tq = fmaf(wt.P2x, r1, wt.P00 * r0);
+  const float sw_any = wt.wc * fast_rsqrt(fmaf(tq, r0, fmaf(wt.P11 * r1, r1, wt.wk)));
+  const float sw = valid ? sw_any : 0.0f;
+  // gradient rows scaled by sqrt(w); a lane without a constraint has sw = 0 and every product in which one of its NaN terms meets
+  // that zero is a LEGACY multiply (0 x anything = 0): no control flow on validity (an unfilled window cell may hold anything)
+  const float gix = mul_legacy(sw * g.half_wi_x, cIx + r.gx), giy = mul_legacy(sw * g.half_wi_y, cIy + r.gy);
+  const float gzx = mul_legacy(sw * g.half_fx, cZx), gzy = mul_legacy(sw * g.half_fy, cZy);
+  const float iz = fast_rcp(r.z);
+  const float txy = tx * ty, cy = fmaf(ty, ty, 1.0f);
+  const float sz = mul_legacy(sw, r.z);
+  float c[14];
+  c[0] = mul_legacy(gix, iz);
+  c[1] = mul_legacy(giy, iz);
+  c[2] = fmaf(-ty, c[1], -tx * c[0]);
+  c[3] = fmaf(-giy, cy, -gix * txy);
+  c[4] = fmaf(gix, cx, giy * txy);
+  c[5] = fmaf(giy, tx, -gix * ty);
+  c[6] = mul_legacy(gzx, iz);
+  c[7] = mul_legacy(gzy, iz);
+  c[8] = fmaf(-ty, c[7], fmaf(-tx, c[6], -sw));
+  c[9] = fmaf(-ty, fmaf(gzx, tx, sz), -gzy * cy);            // -(gzy cy + gzx tx ty + sw y),  y = ty z
+  c[10] = fmaf(tx, fmaf(gzy, ty, sz), gzx * cx);             //   gzx cx + gzy tx ty + sw x,   x = tx z
+  c[11] = fmaf(gzy, tx, -gzx * ty);
+  const float sr = sw * kResidualScale;
+  c[12] = mul_legacy(sr, r0);
+  c[13] = mul_legacy(sr, r1);
+  fast_gram_row<SWAP>(my, lane, c, acc0, acc1);
+}
+
+// epilogue: G = H H^T + S + S^T summed over the four wavefronts by the 85 threads that own an accumulator (slab[w]: H H^T at [0, 256),
+// S at [256, 512), entry row * 16 + col)
+__device__ __forceinline__ void fast_epilogue(float (*slab)[kSlabFloatsF16], const int* counts, unsigned gram_entries, float* __restrict__ out_row,
+                                              int* __restrict__ f16_range_flag) {
+  const int kk = threadIdx.x;
+  if (kk < kNumAcc) {
+    auto G = [&](int e) {                                      // entry e of the tile's Gram matrix, residual scale removed
+      const int et = (e & 15) * 16 + (e >> 4);
+      float t = 0.0f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) t += (slab[w4][e] + slab[w4][256 + e]) + slab[w4][256 + et];
+      const float s = ((e & 15) >= 12 ? 1.0f / kResidualScale : 1.0f) * ((e >> 4) >= 12 ? 1.0f / kResidualScale : 1.0f);
+      return t * s;
+    };
+    float v;
+    if (kk == kAccN) {
+      v = float((counts[0] + counts[1]) + (counts[2] + counts[3]));
+    } else {
+      const int e1 = gram_entries & 0xff, e2 = gram_entries >> 8;
+      v = G(e1);
+      if (e2 != 0xff) v += G(e2);
+      // a component beyond the f16 range became infinite in its high part (v_cvt_pk_f16_f32 rounds to nearest: overflow = infinity)
+      // and every sum it enters is infinite or not-a-number: the caller repeats the work with the f32 Gram
+      if (f16_range_flag && !(__builtin_fabsf(v) < __builtin_inff())) __hip_atomic_store(f16_range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    out_row[kk] = v;
+  }
+}
+
+__device__ __forceinline__ void fast_count_fallbacks(unsigned long long* __restrict__ fallback_count, unsigned n_fallback, int lane) {
+  const unsigned long long lanes = __ballot(n_fallback != 0);
+  if (lanes) {
+    unsigned t = n_fallback;
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (lane == 0) atomicAdd(fallback_count, (unsigned long long)t);
+  }
+}
+
+// ===================================================================================================================================
+// variants 8 / 9: every pixel of the tile, one wavefront row = one image row of 64 pixels
+// ===================================================================================================================================
 template <bool SWAP>
 __global__ __launch_bounds__(256, 5) void k_sweep_fast(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
@@ -169,13 +415,12 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
   const __amdgpu_buffer_rsrc_t refR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.refR), 0, plane_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t curC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.curC), 0, plane_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t resid = __builtin_amdgcn_make_buffer_rsrc(scratch + size_t(pair) * size_t(g.w) * g.h, 0, plane_bytes, 0x00020000);
-
+  // (rows below the image -- a level whose height is no multiple of 16 -- go to a resource of no bytes: no branch around the store)
   const __amdgpu_buffer_rsrc_t resid_none = __builtin_amdgcn_make_buffer_rsrc(scratch, 0, 0, 0x00020000);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned gram_entries = kGramEntryTable.e[min(int(threadIdx.x), kNumAcc - 1)];
   const int u_r = tile_x * kTileW + lane;
   const int row_bytes = g.w * 8;
-  const float nanv = __builtin_nanf("");
   const float tx_u = g.tx[u_r];
   const float cx_u = fmaf(tx_u, tx_u, 1.0f);
 
@@ -219,9 +464,8 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
       const float right = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ie, ic, 0x130, 0xf, 0xf, false));   // wave_shl:1
       const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ie, ic, 0x138, 0xf, 0xf, false));    // wave_shr:1
       const float z = zv[k];
-      const float ty = ty_rows[k];
       float u, v, qz;
-      fast_project(st.KT, c0, c1, c2, z, ty, u, v, qz);
+      fast_project(st.KT, c0, c1, c2, z, ty_rows[k], u, v, qz);
       // 0 <= u <= w - 2 on the integer image of the float: negative numbers and NaNs (sign or exponent bits) compare above every
       // non-negative bound (Q4; a hole's NaN depth fails here, Q19).  -0.0f fails too -- one float out of 2^32.
       const unsigned long long ok_mask = v_r < g.h ? __builtin_amdgcn_ballot_w64(__builtin_bit_cast(unsigned, u) <= w2_bits) &
@@ -248,187 +492,33 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
     bbox[wave][0] = umin | (vmin << 16); bbox[wave][1] = umax | (vmax << 16);
   }
   __syncthreads();
-  int x0, y0, ww, wh;                                          // window origin (image coordinates, may be -1 / -2) and the extent in use
-  bool all_in;                                                 // every projected neighbourhood of the tile lies inside the window
-  {
-    fast_i16x2 lo = __builtin_bit_cast(fast_i16x2, bbox[0][0]), hi = __builtin_bit_cast(fast_i16x2, bbox[0][1]);
-#pragma unroll
-    for (int w4 = 1; w4 < 4; ++w4) {
-      lo = __builtin_elementwise_min(lo, __builtin_bit_cast(fast_i16x2, bbox[w4][0]));
-      hi = __builtin_elementwise_max(hi, __builtin_bit_cast(fast_i16x2, bbox[w4][1]));
-    }
-    const int lo_s = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lo)), hi_s = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi));
-    const int bu0 = lo_s & 0xffff, bv0 = (lo_s >> 16) & 0xffff, bu1 = hi_s & 0xffff, bv1 = (hi_s >> 16) & 0xffff;
-    x0 = (bu0 - 1) & ~1; y0 = bv0 - 1;                         // even: a 16-byte load holds two window cells
-    const bool any = bu0 != 0x7fff;
-    ww = any ? min(bu1 + 3 - x0, kFastCols) : 0;               // columns x0 .. umax + 2
-    wh = any ? min(bv1 + 3 - y0, kFastRows) : 0;
-    all_in = !any || (bu1 + 3 - x0 <= kFastCols && bv1 + 3 - y0 <= kFastRows);
-  }
+  const FastWindow wnd = fast_window_of(bbox);
 
   // ---- phase B: the window into LDS ----------------------------------------------------------------------------------------------
-  // Thread t loads column pair t % 42 of rows t / 42, t / 42 + 6, ...  Cells outside the extent in use are not loaded at all.
-  {
-    const int t = threadIdx.x;
-    const int rg = t / kFastPairs, cxp = t - rg * kFastPairs;
-    f32x4* dst = reinterpret_cast<f32x4*>(win) + rg * (kFastPitch / 2) + cxp;
-    const bool interior = x0 >= 0 && x0 + kFastCols <= g.w && y0 >= 0 && y0 + kFastRows <= g.h;   // (uniform)
-    if (rg < kFastRowGroups && 2 * cxp < ww) {
-      if (interior) {
-        // no clamping anywhere: one vector offset per thread, the row group's offset is a scalar
-        const int voff = (y0 + rg) * row_bytes + (x0 + 2 * cxp) * 8;
-        f32x4 cell[kFastLoads];
-#pragma unroll
-        for (int j = 0; j < kFastLoads; ++j)
-          if (j * kFastRowGroups < wh)                                                              // (uniform)
-            cell[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(curC, voff, j * kFastRowGroups * row_bytes, 0));
-#pragma unroll
-        for (int j = 0; j < kFastLoads; ++j)
-          if (j * kFastRowGroups < wh && rg + j * kFastRowGroups < kFastRows) dst[j * kFastRowGroups * (kFastPitch / 2)] = cell[j];
-      } else {
-        // a window that reaches over the image border: coordinates clamped like the frame build's border code (rgbd_image.cpp:419-489),
-        // so that the clamped central differences come out of the same subtraction.  Image width and window origin are even: a pair
-        // lies entirely inside the image, entirely left of it (both cells = column 0) or entirely right of it (both = column w - 1).
-        const int x = x0 + 2 * cxp;
-        const int xl = min(max(x, 0), g.w - 2) * 8;
-        f32x4 cell[kFastLoads];
-#pragma unroll
-        for (int j = 0; j < kFastLoads; ++j) {
-          const int cy = rg + j * kFastRowGroups;
-          const int y = min(max(y0 + cy, 0), g.h - 1);
-          cell[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(curC, cy < wh ? y * row_bytes + xl : 0x7ffffff0, 0, 0));
-        }
-        if (x < 0) {
-#pragma unroll
-          for (int j = 0; j < kFastLoads; ++j) { cell[j].z = cell[j].x; cell[j].w = cell[j].y; }
-        }
-        if (x >= g.w) {
-#pragma unroll
-          for (int j = 0; j < kFastLoads; ++j) { cell[j].x = cell[j].z; cell[j].y = cell[j].w; }
-        }
-#pragma unroll
-        for (int j = 0; j < kFastLoads; ++j)
-          if (rg + j * kFastRowGroups < kFastRows) dst[j * kFastRowGroups * (kFastPitch / 2)] = cell[j];
-      }
-    }
-  }
+  fast_fill_window(g, curC, win, wnd, row_bytes);
   __syncthreads();
 
   // ---- phase C: taps from LDS, residual, weight, Jacobian, Gram accumulation ----------------------------------------------------
-  // weights: sqrt(7 / (5 + r^T P r)) = c rsq(k + r^T P r); the first pass of a level (unit weights) rides the same code as 2 rsq(4 + 0)
-  const bool first = st.first != 0;
-  const float P00 = first ? 0.0f : st.P_prev[0], P11 = first ? 0.0f : st.P_prev[3], P2x = first ? 0.0f : st.P_prev[1] + st.P_prev[2];
-  const float wk = first ? 4.0f : 5.0f, wc = first ? 2.0f : 2.6457513110645906f;
-  const int neg_base = -8 * ((x0 + 1) + kFastPitch * (y0 + 1));   // LDS byte address of a lane's neighbourhood = 8 idx + neg_base
+  const FastWeights wt(st);
+  const int neg_base = -8 * ((wnd.x0 + 1) + kFastPitch * (wnd.y0 + 1));   // LDS byte address of a lane's neighbourhood = 8 idx + neg_base
   f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   int n_valid = 0;
   unsigned n_fallback = 0;
-  // one pixel row of the wavefront.  CHECKED = false: every projected neighbourhood of the tile lies inside the window (the common
-  // case: no per-lane test, no second source -- and no vector-memory load whose counter the row would have to wait for)
   auto sweep_row = [&](int k, auto checked_tag) __attribute__((always_inline)) {
     constexpr bool CHECKED = decltype(checked_tag)::value;
     const int v_r = row0 + k * 4;
-    const FastRow& r = rs[k];
-    const bool ok = __builtin_amdgcn_inverse_ballot_w64(ok_row[k]);
+#if DVO_FAST_SKIP
+    if (ok_row[k] == 0ull) {                                   // (uniform) no pixel of the row projects into the image: NaN pairs, nothing else
+      const f32x2 nan2 = {__builtin_nanf(""), __builtin_nanf("")};
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fast_u32v2, nan2), v_r < g.h ? resid : resid_none, off_px, v_r * row_bytes, 0);
+      return;
+    }
+#endif
     f32x2 P[4][4];
-    typedef const volatile __attribute__((address_space(3))) f32x2* LdsCellPtr;
-    // (volatile: twelve ds_read_b64, two LDS cycles each; the compiler otherwise pairs them into ds_read2_b64, eight cycles a pair)
-    if constexpr (!CHECKED) {
-      const int addr = (r.idx << 3) + neg_base;
-      LdsCellPtr q = (LdsCellPtr)(reinterpret_cast<const char*>(win) + (ok ? addr : 0));
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-          if ((rr == 1 || rr == 2) || (cc == 1 || cc == 2)) P[rr][cc] = q[rr * kFastPitch + cc];
-    } else {
-      // a tile whose projections spread beyond the window (a depth discontinuity under a large motion): lanes inside read the window,
-      // the others fetch their twelve cells from memory, coordinates clamped like the window's -- correct for any motion
-      // (the tap corner is not kept apart from the window index: projected again, the same instructions as in phase A)
-      float pu, pv, pqz;
-      fast_project(st.KT, fmaf(st.KT[0], tx_u, st.KT[2]), fmaf(st.KT[4], tx_u, st.KT[6]), fmaf(st.KT[8], tx_u, st.KT[10]), r.z, ty_rows[k], pu, pv, pqz);
-      const int u0 = int(pu), v0 = int(pv);
-      const int cx = u0 - x0 - 1, cy = v0 - y0 - 1;
-      const bool in_win = ok && unsigned(cx) <= unsigned(kFastCols - 4) && unsigned(cy) <= unsigned(kFastRows - 4);
-      LdsCellPtr q = (LdsCellPtr)(win + (in_win ? cy * kFastPitch + cx : 0));
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-          if ((rr == 1 || rr == 2) || (cc == 1 || cc == 2)) P[rr][cc] = q[rr * kFastPitch + cc];
-      if (ok && !in_win) {
-        n_fallback += 1;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc)
-            if ((rr == 1 || rr == 2) || (cc == 1 || cc == 2)) {
-              const int x = min(max(u0 - 1 + cc, 0), g.w - 1), y = min(max(v0 - 1 + rr, 0), g.h - 1);
-              P[rr][cc] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(curC, (y * g.w + x) * 8, 0, 0));
-            }
-      }
-    }
-    // separable blend (rows first): E_j = row j of the neighbourhood at the tap's column position; intensity / depth, TWICE the
-    // vertical and TWICE the horizontal central difference, each blended between rows 1 and 2
-    const float a1 = r.a1, b1 = r.b1;
-    float cI, cZ, cIx, cIy, cZx, cZy;
-#define DVO_BLEND(f, cV, cVx, cVy)                                                                                 \
-  {                                                                                                                \
-    const float e0 = fast_lerp(P[0][1].f, P[0][2].f, a1), e1 = fast_lerp(P[1][1].f, P[1][2].f, a1);                \
-    const float e2 = fast_lerp(P[2][1].f, P[2][2].f, a1), e3 = fast_lerp(P[3][1].f, P[3][2].f, a1);                \
-    cV = fast_lerp(e1, e2, b1);                                                                                    \
-    cVy = fast_lerp(e2 - e0, e3 - e1, b1);                                                                         \
-    const float d1 = fast_lerp(P[1][2].f - P[1][0].f, P[1][3].f - P[1][1].f, a1);                                  \
-    const float d2 = fast_lerp(P[2][2].f - P[2][0].f, P[2][3].f - P[2][1].f, a1);                                  \
-    cVx = fast_lerp(d1, d2, b1);                                                                                   \
-  }
-    DVO_BLEND(x, cI, cIx, cIy)
-    DVO_BLEND(y, cZ, cZx, cZy)
-#undef DVO_BLEND
-    const float r0 = (cI - r.i) * (1.0f / 255.0f);             // dense_tracking.cpp:217-220
-    const float r1 = cZ - r.qz;                                // reference depth := transformed z (dense_tracking_impl.cpp:269)
-    const float dz = r.z - 0.4f;                               // occlusion threshold -20 (0.0012 + 0.0019 (z - 0.4)^2) (:122-128, Q5)
-    const float thr = fmaf(dz * -0.038f, dz, -0.024f);
-    // Q9: a hole in any of the twelve cells makes cZ (hence r1), cZx or cZy not-a-number; intensities are never holes
-    const unsigned long long valid_mask = ok_row[k] & __builtin_amdgcn_ballot_w64(r1 > thr) & __builtin_amdgcn_ballot_w64(!__builtin_isunordered(cZx, cZy));
-    const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_mask);
-    n_valid += __popcll(valid_mask);
-    {
-      // (rows below the image -- a level whose height is no multiple of 16 -- go to a resource of no bytes: no branch around the store)
-      const f32x2 rr2 = {valid ? r0 : nanv, r1};               // (the log-likelihood pass tests the first component)
-      typedef unsigned __attribute__((__vector_size__(2 * sizeof(unsigned)))) u32v2;
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32v2, rr2), v_r < g.h ? resid : resid_none, off_px, v_r * row_bytes, 0);
-    }
-    const float tq = fmaf(P2x, r1, P00 * r0);
-    const float sw_any = wc * fast_rsqrt(fmaf(tq, r0, fmaf(P11 * r1, r1, wk)));
-    const float sw = valid ? sw_any : 0.0f;
-    // gradient rows scaled by sqrt(w); a lane without a constraint has sw = 0 and every product in which one of its NaN terms meets
-    // that zero is a LEGACY multiply (0 x anything = 0): no control flow on validity
-    const float gix = mul_legacy(sw * g.half_wi_x, cIx + r.gx), giy = mul_legacy(sw * g.half_wi_y, cIy + r.gy);   // (an unfilled window cell may hold anything)
-    const float gzx = mul_legacy(sw * g.half_fx, cZx), gzy = mul_legacy(sw * g.half_fy, cZy);
-    const float ty = ty_rows[k];
-    const float iz = fast_rcp(r.z);
-    const float txy = tx_u * ty, cy_r = fmaf(ty, ty, 1.0f);
-    const float sz = mul_legacy(sw, r.z);
-    float c[14];
-    c[0] = mul_legacy(gix, iz);
-    c[1] = mul_legacy(giy, iz);
-    c[2] = fmaf(-ty, c[1], -tx_u * c[0]);
-    c[3] = fmaf(-giy, cy_r, -gix * txy);
-    c[4] = fmaf(gix, cx_u, giy * txy);
-    c[5] = fmaf(giy, tx_u, -gix * ty);
-    c[6] = mul_legacy(gzx, iz);
-    c[7] = mul_legacy(gzy, iz);
-    c[8] = fmaf(-ty, c[7], fmaf(-tx_u, c[6], -sw));
-    c[9] = fmaf(-ty, fmaf(gzx, tx_u, sz), -gzy * cy_r);        // -(gzy cy + gzx tx ty + sw y),  y = ty z
-    c[10] = fmaf(tx_u, fmaf(gzy, ty, sz), gzx * cx_u);         //   gzx cx + gzy tx ty + sw x,   x = tx z
-    c[11] = fmaf(gzy, tx_u, -gzx * ty);
-    const float sr = sw * kResidualScale;
-    c[12] = mul_legacy(sr, r0);
-    c[13] = mul_legacy(sr, r1);
-    fast_gram_row<SWAP>(my, lane, c, acc0, acc1);
+    fast_fetch_cells<CHECKED>(g, st.KT, curC, win, wnd, neg_base, rs[k], __builtin_amdgcn_inverse_ballot_w64(ok_row[k]), tx_u, ty_rows[k], P, n_fallback);
+    fast_row_tail<SWAP>(g, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_px, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
   };
-  if (all_in) {                                                // (uniform)
+  if (wnd.all_in) {                                            // (uniform)
 #pragma unroll
     for (int k = 0; k < RPW; ++k) sweep_row(k, std::false_type{});
   } else {
@@ -436,7 +526,6 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
     for (int k = 0; k < RPW; ++k) sweep_row(k, std::true_type{});
   }
 
-  // ---- epilogue: G = H H^T + S + S^T summed over the four wavefronts by the 85 threads that own an accumulator -------------------
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i];
@@ -444,47 +533,18 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
   }
   if (lane == 0) counts[wave] = n_valid;
   __syncthreads();
-  const int kk = threadIdx.x;
-  if (kk < kNumAcc) {
-    auto G = [&](int e) {                                      // entry e = row * 16 + col of the tile's Gram matrix, residual scale removed
-      const int et = (e & 15) * 16 + (e >> 4);
-      float t = 0.0f;
-#pragma unroll
-      for (int w4 = 0; w4 < 4; ++w4) t += (slab[w4][e] + slab[w4][256 + e]) + slab[w4][256 + et];
-      const float s = ((e & 15) >= 12 ? 1.0f / kResidualScale : 1.0f) * ((e >> 4) >= 12 ? 1.0f / kResidualScale : 1.0f);
-      return t * s;
-    };
-    float v;
-    if (kk == kAccN) {
-      v = float((counts[0] + counts[1]) + (counts[2] + counts[3]));
-    } else {
-      const int e1 = gram_entries & 0xff, e2 = gram_entries >> 8;
-      v = G(e1);
-      if (e2 != 0xff) v += G(e2);
-      // a component beyond the f16 range became infinite in its high part (v_cvt_pk_f16_f32 rounds to nearest: overflow = infinity)
-      // and every sum it enters is infinite or not-a-number: the caller repeats the work with the f32 Gram
-      if (f16_range_flag && !(__builtin_fabsf(v) < __builtin_inff())) __hip_atomic_store(f16_range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    partials[(size_t(pair) * tiles + tile) * kAccStride + kk] = v;
-  }
-  if (fallback_count && !all_in) {
-    const unsigned long long lanes = __ballot(n_fallback != 0);
-    if (lanes) {
-      unsigned t = n_fallback;
-      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-      if (lane == 0) atomicAdd(fallback_count, (unsigned long long)t);
-    }
-  }
+  fast_epilogue(slab, counts, gram_entries, partials + (size_t(pair) * tiles + tile) * kAccStride, f16_range_flag);
+  if (fallback_count && !wnd.all_in) fast_count_fallbacks(fallback_count, n_fallback, lane);
 }
 
 bool fast_sweep_supports(const LevelGeom& g) { return !g.linear && g.w % kTileW == 0 && g.w >= kFastCols && g.w < 32768 && g.h < 32768 && !g.rcp_table; }
 
-void launch_sweep_fast(hipStream_t s, bool swap_stores, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
+void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                        float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag) {
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(256);
-  if (swap_stores) k_sweep_fast<true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+  if (variant == 8) k_sweep_fast<true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
   else k_sweep_fast<false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
 }
 

@@ -151,7 +151,7 @@ static void launch_rr(hipStream_t s, bool finest, const LevelGeom& g, const Pair
 void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
                             const PairState* states, int n_pairs, float* partials, float2* scratch, unsigned long long* window_fallbacks, int* f16_range_flag) {
   if (variant >= 8 && rows_per_wave == 4 && fast_sweep_supports(g)) {
-    launch_sweep_fast(s, variant == 8, g, pairs, states, n_pairs, partials, scratch, window_fallbacks, f16_range_flag);
+    launch_sweep_fast(s, variant, g, pairs, states, n_pairs, partials, scratch, window_fallbacks, f16_range_flag);
     return;
   }
   if (variant >= 6 && rows_per_wave == 4 && window_sweep_supports(g)) {

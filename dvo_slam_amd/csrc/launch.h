@@ -55,9 +55,9 @@ bool window_sweep_supports(const LevelGeom& g);
 void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                          float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag = nullptr);
 // align_fast.hip: variants 8 / 9 -- the window sweep with contracted per-pixel arithmetic (same function, rounding differences of a few
-// ulp against variants 6 / 7; window 84 x 28 cells at a pitch of 96).  swap_stores (variant 8): operand rows written by all 64 lanes.
+// ulp against variants 6 / 7; window 84 x 28 cells at a pitch of 96; 8: operand rows written by all 64 lanes, 9: by 32).
 bool fast_sweep_supports(const LevelGeom& g);
-void launch_sweep_fast(hipStream_t s, bool swap_stores, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
+void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                        float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag = nullptr);
 // scratch == null: read-only (one float per workgroup goes to `sink`, which must hold a float per (8 * 256)-pixel block)
 // window_planes: the planes the window sweep reads (reference 8 B + current {I, Z} 8 B) instead of the gathering sweep's 8 + 16 + 8 B

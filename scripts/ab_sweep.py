@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B of two or more builds of libdvo_hip.so on ONE box: the finest-level sweep (and level 1) at 1024 pairs, converged transform,
 weights on, timed in alternation (ABAB...), one process per measurement (DVO_HIP_LIBRARY selects the build).
-usage: ab_sweep.py <lib A> <lib B> ... [--rounds N] [--variant V]       (child mode: ab_sweep.py --child <variant>)"""
+usage: ab_sweep.py <lib A>[@rows per wave][#variant] <lib B> ... [--rounds N] [--variant V]       (child mode: ab_sweep.py --child <variant>)"""
 import os
 import subprocess
 import sys
@@ -40,11 +40,12 @@ libs = args
 res = {lib: [] for lib in libs}
 for r in range(rounds):
     for lib in libs:
-        path, _, rpw = lib.partition("@")                       # "<lib>@<rows per wave>"
+        spec, _, var = lib.partition("#")                       # "<lib>[@<rows per wave>][#<variant>]"
+        path, _, rpw = spec.partition("@")
         env = dict(os.environ, DVO_HIP_LIBRARY=os.path.join(HERE, path))
         if rpw:
             env["AB_RPW"] = rpw
-        o = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(variant)], env=env, capture_output=True, text=True)
+        o = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", var or str(variant)], env=env, capture_output=True, text=True)
         if o.returncode != 0:
             print(lib, "failed:", o.stderr[-400:])
             continue

@@ -22,7 +22,7 @@ for f in sorted(glob.glob('gpurun_out/pmc/*/*counter_collection.csv')):
         k = row['Kernel_Name'][:60]
         agg[k][row['Counter_Name']] += float(row['Counter_Value']); cnt[(k,row['Counter_Name'])] += 1
     for k in agg:
-        if 'residual_reduce' in k or 'sweep_window' in k:
+        if 'residual_reduce' in k or 'sweep_window' in k or 'sweep_fast' in k:
             print(f.split('/')[-2], k)
             for c, v in agg[k].items(): print("    %-32s total %.4g  per-dispatch %.4g  (n=%d)" % (c, v, v/cnt[(k,c)], cnt[(k,c)]))
 # summary consumed by bench.py (roofline.traffic): FETCH_SIZE is in KB and reports half of a wide coalesced stream on gfx950
@@ -31,14 +31,14 @@ vals = {}
 for f in glob.glob('gpurun_out/pmc/*/*counter_collection.csv'):
     per = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
-        if ('residual_reduce' in row['Kernel_Name'] or 'sweep_window' in row['Kernel_Name']) and row['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+        if ('residual_reduce' in row['Kernel_Name'] or 'sweep_window' in row['Kernel_Name'] or 'sweep_fast' in row['Kernel_Name']) and row['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
             per[row['Counter_Name']].append(float(row['Counter_Value']))
     for c, v in per.items():
         big = [x for x in v if x > 0.5 * max(v)]
         vals[c] = sum(big) / len(big)
 import hashlib, os
 h = hashlib.sha256()
-for f in ("align_window.hip", "gram_f16.h", "sweep_parts.h", "pixel_math.h"):
+for f in ("align_fast.hip", "gram_f16.h", "sweep_parts.h", "pixel_math.h"):
     h.update(open(os.path.join("dvo_slam_amd", "csrc", f), "rb").read())
 pairs = int(os.environ.get("PMC_PAIRS", "1024"))
 if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
