@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--resident", type=int, default=-1, help="library option resident (-1 default policy, 0 launch path only, 1 every level resident)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses GPU 0 (with --backend gloo)")
+    ap.add_argument("--force-gather", action="store_true", help="run the N > 1 record path (process group, pinned staging, asynchronous all-gather, "
+                    "drain) even with one rank: exercises the RCCL code path on a one-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -133,8 +135,14 @@ def main():
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    gathering = world > 1 or args.force_gather
+    if gathering:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                      # (a lone rank started without the launcher)
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -211,7 +219,7 @@ def main():
         last["T"] = res["transformation"].reshape(B, 4, 4)
         last["information"] = res["information"].reshape(B, 6, 6)
         last["loglik"] = res["loglik"]
-        if world > 1:
+        if gathering:
             # the records of this batch travel (one all-gather, RCCL) while the next batch is aligned; buffers allocated once
             rec = pipe.records()                                        # packed by the pipeline object (stream_pipeline.cpp)
             if pending[0] is not None:
@@ -220,7 +228,7 @@ def main():
         return None
 
     pending, gathered = [None], [None]
-    gatherer = parallel.RecordGatherer(n_total, rank, world, device=comm_dev) if world > 1 else None
+    gatherer = parallel.RecordGatherer(n_total, rank, world, device=comm_dev) if gathering else None
 
     def drain():
         if pending[0] is not None:
@@ -229,7 +237,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if gathering:
             dist.barrier()
 
     if n_sets > 1:
@@ -244,7 +252,7 @@ def main():
     drain()                                                             # the last batch's records have arrived on every rank
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if gathering:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -252,7 +260,7 @@ def main():
     # ---- everything below is outside the timed region -------------------------------------------------------
     twist_err = float(np.abs(parallel.twists_of(last["T"]) - pairs_np["xi_true"]).max())
     if args.records_out and rank == 0:
-        full = gathered[0] if world > 1 else parallel.pack_records(parallel.twists_of(last["T"]), last["information"], last["loglik"])
+        full = gathered[0] if gathering else parallel.pack_records(parallel.twists_of(last["T"]), last["information"], last["loglik"])
         np.save(args.records_out, full)
     nan_results = int((~np.isfinite(last["T"]).all(axis=(1, 2)) | ~np.isfinite(last["information"]).all(axis=(1, 2))).sum())
     t_match0 = time.perf_counter()
@@ -469,10 +477,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pairs_np, cfg_kwargs, args.cpu_sample_pairs, args.cpu_matches_per_thread, args.cpu_trials)
-    if world > 1:
+    if gathering:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if out is not None and args.force_gather:
+            out["forced_gather"] = {"backend": args.backend, "world_size": world}
         print(json.dumps(out))
 
 

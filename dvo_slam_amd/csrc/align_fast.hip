@@ -15,12 +15,21 @@
 //   * the validity of a pixel travels as a lane mask in scalar registers, not as a sentinel in a vector register
 //   * window pitch 96 cells = 768 B = 0 banks mod 64: the tap reads of a wavefront whose warped row steps to the next window row no
 //     longer collide (23 % of the LDS cycles of variant 7); 84 x 28 cells in use
-//   * SWAP: the operand rows of 32 pixels are written by all 64 lanes (v_permlane32_swap_b32 moves half of every row to the idle
-//     half of the wavefront): 4 instead of 8 sixteen-byte stores per pixel row, each of which costs 8 LDS cycles whatever its lanes
+//   * the operand rows are written by all 64 lanes -- a 16-byte LDS store costs 8 array cycles whatever its active lanes: high and low
+//     parts take turns in the slab (fast_gram_row), 4 instead of 8 stores per pixel row
 //   * the window fill of a tile whose window lies inside the image needs no clamping: one address per thread, scalar row offsets
 //   * the epilogue leaves H H^T and S to the 85 reducing threads instead of symmetrising per wavefront
 //
-// (Measured and dropped, round 4: packing the tile's SELECTED reference pixels -- Zsel not NaN -- into a list in LDS first and sweeping
+// Measured and dropped in round 4 (scripts/ab_sweep.py, builds alternated on one box; base 2.18-2.24 ms per 1024-pair launch):
+//   * the scheduler that maximises instruction-level parallelism (align_window.hip's flag): 4 registers spilled, 2.48 ms;
+//   * a uniform branch around rows without a projection or without a constraint (4-16 % of the bench's rows): 2.45 ms -- the four rows
+//     of a wavefront are one basic block and every branch is a scheduling barrier;
+//   * level constants and per-row scalars copied into vector registers (an instruction with a scalar operand issues in ~4.5 cycles,
+//     with vector operands in ~3: scripts/ubench/issue_rate.hip): +2 %, the copies pin the schedule;
+//   * the window requested from a GUESSED origin before phase A (what a per-tile depth range from the frame build would allow: one memory
+//     round trip per tile instead of two): -1.3 % only, not worth seven writers of the reference plane;
+//   * four workgroups per compute unit with 128 registers each: level with five at the default scheduler, 2.35 ms with max-ilp.
+// (Also measured and dropped: packing the tile's SELECTED reference pixels -- Zsel not NaN -- into a list in LDS first and sweeping
 // ceil(n / 64) instead of 16 wavefront rows, what the reference's PointSelection does once per key frame.  Correct, same residuals;
 // 2.45 ms instead of 2.18 per 1024-pair launch: 81 % of the bench's reference pixels are selected -- the constraints that are lost
 // are lost to holes of the CURRENT frame, known only after the taps -- so a tile keeps 13-14 of its 16 rows and the list costs more
@@ -34,9 +43,6 @@
 
 #include "gram_f16.h"
 
-#ifndef DVO_FAST_SKIP
-#define DVO_FAST_SKIP 0
-#endif
 
 namespace dvo_hip {
 
@@ -82,6 +88,7 @@ struct FastRow {                                        // what phase A leaves f
 };
 
 __device__ __forceinline__ float fast_lerp(float p, float q, float t) { return fmaf(t, q - p, p); }
+__device__ __forceinline__ f32x2 fast_lerp2(f32x2 p, f32x2 q, f32x2 t) { return __builtin_elementwise_fma(t, q - p, p); }
 
 // q = K T (tx z, ty z, z, 1) as z (KT.col0 tx + KT.col1 ty + KT.col2) + KT.col3 and u = qx rcp(qz), v = qy rcp(qz) (v_rcp_f32, 1 ulp).
 // c0..c2: the column's part of the bracket, fmaf(KT[4 i], tx, KT[4 i + 2]).  One instruction sequence for phase A and for the lanes that
@@ -210,17 +217,61 @@ __device__ __forceinline__ void fast_fetch_cells(const LevelGeom& g, const float
   }
 }
 
-// ---- the operand rows of a pixel row on the f16 matrix pipe, 32 pixels at a time.  SWAP: see the header ------------------------------
-template <bool SWAP>
+// ---- the operand rows of a pixel row on the f16 matrix pipe -------------------------------------------------------------------------
+// v = H + L (f16 high and low parts, gram_f16.h::split_pairs); G = H H^T + S + S^T with S = H L^T.  A 16-byte LDS store costs 8 array
+// cycles whatever its active lanes (profiles/r03_pmc_utilisation.md), so all 64 lanes should store.  Two ways:
+//   STORE 2 (variant 8, default): high parts and low parts take turns in the slab.  All 64 pixels' high blocks (32 B each: 2 KB) are
+//     stored by their own lanes, read back transposed and KEPT as matrix operands (8 registers) for H H^T; then the low blocks
+//     overwrite them and are read back for H L^T.  4 stores, 8 transposing reads, 4 matrix instructions per row, no cross-lane moves.
+//     Layout: pixel p at 32 p + 16 (p >> 3) bytes -- 32-byte rows, 16 bytes of padding behind every eighth (conflict-free stores: the
+//     first halves of a 16-lane group cover banks 8 l .. 8 l + 3 and, for the second eight lanes, 8 (l - 8) + 4 .. + 7); the four lanes
+//     that fetch a pixel for the transposing read must address consecutive bytes (the hardware fetches a pixel's 32 bytes as one
+//     access: a layout that exchanged the halves of some rows read garbage); lane group g of a matrix operand takes pixels 4 g .. 4 g + 3
+//     and 16 + 4 g .. 19 + 4 g of its 32 (eight consecutive rows per 32-lane pass: conflict-free reads).  Which pixel is which k index
+//     does not matter to a sum over k as long as both operands agree.
+//   STORE 1 (variant 9): high and low blocks side by side (80-byte rows, gram_f16.h), 32 pixels at a time; v_permlane32_swap_b32 moves
+//     half of every row to the idle half of the wavefront -- 8 swaps per row at 8.3 issue cycles each (scripts/ubench/issue_rate.hip).
+template <int STORE>
 __device__ __forceinline__ void fast_gram_row(float* my, int lane, const float (&comps)[14], f32x4& acc0, f32x4& acc1) {
   typedef volatile __attribute__((address_space(3))) u32x4* LdsQuadPtr;
   unsigned hh[7], ll[7];
   split_pairs(comps, hh, ll);
-  const _Float16* img = reinterpret_cast<const _Float16*>(my);
   // the padding components (14, 15) may hold anything: they only reach rows / columns 14, 15 of the Gram matrix, which nobody reads
   unsigned pad;
   asm volatile("" : "=v"(pad));                           // (defined by nothing: no instruction, any register)
-  if constexpr (SWAP) {
+  if constexpr (STORE == 2) {
+    char* base = reinterpret_cast<char*>(my);
+    LdsQuadPtr w0 = (LdsQuadPtr)(base + lane * 32 + (lane >> 3) * 16);   // the lane's pixel: two 16-byte halves
+    const int i = lane & 15, gq = lane >> 4;
+    typedef __attribute__((address_space(3))) fp16x4* LdsTrPtr;
+    char* rd = base + gq * 128 + (gq >> 1) * 16 + (i >> 2) * 32 + (i & 3) * 8;
+    auto operand = [&](int block) {                       // pixels 32 block .. 32 block + 31 (k index) x 16 components
+      const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LdsTrPtr)(rd + block * 1088));
+      const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LdsTrPtr)(rd + block * 1088 + 544));
+      return f16x8{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
+    };
+    w0[0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+    w0[1] = u32x4{hh[4], hh[5], hh[6], pad};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const f16x8 h0 = operand(0), h1 = operand(1);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, h0, acc0, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, h1, acc0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    w0[0] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    w0[1] = u32x4{ll[4], ll[5], ll[6], pad};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const f16x8 l0 = operand(0), l1 = operand(1);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, l0, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, l1, acc1, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    const _Float16* img = reinterpret_cast<const _Float16*>(my);
     // E = components 0..7 (first 16 bytes of a pixel's hi / lo block), O = components 8..15 (second 16 bytes).  After the swaps
     // register set E holds, in lanes 0..31, E of pixel `lane` and, in lanes 32..63, O of pixel `lane - 32`: everything of the first
     // 32 pixels; set O likewise everything of pixels 32..63.
@@ -248,11 +299,6 @@ __device__ __forceinline__ void fast_gram_row(float* my, int lane, const float (
     __builtin_amdgcn_wave_barrier();
     hw[0] = u32x4{hO[0], hO[1], hO[2], hO[3]};
     hw[2] = u32x4{lO[0], lO[1], lO[2], lO[3]};
-  } else {
-    LdsQuadPtr hw = (LdsQuadPtr)(reinterpret_cast<char*>(my) + (lane & 31) * (kHalfRow * 2));
-    const u32x4 h0 = {hh[0], hh[1], hh[2], hh[3]}, h1 = {hh[4], hh[5], hh[6], pad};
-    const u32x4 l0 = {ll[0], ll[1], ll[2], ll[3]}, l1 = {ll[4], ll[5], ll[6], pad};
-    if (lane < 32) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -263,18 +309,7 @@ __device__ __forceinline__ void fast_gram_row(float* my, int lane, const float (
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane >= 32) { hw[0] = h0; hw[1] = h1; hw[2] = l0; hw[3] = l1; }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  {
-    const f16x8 h = read_operand_f16(img, lane, 0), l = read_operand_f16(img + 16, lane, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, h, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, l, acc1, 0, 0, 0);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
 }
 
 // weights: sqrt(7 / (5 + r^T P r)) = c rsq(k + r^T P r); the first pass of a level (unit weights) rides the same code as 2 rsq(4 + 0)
@@ -290,27 +325,22 @@ struct FastWeights {
 // Everything of a pixel row behind its twelve cells: blend, residual pair (stored for the log-likelihood pass: `resid` at vector offset
 // off_v + scalar offset off_s), validity, weight, Jacobian at the untransformed point, Gram accumulation.  tx, ty, cx = 1 + tx^2:
 // normalised coordinates of the lane's reference pixel.
-template <bool SWAP>
+template <int STORE>
 __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const f32x2 (&P)[4][4], const FastRow& r, unsigned long long ok_mask, float tx, float ty,
                                               float cx, const FastWeights& wt, __amdgpu_buffer_rsrc_t resid, int off_v, int off_s, float* my, int lane,
                                               f32x4& acc0, f32x4& acc1, int& n_valid) {
   // separable blend (rows first): E_j = row j of the neighbourhood at the tap's column position; intensity / depth, TWICE the
-  // vertical and TWICE the horizontal central difference, each blended between rows 1 and 2
-  const float a1 = r.a1, b1 = r.b1;
-  float cI, cZ, cIx, cIy, cZx, cZy;
-#define DVO_BLEND(f, cV, cVx, cVy)                                                                                 \
-  {                                                                                                                \
-    const float e0 = fast_lerp(P[0][1].f, P[0][2].f, a1), e1 = fast_lerp(P[1][1].f, P[1][2].f, a1);                \
-    const float e2 = fast_lerp(P[2][1].f, P[2][2].f, a1), e3 = fast_lerp(P[3][1].f, P[3][2].f, a1);                \
-    cV = fast_lerp(e1, e2, b1);                                                                                    \
-    cVy = fast_lerp(e2 - e0, e3 - e1, b1);                                                                         \
-    const float d1 = fast_lerp(P[1][2].f - P[1][0].f, P[1][3].f - P[1][1].f, a1);                                  \
-    const float d2 = fast_lerp(P[2][2].f - P[2][0].f, P[2][3].f - P[2][1].f, a1);                                  \
-    cVx = fast_lerp(d1, d2, b1);                                                                                   \
-  }
-  DVO_BLEND(x, cI, cIx, cIy)
-  DVO_BLEND(y, cZ, cZx, cZy)
-#undef DVO_BLEND
+  // vertical and TWICE the horizontal central difference, each blended between rows 1 and 2.  A cell is an {I, Z} register pair and
+  // both channels go through the same formula: packed f32 instructions (v_pk_add_f32 / v_pk_fma_f32), 24 instead of 38 instructions
+  const f32x2 a1 = {r.a1, r.a1}, b1 = {r.b1, r.b1};
+  const f32x2 e0 = fast_lerp2(P[0][1], P[0][2], a1), e1 = fast_lerp2(P[1][1], P[1][2], a1);
+  const f32x2 e2 = fast_lerp2(P[2][1], P[2][2], a1), e3 = fast_lerp2(P[3][1], P[3][2], a1);
+  const f32x2 cV = fast_lerp2(e1, e2, b1);
+  const f32x2 cVy = fast_lerp2(e2 - e0, e3 - e1, b1);
+  const f32x2 d1 = fast_lerp2(P[1][2] - P[1][0], P[1][3] - P[1][1], a1);
+  const f32x2 d2 = fast_lerp2(P[2][2] - P[2][0], P[2][3] - P[2][1], a1);
+  const f32x2 cVx = fast_lerp2(d1, d2, b1);
+  const float cI = cV.x, cZ = cV.y, cIx = cVx.x, cZx = cVx.y, cIy = cVy.x, cZy = cVy.y;
   const float r0 = (cI - r.i) * (1.0f / 255.0f);             // dense_tracking.cpp:217-220
   const float r1 = cZ - r.qz;                                // reference depth := transformed z (dense_tracking_impl.cpp:269)
   const float dz = r.z - 0.4f;                               // occlusion threshold -20 (0.0012 + 0.0019 (z - 0.4)^2) (:122-128, Q5)
@@ -323,9 +353,6 @@ __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const f32x2 (&
     const f32x2 rr2 = {valid ? r0 : __builtin_nanf(""), r1};  // (the log-likelihood pass tests the first component)
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fast_u32v2, rr2), resid, off_v, off_s, 0);
   }
-#if DVO_FAST_SKIP
-  if (valid_mask == 0ull) return;                            // (uniform) a row without a constraint adds nothing to the sums
-#endif
   const float tq = fmaf(wt.P2x, r1, wt.P00 * r0);
   const float sw_any = wt.wc * fast_rsqrt(fmaf(tq, r0, fmaf(wt.P11 * r1, r1, wt.wk)));
   const float sw = valid ? sw_any : 0.0f;
@@ -333,7 +360,7 @@ __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const f32x2 (&
   // that zero is a LEGACY multiply (0 x anything = 0): no control flow on validity (an unfilled window cell may hold anything)
   const float gix = mul_legacy(sw * g.half_wi_x, cIx + r.gx), giy = mul_legacy(sw * g.half_wi_y, cIy + r.gy);
   const float gzx = mul_legacy(sw * g.half_fx, cZx), gzy = mul_legacy(sw * g.half_fy, cZy);
-  const float iz = fast_rcp(r.z);
+  const float iz = rcp_for_inline_asm(r.z);
   const float txy = tx * ty, cy = fmaf(ty, ty, 1.0f);
   const float sz = mul_legacy(sw, r.z);
   float c[14];
@@ -352,7 +379,7 @@ __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const f32x2 (&
   const float sr = sw * kResidualScale;
   c[12] = mul_legacy(sr, r0);
   c[13] = mul_legacy(sr, r1);
-  fast_gram_row<SWAP>(my, lane, c, acc0, acc1);
+  fast_gram_row<STORE>(my, lane, c, acc0, acc1);
 }
 
 // epilogue: G = H H^T + S + S^T summed over the four wavefronts by the 85 threads that own an accumulator (slab[w]: H H^T at [0, 256),
@@ -396,7 +423,7 @@ __device__ __forceinline__ void fast_count_fallbacks(unsigned long long* __restr
 // ===================================================================================================================================
 // variants 8 / 9: every pixel of the tile, one wavefront row = one image row of 64 pixels
 // ===================================================================================================================================
-template <bool SWAP>
+template <int STORE>
 __global__ __launch_bounds__(256, 5) void k_sweep_fast(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count, int* __restrict__ f16_range_flag) {
@@ -507,16 +534,9 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
   auto sweep_row = [&](int k, auto checked_tag) __attribute__((always_inline)) {
     constexpr bool CHECKED = decltype(checked_tag)::value;
     const int v_r = row0 + k * 4;
-#if DVO_FAST_SKIP
-    if (ok_row[k] == 0ull) {                                   // (uniform) no pixel of the row projects into the image: NaN pairs, nothing else
-      const f32x2 nan2 = {__builtin_nanf(""), __builtin_nanf("")};
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fast_u32v2, nan2), v_r < g.h ? resid : resid_none, off_px, v_r * row_bytes, 0);
-      return;
-    }
-#endif
     f32x2 P[4][4];
     fast_fetch_cells<CHECKED>(g, st.KT, curC, win, wnd, neg_base, rs[k], __builtin_amdgcn_inverse_ballot_w64(ok_row[k]), tx_u, ty_rows[k], P, n_fallback);
-    fast_row_tail<SWAP>(g, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_px, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
+    fast_row_tail<STORE>(g, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_px, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
   };
   if (wnd.all_in) {                                            // (uniform)
 #pragma unroll
@@ -544,8 +564,8 @@ void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const Pai
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(256);
-  if (variant == 8) k_sweep_fast<true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
-  else k_sweep_fast<false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+  if (variant == 8) k_sweep_fast<2><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+  else k_sweep_fast<1><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
 }
 
 }  // namespace dvo_hip

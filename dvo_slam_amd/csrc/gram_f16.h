@@ -63,10 +63,24 @@ __device__ __forceinline__ f16x8 read_operand_f16(const _Float16* img, int lane,
   return f16x8{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
 }
 
-// v_mul_legacy_f32: the multiply with 0 x anything = 0 (NaN and infinity included); the ordinary product otherwise
+// v_mul_legacy_f32: the multiply with 0 x anything = 0 (NaN and infinity included); the ordinary product otherwise.  (Inline assembly:
+// this compiler has no builtin for it.)
 __device__ __forceinline__ float mul_legacy(float a, float b) {
   float r;
   asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// A reciprocal whose first consumer is inline assembly (mul_legacy above).  On gfx950 an instruction that reads the result of a
+// transcendental instruction (v_rcp_f32, v_rsq_f32) needs a wait state between the two; the compiler inserts it for the instructions
+// it knows, but it does not look into inline assembly -- and whenever its scheduler happened to place the reciprocal of the depth
+// right in front of the first legacy product, that product read the register's OLD value (round 4: rows / columns 0 and 2 of the
+// normal equations off by factors of 20 to 1000 in one build of a kernel and exact in its sibling; scripts/ubench/trans_hazard.hip
+// reproduces it in six lines).  This is round 3's "wrong sums in the gathering sweep for a reason not found" (12-byte slab stores):
+// that change moved the same two instructions together.  The wait states travel with the value here.
+__device__ __forceinline__ float rcp_for_inline_asm(float x) {
+  float r = fast_rcp(x);
+  asm volatile("s_nop 1" : "+v"(r));
   return r;
 }
 
@@ -74,7 +88,7 @@ __device__ __forceinline__ float mul_legacy(float a, float b) {
 // where the reference point or a tap is a hole) meets a zero is v_mul_legacy_f32 -- 0 x anything = 0.  For a valid lane the legacy
 // multiply is the ordinary one.
 __device__ __forceinline__ void jacobian_rows_masked(const PixelTerms& t, float s, float tx, float ty, float cx, float cy, float* J0, float* J1) {
-  const float iz = fast_rcp(t.Z);
+  const float iz = rcp_for_inline_asm(t.Z);
   const float txy = tx * ty;
   const float gix = mul_legacy(s, t.gix), giy = mul_legacy(s, t.giy);
   const float gzx = mul_legacy(s, t.gzx), gzy = mul_legacy(s, t.gzy);

@@ -55,7 +55,7 @@ bool window_sweep_supports(const LevelGeom& g);
 void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                          float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag = nullptr);
 // align_fast.hip: variants 8 / 9 -- the window sweep with contracted per-pixel arithmetic (same function, rounding differences of a few
-// ulp against variants 6 / 7; window 84 x 28 cells at a pitch of 96; 8: operand rows written by all 64 lanes, 9: by 32).
+// ulp against variants 6 / 7; window 84 x 28 cells at a pitch of 96; 8: high and low operand parts take turns in the slab, 9: side by side, moved with v_permlane32_swap).
 bool fast_sweep_supports(const LevelGeom& g);
 void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                        float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag = nullptr);

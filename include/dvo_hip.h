@@ -253,7 +253,7 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * kernel: 8 (default) = the current frame's {I, Z} window staged in LDS, contracted per-pixel arithmetic (fused multiply-adds,
  * v_rcp_f32 in the projection, separable blends: the same function as 7 to a few ulp of the tap coordinate -- residuals within 2e-5,
  * constraint counts equal except at pixels on a bound) + Gram accumulation on the f16 matrix pipe, on every level whose width is a
- * multiple of 64 and the schedule of 7 elsewhere; 9 = 8 without the full-wavefront operand stores (measurement); 7 = the window sweep
+ * multiple of 64 and the schedule of 7 elsewhere; 9 = 8 with another way of storing the matrix operands (v_permlane32_swap; measurement); 7 = the window sweep
  * whose residuals and constraint counts equal the oracle's MATH mode BIT FOR BIT (no contraction, correctly rounded divisions), f16
  * Gram; 6 = the same with the f32 Gram (bit-identical to 5); 5 = gathered taps, f32 Gram accumulation on the matrix cores; 0 =
  * all-VALU with the DPP + LDS reduction),

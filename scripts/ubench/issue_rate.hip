@@ -9,6 +9,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b) {
   float x[16];
   for (int i = 0; i < 16; ++i) x[i] = threadIdx.x * 0.001f + i + 1.0f;
+  const unsigned long long mask = __builtin_amdgcn_ballot_w64(threadIdx.x & 1);
+  const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a)));
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -27,6 +29,19 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
       if (MODE == 12) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(x[i]) : "v"(a));
       if (MODE == 13) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(x[i]), "v"(a) : "vcc");
       if (MODE == 14) asm volatile("v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x[i]));
+      if (MODE == 15) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "s"(mask));
+      if (MODE == 16) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+      if (MODE == 17) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+      if (MODE == 18) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x[i]) : "v"(a));
+      if (MODE == 19) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+      if (MODE == 24) asm volatile("v_min_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+      if (MODE == 25) asm volatile("v_floor_f32 %0, %0" : "+v"(x[i]));
+      if (MODE == 26) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(x[i]) : "v"(a));
+      if (MODE == 27) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+      if (MODE == 28) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "s"(sa), "v"(b));
+      if (MODE == 29) asm volatile("v_cmp_le_u32 vcc, %0, %1" : : "v"(x[i]), "v"(a) : "vcc");
+      if (MODE == 30) asm volatile("v_mov_b32 %0, %1" : "+v"(x[i]) : "v"(a));
+      if (MODE == 31) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "s"(sa));
     }
     if (MODE == 20) {
 #pragma unroll
@@ -86,6 +101,19 @@ int main() {
   run<12>("v_pk_min_i16", 16);
   run<13>("v_cmp_gt_f32", 16);
   run<14>("v_max_i32_dpp", 16);
+  run<15>("v_cndmask_b32_e64 sgpr", 16);
+  run<16>("v_and_b32", 16);
+  run<17>("v_add_u32", 16);
+  run<18>("v_lshl_add_u32", 16);
+  run<19>("v_sub_f32", 16);
+  run<24>("v_min_f32", 16);
+  run<25>("v_floor_f32", 16);
+  run<26>("v_mad_u32_u24", 16);
+  run<27>("v_fmac_f32", 16);
+  run<28>("v_fma_f32 sgpr operand", 16);
+  run<29>("v_cmp_le_u32", 16);
+  run<30>("v_mov_b32", 16);
+  run<31>("v_mul_f32 sgpr operand", 16);
   run<20>("v_pk_add_f32", 8);
   run<21>("v_pk_fma_f32", 8);
   run<23>("v_pk_mul_f32", 8);

@@ -148,7 +148,7 @@ def test_window_sweep_against_the_gathering_sweep(w, h, xi):
                                     (640, 480, [0.3, -0.2, 0.1, 0.2, 0.3, -0.4]), (192, 80, [-0.05, 0.08, 0.02, 0.1, -0.1, 0.2]),
                                     (1280, 960, [0.01, -0.01, 0.005, 0.01, 0.01, -0.01]), (640, 250, [0.01, 0.02, -0.01, -0.01, 0.02, 0.01])])
 def test_contracted_sweep_against_the_exact_one(w, h, xi):
-    """The default schedule (variant 8, align_fast.hip; 9 = the same without the full-wavefront operand stores) against the window sweep
+    """The default schedule (variant 8, align_fast.hip; 9 = the same with the matrix operands stored through lane swaps) against the window sweep
     whose residuals are the oracle's bit for bit (variant 7).  Same function, other rounding: the tap coordinate u = qx rcp(qz) carries
     up to ~3 ulp(u) where the exact schedule's quotient is correctly rounded (of inputs that themselves carry 2 ulp), the blends are
     contracted.  Stated and checked here, per pixel:

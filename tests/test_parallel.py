@@ -117,6 +117,29 @@ def test_two_ranks_gather_the_records_of_one_rank(tmp_path):
     assert ja["nan_results"] == 0 and ja["max_twist_error_vs_truth"] < 1e-4
 
 
+@pytest.mark.gpu
+def test_rccl_record_path_on_one_gpu(tmp_path):
+    """The RCCL code path of the N > 1 record exchange, executed on the one GPU a test box has: bench.py with the gatherer forced on under
+    init_process_group("nccl", world_size=1) -- device tensors, pinned staging, the asynchronous all-gather on RCCL's stream, the drain at
+    the end of the timed region -- delivers exactly the records a run without any process group packs from its local results.  (What a
+    world of one cannot show is the exchange between GPUs over xGMI: the N > 1 curve is the driver's to measure.)"""
+    common = ["--pairs", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-from-host", "--no-scaling-model", "--rows-per-wave", "8",
+              "--resident-group", "1"]
+    plain, forced = str(tmp_path / "plain.npy"), str(tmp_path / "forced.npy")
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--records-out", plain] + common,
+                       capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0, a.stderr[-2000:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--backend", "nccl", "--records-out", forced] + common,
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert b.returncode == 0, b.stderr[-2000:]
+    jb = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
+    assert jb["forced_gather"] == {"backend": "nccl", "world_size": 1} and jb["n_gpus"] == 1 and jb["nan_results"] == 0
+    ra, rb = np.load(plain), np.load(forced)
+    assert ra.shape == rb.shape == (12, par.RECORD)
+    assert np.array_equal(ra, rb)
+
+
 def test_pipeline_object_packs_the_same_records():
     from oracle import pyoracle as po
     """dvo_stream_pack_records (dvo_slam_amd/apps/stream_pipeline.cpp) -- the per-step record packing of a multi-GPU job done by the
