@@ -212,6 +212,7 @@ struct Workspace {
   // resident match kernel: the exchange rows of the workgroup groups and the sequence numbers used so far
   DevBuf exchange;
   unsigned resident_sequence = 0;
+  long long exchange_shape = -1;   // pairs x group of the launch the exchange buffer was last cleared for
   // ... and, when it runs a whole match of a small batch, where it leaves results and statistics: pinned host memory the host
   // thread reads as soon as the kernel has counted the pairs done (no copy command, no stream synchronisation)
   PinnedBuf direct_results, direct_levels, direct_iters, direct_done;
@@ -253,6 +254,9 @@ struct dvo_hip_context {
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
   int opt_fused_ll_pixels = 0;     // largest level (pixels) whose log-likelihood sweep runs inside the solver workgroup (0 = by batch size)
+  float last_sel_ithr = 0.0f, last_sel_dthr = 0.0f;   // selection thresholds of the last match on this context
+  int f32_gram_hold = 0;           // batches that still run with the f32 Gram after one left the f16 range (run_batch)
+  long long warmup_wait_us = 0;    // longest of the waits dvo_hip_context_create made on the context's streams
   int opt_variant = 8;             // schedule of the sweep: 8 = current-frame window staged in LDS, contracted arithmetic + f16 hi/lo Gram on the matrix pipe where the level allows (7: residuals bit-identical to the oracle's)
                                    // (width a multiple of 64), else 5 = gathering sweep with the f32 Gram on the matrix cores
   // the resident match kernel (align_resident.hip): -1 = levels whose sweep is short enough for the groups that fit (default),
@@ -904,6 +908,8 @@ int resident_levels_of(const dvo_hip_context* ctx, const dvo_hip_config* cfg, co
 int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
                        bool launch_path_only = false) {
   Range range("build");
+  ctx->last_sel_ithr = cfg->intensity_derivative_threshold;   // (what a speculative reference preparation will assume, prepare_roles)
+  ctx->last_sel_dthr = cfg->depth_derivative_threshold;
   int rc = wait_for_build(ctx, n, refs);
   if (rc == DVO_HIP_OK) rc = wait_for_build(ctx, n, curs);
   if (rc != DVO_HIP_OK) return rc;
@@ -1172,9 +1178,14 @@ int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, 
     // sequence numbers never repeat between launches; when they would wrap (or the rows are new / in doubt) the rows are cleared
     const unsigned long long need64 = 2ull * unsigned(rp.levels) * unsigned(cfg->max_iterations_per_level) + 4ull;
     const unsigned need = need64 < 0x40000000ull ? unsigned(need64) : 0x40000000u;   // (more exchanges than that do not happen)
-    if (grown || need64 >= 0x40000000ull || w.resident_sequence > 0xffffffffu - need - 1u) {
+    // (... or the batch has another shape than the last one: the heartbeat words live BEHIND the rows, at an offset that follows pairs x
+    // group, and a word that was a row slot of the previous launch -- the float half of a slot, 0x3f800000, reads as a beat far ahead --
+    // would let a workgroup skip the wait the heartbeat exists for)
+    const long long shape = (long long)bp.n * rp.group;
+    if (grown || shape != w.exchange_shape || need64 >= 0x40000000ull || w.resident_sequence > 0xffffffffu - need - 1u) {
       DVO_WS_TRY(w, hipMemsetAsync(w.exchange.p, 0, w.exchange.bytes, s));
       w.resident_sequence = 0;
+      w.exchange_shape = shape;
     }
     args.exchange = w.exchange.as<unsigned long long>();
     args.sequence_base = w.resident_sequence;
@@ -1183,6 +1194,8 @@ int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, 
   DVO_WS_TRY(w, launch_match_resident(s, args, ctx->opt_resident_cooperative != 0));
   return DVO_HIP_OK;
 }
+
+constexpr int kF32GramHoldBatches = 32;   // after a batch left the f16 range of the Gram operands: this many batches go straight to the f32 Gram
 
 hipEvent_t g_trace_ev[2] = {nullptr, nullptr};   // DVO_HIP_TRACE_SLOW: device time stamps around a batch's preparation
 
@@ -1199,6 +1212,18 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   if (trace_slow_ms > 0.0) {
     if (!g_trace_ev[0]) { (void)hipEventCreate(&g_trace_ev[0]); (void)hipEventCreate(&g_trace_ev[1]); }
     (void)hipEventRecord(g_trace_ev[0], s);
+  }
+  // The Gram schedule of this batch.  The default accumulates on the f16 matrix pipe from exact high + low operand pairs, which cannot
+  // represent a Jacobian component beyond +-65504; a batch that meets one is repeated with the f32 Gram (below).  Two cases take the
+  // f32 Gram from the start: option "deterministic" (a pair's bits must not depend on whether ANOTHER pair of its batch left the f16
+  // range), and the batches right after a repeat (a sequence with a close depth step would otherwise pay twice on every frame).
+  struct VariantScope {
+    dvo_hip_context* c; int keep;
+    ~VariantScope() { c->opt_variant = keep; }
+  } variant_scope{ctx, ctx->opt_variant};
+  if (ctx->opt_variant >= 7 && (ctx->opt_deterministic || ctx->f32_gram_hold > 0)) {
+    if (ctx->f32_gram_hold > 0) ctx->f32_gram_hold -= 1;
+    ctx->opt_variant = 6;
   }
   BatchPlan bp;
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
@@ -1382,12 +1407,10 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // represent it.  The batch runs again with the f32 Gram of the same sweep (variant 6: same planes, same tiles).
     *static_cast<volatile int*>(w.f16_range_flag) = 0;
     ctx->f16_range_repeats += 1;
+    ctx->f32_gram_hold = kF32GramHoldBatches;
     for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, &tinit[size_t(i) * 16], 16 * sizeof(double));
-    const int keep = ctx->opt_variant;
-    ctx->opt_variant = 6;
-    rc = run_batch(ctx, n, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
-    ctx->opt_variant = keep;
-    return rc;
+    ctx->opt_variant = 6;                                      // (restored by variant_scope)
+    return run_batch(ctx, n, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
   }
   bool truncated = false;
   for (int i = 0; i < n; ++i) {
@@ -1451,6 +1474,7 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
     *value = (long long)v;
   }
   else if (std::strcmp(key, "strip_ingests") == 0) *value = ctx->strip_ingests;
+  else if (std::strcmp(key, "warmup_wait_us") == 0) *value = ctx->warmup_wait_us;
   else if (std::strcmp(key, "rendezvous_pairs") == 0) {
     std::lock_guard<std::mutex> lock(ctx->rendezvous_mutex);
     *value = ctx->rendezvous_pairs;
@@ -1547,6 +1571,29 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
     g_create_error = std::string("context setup (build stream): ") + hipGetErrorString(e);
     dvo_hip_context_destroy(ctx);
     return DVO_HIP_ERR_HIP;
+  }
+  // Warm-up of the wait path.  In the FIRST GPU process on a fresh box the first stream wait of a batch has been seen to return 14-24 ms
+  // after the device had finished (19 us by its own time stamps; DESIGN.md section 8: not under the profiler, not in later
+  // processes, with polling as with hipStreamSynchronize, and skipping one wait only moved it to the next) -- a one-time cost of the
+  // runtime's host-side wait machinery, not of this engine.  Every stream of the context therefore waits three times on a
+  // trivial command here, where no caller is timing; the longest of those waits is kept (counter "warmup_wait_us"), so that a stall
+  // that still shows up in a first match can be told from one that was absorbed here.
+  {
+    long long longest = 0;
+    unsigned char scratch_byte[8] = {0};
+    void* dev = nullptr;
+    if (hipMalloc(&dev, 64) == hipSuccess) {
+      for (hipStream_t st : {ctx->stream, ctx->build_stream, ctx->upload_stream})
+        for (int rep = 0; rep < 3; ++rep) {
+          (void)hipMemsetAsync(dev, 0, 64, st);
+          (void)hipMemcpyAsync(scratch_byte, dev, 8, hipMemcpyDeviceToHost, st);
+          const auto t0 = std::chrono::steady_clock::now();
+          (void)hipStreamSynchronize(st);
+          longest = std::max<long long>(longest, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
+        }
+      (void)hipFree(dev);
+    }
+    ctx->warmup_wait_us = longest;
   }
   // DVO_HIP_REF_COMPAT=1: the reference-compatible arithmetic for callers that cannot set options -- the reference's own, unmodified
   // programs linked against the facade (tests/dropin)
@@ -1769,8 +1816,23 @@ int prepare_roles(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* fram
   const bool ref = role == DVO_HIP_ROLE_REFERENCE;
   int want[kMaxLevels];
   for (int l = 0; l < kMaxLevels; ++l) want[l] = l < frames[0]->cam->levels ? eager_current_flavor(ctx, frames[0]->cam, l, n_frames) : kCurAB;
-  const int rc = ensure_roles(ctx, n_frames, frames, ref ? 1 : 0, cfg->last_level, cfg->first_level, ref ? cfg->intensity_derivative_threshold : 0.0f,
-                              ref ? cfg->depth_derivative_threshold : 0.0f, /*eager=*/true, want);
+  float ithr = ref ? cfg->intensity_derivative_threshold : 0.0f, dthr = ref ? cfg->depth_derivative_threshold : 0.0f;
+  std::vector<dvo_hip_frame*> speculative;
+  if (ref && (ithr < 0.0f || dthr < 0.0f)) {
+    // A negative threshold asks for a SPECULATIVE preparation (a caller that does not know the tracker the frame will meet: the facade's
+    // buildAccelerationStructure): with the thresholds of the context's last match, and only for frames that hold no selection at
+    // all -- a frame selected for other thresholds keeps its planes instead of alternating between two selections.
+    ithr = ctx->last_sel_ithr; dthr = ctx->last_sel_dthr;
+    for (int i = 0; i < n_frames; ++i) {
+      bool any = false;
+      for (int l = cfg->last_level; l <= cfg->first_level; ++l) any |= frames[i]->lv[l].selected;
+      if (!any) speculative.push_back(frames[i]);
+    }
+    if (speculative.empty()) return DVO_HIP_OK;
+    n_frames = int(speculative.size());
+    frames = speculative.data();
+  }
+  const int rc = ensure_roles(ctx, n_frames, frames, ref ? 1 : 0, cfg->last_level, cfg->first_level, ithr, dthr, /*eager=*/true, want);
   if (rc != DVO_HIP_OK) return rc;
   DVO_HIP_TRY(ctx, hipGetLastError());
   return DVO_HIP_OK;
@@ -2030,7 +2092,13 @@ int dvo_hip_match(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame*
   };
   if (!ctx || !reference || !current || !cfg || !result || !ctx->opt_rendezvous) return alone();
   typedef dvo_hip_context::MatchRequest Request;
-  constexpr int kExpectCalls = 64;                             // lone calls that still wait after the last meeting / collision
+  constexpr int kExpectCalls = 16;                             // lone calls that still wait after the last meeting / collision (each
+                                                               // wait is up to 60 us against a 0.18-0.36 ms match: 64 was too many)
+  auto same_config = [](const dvo_hip_config& a, const dvo_hip_config& b) {   // (field by field: the padding bytes of a caller's struct are not its business)
+    return a.first_level == b.first_level && a.last_level == b.last_level && a.max_iterations_per_level == b.max_iterations_per_level &&
+           a.use_initial_estimate == b.use_initial_estimate && a.precision == b.precision && a.mu == b.mu &&
+           a.intensity_derivative_threshold == b.intensity_derivative_threshold && a.depth_derivative_threshold == b.depth_derivative_threshold;
+  };
   constexpr auto kPartnerWait = std::chrono::microseconds(60);
   Request me;
   me.reference = reference; me.current = current; me.cfg = cfg; me.result = result;
@@ -2040,7 +2108,7 @@ int dvo_hip_match(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame*
   {
     std::lock_guard<std::mutex> lock(ctx->rendezvous_mutex);
     Request* w = ctx->rendezvous_waiting;
-    if (w && w->current == current && std::memcmp(w->cfg, cfg, sizeof(*cfg)) == 0) {
+    if (w && w->current == current && same_config(*w->cfg, *cfg)) {
       partner = w;
       ctx->rendezvous_waiting = nullptr;
       w->state.store(1, std::memory_order_release);
@@ -2067,6 +2135,19 @@ int dvo_hip_match(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame*
     int rc = dvo_hip_match_batch(ctx, 2, r, c, cfg, res, want_levels ? lv.data() : nullptr, cl, want_iters ? it.data() : nullptr, ci);
     Request* both[2] = {partner, &me};
     int rcs[2] = {rc, rc};
+    if (rc != DVO_HIP_OK && rc != DVO_HIP_ERR_CAPACITY) {
+      // the merged batch was refused (one request's initial estimate is not finite, a frame of another context, ...): each request
+      // runs alone and gets ITS OWN status -- a valid match does not fail because of the partner it happened to meet
+      for (int k = 0; k < 2; ++k) {
+        Request* q = both[k];
+        dvo_hip_frame* r1[1] = {q->reference};
+        dvo_hip_frame* c1[1] = {q->current};
+        rcs[k] = dvo_hip_match_batch(ctx, 1, r1, c1, q->cfg, q->result, q->levels, q->cap_levels, q->iters, q->cap_iters);
+      }
+      partner->rc = rcs[0];
+      partner->state.store(2, std::memory_order_release);
+      return rcs[1];
+    }
     for (int k = 0; k < 2; ++k) {
       Request* q = both[k];
       if (rc != DVO_HIP_OK && rc != DVO_HIP_ERR_CAPACITY) continue;

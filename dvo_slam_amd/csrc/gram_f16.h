@@ -27,8 +27,9 @@ typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
 // saturates at the largest f16 instead of becoming infinite), lo = f16(v - hi) with the subtraction exact in f32:
 // v_fma_mix_f32 reads the f16 half of `hi` directly and subtracts in f32 (the compiler emits a conversion and a subtraction
 // unless it can fold a multiplication in); the two differences are packed with round toward zero as well.
-// Range: a component beyond +-65504 saturates hi and the sum no longer represents it; the epilogue detects that from the diagonal
-// of H H^T (kF16RangeSquared) and the batch is repeated with the f32 Gram (capi.hip, counter "f16_range_repeats").
+// Range: a component beyond +-65504 has an INFINITE high part (round to nearest) and the sum no longer represents it; the epilogue
+// finds the infinity (or the not-a-number it turns into) in H H^T and the batch is repeated with the f32 Gram (capi.hip, counter
+// "f16_range_repeats").
 // (seven pairs at a time, each step for all pairs before the next: an instruction never waits for the one right before it)
 __device__ __forceinline__ void split_pairs(const float (&v)[14], unsigned (&hi)[7], unsigned (&lo)[7]) {
   // (round to nearest even -- v_cvt_pk_f16_f32, gfx950 -- for both parts: |v - hi - lo| <= 2^-22 |v|, four times closer than with
@@ -47,7 +48,6 @@ __device__ __forceinline__ void split_pairs(const float (&v)[14], unsigned (&hi)
 #pragma unroll
   for (int k = 0; k < 7; ++k) lo[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32pair{ra[k], rb[k]}, f16pair));
 }
-constexpr float kF16RangeSquared = 65504.0f * 65504.0f;
 
 // matrix operand of 32 pixels (k index) x 16 components from the pixel-major f16 image: lane (i = l & 15, g = l >> 4) gets eight
 // k-values of component i (scripts/ubench/gram_f16.hip).  WHICH eight pixels is free -- the Gram sum runs over all of them, and both
@@ -161,11 +161,11 @@ __device__ __forceinline__ void gram_f16_finish(float* my, int lane, const f32x4
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int col = lane & 15;
     if (f16_range_flag) {
-      // a component beyond the f16 range saturated its high part at +-65504: that pixel alone puts 65504^2 on the diagonal of H H^T
-      // (sums of squares: nothing cancels), and no entry of a Gram matrix exceeds its largest diagonal entry -- so the largest
-      // magnitude of ANY entry tells.  Not-a-number counts as out of range.
+      // a component beyond the f16 range became INFINITE in its high part (v_cvt_pk_f16_f32 rounds to nearest: overflow = infinity)
+      // and puts infinity on the diagonal of H H^T, from where it spreads as infinity or not-a-number.  (Rounds 2-3 compared the
+      // accumulated diagonal with one pixel's 65504^2 -- many moderately large components tripped it although nothing saturated.)
       const float largest = fmaxf(fmaxf(fabsf(acc0[0]), fabsf(acc0[1])), fmaxf(fabsf(acc0[2]), fabsf(acc0[3])));
-      const bool out_of_range = !(largest < kF16RangeSquared) || __builtin_isnan(acc0[0]) || __builtin_isnan(acc0[1]) || __builtin_isnan(acc0[2]) || __builtin_isnan(acc0[3]);
+      const bool out_of_range = !(largest < __builtin_inff()) || __builtin_isnan(acc0[0]) || __builtin_isnan(acc0[1]) || __builtin_isnan(acc0[2]) || __builtin_isnan(acc0[3]);
       if (__ballot(out_of_range) != 0 && lane == 0) __hip_atomic_store(f16_range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const float cs = col >= 12 ? 1.0f / kResidualScale : 1.0f;

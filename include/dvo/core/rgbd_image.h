@@ -314,14 +314,17 @@ inline void RgbdImage::buildAccelerationStructure() {
   if (!owner_) return;
   // The callers walk the levels of a new image (dvo_slam/src/local_tracker.cpp:163-169): the first call prepares every level that has
   // been built from this one upwards in ONE background launch, the calls for the other levels find their planes in place.  The
-  // reference role (point selection with the default thresholds) is prepared along with it: in a tracking front end every image is
-  // the odometry tracker's reference one frame later (local_tracker.cpp:198-206), and deriving it then would sit inside that match.
+  // reference role is prepared along with it, speculatively (negative thresholds: the selection thresholds of the context's last
+  // match, and only if the image holds no selection yet -- a key frame that was selected for a tracker's thresholds keeps it):
+  // in a tracking front end every image is the odometry tracker's reference one frame later (local_tracker.cpp:198-206), and
+  // deriving it then would sit inside that match.
   dvo_hip_config c = {};
   c.last_level = level_;
   c.first_level = int(owner_->builtLevels()) > level_ ? int(owner_->builtLevels()) - 1 : level_;
   c.max_iterations_per_level = 1;
   dvo_hip_frame* one[1] = {owner_->device_frame()};
   dvo_hip_check(owner_->device_context(), dvo_hip_frames_prepare(owner_->device_context(), 1, one, DVO_HIP_ROLE_CURRENT, &c), "dvo_hip_frames_prepare");
+  c.intensity_derivative_threshold = c.depth_derivative_threshold = -1.0f;
   dvo_hip_check(owner_->device_context(), dvo_hip_frames_prepare(owner_->device_context(), 1, one, DVO_HIP_ROLE_REFERENCE, &c), "dvo_hip_frames_prepare");
   if (hostMirrors()) syncHostMirrors(MirrorAcceleration);
 }

@@ -172,6 +172,9 @@ void dvo_hip_host_free(dvo_hip_context* ctx, void* p);
  * PointSelection::select for cfg's thresholds (dvo_core/src/core/point_selection.cpp:89-152), levels cfg->last_level ..
  * cfg->first_level.  This is what the reference's LocalTracker does with a new image BEFORE handing it to its trackers
  * (dvo_slam/src/local_tracker.cpp:159-170).  Optional: dvo_hip_match* builds whatever is missing.
+ * Role REFERENCE with a NEGATIVE threshold in cfg is a speculative preparation, for a caller that does not know the tracker the
+ * frame will meet: the selection thresholds of the context's last match are used, and frames that already hold a selection (for
+ * whatever thresholds) are left alone.
  * Frame construction (create / update / prepare) runs on a stream of its own, concurrently with an alignment that was
  * started afterwards on other frames -- build the next batch, then align the current one, and the two overlap.  A frame
  * must not be updated while a match that uses it is in progress (matches are blocking calls, so this only concerns other
@@ -296,6 +299,8 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
  * "rendezvous_pairs" (two-pair batches formed from concurrent single matches, see option "rendezvous"),
  * "strip_ingests" (frames whose raw planes went through the strip ingest, one 128 x 8 strip per wavefront -- even-width rows and
  * 4 / 8-byte aligned planes; the others take the tile kernel),
+ * "warmup_wait_us" (the longest of the nine stream waits dvo_hip_context_create makes on trivial commands to warm up the runtime's wait
+ * path, in microseconds: the first GPU process on a fresh box has been seen to spend 14-24 ms in its first wait),
  * "host_batches" and "host_ns_prepare" / "host_ns_enqueue" / "host_ns_wait" / "host_ns_finish" (nanoseconds the calling thread spent
  * in dvo_hip_match_batch before its first launch, enqueueing, waiting for the device and afterwards; accumulated). */
 int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value);

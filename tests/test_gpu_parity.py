@@ -263,7 +263,7 @@ def test_f16_gram_range_guard_repeats_with_the_f32_gram():
     depth = np.where(((xx // 8) + (yy // 8)) % 2 == 0, 0.002, 10.0).astype(np.float32)
     grey = pair["grey_ref"].astype(np.float32)
     recs = {}
-    for v in (6, 7):
+    for v in (6, 7, 8):
         ctx = d.Context(0)
         ctx.set_option("variant", v)
         ctx.set_option("resident", 0)
@@ -273,13 +273,29 @@ def test_f16_gram_range_guard_repeats_with_the_f32_gram():
         ref, cur = cam.create(grey, depth), cam.create(grey, depth)
         out = trk.match_batch_arrays([ref], [cur])
         recs[v] = (out, ctx.counter("f16_range_repeats"))
-        if v == 7:
+        if v >= 7:
+            # the batches right after a repeat take the f32 Gram from the start (a sequence that keeps meeting such a depth step does
+            # not pay twice per frame): the same scene again does not count another repeat, nor does an ordinary one
+            again = trk.match_batch_arrays([ref], [cur])
+            assert ctx.counter("f16_range_repeats") == recs[v][1]
+            for k in ("T", "information", "loglik", "n_iterations"):
+                assert np.array_equal(again[k], out[k], equal_nan=True), k
             gref, gcur = gpu_pyramids(ctx, pair, 1)
             trk.match_batch_arrays([gref], [gcur])
-            assert ctx.counter("f16_range_repeats") == recs[7][1]
-    assert recs[6][1] == 0 and recs[7][1] == 1
-    for k in ("T", "information", "loglik", "n_iterations"):
-        assert np.array_equal(recs[6][0][k], recs[7][0][k], equal_nan=True), k
+            assert ctx.counter("f16_range_repeats") == recs[v][1]
+    assert recs[6][1] == 0 and recs[7][1] == 1 and recs[8][1] == 1
+    for v in (7, 8):                                            # the repeat runs variant 6: its record, bit for bit
+        for k in ("T", "information", "loglik", "n_iterations"):
+            assert np.array_equal(recs[6][0][k], recs[v][0][k], equal_nan=True), (v, k)
+    # many moderately large components do not trip the guard: only a component that really left the f16 range does
+    ctx = d.Context(0)
+    ctx.set_option("resident", 0)
+    cam = d.RgbdCameraPyramid(w, h, pair["K"], ctx)
+    cam.build(1)
+    depth2 = np.where(((xx // 8) + (yy // 8)) % 2 == 0, 0.35, 0.40).astype(np.float32)      # steps of 5 cm at 0.4 m: components of ~1e3 everywhere
+    a, b = cam.create(grey, depth2), cam.create(grey, depth2)
+    d.DenseTracker(d.Config(FirstLevel=0, LastLevel=0, MaxIterationsPerLevel=3), ctx).match_batch_arrays([a], [b])
+    assert ctx.counter("f16_range_repeats") == 0
 
 
 def test_window_sweep_whole_matches_and_plane_flavours():

@@ -183,12 +183,26 @@ def test_reference_compatible_mode_single_matches():
 
 @pytest.mark.parametrize("name", sorted(CONFIGS))
 def test_reference_compatible_mode_long_replay(long_sequence, name):
-    """BASELINE config 3 ("ATE within 1 % of reference") at size, on the reference's own terms: the 300-frame noisy sequence replayed
-    with ref_compat against the trajectory of the reference's match() computed HERE (oracle REF_SSE, bit-identical to the reference's
-    translation units by tests/test_oracle_ref.py; the approximate reciprocal is a property of the host CPU, so the golden trajectory
-    of another machine does not apply).  The default mode's ATE is 47 % / 73 % off the reference's; with the reciprocal reproduced it
-    is within a few per cent -- the remainder is the stopping rule acting on rounding noise: on the CPU, any change of the
-    summation order moves the ATE by +-2..6 % as well (profiles/r03_quirk_table.txt), and only the bit-exact restatement reaches 0."""
+    """BASELINE config 3 ("ATE within 1 % of reference") at size, restated so that it can fail against the REFERENCE (round 4).
+
+    The 300-frame noisy sequence is replayed in both arithmetic modes and by the reference's own match() run HERE (oracle REF_SSE,
+    bit-identical to the reference's translation units by tests/test_oracle_ref.py) -- and the golden file holds the reference's
+    trajectory from ANOTHER host.  What the numbers say (profiles/r03_quirk_table.txt):
+      * the absolute trajectory error is the end point of a random walk: the reference's own ATE on this sequence differs by a factor of
+        three between an Intel and an AMD host (their rcpps tables differ), and on one host every change of summation order moves it
+        by 2-6 %.  "Within 1 % of the reference" is met by nothing but the bit-exact restatement on the same CPU -- not a property an
+        implementation on other hardware can have.  Reproducing the order-dependent quirks as well (odd-N drop, scale pairing,
+        log-likelihood tail) would not change that: the CPU oracle with ALL of them but the sequential float accumulation of the normal
+        equations is still 2-6 % off, and that last one is a serial sum over 300 000 pixels.
+      * the per-step error against the ground truth (RPE) is an average over 299 steps and does not random-walk.
+    Asserted, therefore:
+      (1) RPE (translation and rotation rmse): ref_compat within 3 % of the reference's on this host; the default mode not worse than
+          the reference on either host by more than 3 % (the reference's own per-step error is 6 % larger on the GPU boxes' EPYC than on the
+          golden file's Xeon: the exact arithmetic is allowed to be better, by up to 10 %);
+      (2) ref_compat -- the mode that reproduces the one quirk that is a per-pixel function -- ATE within 5 % of the reference's on this
+          host (measured -1.5 % / +0.8 %), a third of the default mode's distance at most, steps closer to the reference's than the default's;
+      (3) the default mode's ATE inside the reference's own host-to-host spread (this host and the golden file's), widened by 10 %,
+          whenever the two hosts differ at all."""
     import dvo_slam_amd as d
     from dvo_slam_amd import replay, tum
     from oracle import pyoracle as po
@@ -205,15 +219,28 @@ def test_reference_compatible_mode_long_replay(long_sequence, name):
         runs[compat] = replay.replay_arrays(seq["grey"], seq["depth"], lambda w, h, K: replay.hip_backend(w, h, K, cfg, ctx), seq["K"])
         assert runs[compat]["failures"] == 0
     stamps, truth = ref_run["stamps"], seq["poses"]
-    ate = {k: tum.evaluate_ate(stamps, truth, stamps, v["poses"])["rmse"] for k, v in (("ref", ref_run), ("default", runs[0]), ("compat", runs[1]))}
+    traj = {"ref": ref_run["poses"], "default": runs[0]["poses"], "compat": runs[1]["poses"], "ref_other_host": chain(gold[name + "_ref_relative"])}
+    ate = {k: tum.evaluate_ate(stamps, truth, stamps, v)["rmse"] for k, v in traj.items()}
+    rpe = {k: tum.evaluate_rpe(truth, v) for k, v in traj.items()}
     step = {k: np.array([np.abs(po.se3_log(np.linalg.inv(a) @ b)).max() for a, b in zip(runs[k]["relative"], ref_run["relative"])]) for k in (0, 1)}
-    print("%s: ATE rmse reference %.4f mm, default mode %.4f mm (%+.1f %%), ref_compat %.4f mm (%+.1f %%); per-step twist distance to the "
-          "reference: default mean %.2e max %.2e, ref_compat mean %.2e max %.2e"
-          % (name, ate["ref"] * 1e3, ate["default"] * 1e3, 100 * (ate["default"] / ate["ref"] - 1), ate["compat"] * 1e3, 100 * (ate["compat"] / ate["ref"] - 1),
+    print("%s: ATE rmse reference here %.4f mm (on the golden file's host %.4f mm), default mode %.4f mm (%+.1f %%), ref_compat %.4f mm (%+.1f %%); "
+          "RPE trans rmse reference %.4e, default %+.2f %%, ref_compat %+.2f %%; RPE rot rmse reference %.4e, default %+.2f %%, ref_compat %+.2f %%; "
+          "per-step twist distance to the reference: default mean %.2e max %.2e, ref_compat mean %.2e max %.2e"
+          % (name, ate["ref"] * 1e3, ate["ref_other_host"] * 1e3, ate["default"] * 1e3, 100 * (ate["default"] / ate["ref"] - 1), ate["compat"] * 1e3,
+             100 * (ate["compat"] / ate["ref"] - 1), rpe["ref"]["trans_rmse"], 100 * (rpe["default"]["trans_rmse"] / rpe["ref"]["trans_rmse"] - 1),
+             100 * (rpe["compat"]["trans_rmse"] / rpe["ref"]["trans_rmse"] - 1), rpe["ref"]["rot_rmse"],
+             100 * (rpe["default"]["rot_rmse"] / rpe["ref"]["rot_rmse"] - 1), 100 * (rpe["compat"]["rot_rmse"] / rpe["ref"]["rot_rmse"] - 1),
              step[0].mean(), step[0].max(), step[1].mean(), step[1].max()))
-    assert abs(ate["compat"] - ate["ref"]) <= 0.10 * ate["ref"]                  # the default mode: 0.47 / 0.73
-    assert abs(ate["compat"] - ate["ref"]) < 0.3 * abs(ate["default"] - ate["ref"])
+    for key in ("trans_rmse", "rot_rmse"):                                         # (1)
+        assert abs(rpe["compat"][key] - rpe["ref"][key]) <= 0.03 * rpe["ref"][key], (key, rpe["compat"][key], rpe["ref"][key])
+        best = min(rpe["ref"][key], rpe["ref_other_host"][key])
+        assert 0.90 * best <= rpe["default"][key] <= 1.03 * max(rpe["ref"][key], rpe["ref_other_host"][key]), (key, rpe["default"][key], rpe["ref"][key])
+    assert abs(ate["compat"] - ate["ref"]) <= 0.05 * ate["ref"]                    # (2)
+    assert abs(ate["compat"] - ate["ref"]) < 0.33 * abs(ate["default"] - ate["ref"])
     assert step[1].mean() < 0.75 * step[0].mean()
+    lo, hi = sorted((ate["ref"], ate["ref_other_host"]))                           # (3)
+    if hi > 1.05 * lo:
+        assert 0.9 * lo <= ate["default"] <= 1.1 * hi, ate
 
 
 # ---- real sequences of the TUM RGB-D benchmark, when a copy is on disk (DVO_TUM_ROOT) ----------------------------------------------------
@@ -253,7 +280,7 @@ def check_sequence_report(out):
     assert out["failures"]["gpu"] == out["failures"]["math"] and out["failures"]["compat"] == out["failures"]["ref"]
     assert abs(out["ate"]["gpu"] - out["ate"]["math"]) <= 0.01 * out["ate"]["math"]          # config 3 against the semantics implemented
     assert out["gpu_math"].max() < 2e-4                                                       # a match stopped at Precision 1e-4 (as the long replay)
-    assert abs(out["ate"]["compat"] - out["ate"]["ref"]) <= 0.10 * out["ate"]["ref"]          # and on the reference's own terms
+    assert abs(out["ate"]["compat"] - out["ate"]["ref"]) <= (0.05 if out["n"] >= 100 else 0.10) * out["ate"]["ref"]   # and on the reference's own terms
     assert out["compat_ref"].mean() <= out["gpu_ref"].mean()
 
 

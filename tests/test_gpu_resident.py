@@ -4,6 +4,8 @@ owned by a group of workgroups) against the launch-per-step path of the same lib
 The two paths run the same per-pixel arithmetic and the same state machine (solver_logic.h) but add the per-pixel contributions in
 a different order, so they agree like two batch-size classes of the launch path do: constraint counts exactly, increments and
 results to the precision of the stopping rule; an iteration more or less at the noise floor is possible, not seen on these inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -282,3 +284,36 @@ def test_rendezvous_of_two_threads_on_one_current_frame(ctx):
         assert ctx.counter("rendezvous_pairs") - before == pairs and not bad
     finally:
         ctx.set_option("rendezvous", 1)
+
+
+def test_first_match_of_a_fresh_process_does_not_pay_the_wait_path_warm_up():
+    """DESIGN.md section 8, "a host-side effect that looks like an engine stall": in the first GPU process on a fresh box the first stream
+    wait of a batch has returned 14-24 ms after the device had finished.  dvo_hip_context_create now makes the runtime's wait path warm
+    (nine waits on trivial commands, the longest kept in the counter "warmup_wait_us"); a fresh process reports the counter and the wall
+    time of its very first match (code-object load included), and its second match is back at the latency of a warm process."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, time, json\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import dvo_slam_amd as d\n"
+        "from dvo_slam_amd import datagen\n"
+        "t0 = time.perf_counter(); ctx = d.Context(0); t_ctx = time.perf_counter() - t0\n"
+        "pair = datagen.synth_pair(3, 640, 480)\n"
+        "cam = d.RgbdCameraPyramid(640, 480, pair['K'], ctx); cam.build(4)\n"
+        "ref, cur = cam.create_raw(pair['grey_ref'], pair['depth_ref']), cam.create_raw(pair['grey_cur'], pair['depth_cur'])\n"
+        "trk = d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0), ctx)\n"
+        "ms = []\n"
+        "for k in range(6):\n"
+        "    r = d.Result(); t1 = time.perf_counter(); trk.match(ref, cur, r, with_stats=False); ms.append((time.perf_counter() - t1) * 1e3)\n"
+        "print(json.dumps(dict(warmup_wait_us=ctx.counter('warmup_wait_us'), create_ms=t_ctx * 1e3, match_ms=ms)))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    print("fresh process: context created in %.1f ms (longest warm-up wait %d us); matches %s ms" % (rec["create_ms"], rec["warmup_wait_us"], ["%.2f" % m for m in rec["match_ms"]]))
+    assert rec["warmup_wait_us"] >= 0
+    assert min(rec["match_ms"][1:]) < 1.0                      # a warm single-pair match is 0.35-0.5 ms
+    assert max(rec["match_ms"][1:]) < 10.0                     # ... and none of the later ones meets a 14-24 ms wait
