@@ -108,10 +108,12 @@ def main():
     ap.add_argument("--build-workgroups", type=int, default=-1, help="cap on the workgroups of a background build kernel (library option build_workgroups; -1 = bench default)")
     ap.add_argument("--no-overlap", action="store_true", help="build each batch right before its match on one frame set (no build/match overlap)")
     ap.add_argument("--no-from-host", action="store_true", help="skip the PCIe-inclusive leg (raw planes handed over in pinned host memory)")
+    ap.add_argument("--no-ref-compat", action="store_true", help="skip the leg that repeats the timed loop with option ref_compat on")
     ap.add_argument("--no-scaling-model", action="store_true", help="skip the one-GPU step times at pairs/2, pairs/4, pairs/8 per step")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--resident-group", type=int, default=0, help="workgroups per pair in the resident match kernel (0 = as many as fit); "
                     "with --rows-per-wave: records that do not depend on the batch size")
+    ap.add_argument("--resident-rows", type=int, default=0, help="library option resident_rows (0 = default 24)")
     ap.add_argument("--iters-per-sync", type=int, default=0)
     ap.add_argument("--resident", type=int, default=-1, help="library option resident (-1 default policy, 0 launch path only, 1 every level resident)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU dry runs)")
@@ -178,6 +180,8 @@ def main():
         ctx.set_option("resident_group", args.resident_group)
     if args.resident != -1:
         ctx.set_option("resident", args.resident)
+    if args.resident_rows:
+        ctx.set_option("resident_rows", args.resident_rows)
     if args.iters_per_sync:
         ctx.set_option("iters_per_sync", args.iters_per_sync)
     if not args.no_overlap:
@@ -342,6 +346,11 @@ def main():
     ctx.set_option("resident", 0)
     latency["pairs_1_launch_path"] = median_ms(lambda: tracker.match(refs[0], curs[0], one, with_stats=False))
     ctx.set_option("resident", -1)
+    # ... and in the reference-compatible mode (option ref_compat), which the resident kernel carries since round 4
+    ctx.set_option("ref_compat", 1)
+    latency["ref_compat_pairs_1"] = median_ms(lambda: tracker.match(refs[0], curs[0], one, with_stats=False))
+    latency["ref_compat_front_end_config_pairs_2"] = median_ms(lambda: front_end.match_batch_arrays(refs[:2], curs[:2], T_init=guess))
+    ctx.set_option("ref_compat", 0)
 
     # What the one-GPU measurements predict for N GPUs (strong scaling of the fixed 1024-pair total: every rank gets pairs / N): the
     # same streaming loop timed on the first pairs / N pairs of this rank.  The driver measures the real curve; this is the prediction
@@ -378,7 +387,7 @@ def main():
     # The reference-compatible mode (option "ref_compat": projection and weights multiply with the host CPU's _mm_rcp_ps like the reference's
     # SSE path) on the same streaming loop: every level on the launch path, a table lookup per pixel
     ref_compat = None
-    if world == 1:
+    if world == 1 and not args.no_ref_compat:
         ctx.set_option("ref_compat", 1)
         pipe.step(now=None, nxt=counter[0] % n_sets)
         for j in range(2):

@@ -148,6 +148,9 @@ extern "C" int dvo_hip_debug_resident_clocks(unsigned long long* out32, int rese
 #define CLK(i) ((void)0)
 #endif
 
+// COMPAT: the reference's x * rcp(z) in projection and weights with the host CPU's reciprocal table (option "ref_compat",
+// LevelGeom::rcp_table) -- the arithmetic of the launch path's sweeps in that mode
+template <bool COMPAT>
 __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const ResidentArgs a) {
   extern __shared__ __attribute__((aligned(16))) float slab_mem[];          // one slab of kSlabFloats per SWEEPING wavefront
   __shared__ PairState st, st_before[2];                                    // st_before[p & 1]: the state pass p's loop body started from
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
           int row, col;
           locate(in_image ? idx : 0, row, col);
           const float tx_p = g.tx[col], ty_p = g.ty[row];
-          const PixelProj p = pixel_project_flat(g, KT, in_image ? ref.x : nanv, tx_p, ty_p);
+          const PixelProj p = pixel_project_flat<COMPAT>(g, KT, in_image ? ref.x : nanv, tx_p, ty_p);
           PixelTaps t;
           if (p.ok) taps.fetch(p.base, t);
           PixelTerms o;
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(kResidentBlock) void k_match_resident(const Residen
             ++held;
           }
           if (valid) {
-            const float sw = first ? 1.0f : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);   // previous pass' precision (Q11)
+            const float sw = first ? 1.0f : COMPAT ? tdist_weight_sqrt_compat(g.rcp_table, g.rcp_shift, o.r0, o.r1, st.P_prev)
+                                                   : tdist_weight_sqrt_fast(o.r0, o.r1, P00, P2x, P11);   // previous pass' precision (Q11)
             float J0[6], J1[6];
             jacobian_rows_fast(o, sw, tx_p, ty_p, fmaf(tx_p, tx_p, 1.0f), fmaf(ty_p, ty_p, 1.0f), J0, J1);
             wr[0] = f32x4{J0[0], J0[1], J0[2], J0[3]};
@@ -620,17 +624,21 @@ hipError_t launch_match_resident(hipStream_t s, const ResidentArgs& args, bool c
   hipError_t e = hipGetDevice(&device);
   if (e != hipSuccess) return e;
   if (device >= 64 || !configured[device]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resident), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resident<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resident<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
     if (device < 64) configured[device] = true;
   }
+  const bool compat = args.geom[args.first_level].rcp_table != nullptr;   // (option "ref_compat": every level's geometry carries the table)
   const dim3 grid(args.n_pairs * args.group), block(kResidentBlock);
   if (args.group > 1 && cooperative) {
     ResidentArgs copy = args;
     void* params[] = {&copy};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_match_resident), grid, block, params, unsigned(lds), s);
+    return hipLaunchCooperativeKernel(compat ? reinterpret_cast<const void*>(k_match_resident<true>) : reinterpret_cast<const void*>(k_match_resident<false>),
+                                      grid, block, params, unsigned(lds), s);
   }
-  k_match_resident<<<grid, block, lds, s>>>(args);
+  if (compat) k_match_resident<true><<<grid, block, lds, s>>>(args);
+  else k_match_resident<false><<<grid, block, lds, s>>>(args);
   return hipGetLastError();
 }
 

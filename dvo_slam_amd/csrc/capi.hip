@@ -1094,7 +1094,7 @@ constexpr size_t kResidentDirectStatsBytes = size_t(64) << 20;
 
 ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const BatchPlan& bp) {
   ResidentPlan rp;
-  if (ctx->opt_resident == 0 || ctx->opt_ref_compat || ctx->opt_deterministic) return rp;   // (the resident kernel does not carry the reference-compatible arithmetic)
+  if (ctx->opt_resident == 0 || ctx->opt_deterministic) return rp;   // (deterministic: one path whatever the batch size, and that is the launch path)
   const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
   // more pairs than compute units: the workgroups would run in shifts, and the launch path, which gives every phase the whole chip,
   // is as fast (measured: 256 pairs -3 %, 512 pairs +1.6 % against it).  (Not with a pinned group size: the caller asks for

@@ -230,8 +230,8 @@ DVO_HD void jacobian_rows(const PixelTerms& t, float* J0, float* J1) { jacobian_
 // two forms against each other.  (Measured and dropped: fused multiply-adds throughout, u = qx * rcp(qz), the blend as four
 // shared tap weights -- 35 fewer vector instructions per pixel, not a microsecond faster in the sweep, which is not bound by
 // vector-ALU issue)
-// COMPAT: the reference's u = x * rcp(z) with the host CPU's reciprocal table (option "ref_compat"; the resident kernel does not
-// carry it: with the option on every level runs on the launch path)
+// COMPAT: the reference's u = x * rcp(z) with the host CPU's reciprocal table (option "ref_compat"; launch path and, since round 4,
+// the resident kernel)
 template <bool COMPAT = false>
 DVO_HD PixelProj pixel_project_flat(const LevelGeom& g, const float* KT, float Z, float tx, float ty) {
 #pragma clang fp contract(off)

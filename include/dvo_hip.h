@@ -273,7 +273,7 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * "ref_compat" (1: the projection and the t-distribution weights multiply with the HOST CPU's approximate reciprocal _mm_rcp_ps, like
  * the reference's SSE path does (dvo_core/src/dense_tracking_impl.cpp:192, :700), instead of dividing exactly -- the one quirk of the
  * reference that separates its trajectories from the exact arithmetic's; the instruction is dumped into a table
- * when the option is first switched on; every level then runs on the launch path; also switched on by the environment variable
+ * when the option is first switched on; the latency path (option "resident") carries the same arithmetic; also switched on by the environment variable
  * DVO_HIP_REF_COMPAT=1 when a context is created; default 0),
  * "resident" (-1 default: small batches and coarse levels run in ONE launch per match, each pair owned by a group of resident
  * workgroups -- the latency path; 0: one to three launches per Gauss-Newton step always; 1: every level

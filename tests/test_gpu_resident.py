@@ -93,6 +93,53 @@ def test_resident_match_equals_launch_path_and_oracle(ctx, seed, w, h, first, la
     assert cm.twist_matrix_error(res.Transformation, o["T"]) < (2e-5 if precision > 1e-6 else 1e-6)
 
 
+@pytest.mark.parametrize("seed,w,h,first,last,mu,init,precision", [
+    (1234, 640, 480, 3, 0, 0.0, False, 5e-7),     # BASELINE config 2
+    (5, 640, 480, 3, 1, 0.05, True, 1e-4),        # the front end's configuration (benchmark.yaml)
+])
+@pytest.mark.parametrize("group", [0, 1, 4])
+def test_reference_compatible_arithmetic_on_the_resident_kernel(seed, w, h, first, last, mu, init, precision, group):
+    """Option ref_compat (projection and weights multiply with the host CPU's _mm_rcp_ps, like the reference's SSE path) on the latency
+    path: since round 4 the resident kernel carries that arithmetic too (rounds 2-3 sent every ref_compat match to the launch path), so
+    the reference's front-end pattern -- one or two pairs per frame (dvo_slam/src/local_tracker.cpp:157-216) -- has a
+    reference-compatible one-launch match.  Against the launch path in the same mode: the same passes, the same constraint counts on
+    a level's first pass, results to the precision of the stopping rule; against the reference's own match(): the distance of the
+    launch path's ref_compat results (a fraction of the default mode's, tests/test_gpu_replay.py)."""
+    ctx = d.Context(0)
+    ctx.set_option("ref_compat", 1)
+    ctx.set_option("variant", 6)                   # (the f32 Gram on the launch path, like the resident kernel's: see the fixture above)
+    pair = cm.synth(seed, w, h)
+    gref, gcur = gpu_pyramids(ctx, pair, first + 1)
+    cfg = d.Config(FirstLevel=first, LastLevel=last, Mu=mu, UseInitialEstimate=init, Precision=precision, MaxIterationsPerLevel=50 if init else 100)
+    T0 = po.se3_exp(0.5 * pair["xi_true"]) if init else None
+    ctx.set_option("resident", 0)
+    base = stats_of(ctx, cfg, [gref], [gcur], T0)[0]
+    before = ctx.counter("resident_launches")
+    ctx.set_option("resident", 1)
+    ctx.set_option("resident_group", group)
+    res = stats_of(ctx, cfg, [gref], [gcur], T0)[0]
+    assert ctx.counter("resident_launches") == before + 1 and ctx.counter("resident_timeouts") == 0
+    shape = lambda r: [(L.Id, len(L.Iterations)) for L in r.Statistics.Levels]
+    assert shape(res) == shape(base), (shape(res), shape(base))
+    for La, Lb in zip(res.Statistics.Levels, base.Statistics.Levels):
+        if La.Id == first:
+            assert La.Iterations[0].ValidConstraints == Lb.Iterations[0].ValidConstraints   # same estimate, same arithmetic: exact
+    dT = cm.twist_matrix_error(res.Transformation, base.Transformation)
+    oref, ocur = cm.oracle_pyramids(pair, first + 1)
+    r = po.match(oref, ocur, cm.oracle_config_from(cfg, po.REF_SSE), T0)            # = the reference's own match(), bit for bit
+    d_ref, d_ref_base = cm.twist_matrix_error(res.Transformation, r["T"]), cm.twist_matrix_error(base.Transformation, r["T"])
+    ctx.set_option("ref_compat", 0)
+    ctx.set_option("resident", 0)
+    exact = stats_of(ctx, cfg, [gref], [gcur], T0)[0]
+    d_exact = cm.twist_matrix_error(exact.Transformation, r["T"])
+    print("group %d: resident vs launch path (both ref_compat) %.1e; to the reference's match(): resident %.1e, launch path %.1e, exact arithmetic %.1e"
+          % (group, dT, d_ref, d_ref_base, d_exact))
+    assert dT < 2e-6
+    assert d_ref < d_ref_base + 2e-6
+    if precision < 1e-6:
+        assert d_ref < 0.5 * d_exact + 1e-6       # (at Precision 1e-4 two runs of any two arithmetics stop up to 1e-4 apart)
+
+
 def test_default_policy_uses_the_resident_kernel_for_small_batches_only(ctx):
     b = datagen.synth_batch(3, 40, 320, 240)
     cam = d.RgbdCameraPyramid(320, 240, b["K"], ctx)
