@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--resident-group", type=int, default=0, help="workgroups per pair in the resident match kernel (0 = as many as fit); "
                     "with --rows-per-wave: records that do not depend on the batch size")
+    ap.add_argument("--option", action="append", default=[], help="library option key=value (dvo_hip_set_option), for experiments")
     ap.add_argument("--resident-rows", type=int, default=0, help="library option resident_rows (0 = default 24)")
     ap.add_argument("--iters-per-sync", type=int, default=0)
     ap.add_argument("--resident", type=int, default=-1, help="library option resident (-1 default policy, 0 launch path only, 1 every level resident)")
@@ -182,6 +183,9 @@ def main():
         ctx.set_option("resident", args.resident)
     if args.resident_rows:
         ctx.set_option("resident_rows", args.resident_rows)
+    for kv in args.option:
+        key, _, value = kv.partition("=")
+        ctx.set_option(key, int(value))
     if args.iters_per_sync:
         ctx.set_option("iters_per_sync", args.iters_per_sync)
     if not args.no_overlap:
