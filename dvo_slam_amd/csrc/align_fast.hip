@@ -223,12 +223,10 @@ __device__ __forceinline__ void fast_fetch_cells(const LevelGeom& g, const float
 //   STORE 2 (variant 8, default): high parts and low parts take turns in the slab.  All 64 pixels' high blocks (32 B each: 2 KB) are
 //     stored by their own lanes, read back transposed and KEPT as matrix operands (8 registers) for H H^T; then the low blocks
 //     overwrite them and are read back for H L^T.  4 stores, 8 transposing reads, 4 matrix instructions per row, no cross-lane moves.
-//     Layout: pixel p at 32 p + 16 (p >> 3) bytes -- 32-byte rows, 16 bytes of padding behind every eighth (conflict-free stores: the
-//     first halves of a 16-lane group cover banks 8 l .. 8 l + 3 and, for the second eight lanes, 8 (l - 8) + 4 .. + 7); the four lanes
-//     that fetch a pixel for the transposing read must address consecutive bytes (the hardware fetches a pixel's 32 bytes as one
-//     access: a layout that exchanged the halves of some rows read garbage); lane group g of a matrix operand takes pixels 4 g .. 4 g + 3
-//     and 16 + 4 g .. 19 + 4 g of its 32 (eight consecutive rows per 32-lane pass: conflict-free reads).  Which pixel is which k index
-//     does not matter to a sum over k as long as both operands agree.
+//     Layout: pixel p at 32 p bytes, nothing else; lane group g of a matrix operand takes pixels 4 g .. 4 g + 3 and 16 + 4 g .. 19 + 4 g of
+//     its 32 (a transposing read covers 16 consecutive rows = 512 contiguous bytes).  Which pixel is which k index does not matter to a
+//     sum over k as long as both operands agree.  (Measured, scripts/lds_conflicts.sh + scripts/ab_sweep.py: 16 bytes of padding behind
+//     every eighth row, or the halves of every other 16 rows exchanged, give the same conflict count and the same time +-1 %.)
 //   STORE 1 (variant 9): high and low blocks side by side (80-byte rows, gram_f16.h), 32 pixels at a time; v_permlane32_swap_b32 moves
 //     half of every row to the idle half of the wavefront -- 8 swaps per row at 8.3 issue cycles each (scripts/ubench/issue_rate.hip).
 template <int STORE>
@@ -241,13 +239,13 @@ __device__ __forceinline__ void fast_gram_row(float* my, int lane, const float (
   asm volatile("" : "=v"(pad));                           // (defined by nothing: no instruction, any register)
   if constexpr (STORE == 2) {
     char* base = reinterpret_cast<char*>(my);
-    LdsQuadPtr w0 = (LdsQuadPtr)(base + lane * 32 + (lane >> 3) * 16);   // the lane's pixel: two 16-byte halves
     const int i = lane & 15, gq = lane >> 4;
     typedef __attribute__((address_space(3))) fp16x4* LdsTrPtr;
-    char* rd = base + gq * 128 + (gq >> 1) * 16 + (i >> 2) * 32 + (i & 3) * 8;
+    LdsQuadPtr w0 = (LdsQuadPtr)(base + lane * 32);       // the lane's pixel: two 16-byte halves
+    char* rd = base + gq * 128 + (i >> 2) * 32 + (i & 3) * 8;
     auto operand = [&](int block) {                       // pixels 32 block .. 32 block + 31 (k index) x 16 components
-      const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LdsTrPtr)(rd + block * 1088));
-      const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LdsTrPtr)(rd + block * 1088 + 544));
+      const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LdsTrPtr)(rd + block * 1024));
+      const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LdsTrPtr)(rd + block * 1024 + 512));
       return f16x8{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
     };
     w0[0] = u32x4{hh[0], hh[1], hh[2], hh[3]};

@@ -49,3 +49,5 @@ if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
     json.dump(rec, open('gpurun_out/pmc/pmc_finest_kernel.json', 'w'), indent=1)
     print(rec)
 PY
+# the raw per-dispatch CSVs are large (gpurun_out/ merges back at most 64 MiB): only the summaries stay
+find $R/gpurun_out/pmc* -name "*kernel_trace.csv" -delete 2>/dev/null; find $R/gpurun_out/pmc* -name "*agent_info.csv" -delete 2>/dev/null

@@ -31,3 +31,5 @@ for f in sorted(glob.glob(O + '/*/*counter_collection.csv')):
                 print("%-4s %-40s %-34s per-dispatch %.5g  (n=%d of %d)" % (f.split('/')[-2], k[9:49], c, sum(big) / len(big), len(big), len(v)))
 PY
 cat $O/summary.txt
+# the raw per-dispatch CSVs are large (gpurun_out/ merges back at most 64 MiB): only the summaries stay
+find $R/gpurun_out/pmc* -name "*kernel_trace.csv" -delete 2>/dev/null; find $R/gpurun_out/pmc* -name "*agent_info.csv" -delete 2>/dev/null
