@@ -159,7 +159,7 @@ void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool 
     return;
   }
   if (variant >= 5) {
-    launch_residual_reduce_mfma(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, variant >= 7, f16_range_flag);
+    launch_residual_reduce_mfma(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, variant >= 8 ? 2 : variant >= 7 ? 1 : 0, f16_range_flag);
     return;
   }
   switch (rows_per_wave) {

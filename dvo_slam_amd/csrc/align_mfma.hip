@@ -32,12 +32,18 @@ struct RefRow {
 
 // LINEAR: the level is walked as one row of w*h pixels in 64-pixel segments (LevelGeom::linear) -- same per-pixel arithmetic,
 // the pixel coordinates come from a division instead of the tile position.
-// F16: the Gram accumulation on the f16 matrix pipe (gram_f16.h, schedule variant 7) instead of the f32 matrix instruction.
+// MODE 0: f32 Gram (the f32 matrix instruction); 1: the Gram accumulation on the f16 matrix pipe (gram_f16.h, schedule variant 7); 2 (round 4:
+// what the default schedule, variant 8, runs on the levels the window sweep does not take): 1 with the CONTRACTED per-pixel arithmetic
+// of align_fast.hip -- projection as z (KT.col0 tx + KT.col1 ty + KT.col2) + KT.col3 in fused multiply-adds, u = qx rcp(qz), the
+// bounds test on the float's bits, the six channels blended in lerp form on packed f32 -- the same function, a few ulp of the tap
+// coordinate apart (tests/test_gpu_parity.py::test_contracted_gathering_sweep_against_the_exact_one).
 // FINEST: not used in the body -- it only gives the launches of pyramid level 0 a kernel name of their own in profiler traces.
-template <int RPW, bool FINEST, bool LINEAR, bool F16>
+template <int RPW, bool FINEST, bool LINEAR, int MODE>
 __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, int* __restrict__ f16_range_flag) {
+  constexpr bool F16 = MODE >= 1;
+  constexpr bool FAST = MODE == 2;
   // XCD-aware (pair, tile) -> workgroup mapping, see k_residual_reduce
   const int tiles = g.tiles_x * g.tiles_y;
   const int total = tiles * n_pairs;
@@ -179,12 +185,51 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
       ty_p = g.ty[min(v_r, g.h - 1)];
       cx = cx_u;
     }
-    const PixelProj p = g.rcp_table ? pixel_project_flat<true>(g, KT, in_image ? ref.x : nanv, tx_p, ty_p)      // (uniform; option "ref_compat")
-                                    : pixel_project_flat<false>(g, KT, in_image ? ref.x : nanv, tx_p, ty_p);
+    PixelProj p;
+    if constexpr (FAST) {
+      const float Z = in_image ? ref.x : nanv;
+      const float qx = fmaf(Z, fmaf(KT[1], ty_p, fmaf(KT[0], tx_p, KT[2])), KT[3]);
+      const float qy = fmaf(Z, fmaf(KT[5], ty_p, fmaf(KT[4], tx_p, KT[6])), KT[7]);
+      const float qz = fmaf(Z, fmaf(KT[9], ty_p, fmaf(KT[8], tx_p, KT[10])), KT[11]);
+      const float rq = __builtin_amdgcn_rcpf(qz);
+      const float u = qx * rq, v = qy * rq;
+      // 0 <= u <= w - 2 on the integer image of the float (negative numbers and NaNs compare above every non-negative bound; Q4, Q19)
+      p.ok = __builtin_bit_cast(unsigned, u) <= __builtin_bit_cast(unsigned, float(g.w - 2)) &&
+             __builtin_bit_cast(unsigned, v) <= __builtin_bit_cast(unsigned, float(g.h - 2));
+      p.Z = Z; p.X = tx_p * Z; p.Y = ty_p * Z; p.qz = qz;
+      p.a1 = __builtin_amdgcn_fractf(u); p.b1 = __builtin_amdgcn_fractf(v);
+      p.base = int(v) * g.w + int(u);                          // (meaningless unless ok)
+    } else {
+      p = g.rcp_table ? pixel_project_flat<true>(g, KT, in_image ? ref.x : nanv, tx_p, ty_p)      // (uniform; option "ref_compat")
+                      : pixel_project_flat<false>(g, KT, in_image ? ref.x : nanv, tx_p, ty_p);
+    }
     PixelTaps t;
     if (p.ok) taps.fetch(p.base, t);                          // lanes without a usable projection are masked out of `valid`
     PixelTerms o;
-    const bool valid = pixel_finish_flat(g, ref, p, t, o) && p.ok;
+    bool valid;
+    if constexpr (FAST) {
+      // the six channels {I, Z}, {Idx, Idy}, {Zdx, Zdy} as three register pairs through one lerp formula (packed f32)
+      const f32x2 a1 = {p.a1, p.a1}, b1 = {p.b1, p.b1};
+      auto blend = [&](f32x2 v00, f32x2 v10, f32x2 v01, f32x2 v11) {
+        const f32x2 top = __builtin_elementwise_fma(a1, v10 - v00, v00), bot = __builtin_elementwise_fma(a1, v11 - v01, v01);
+        return __builtin_elementwise_fma(b1, bot - top, top);
+      };
+      const f32x2 cIZ = blend(f32x2{t.A00.x, t.A00.y}, f32x2{t.A10.x, t.A10.y}, f32x2{t.A01.x, t.A01.y}, f32x2{t.A11.x, t.A11.y});
+      const f32x2 cIg = blend(f32x2{t.A00.z, t.A00.w}, f32x2{t.A10.z, t.A10.w}, f32x2{t.A01.z, t.A01.w}, f32x2{t.A11.z, t.A11.w});
+      const f32x2 cZg = blend(f32x2{t.B00.x, t.B00.y}, f32x2{t.B10.x, t.B10.y}, f32x2{t.B01.x, t.B01.y}, f32x2{t.B11.x, t.B11.y});
+      o.r0 = (cIZ.x - ref.y) * (1.0f / 255.0f);
+      o.r1 = cIZ.y - p.qz;
+      const float dz = p.Z - 0.4f;
+      o.gix = g.wi_x * (cIg.x + ref.z);
+      o.giy = g.wi_y * (cIg.y + ref.w);
+      o.gzx = g.fx * cZg.x;
+      o.gzy = g.fy * cZg.y;
+      o.X = p.X; o.Y = p.Y; o.Z = p.Z;
+      // Q9: a hole under any tap makes cZ (hence r1), cZx or cZy not-a-number; Q5: the occlusion threshold -20 (0.0012 + 0.0019 (z - 0.4)^2)
+      valid = p.ok && o.r1 > fmaf(dz * -0.038f, dz, -0.024f) && !__builtin_isunordered(cZg.x, cZg.y);
+    } else {
+      valid = pixel_finish_flat(g, ref, p, t, o) && p.ok;
+    }
     n_valid += __popcll(__ballot(valid));                     // exact count on the scalar unit
     if (in_image) scratch[pix_base + pix] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);   // one full-width store
     if constexpr (F16) {
@@ -266,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   }
 }
 
-template <int RPW, bool F16>
+template <int RPW, int F16>
 static void launch_m(hipStream_t s, bool finest, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                      float* partials, float2* scratch, int* f16_range_flag) {
   const int total = g.tiles_x * g.tiles_y * n_pairs;
@@ -281,7 +326,7 @@ static void launch_m(hipStream_t s, bool finest, const LevelGeom& g, const PairP
   }
 }
 
-template <bool F16>
+template <int F16>
 static void launch_rpw(hipStream_t s, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs, const PairState* states,
                        int n_pairs, float* partials, float2* scratch, int* f16_range_flag) {
   switch (rows_per_wave) {
@@ -294,9 +339,11 @@ static void launch_rpw(hipStream_t s, int rows_per_wave, bool finest, const Leve
 }
 
 void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
-                                 const PairState* states, int n_pairs, float* partials, float2* scratch, bool f16, int* f16_range_flag) {
-  if (f16) launch_rpw<true>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, f16_range_flag);
-  else launch_rpw<false>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, nullptr);
+                                 const PairState* states, int n_pairs, float* partials, float2* scratch, int mode, int* f16_range_flag) {
+  if (mode == 2 && g.rcp_table) mode = 1;                       // (option "ref_compat": the exact arithmetic with the table's reciprocal)
+  if (mode == 2) launch_rpw<2>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, f16_range_flag);
+  else if (mode == 1) launch_rpw<1>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, f16_range_flag);
+  else launch_rpw<0>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, nullptr);
 }
 
 }  // namespace dvo_hip

@@ -43,9 +43,10 @@ void launch_unpack_plane(hipStream_t s, const float4* A, const float2* B, int n,
 void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
                             const PairState* states, int n_pairs, float* partials, float2* scratch, unsigned long long* window_fallbacks = nullptr,
                             int* f16_range_flag = nullptr);
-// f16: Gram accumulation on the f16 matrix pipe (gram_f16.h; variant 7) instead of the f32 matrix instruction
+// mode 0: f32 Gram (the f32 matrix instruction); 1: Gram accumulation on the f16 matrix pipe (gram_f16.h; variant 7); 2: 1 with the contracted
+// per-pixel arithmetic of align_fast.hip (variants 8 / 9 on the levels the window sweep does not take)
 void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
-                                 const PairState* states, int n_pairs, float* partials, float2* scratch, bool f16 = false,
+                                 const PairState* states, int n_pairs, float* partials, float2* scratch, int mode = 0,
                                  int* f16_range_flag = nullptr);
 // align_window.hip: variants 6 (f32 Gram) and 7 (f16 hi/lo Gram) -- the current frame's {I, Z} window staged in LDS; tiled levels whose
 // width is a multiple of 64 only (window_sweep_supports), tile height 16 (rows_per_wave 4).  fallback_count (may be null): lanes
