@@ -295,7 +295,7 @@ def main():
     achieved = algo_bytes / (k_ms[0] * 1e-3) / 1e9
     traffic = _pmc_traffic(B)
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                    traffic=traffic, kernel="dvo_hip::k_sweep_fast<true> (pyramid level 0, %d pairs per launch; 64 x 16 tiles, the current "
+                    traffic=traffic, kernel="dvo_hip::k_sweep_fast<2, false> (pyramid level 0, %d pairs per launch; 64 x 16 tiles, the current "
                                             "frame's {I, Z} window staged in LDS, contracted f32 pixel arithmetic, Gram accumulation on the f16 "
                                             "matrix pipe from exact hi + lo operand pairs)" % B,
                     kernel_ms=round(k_ms[0], 4), kernel_ms_is="mean of %d back-to-back launches (HIP events on the context stream)" % ROOFLINE_REPS,

@@ -421,7 +421,7 @@ __device__ __forceinline__ void fast_count_fallbacks(unsigned long long* __restr
 // ===================================================================================================================================
 // variants 8 / 9: every pixel of the tile, one wavefront row = one image row of 64 pixels
 // ===================================================================================================================================
-template <int STORE>
+template <int STORE, bool PARTIAL>
 __global__ __launch_bounds__(256, 5) void k_sweep_fast(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count, int* __restrict__ f16_range_flag) {
@@ -444,7 +444,12 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
   const __amdgpu_buffer_rsrc_t resid_none = __builtin_amdgcn_make_buffer_rsrc(scratch, 0, 0, 0x00020000);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned gram_entries = kGramEntryTable.e[min(int(threadIdx.x), kNumAcc - 1)];
-  const int u_r = tile_x * kTileW + lane;
+  // A level whose width is no multiple of 64 (160 x 120): the last tile column hangs over the right edge.  Its lanes beyond the image
+  // read the last column again (the clamp the horizontal gradient wants there anyway), never count as projected (col_mask) and store
+  // their residual past the end of the buffer resource, where stores are dropped.
+  // (PARTIAL: an instantiation of its own -- widths that are multiples of 64 run the kernel without these three operations)
+  const int u_r = PARTIAL ? min(tile_x * kTileW + lane, g.w - 1) : tile_x * kTileW + lane;
+  const unsigned long long col_mask = PARTIAL ? __builtin_amdgcn_ballot_w64(tile_x * kTileW + lane < g.w) : ~0ull;
   const int row_bytes = g.w * 8;
   const float tx_u = g.tx[u_r];
   const float cx_u = fmaf(tx_u, tx_u, 1.0f);
@@ -455,6 +460,7 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
   __shared__ int counts[4];
   float* my = slab[wave];
   const int off_px = u_r * 8;
+  const int off_store = !PARTIAL || tile_x * kTileW + lane < g.w ? off_px : plane_bytes;
   const int off_edge = (lane == 0 ? max(u_r - 1, 0) : lane == 63 ? min(u_r + 1, g.w - 1) : u_r) * 8 + 4;
 
   const int row0 = tile_y * kFastTileRows + wave;
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
       // 0 <= u <= w - 2 on the integer image of the float: negative numbers and NaNs (sign or exponent bits) compare above every
       // non-negative bound (Q4; a hole's NaN depth fails here, Q19).  -0.0f fails too -- one float out of 2^32.
       const unsigned long long ok_mask = v_r < g.h ? __builtin_amdgcn_ballot_w64(__builtin_bit_cast(unsigned, u) <= w2_bits) &
-                                                         __builtin_amdgcn_ballot_w64(__builtin_bit_cast(unsigned, v) <= h2_bits) : 0ull;
+                                                         __builtin_amdgcn_ballot_w64(__builtin_bit_cast(unsigned, v) <= h2_bits) & col_mask : 0ull;
       const bool ok = __builtin_amdgcn_inverse_ballot_w64(ok_mask);
       const int u0 = int(u), v0 = int(v);                      // (u, v >= 0 where it matters: truncation is the floor)
       rs[k].z = z;
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
     const int v_r = row0 + k * 4;
     f32x2 P[4][4];
     fast_fetch_cells<CHECKED>(g, st.KT, curC, win, wnd, neg_base, rs[k], __builtin_amdgcn_inverse_ballot_w64(ok_row[k]), tx_u, ty_rows[k], P, n_fallback);
-    fast_row_tail<STORE>(g, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_px, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
+    fast_row_tail<STORE>(g, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_store, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
   };
   if (wnd.all_in) {                                            // (uniform)
 #pragma unroll
@@ -555,15 +561,20 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
   if (fallback_count && !wnd.all_in) fast_count_fallbacks(fallback_count, n_fallback, lane);
 }
 
-bool fast_sweep_supports(const LevelGeom& g) { return !g.linear && g.w % kTileW == 0 && g.w >= kFastCols && g.w < 32768 && g.h < 32768 && !g.rcp_table; }
+bool fast_sweep_takes_width(int w) { return w >= kFastCols && w % 2 == 0; }
+
+bool fast_sweep_supports(const LevelGeom& g) { return !g.linear && fast_sweep_takes_width(g.w) && g.w < 32768 && g.h < 32768 && !g.rcp_table; }
 
 void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                        float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag) {
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(256);
-  if (variant == 8) k_sweep_fast<2><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
-  else k_sweep_fast<1><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+  const bool partial = g.w % kTileW != 0;
+  if (variant == 8 && !partial) k_sweep_fast<2, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+  else if (variant == 8) k_sweep_fast<2, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+  else if (!partial) k_sweep_fast<1, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+  else k_sweep_fast<1, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
 }
 
 }  // namespace dvo_hip

@@ -491,10 +491,17 @@ void level_tiles(int w, int h, int rows_per_wave, bool linear, int* tiles_x, int
   }
 }
 
-bool level_is_linear(const dvo_hip_context* ctx, int w) { return ctx->opt_variant >= 5 && w % kTileW != 0; }
+// the contracted window sweep (align_fast.hip, variants 8 / 9) also takes widths that are no multiple of its 64 columns (160 x 120)
+bool level_uses_fast_window(const dvo_hip_context* ctx, int w, int h) {
+  return ctx->opt_variant >= 8 && !ctx->opt_ref_compat && fast_sweep_takes_width(w) && w < 32768 && h < 32768;
+}
 
-// the sweep that stages the current frame's window in LDS (align_window.hip, variants 6 / 7) handles this level; its tile is 64 x 16
-bool level_uses_window(const dvo_hip_context* ctx, int w, int h) { return ctx->opt_variant >= 6 && w % kTileW == 0 && w < 32768 && h < 32768; }
+bool level_is_linear(const dvo_hip_context* ctx, int w) { return ctx->opt_variant >= 5 && w % kTileW != 0 && !level_uses_fast_window(ctx, w, 4); }
+
+// the sweep that stages the current frame's window in LDS (align_window.hip, variants 6 / 7; align_fast.hip) handles this level; its tile is 64 x 16
+bool level_uses_window(const dvo_hip_context* ctx, int w, int h) {
+  return (ctx->opt_variant >= 6 && w % kTileW == 0 && w < 32768 && h < 32768) || level_uses_fast_window(ctx, w, h);
+}
 
 LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int rows_per_wave) {
   LevelGeom g;
@@ -532,6 +539,9 @@ int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int le
   return 1;
 }
 
+// (whatever the schedule variant of the moment: a frame outlives option changes)
+static bool width_may_use_window(int w) { return w % kTileW == 0 || fast_sweep_takes_width(w); }
+
 // device layout of a frame: [raw staging][per level: I Z A B R][sel counts]
 int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, dvo_hip_frame** out, size_t* raw_off) {
   if (!ctx) return DVO_HIP_ERR_INVALID;
@@ -550,7 +560,7 @@ int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels
   for (int l = 0; l < levels; ++l) {
     const size_t n = size_t(cam->w[l]) * cam->h[l];
     // (C = {I, Z} of a current frame, the plane the window sweep stages in LDS: levels that sweep can handle)
-    const size_t sz[6] = {n * 4, n * 4, n * 16, n * 8, n * 8, cam->w[l] % kTileW == 0 ? n * 8 : 0};
+    const size_t sz[6] = {n * 4, n * 4, n * 16, n * 8, n * 8, width_may_use_window(cam->w[l]) ? n * 8 : 0};
     for (int k = 0; k < 6; ++k) {
       offs[l][k] = total;
       total += align_up(sz[k], 256);
@@ -582,7 +592,7 @@ int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels
     L.A = reinterpret_cast<float4*>(base + offs[l][2]);
     L.B = reinterpret_cast<float2*>(base + offs[l][3]);
     L.R = reinterpret_cast<float2*>(base + offs[l][4]);
-    L.C = cam->w[l] % kTileW == 0 ? reinterpret_cast<float2*>(base + offs[l][5]) : nullptr;
+    L.C = width_may_use_window(cam->w[l]) ? reinterpret_cast<float2*>(base + offs[l][5]) : nullptr;
   }
   f->sel_count = reinterpret_cast<int*>(base + cnt_off);
   *out = f;
@@ -1224,6 +1234,10 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   if (ctx->opt_variant >= 7 && (ctx->opt_deterministic || ctx->f32_gram_hold > 0)) {
     if (ctx->f32_gram_hold > 0) ctx->f32_gram_hold -= 1;
     ctx->opt_variant = 6;
+    // (the roles were ensured for the schedule the options name: the f32 one reads levels whose width is no multiple of 64 through
+    // the taps A + B where the contracted window sweep reads plane C)
+    const int rc_roles = ensure_batch_roles(ctx, n, refs, curs, cfg);
+    if (rc_roles != DVO_HIP_OK) return rc_roles;
   }
   BatchPlan bp;
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
@@ -1410,6 +1424,8 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     ctx->f32_gram_hold = kF32GramHoldBatches;
     for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, &tinit[size_t(i) * 16], 16 * sizeof(double));
     ctx->opt_variant = 6;                                      // (restored by variant_scope)
+    rc = ensure_batch_roles(ctx, n, refs, curs, cfg);          // (another sweep, maybe another flavour of the current planes)
+    if (rc != DVO_HIP_OK) return rc;
     return run_batch(ctx, n, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
   }
   bool truncated = false;

@@ -57,6 +57,7 @@ void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const Pair
                          float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag = nullptr);
 // align_fast.hip: variants 8 / 9 -- the window sweep with contracted per-pixel arithmetic (same function, rounding differences of a few
 // ulp against variants 6 / 7; window 84 x 28 cells at a pitch of 96; 8: high and low operand parts take turns in the slab, 9: side by side, moved with v_permlane32_swap).
+bool fast_sweep_takes_width(int w);   // (64-column tiles; a width that is no multiple of 64 leaves the last tile column partly empty)
 bool fast_sweep_supports(const LevelGeom& g);
 void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                        float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag = nullptr);

@@ -200,6 +200,44 @@ def test_contracted_sweep_against_the_exact_one(w, h, xi):
         assert np.abs(out[8][k]["A"] - out[9][k]["A"]).max() <= 1e-6 * np.abs(out[8][k]["A"]).max()
 
 
+@pytest.mark.parametrize("w,h,rpw,xi", [(160, 120, 2, [0.01, -0.008, 0.006, 0.012, -0.01, 0.008]), (80, 60, 2, [0.02, 0.01, -0.015, -0.02, 0.025, 0.03]),
+                                        (160, 120, 4, [0.05, -0.04, 0.03, 0.05, 0.04, -0.06]), (100, 76, 1, [0.01, 0.02, -0.01, -0.01, 0.02, 0.01]),
+                                        (40, 30, 2, [0.003, 0.001, -0.002, 0.004, 0.002, -0.003]), (200, 64, 16, [-0.05, 0.08, 0.02, 0.1, -0.1, 0.2])])
+def test_contracted_gathering_sweep_against_the_exact_one(w, h, rpw, xi):
+    """The levels the window sweep does not take (narrower than 84 pixels or not a multiple of 64 wide: levels 2 and 3 of a 640 x 480
+    pyramid) run the gathering sweep; under the default schedule with the contracted per-pixel arithmetic too (align_mfma.hip, MODE 2).
+    Same statement as test_contracted_sweep_against_the_exact_one, against the same anchor (variant 7: residuals the oracle's bit for
+    bit)."""
+    pair = cm.synth(37, w, h)
+    T34 = po.se3_exp(np.array(xi, np.float64))[:3]
+    out = {}
+    for v in (EXACT_VARIANT, 8):
+        ctx = d.Context(0)
+        ctx.set_option("variant", v)
+        ctx.set_option("rows_per_wave", rpw)
+        gref, gcur = gpu_pyramids(ctx, pair, 1)
+        trk = d.DenseTracker(d.Config(FirstLevel=0, LastLevel=0), ctx)
+        out[v] = [trk.level_iteration(gref, gcur, 0, T34, P_prev=[900.0, 3.0, 3.0, 400.0], first=f, want_residuals=True) for f in (True, False)]
+    for k in (0, 1):
+        a, b = out[EXACT_VARIANT][k], out[8][k]
+        ra, rb = a["residuals"].reshape(-1, 2), b["residuals"].reshape(-1, 2)
+        va, vb = ~np.isnan(ra[:, 0]), ~np.isnan(rb[:, 0])
+        flipped = int((va != vb).sum())
+        both = va & vb
+        d0 = float(np.abs(ra[both, 0] - rb[both, 0]).max())
+        d1 = float(np.abs(ra[both, 1] - rb[both, 1]).max())
+        print("%dx%d rows per wave %d first=%d: n %d vs %d, %d pixels flipped, max |dr_I| %.2e |dr_Z| %.2e, A rel %.1e, b rel %.1e"
+              % (w, h, rpw, 1 - k, a["n"], b["n"], flipped, d0, d1, np.abs(a["A"] - b["A"]).max() / np.abs(a["A"]).max(),
+                 np.abs(a["b"] - b["b"]).max() / np.abs(a["b"]).max()))
+        assert a["n_selected"] == b["n_selected"] and b["n"] == int(vb.sum()) and a["n"] > 0.2 * w * h
+        assert flipped <= max(1, int(1e-4 * a["n"]))
+        assert d0 <= 2e-5 and d1 <= 4e-6
+        if flipped == 0:
+            assert np.abs(a["A"] - b["A"]).max() <= 1e-5 * np.abs(a["A"]).max()
+            assert np.abs(a["b"] - b["b"]).max() <= 1e-5 * np.abs(a["b"]).max() + 1e-9 * np.abs(a["A"]).max()
+            assert abs(a["neg_ll"] - b["neg_ll"]) <= 2e-5 * abs(a["neg_ll"])
+
+
 def test_contracted_sweep_at_the_identity():
     """Identical frames, identity transform: every reference pixel projects EXACTLY onto a pixel centre of the current frame -- the
     discontinuity of floor().  Whichever side of it a rounding lands on, the blend is continuous (weight 0 or 1 on the same pixel),
@@ -252,12 +290,13 @@ def test_f16_gram_does_not_lengthen_the_levels():
     assert (its[8].max(0) <= its[5].max(0) + 3).all()
 
 
-def test_f16_gram_range_guard_repeats_with_the_f32_gram():
+@pytest.mark.parametrize("w,h", [(128, 96), (160, 120)])
+def test_f16_gram_range_guard_repeats_with_the_f32_gram(w, h):
     """The default schedule forms its Gram operands as f16 high + low parts: a Jacobian component beyond +-65504 (a depth step of
     ten metres one centimetre in front of the camera: fx * 5 m/px / 0.01 m) is not representable.  The sweep notices (the diagonal of
     H H^T reaches 65504^2), the batch runs again with the f32 Gram: same record as the f32 schedule, the counter shows the repeat.
-    An ordinary scene on the same context does not repeat."""
-    w, h = 128, 96
+    An ordinary scene on the same context does not repeat.  (160 x 120: the contracted window sweep takes the level, the f32 schedule
+    of the repeat is the gathering sweep -- another flavour of the current frame's planes, derived for the repeat.)"""
     pair = cm.synth(4, w, h)
     yy, xx = np.mgrid[0:h, 0:w]
     depth = np.where(((xx // 8) + (yy // 8)) % 2 == 0, 0.002, 10.0).astype(np.float32)
@@ -367,17 +406,27 @@ def test_golden_linearisation(gpu_ctx):
     pair = dict(grey_ref=g["grey_ref"], depth_ref=g["depth_ref"], grey_cur=g["grey_cur"], depth_cur=g["depth_cur"], K=g["K"])
     gref, gcur = gpu_pyramids(gpu_ctx, pair, 3)
     trk = d.DenseTracker(d.Config(FirstLevel=0, LastLevel=0), gpu_ctx)
-    a = trk.level_iteration(gref, gcur, 0, g["lin_T34"], first=True)
-    exp = g["lin_math_first"]
-    assert a["n"] == int(exp[0])
-    assert abs(a["neg_ll"] - exp[1]) <= 1e-6 * abs(exp[1])
-    assert np.allclose(a["P"].ravel(), exp[5:9], rtol=1e-5)
-    assert np.abs(a["A"].ravel() - exp[9:45]).max() <= 1e-5 * np.abs(exp[9:45]).max()
-    assert np.abs(a["b"] - exp[45:51]).max() <= 1e-5 * np.abs(exp[45:51]).max()
-    b = trk.level_iteration(gref, gcur, 0, g["lin_T34"], P_prev=exp[5:9], first=False)
-    exp2 = g["lin_math_weighted"]
-    assert b["n"] == int(exp2[0])
-    assert np.abs(b["A"].ravel() - exp2[9:45]).max() <= 1e-5 * np.abs(exp2[9:45]).max()
+    # the exact schedule, and the default one (contracted arithmetic: a 160-pixel level is the window sweep's since round 4, its last
+    # tile column half empty) at the log-likelihood tolerance test_contracted_sweep_against_the_exact_one states
+    try:
+        for variant, ll_tol in ((EXACT_VARIANT, 1e-6), (DEFAULT_VARIANT, 2e-5)):
+            gpu_ctx.set_option("variant", variant)
+            a = trk.level_iteration(gref, gcur, 0, g["lin_T34"], first=True)
+            exp = g["lin_math_first"]
+            assert a["n"] == int(exp[0])
+            assert abs(a["neg_ll"] - exp[1]) <= ll_tol * abs(exp[1])
+            if variant == EXACT_VARIANT:
+                assert np.allclose(a["P"].ravel(), exp[5:9], rtol=1e-5)
+            else:                                                        # (the small off-diagonal term is a difference of large ones)
+                assert np.abs(a["P"].ravel() - exp[5:9]).max() <= 1e-5 * np.abs(exp[5:9]).max()
+            assert np.abs(a["A"].ravel() - exp[9:45]).max() <= 1e-5 * np.abs(exp[9:45]).max()
+            assert np.abs(a["b"] - exp[45:51]).max() <= 1e-5 * np.abs(exp[45:51]).max()
+            b = trk.level_iteration(gref, gcur, 0, g["lin_T34"], P_prev=exp[5:9], first=False)
+            exp2 = g["lin_math_weighted"]
+            assert b["n"] == int(exp2[0])
+            assert np.abs(b["A"].ravel() - exp2[9:45]).max() <= 1e-5 * np.abs(exp2[9:45]).max()
+    finally:
+        gpu_ctx.set_option("variant", DEFAULT_VARIANT)
 
 
 def run_gpu_match(ctx, gref, gcur, cfg, T_init=None):
