@@ -125,4 +125,62 @@ __device__ __forceinline__ double loglik_partial(const float2* __restrict__ res,
   return log(prod) + double(exponent) * 0.6931471805599453094;
 }
 
+// The same sum over the PACKED residuals of a level (LevelGeom::compact): wavefront `wave_id` of `n_waves` takes the wavefront slots
+// wave_id, wave_id + n_waves, ... of the pair (4 per tile, kCompactWaveEntries entries each of which the first count_q are there);
+// SLOTS of them per round, two 16-B loads per lane and slot, the counts of the next round fetched while this one's pairs arrive.
+// rows: the pair's partial rows (the counts); res: the pair's residual buffer.
+template <int SLOTS>
+__device__ __forceinline__ double loglik_partial_compact(const float2* __restrict__ res, const float* __restrict__ rows, int n_slots, const float* P,
+                                                         int wave_id, int n_waves) {
+  typedef const __attribute__((address_space(1))) float* G1;
+  typedef float __attribute__((ext_vector_type(2))) f32x2;
+  // (a buffer resource: the loads of a lane beyond its slot's count go to an offset outside of it -- zeros, no memory access, no branch)
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(res), 0, n_slots * kCompactWaveEntries * 8, 0x00020000);
+  const G1 counts = (G1)rows;
+  const int lane = threadIdx.x & 63;
+  double prod = 1.0;
+  int exponent = 0;
+  auto count_of = [&](int slot) -> float {                     // (both counts of the slot's half tile; the caller picks)
+    const int sl = slot < n_slots ? slot : n_slots - 1;
+    return counts[size_t(sl >> 2) * kAccStride + kAccCounts + ((sl >> 1) & 1)];
+  };
+  float packed[SLOTS];
+#pragma unroll
+  for (int j = 0; j < SLOTS; ++j) packed[j] = count_of(wave_id + j * n_waves);
+  constexpr int kChunks = kCompactWaveEntries / 64;            // a slot in chunks of one entry per lane: only the chunks that hold any are touched
+  for (int s0 = wave_id; s0 < n_slots; s0 += SLOTS * n_waves) {
+    f32x2 rr[SLOTS][kChunks];
+    int cnt[SLOTS];
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+      const int slot = s0 + j * n_waves;
+      const int both = __builtin_amdgcn_readfirstlane(int(packed[j]));
+      cnt[j] = slot < n_slots ? ((slot & 1) ? both >> 9 : both & 511) : 0;
+#pragma unroll
+      for (int m = 0; m < kChunks; ++m) {
+        rr[j][m] = f32x2{0.0f, 0.0f};
+        if (cnt[j] > 64 * m) {                                 // (uniform)
+          const int i = lane + 64 * m;
+          rr[j][m] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, i < cnt[j] ? i * 8 : 0x7ffffff8, slot * (kCompactWaveEntries * 8), 0));
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) packed[j] = count_of(s0 + (SLOTS + j) * n_waves);
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+#pragma unroll
+      for (int m = 0; m < kChunks; ++m)
+        if (cnt[j] > 64 * m) {                                 // (uniform)
+          const double f = 1.0 + 0.2 * double(mahalanobis(rr[j][m].x, rr[j][m].y, P));
+          prod *= lane + 64 * m < cnt[j] ? f : 1.0;
+        }
+      int e;                                                   // four factors at most between renormalisations (loglik_partial: eight)
+      prod = frexp(prod, &e);
+      exponent += e;
+    }
+  }
+  return log(prod) + double(exponent) * 0.6931471805599453094;
+}
+
 }  // namespace dvo_hip

@@ -323,7 +323,8 @@ struct FastWeights {
 // Everything of a pixel row behind its twelve cells: blend, residual pair (stored for the log-likelihood pass: `resid` at vector offset
 // off_v + scalar offset off_s), validity, weight, Jacobian at the untransformed point, Gram accumulation.  tx, ty, cx = 1 + tx^2:
 // normalised coordinates of the lane's reference pixel.
-template <int STORE>
+// COMPACT (LevelGeom::compact): only a constraint's pair is stored, at the next free entry of the wavefront's slot (off_s: the slot).
+template <int STORE, bool COMPACT>
 __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const f32x2 (&P)[4][4], const FastRow& r, unsigned long long ok_mask, float tx, float ty,
                                               float cx, const FastWeights& wt, __amdgpu_buffer_rsrc_t resid, int off_v, int off_s, float* my, int lane,
                                               f32x4& acc0, f32x4& acc1, int& n_valid) {
@@ -346,11 +347,16 @@ __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const f32x2 (&
   // Q9: a hole in any of the twelve cells makes cZ (hence r1), cZx or cZy not-a-number; intensities are never holes
   const unsigned long long valid_mask = ok_mask & __builtin_amdgcn_ballot_w64(r1 > thr) & __builtin_amdgcn_ballot_w64(!__builtin_isunordered(cZx, cZy));
   const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_mask);
-  n_valid += __popcll(valid_mask);
-  {
+  if constexpr (COMPACT) {
+    // a constraint's place: the wavefront's constraints so far (scalar) + those in the lanes below; the others store past the resource
+    const int below = __builtin_amdgcn_mbcnt_hi(unsigned(valid_mask >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(valid_mask), 0));
+    const f32x2 rr2 = {r0, r1};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fast_u32v2, rr2), resid, valid ? below * 8 : 0x7ffffff8, off_s + n_valid * 8, 0);
+  } else {
     const f32x2 rr2 = {valid ? r0 : __builtin_nanf(""), r1};  // (the log-likelihood pass tests the first component)
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fast_u32v2, rr2), resid, off_v, off_s, 0);
   }
+  n_valid += __popcll(valid_mask);
   const float tq = fmaf(wt.P2x, r1, wt.P00 * r0);
   const float sw_any = wt.wc * fast_rsqrt(fmaf(tq, r0, fmaf(wt.P11 * r1, r1, wt.wk)));
   const float sw = valid ? sw_any : 0.0f;
@@ -406,6 +412,10 @@ __device__ __forceinline__ void fast_epilogue(float (*slab)[kSlabFloatsF16], con
       if (f16_range_flag && !(__builtin_fabsf(v) < __builtin_inff())) __hip_atomic_store(f16_range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     out_row[kk] = v;
+  } else if (kk < kNumAcc + 2) {
+    // the wavefronts' counts, two per spare float of the row: where their packed residual pairs end (LevelGeom::compact)
+    const int q = (kk - kNumAcc) * 2;
+    out_row[kAccCounts + (kk - kNumAcc)] = float(counts[q] + 512 * counts[q + 1]);
   }
 }
 
@@ -421,7 +431,7 @@ __device__ __forceinline__ void fast_count_fallbacks(unsigned long long* __restr
 // ===================================================================================================================================
 // variants 8 / 9: every pixel of the tile, one wavefront row = one image row of 64 pixels
 // ===================================================================================================================================
-template <int STORE, bool PARTIAL>
+template <int STORE, bool PARTIAL, bool COMPACT>
 __global__ __launch_bounds__(256, 5) void k_sweep_fast(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count, int* __restrict__ f16_range_flag) {
@@ -439,7 +449,8 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
   const int plane_bytes = g.w * g.h * 8;
   const __amdgpu_buffer_rsrc_t refR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.refR), 0, plane_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t curC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.curC), 0, plane_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t resid = __builtin_amdgcn_make_buffer_rsrc(scratch + size_t(pair) * size_t(g.w) * g.h, 0, plane_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t resid = COMPACT ? __builtin_amdgcn_make_buffer_rsrc(scratch + size_t(pair) * tiles * kCompactTileEntries, 0, tiles * kCompactTileEntries * 8, 0x00020000)
+                                               : __builtin_amdgcn_make_buffer_rsrc(scratch + size_t(pair) * size_t(g.w) * g.h, 0, plane_bytes, 0x00020000);
   // (rows below the image -- a level whose height is no multiple of 16 -- go to a resource of no bytes: no branch around the store)
   const __amdgpu_buffer_rsrc_t resid_none = __builtin_amdgcn_make_buffer_rsrc(scratch, 0, 0, 0x00020000);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -540,7 +551,10 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
     const int v_r = row0 + k * 4;
     f32x2 P[4][4];
     fast_fetch_cells<CHECKED>(g, st.KT, curC, win, wnd, neg_base, rs[k], __builtin_amdgcn_inverse_ballot_w64(ok_row[k]), tx_u, ty_rows[k], P, n_fallback);
-    fast_row_tail<STORE>(g, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_store, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
+    if constexpr (COMPACT)
+      fast_row_tail<STORE, true>(g, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, resid, 0, (tile * kCompactTileEntries + wave * kCompactWaveEntries) * 8, my, lane, acc0, acc1, n_valid);
+    else
+      fast_row_tail<STORE, false>(g, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_store, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
   };
   if (wnd.all_in) {                                            // (uniform)
 #pragma unroll
@@ -570,11 +584,22 @@ void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const Pai
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(256);
-  const bool partial = g.w % kTileW != 0;
-  if (variant == 8 && !partial) k_sweep_fast<2, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
-  else if (variant == 8) k_sweep_fast<2, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
-  else if (!partial) k_sweep_fast<1, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
-  else k_sweep_fast<1, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+  const bool partial = g.w % kTileW != 0, compact = g.compact != 0;
+  auto go = [&](auto store_tag, auto partial_tag, auto compact_tag) {
+    k_sweep_fast<decltype(store_tag)::value, decltype(partial_tag)::value, decltype(compact_tag)::value>
+        <<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+  };
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using T = std::true_type;
+  using F = std::false_type;
+  if (variant == 8) {
+    if (compact) { if (partial) go(S2{}, T{}, T{}); else go(S2{}, F{}, T{}); }
+    else { if (partial) go(S2{}, T{}, F{}); else go(S2{}, F{}, F{}); }
+  } else {
+    if (compact) { if (partial) go(S1{}, T{}, T{}); else go(S1{}, F{}, T{}); }
+    else { if (partial) go(S1{}, T{}, F{}); else go(S1{}, F{}, F{}); }
+  }
 }
 
 }  // namespace dvo_hip

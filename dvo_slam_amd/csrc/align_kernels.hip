@@ -128,9 +128,16 @@ __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const Pair
   reduce_partials_scale(partials, pair, g.tiles_x * g.tiles_y, stage, sh, sums);
   const int n = scale_from_sums(sums, C, P);
   double total = 0.0;
-  if (n >= 6) total = loglik_partial<LOADS>(scratch + size_t(pair) * g.w * g.h, g.w * g.h, P, blockIdx.x, blocks_per_pair);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (n >= 6) {
+    const int tiles = g.tiles_x * g.tiles_y;
+    if (g.compact)                                            // (uniform) the packed residuals of the contracted window sweep
+      total = loglik_partial_compact<4>(scratch + size_t(pair) * residual_entries(g), partials + size_t(pair) * tiles * kAccStride, tiles * 4, P,
+                                        blockIdx.x * kWavesPerBlock + wave, blocks_per_pair * kWavesPerBlock);
+    else
+      total = loglik_partial<LOADS>(scratch + size_t(pair) * g.w * g.h, g.w * g.h, P, blockIdx.x, blocks_per_pair);
+  }
   total = wave_sum_double(total);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) sh[wave] = total;
   __syncthreads();

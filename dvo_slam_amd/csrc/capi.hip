@@ -251,6 +251,8 @@ struct dvo_hip_context {
   long long f16_range_repeats = 0; // batches repeated with the f32 Gram because a Jacobian left the f16 range (counter "f16_range_repeats")
   long long strip_ingests = 0;     // frames ingested by the strip kernel (ingest_strips.hip), counter "strip_ingests"
   int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
+  int opt_ll_blocks = 0;           // workgroups per pair of the log-likelihood pass (0 = by batch size)
+  int opt_compact_residuals = 1;   // the contracted window sweep stores only the residual pairs of constraints, packed (LevelGeom::compact)
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
   int opt_fused_ll_pixels = 0;     // largest level (pixels) whose log-likelihood sweep runs inside the solver workgroup (0 = by batch size)
@@ -421,6 +423,7 @@ int wait_for_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames) {
 constexpr int kResidentErrorWords = 8;
 
 const int kLlBlocksPerPair = 32;
+const int kLlBlocksPerPairBatch = 8;   // (a batch of 256 pairs or more, packed residuals; see run_batch)
 const int kFusedLoglikMaxPixels = 160 * 120;      // any batch
 const int kFusedLoglikMaxPixelsBatch = 320 * 240;  // batches that fill the chip with one solver workgroup per pair
 
@@ -514,6 +517,7 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   level_tiles(g.w, g.h, rows_per_wave, g.linear != 0, &g.tiles_x, &g.tiles_y);
   g.rcp_table = ctx->opt_ref_compat ? ctx->rcp_table.as<float>() : nullptr;
   g.rcp_shift = ctx->rcp_shift;
+  g.compact = ctx->opt_compact_residuals && ctx->opt_variant >= 8 && rows_per_wave == 4 && fast_sweep_supports(g) ? 1 : 0;   // (launch_residual_reduce's test)
   return g;
 }
 
@@ -942,7 +946,8 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
   const int n = bp.n, need_levels = cfg->first_level + 1;
   size_t max_tiles = 1;
   for (int l = cfg->last_level; l <= cfg->first_level; ++l) max_tiles = std::max(max_tiles, size_t(bp.geom[l].tiles_x) * bp.geom[l].tiles_y);
-  const size_t npx = size_t(bp.cam->w[cfg->last_level]) * bp.cam->h[cfg->last_level];
+  size_t npx = 0;                                             // residual entries per pair: the largest level's (packed ones own whole tiles)
+  for (int l = cfg->last_level; l <= cfg->first_level; ++l) npx = std::max(npx, residual_entries(bp.geom[l]));
   DVO_WS_TRY(w, w.states.reserve(size_t(n) * sizeof(PairState)));
   DVO_WS_TRY(w, w.pair_ptrs.reserve(size_t(n) * need_levels * sizeof(PairPtrs)));
   DVO_WS_TRY(w, w.partials.reserve(size_t(n) * max_tiles * kAccStride * sizeof(float)));
@@ -1329,16 +1334,20 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // Chunks of `per_sync` iterations are enqueued ONE AHEAD of the poll: while the host waits for the status word of
     // chunk k, chunk k+1 is already queued, so the GPU never idles for a host round trip.  Iterations enqueued past the
     // end of the level are no-ops (workgroups exit on !active).
+    // workgroups per pair of the log-likelihood pass: each begins by reducing the pair's scale sums (a latency chain of ~10 us), which
+    // a batch that fills the device anyway pays once per workgroup for nothing -- fewer, longer ones then (option ll_blocks to override)
+    const int ll_blocks = ctx->opt_ll_blocks > 0 ? std::min(ctx->opt_ll_blocks, kLlBlocksPerPair)
+                                                 : (g.compact && n >= 256 && !ctx->opt_deterministic ? kLlBlocksPerPairBatch : kLlBlocksPerPair);
     auto enqueue_chunk = [&](int count) {
       for (int c = 0; c < count; ++c, ++step) {
         {
           Range range(kErr[level]);
           launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch, w.win_fallbacks.as<unsigned long long>(),
                                  w.f16_range_flag);
-          if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, kLlBlocksPerPair, ctx->opt_deterministic != 0);
+          if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, ll_blocks, ctx->opt_deterministic != 0);
         }
         Range range(kLinsys[level]);
-        launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, kLlBlocksPerPair, fused_ll ? scratch : nullptr, d_levels, d_iters,
+        launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, ll_blocks, fused_ll ? scratch : nullptr, d_levels, d_iters,
                            tallies + step, w.host_status + step);
       }
     };
@@ -1716,6 +1725,16 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "build_workgroups") == 0) {
     if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "build_workgroups must be >= 0");
     ctx->opt_build_workgroups = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "ll_blocks") == 0) {
+    if (value < 0 || value > kLlBlocksPerPair) return fail(ctx, DVO_HIP_ERR_INVALID, "ll_blocks must be 0..32");
+    ctx->opt_ll_blocks = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "compact_residuals") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "compact_residuals must be 0 or 1");
+    ctx->opt_compact_residuals = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "min_workgroups") == 0) {
@@ -2237,7 +2256,8 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
   int rc = prepare_single(ctx, 1, r, c, &cfg, bp);
   if (rc != DVO_HIP_OK) return rc;
   hipStream_t s = ctx->stream;
-  const LevelGeom& g = bp.geom[level];
+  LevelGeom g = bp.geom[level];
+  if (residuals_or_null) g.compact = 0;                        // (by pixel: one pair at every pixel's place)
   const size_t npx = size_t(g.w) * g.h;
   DVO_HIP_TRY(ctx, ctx->misc.reserve(256 + sizeof(dvo_hip_iteration_out)));
   float* d_T = ctx->misc.as<float>();
@@ -2258,6 +2278,14 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
   if (*static_cast<volatile int*>(ctx->ws[0].f16_range_flag) != 0) {   // (see run_batch: beyond the f16 range, again with the f32 Gram)
     *static_cast<volatile int*>(ctx->ws[0].f16_range_flag) = 0;
     ctx->f16_range_repeats += 1;
+    // geometry and plane flavours of the f32 schedule (a level whose width is no multiple of 64 is the gathering sweep's there)
+    const int keep_variant = ctx->opt_variant;
+    ctx->opt_variant = 6;
+    rc = prepare_single(ctx, 1, r, c, &cfg, bp);
+    ctx->opt_variant = keep_variant;
+    if (rc != DVO_HIP_OK) return rc;
+    g = bp.geom[level];
+    pp = bp.pair_ptrs + size_t(level);
     launch_residual_reduce(s, 6, bp.rpw[level], level == 0, g, pp, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>(),
                            ctx->ws[0].win_fallbacks.as<unsigned long long>());
     launch_loglik(s, g, states, 1, ctx->ws[0].partials.as<float>(), ctx->ws[0].scratch.as<float2>(), ctx->ws[0].ll_partials.as<double>(), kLlBlocksPerPair);

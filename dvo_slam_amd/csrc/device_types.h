@@ -49,7 +49,22 @@ struct LevelGeom {                    // identical for every pair of a batch (on
   // on: rcp(1.m x 2^e) = rcp_table[m >> rcp_shift] x 2^-e (pixel_math.h::rcp_like_the_host).
   const float* rcp_table;
   int rcp_shift;
+  // 1: the sweep stores only the residual pairs of CONSTRAINTS (roughly every second pixel), packed: tile t of the level owns 1024
+  // entries of the pair's residual buffer, wavefront q of the tile the entries [256 q, 256 q + count_q), in the order it met them;
+  // the four counts ride in the two spare floats of the tile's partial row (kAccCounts).  The log-likelihood pass -- the only reader --
+  // then moves half the bytes.  Contracted window sweep only (align_fast.hip); 0 = one pair per pixel at its pixel's place, NaN
+  // where there is no constraint (every other sweep, and whenever the caller wants the residuals by pixel).
+  int compact;
 };
+
+// slot of the tile's partial row that holds count_0 + 512 count_1 (the next one: count_2 + 512 count_3), as exact floats
+constexpr int kAccCounts = kNumAcc;
+constexpr int kCompactTileEntries = 1024, kCompactWaveEntries = 256;
+
+// float2 entries of one pair's residual buffer at this level
+__host__ __device__ inline size_t residual_entries(const LevelGeom& g) {
+  return g.compact ? size_t(g.tiles_x) * size_t(g.tiles_y) * kCompactTileEntries : size_t(g.w) * size_t(g.h);
+}
 
 struct PairPtrs {                     // device planes of one pair at one level
   const float2* refR;                 // {Z (NaN = not selected), I}              8 B / pixel, streamed; the intensity gradient

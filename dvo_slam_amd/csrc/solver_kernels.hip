@@ -97,7 +97,14 @@ __global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n
     float C[3], P[4];
     const int n = scale_from_sums(sums, C, P);
     double t = 0.0;
-    if (n >= 6) t = loglik_partial<16>(scratch_for_fused_ll + size_t(pair) * g.w * g.h, g.w * g.h, P, 0, 1);
+    if (n >= 6) {
+      const int tiles = g.tiles_x * g.tiles_y;
+      if (g.compact)                                          // (uniform) the packed residuals of the contracted window sweep
+        t = loglik_partial_compact<8>(scratch_for_fused_ll + size_t(pair) * residual_entries(g), partials + size_t(pair) * tiles * kAccStride, tiles * 4, P,
+                                      __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kWavesPerBlock);
+      else
+        t = loglik_partial<16>(scratch_for_fused_ll + size_t(pair) * g.w * g.h, g.w * g.h, P, 0, 1);
+    }
     t = wave_sum_double(t);
     if ((threadIdx.x & 63) == 0) ll_waves[threadIdx.x >> 6] = t;
     __syncthreads();

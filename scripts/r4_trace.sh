@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04
 mkdir -p $O
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-from-host --no-scaling-model --no-ref-compat > $O/prof_bench.log 2>&1 ); echo "rocprof rc=$?"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-from-host --no-scaling-model --no-ref-compat $R4_BENCH_ARGS > $O/prof_bench.log 2>&1 ); echo "rocprof rc=$?"
 f=$(find $O/prof -name "*kernel_trace.csv" | head -1)
 python $R/scripts/step_breakdown.py "$f" 3 > $O/step_breakdown.txt; cat $O/step_breakdown.txt
 python $R/scripts/kernel_stats.py "$f" > $O/kernel_stats_insitu.txt

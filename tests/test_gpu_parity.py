@@ -238,6 +238,48 @@ def test_contracted_gathering_sweep_against_the_exact_one(w, h, rpw, xi):
             assert abs(a["neg_ll"] - b["neg_ll"]) <= 2e-5 * abs(a["neg_ll"])
 
 
+@pytest.mark.parametrize("w,h", [(640, 480), (160, 120), (320, 250), (200, 64)])
+def test_packed_residuals_give_the_same_sums(w, h):
+    """The contracted window sweep stores the residual pairs of constraints only, packed per wavefront slot (LevelGeom::compact), for
+    the log-likelihood pass to read half the bytes.  Against the same sweep storing one pair per pixel (option compact_residuals 0):
+    the normal equations are the same bits (their path does not change), the log-likelihood the same sum in another order (float64
+    products: 1e-7 relative on the float it is returned as)."""
+    pair = cm.synth(53, w, h)
+    T34 = po.se3_exp(np.array([0.01, -0.008, 0.006, 0.012, -0.01, 0.008], np.float64))[:3]
+    out = {}
+    for packed in (1, 0):
+        ctx = d.Context(0)
+        ctx.set_option("compact_residuals", packed)
+        gref, gcur = gpu_pyramids(ctx, pair, 1)
+        trk = d.DenseTracker(d.Config(FirstLevel=0, LastLevel=0), ctx)
+        out[packed] = [trk.level_iteration(gref, gcur, 0, T34, P_prev=[900.0, 3.0, 3.0, 400.0], first=f) for f in (True, False)]
+    for k in (0, 1):
+        a, b = out[1][k], out[0][k]
+        assert a["n"] == b["n"] and a["n"] > 0.2 * w * h
+        assert np.array_equal(a["A"], b["A"]) and np.array_equal(a["b"], b["b"]) and np.array_equal(a["P"], b["P"])
+        assert abs(a["neg_ll"] - b["neg_ll"]) <= 1e-7 * abs(b["neg_ll"]), (a["neg_ll"], b["neg_ll"])
+
+
+def test_packed_residuals_whole_matches():
+    """... and whole matches of a batch on the launch path (every pair its own stride in the residual buffer; levels 0-2 packed, level 3
+    by pixel): the same iteration counts, transforms within 1e-9."""
+    n = 24
+    b = datagen.synth_batch(3, n, 640, 480)
+    rec = {}
+    for packed in (1, 0):
+        ctx = d.Context(0)
+        ctx.set_option("compact_residuals", packed)
+        ctx.set_option("resident", 0)
+        cam = d.RgbdCameraPyramid(640, 480, b["K"], ctx)
+        cam.build(4)
+        refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)]
+        curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)]
+        rec[packed] = d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0), ctx).match_batch_arrays(refs, curs)
+    assert np.array_equal(rec[1]["n_iterations"], rec[0]["n_iterations"])
+    assert np.abs(rec[1]["T"] - rec[0]["T"]).max() <= 1e-9
+    assert np.allclose(rec[1]["loglik"], rec[0]["loglik"], rtol=1e-7)
+
+
 def test_contracted_sweep_at_the_identity():
     """Identical frames, identity transform: every reference pixel projects EXACTLY onto a pixel centre of the current frame -- the
     discontinuity of floor().  Whichever side of it a rounding lands on, the blend is continuous (weight 0 or 1 on the same pixel),
