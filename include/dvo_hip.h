@@ -255,11 +255,16 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * "iters_per_sync" (host polling cadence of the batched Gauss-Newton loop), "variant" (schedule of the sweep
  * kernel: 8 (default) = the current frame's {I, Z} window staged in LDS, contracted per-pixel arithmetic (fused multiply-adds,
  * v_rcp_f32 in the projection, separable blends: the same function as 7 to a few ulp of the tap coordinate -- residuals within 2e-5,
- * constraint counts equal except at pixels on a bound) + Gram accumulation on the f16 matrix pipe, on every level whose width is a
- * multiple of 64 and the schedule of 7 elsewhere; 9 = 8 with another way of storing the matrix operands (v_permlane32_swap; measurement); 7 = the window sweep
+ * constraint counts equal except at pixels on a bound) + Gram accumulation on the f16 matrix pipe, on every level of even width >= 84
+ * (a width that is no multiple of 64 leaves the last tile column partly empty) and the gathering sweep with the same arithmetic on
+ * narrower ones; 9 = 8 with another way of storing the matrix operands (v_permlane32_swap; measurement); 7 = the window sweep
  * whose residuals and constraint counts equal the oracle's MATH mode BIT FOR BIT (no contraction, correctly rounded divisions), f16
  * Gram; 6 = the same with the f32 Gram (bit-identical to 5); 5 = gathered taps, f32 Gram accumulation on the matrix cores; 0 =
  * all-VALU with the DPP + LDS reduction),
+ * "compact_residuals" (default 1: the contracted window sweep stores only the residual pairs of constraints, packed per wavefront
+ * slot, for the log-likelihood pass to read half the bytes; 0: one pair per pixel at its pixel's place like every other schedule --
+ * the same normal equations bit for bit, the log-likelihood the same sum in another order),
+ * "ll_blocks" (workgroups per pair of the log-likelihood pass, 1..32; 0 = by batch size),
  * "min_workgroups" (tile-height heuristic: smallest launch that counts as filling the chip; 0 = built-in table),
  * "fused_ll_pixels" (largest level, in pixels, whose log-likelihood sweep runs inside the solver
  * workgroup instead of a launch of its own; 0 = 160x120, and 320x240 for batches of 64 pairs and more),
