@@ -251,6 +251,7 @@ struct dvo_hip_context {
   long long f16_range_repeats = 0; // batches repeated with the f32 Gram because a Jacobian left the f16 range (counter "f16_range_repeats")
   long long strip_ingests = 0;     // frames ingested by the strip kernel (ingest_strips.hip), counter "strip_ingests"
   int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
+  int opt_solver_waves = 0;        // wavefronts of a solver-step workgroup: 0 = by level and batch size, 2, 4
   int opt_ll_blocks = 0;           // workgroups per pair of the log-likelihood pass (0 = by batch size)
   int opt_compact_residuals = 1;   // the contracted window sweep stores only the residual pairs of constraints, packed (LevelGeom::compact)
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
@@ -1338,6 +1339,13 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // a batch that fills the device anyway pays once per workgroup for nothing -- fewer, longer ones then (option ll_blocks to override)
     const int ll_blocks = ctx->opt_ll_blocks > 0 ? std::min(ctx->opt_ll_blocks, kLlBlocksPerPair)
                                                  : (g.compact && n >= 256 && !ctx->opt_deterministic ? kLlBlocksPerPairBatch : kLlBlocksPerPair);
+    // the solver step of the smallest levels in two-wavefront workgroups (four per compute unit instead of two): a batch that otherwise
+    // needs two goes of 512 resident workgroups (option solver_waves 2 / 4 to force; the records do not depend on it).  Measured at
+    // 1024 pairs (scripts/r4_trace.sh): 80 x 60 46 -> 36 us per step; 160 x 120 with packed residuals 77 -> 90 (two wavefronts walk
+    // its 96 slots in six rounds instead of three), 320 x 240 and the finest level level: those keep four.
+    const bool solver_two_waves = ctx->opt_solver_waves == 2 ||
+                                  (ctx->opt_solver_waves == 0 && fused_ll && !g.compact && g.tiles_x * g.tiles_y <= 32 &&
+                                   n > 2 * (ctx->compute_units > 0 ? ctx->compute_units : 256));
     auto enqueue_chunk = [&](int count) {
       for (int c = 0; c < count; ++c, ++step) {
         {
@@ -1348,7 +1356,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
         }
         Range range(kLinsys[level]);
         launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, ll_blocks, fused_ll ? scratch : nullptr, d_levels, d_iters,
-                           tallies + step, w.host_status + step);
+                           tallies + step, w.host_status + step, solver_two_waves);
       }
     };
     int enqueued = std::min(per_sync, per_level);
@@ -1725,6 +1733,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "build_workgroups") == 0) {
     if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "build_workgroups must be >= 0");
     ctx->opt_build_workgroups = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "solver_waves") == 0) {
+    if (value != 0 && value != 2 && value != 4) return fail(ctx, DVO_HIP_ERR_INVALID, "solver_waves must be 0, 2 or 4");
+    ctx->opt_solver_waves = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "ll_blocks") == 0) {

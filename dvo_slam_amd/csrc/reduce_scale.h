@@ -20,32 +20,48 @@ constexpr int kReduceInFlight = 32;
 
 // blockDim.x must be kBlock.  sh: kWavesPerBlock * kAccStride doubles of LDS.  sums: kAccStride doubles of LDS,
 // valid for all threads after the call.
+// WAVES: wavefronts the workgroup really has (4, or 2: the solver step of a small level, so that four of them fit a compute unit).
+// The additions do not depend on it: a real wavefront plays the "virtual" wavefronts w, w + WAVES, ... of a four-wavefront
+// workgroup, each with its own accumulators.
+template <int WAVES = kWavesPerBlock>
 __device__ inline void reduce_partials(const float* __restrict__ partials, int pair, int tiles, double* sh, double* sums) {
+  static_assert(WAVES == 2 || WAVES == 4, "two or four wavefronts");
+  constexpr int kPlayed = kWavesPerBlock / WAVES;           // virtual wavefronts per real one
+  constexpr int kInFlight = kReduceInFlight / kPlayed;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* base = partials + size_t(pair) * tiles * kAccStride;
   const bool hi = lane < kAccStride - 64;
-  double a0 = 0.0, a1 = 0.0;
+  double a0[kPlayed], a1[kPlayed];
+#pragma unroll
+  for (int r = 0; r < kPlayed; ++r) a0[r] = a1[r] = 0.0;
   // independent row loads in flight, then added in tile order (the summation order is part of the contract)
-  for (int t0 = wave; t0 < tiles; t0 += kReduceInFlight * kWavesPerBlock) {
-    float v0[kReduceInFlight], v1[kReduceInFlight];
+  for (int t0 = wave; t0 < tiles; t0 += kInFlight * kWavesPerBlock) {
+    float v0[kPlayed][kInFlight], v1[kPlayed][kInFlight];
     // branch-free: every load is issued (out-of-range rows re-read the last row), the selection happens at the add --
     // a conditional load costs a branch and a full s_waitcnt each, which serialises the round trips
 #pragma unroll
-    for (int j = 0; j < kReduceInFlight; ++j) {
-      const int t = t0 + j * kWavesPerBlock;
-      const float* row = base + size_t(t < tiles ? t : tiles - 1) * kAccStride;
-      v0[j] = row[lane];
-      v1[j] = row[hi ? 64 + lane : 64];
-    }
+    for (int r = 0; r < kPlayed; ++r)
 #pragma unroll
-    for (int j = 0; j < kReduceInFlight; ++j) {
-      const bool in = t0 + j * kWavesPerBlock < tiles;
-      a0 += in ? double(v0[j]) : 0.0;                       // x + 0.0 == x: the masked adds do not perturb the sum
-      a1 += in ? double(v1[j]) : 0.0;
-    }
+      for (int j = 0; j < kInFlight; ++j) {
+        const int t = t0 + r * WAVES + j * kWavesPerBlock;
+        const float* row = base + size_t(t < tiles ? t : tiles - 1) * kAccStride;
+        v0[r][j] = row[lane];
+        v1[r][j] = row[hi ? 64 + lane : 64];
+      }
+#pragma unroll
+    for (int r = 0; r < kPlayed; ++r)
+#pragma unroll
+      for (int j = 0; j < kInFlight; ++j) {
+        const bool in = t0 + r * WAVES + j * kWavesPerBlock < tiles;
+        a0[r] += in ? double(v0[r][j]) : 0.0;               // x + 0.0 == x: the masked adds do not perturb the sum
+        a1[r] += in ? double(v1[r][j]) : 0.0;
+      }
   }
-  sh[wave * kAccStride + lane] = a0;
-  if (hi) sh[wave * kAccStride + 64 + lane] = a1;
+#pragma unroll
+  for (int r = 0; r < kPlayed; ++r) {
+    sh[(wave + r * WAVES) * kAccStride + lane] = a0[r];
+    if (hi) sh[(wave + r * WAVES) * kAccStride + 64 + lane] = a1[r];
+  }
   __syncthreads();
   if (threadIdx.x < kAccStride) {
     const int k = threadIdx.x;

@@ -59,7 +59,11 @@ extern "C" int dvo_hip_debug_solver_clocks(unsigned long long* out16, int reset)
 #define CLK(i) ((void)0)
 #endif
 
-__global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
+// WAVES: 4, or 2 for the small levels of a batch that does not fit the device in one go with four -- the kernel holds 210 registers,
+// two four-wavefront workgroups per compute unit = 512 pairs at a time, and what a workgroup does on a small level is mostly lane 0's
+// serial float64 work.  A two-wavefront workgroup plays the four (reduce_scale.h, loglik_partial_played): the records are the same bits.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
                                                         const float* __restrict__ partials,
                                                         const double* __restrict__ ll_partials, int ll_blocks_per_pair,
                                                         const float2* __restrict__ scratch_for_fused_ll,
@@ -90,23 +94,36 @@ __global__ __launch_bounds__(kBlock) void k_solver_step(PairState* states, int n
   dvo_hip_level_stats* lvl_global = levels + size_t(pair) * prm.cap_levels + level_slot;
   const bool have_level = level_slot >= 0 && level_slot < prm.cap_levels;
   if (have_level) coop_copy(&lvl, lvl_global);
-  reduce_partials(partials, pair, g.tiles_x * g.tiles_y, sh, sums);   // same routine, same order as k_loglik: identical n, S, P
+  reduce_partials<WAVES>(partials, pair, g.tiles_x * g.tiles_y, sh, sums);   // same routine, same order as k_loglik: identical n, S, P
   CLK(1);
   if (scratch_for_fused_ll) {
     // coarse levels: the log-likelihood sweep is small enough for this workgroup, which saves a launch per iteration
     float C[3], P[4];
     const int n = scale_from_sums(sums, C, P);
-    double t = 0.0;
+    constexpr int kPlayed = kWavesPerBlock / WAVES;          // wavefronts of a four-wavefront workgroup each real one plays
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double t[kPlayed];
+#pragma unroll
+    for (int q = 0; q < kPlayed; ++q) t[q] = 0.0;
     if (n >= 6) {
       const int tiles = g.tiles_x * g.tiles_y;
-      if (g.compact)                                          // (uniform) the packed residuals of the contracted window sweep
-        t = loglik_partial_compact<8>(scratch_for_fused_ll + size_t(pair) * residual_entries(g), partials + size_t(pair) * tiles * kAccStride, tiles * 4, P,
-                                      __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kWavesPerBlock);
-      else
-        t = loglik_partial<16>(scratch_for_fused_ll + size_t(pair) * g.w * g.h, g.w * g.h, P, 0, 1);
+      if (g.compact) {                                        // (uniform) the packed residuals of the contracted window sweep
+        if constexpr (WAVES == kWavesPerBlock)
+          t[0] = loglik_partial_compact<8>(scratch_for_fused_ll + size_t(pair) * residual_entries(g), partials + size_t(pair) * tiles * kAccStride, tiles * 4, P,
+                                           wave, kWavesPerBlock);
+        else
+          loglik_partial_compact_played<4, kPlayed>(scratch_for_fused_ll + size_t(pair) * residual_entries(g), partials + size_t(pair) * tiles * kAccStride,
+                                                    tiles * 4, P, wave, WAVES, kWavesPerBlock, t);
+      } else {
+        if constexpr (WAVES == kWavesPerBlock) t[0] = loglik_partial<16>(scratch_for_fused_ll + size_t(pair) * g.w * g.h, g.w * g.h, P, 0, 1);
+        else loglik_partial_played<8, WAVES>(scratch_for_fused_ll + size_t(pair) * g.w * g.h, g.w * g.h, P, t);
+      }
     }
-    t = wave_sum_double(t);
-    if ((threadIdx.x & 63) == 0) ll_waves[threadIdx.x >> 6] = t;
+#pragma unroll
+    for (int q = 0; q < kPlayed; ++q) {
+      const double total = wave_sum_double(t[q]);
+      if ((threadIdx.x & 63) == 0) ll_waves[wave + q * WAVES] = total;
+    }
     __syncthreads();
   }
   CLK(2);
@@ -199,9 +216,14 @@ void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverPar
 
 void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
                         const float* partials, const double* ll_partials, int ll_blocks_per_pair, const float2* scratch_for_fused_ll,
-                        dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, unsigned long long* step_tally, int* host_status) {
-  k_solver_step<<<dim3(n_pairs), dim3(kBlock), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
-                                                       scratch_for_fused_ll, levels, iters, step_tally, host_status);
+                        dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, unsigned long long* step_tally, int* host_status, bool two_waves) {
+  // (two wavefronts: see the kernel; a level of at most 32 tiles -- 160 x 120, 80 x 60 -- of a batch beyond two workgroups per compute unit)
+  if (two_waves)
+    k_solver_step<2><<<dim3(n_pairs), dim3(128), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
+                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status);
+  else
+    k_solver_step<kWavesPerBlock><<<dim3(n_pairs), dim3(kBlock), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
+                                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status);
 }
 
 void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverParams prm,

@@ -280,6 +280,36 @@ def test_packed_residuals_whole_matches():
     assert np.allclose(rec[1]["loglik"], rec[0]["loglik"], rtol=1e-7)
 
 
+def test_solver_step_in_two_wavefront_workgroups_gives_the_same_records():
+    """A large batch runs the solver step of its small levels in two-wavefront workgroups (four per compute unit instead of two); each
+    wavefront plays two of the four (the same additions and products in the same order): every record the same bits, with the packed
+    and with the by-pixel residual layout, statistics included."""
+    n = 12
+    b = datagen.synth_batch(5, n, 640, 480)
+    for packed in (1, 0):
+        rec = {}
+        for waves in (4, 2):
+            ctx = d.Context(0)
+            ctx.set_option("solver_waves", waves)
+            ctx.set_option("compact_residuals", packed)
+            ctx.set_option("resident", 0)
+            cam = d.RgbdCameraPyramid(640, 480, b["K"], ctx)
+            cam.build(4)
+            refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)]
+            curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)]
+            res = [d.Result() for _ in range(n)]
+            d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0), ctx).match_batch(refs, curs, res, with_stats=True)
+            rec[waves] = res
+        for ra, rb in zip(rec[4], rec[2]):
+            assert np.array_equal(ra.Transformation, rb.Transformation) and np.array_equal(ra.Information, rb.Information)
+            assert ra.LogLikelihood == rb.LogLikelihood
+            for La, Lb in zip(ra.Statistics.Levels, rb.Statistics.Levels):
+                assert len(La.Iterations) == len(Lb.Iterations)
+                for Ia, Ib in zip(La.Iterations, Lb.Iterations):
+                    assert Ia.ValidConstraints == Ib.ValidConstraints and Ia.TDistributionLogLikelihood == Ib.TDistributionLogLikelihood
+                    assert np.array_equal(Ia.EstimateIncrement, Ib.EstimateIncrement, equal_nan=True)
+
+
 def test_contracted_sweep_at_the_identity():
     """Identical frames, identity transform: every reference pixel projects EXACTLY onto a pixel centre of the current frame -- the
     discontinuity of floor().  Whichever side of it a rounding lands on, the blend is continuous (weight 0 or 1 on the same pixel),
