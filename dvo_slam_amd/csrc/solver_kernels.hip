@@ -48,11 +48,14 @@ __device__ __forceinline__ void publish_step(unsigned long long* step_tally, int
 
 #ifdef DVO_SOLVER_CLOCKS
 // experiment build only (scripts/ubench/solver_clocks.sh): where the time of a solver step goes, 100 MHz wall clock
-__device__ unsigned long long g_solver_clk[16];
-#define CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = wall_clock64(); g_solver_clk[i] += now_ - clk_prev_; clk_prev_ = now_; } } while (0)
-extern "C" int dvo_hip_debug_solver_clocks(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_solver_clk), sizeof(g_solver_clk)) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_solver_clk), z, sizeof(z)) != hipSuccess) return -1; }
+// (one row of 16 per level class: 640, 320, 160 pixels wide and narrower; [15] of a row counts the steps)
+__device__ unsigned long long g_solver_clk[64];
+#define CLK_ROW (g.w >= 640 ? 0 : g.w >= 320 ? 16 : g.w >= 160 ? 32 : 48)
+// (every 64th workgroup, so that a large batch shows what a step costs with the memory system under load, not only its first workgroup)
+#define CLK(i) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_solver_clk[CLK_ROW + (i)], now_ - clk_prev_); clk_prev_ = now_; } } while (0)
+extern "C" int dvo_hip_debug_solver_clocks(unsigned long long* out64, int reset) {
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_solver_clk), sizeof(g_solver_clk)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_solver_clk), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
 #else
@@ -68,15 +71,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
                                                         const double* __restrict__ ll_partials, int ll_blocks_per_pair,
                                                         const float2* __restrict__ scratch_for_fused_ll,
                                                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters,
-                                                        unsigned long long* step_tally, int* host_status) {
+                                                        unsigned long long* step_tally, int* host_status, int level_slot_hint) {
   const int pair = blockIdx.x;
 #ifdef DVO_SOLVER_CLOCKS
   unsigned long long clk_prev_ = wall_clock64();
 #endif
-  if (!states[pair].active) {         // uniform
-    if (threadIdx.x == 0) publish_step(step_tally, host_status, n_pairs, false);
-    return;
-  }
   // The state machine is one lane of serial float64 work; every global access it made used to be a dependent
   // ~1 us round trip.  Stage the pair's state, its level record and the new iteration record in LDS: loaded and
   // stored by all 256 lanes at once, touched by lane 0 at LDS latency.
@@ -86,15 +85,63 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
   __shared__ double sh[kWavesPerBlock * kAccStride];
   __shared__ double sums[kAccStride];
   __shared__ double ll_waves[kWavesPerBlock];
+  __shared__ double ll_stage[32];
   __shared__ int rec_index;
-  coop_copy(&st, &states[pair]);
+  // ONE round trip for everything whose address does not depend on loaded data (round 4; with 1024 workgroups in flight a dependent
+  // trip costs 4-5 us and the step was a chain of nine): the pair's state, its level record (the slot every live pair of the batch
+  // is at -- a hint from the host, checked below), the partial rows, the log-likelihood partial sums of k_loglik.  A pair that turns
+  // out to be finished has loaded them for nothing.
+  constexpr int kThreads = WAVES * 64;
+  constexpr int kStWords = int(sizeof(PairState) / 4), kLvlWords = int(sizeof(dvo_hip_level_stats) / 4);
+  static_assert(sizeof(PairState) % 4 == 0 && sizeof(dvo_hip_level_stats) % 4 == 0, "copied by words");
+  constexpr int kStPer = (kStWords + kThreads - 1) / kThreads, kLvlPer = (kLvlWords + kThreads - 1) / kThreads;
+  unsigned st_w[kStPer], lvl_w[kLvlPer];
+  const bool hint_ok = level_slot_hint >= 0 && level_slot_hint < prm.cap_levels;
+  {
+    const unsigned* src = reinterpret_cast<const unsigned*>(&states[pair]);
+#pragma unroll
+    for (int k = 0; k < kStPer; ++k) {
+      const int i = int(threadIdx.x) + k * kThreads;
+      st_w[k] = src[i < kStWords ? i : 0];
+    }
+    const unsigned* lsrc = reinterpret_cast<const unsigned*>(levels + size_t(pair) * prm.cap_levels + (hint_ok ? level_slot_hint : 0));
+#pragma unroll
+    for (int k = 0; k < kLvlPer; ++k) {
+      const int i = int(threadIdx.x) + k * kThreads;
+      lvl_w[k] = prm.cap_levels > 0 ? lsrc[i < kLvlWords ? i : 0] : 0u;
+    }
+  }
+  double ll_mine = 0.0;
+  if (!scratch_for_fused_ll && threadIdx.x < 32) ll_mine = ll_partials[size_t(pair) * ll_blocks_per_pair + min(int(threadIdx.x), ll_blocks_per_pair - 1)];
+  reduce_partials<WAVES>(partials, pair, g.tiles_x * g.tiles_y, sh, sums);   // same routine, same order as k_loglik: identical n, S, P
+  {
+    unsigned* dst = reinterpret_cast<unsigned*>(&st);
+#pragma unroll
+    for (int k = 0; k < kStPer; ++k) {
+      const int i = int(threadIdx.x) + k * kThreads;
+      if (i < kStWords) dst[i] = st_w[k];
+    }
+    unsigned* ldst = reinterpret_cast<unsigned*>(&lvl);
+#pragma unroll
+    for (int k = 0; k < kLvlPer; ++k) {
+      const int i = int(threadIdx.x) + k * kThreads;
+      if (i < kLvlWords) ldst[i] = lvl_w[k];
+    }
+    if (threadIdx.x < 32) ll_stage[threadIdx.x] = ll_mine;
+  }
   __syncthreads();
+  if (!st.active) {                   // uniform
+    if (threadIdx.x == 0) publish_step(step_tally, host_status, n_pairs, false);
+    return;
+  }
   CLK(0);
   const int level_slot = st.n_levels - 1;
   dvo_hip_level_stats* lvl_global = levels + size_t(pair) * prm.cap_levels + level_slot;
   const bool have_level = level_slot >= 0 && level_slot < prm.cap_levels;
-  if (have_level) coop_copy(&lvl, lvl_global);
-  reduce_partials<WAVES>(partials, pair, g.tiles_x * g.tiles_y, sh, sums);   // same routine, same order as k_loglik: identical n, S, P
+  if (have_level && !(hint_ok && level_slot == level_slot_hint)) {   // (uniform; not expected: the levels of a batch begin together)
+    coop_copy(&lvl, lvl_global);
+    __syncthreads();
+  }
   CLK(1);
   if (scratch_for_fused_ll) {
     // coarse levels: the log-likelihood sweep is small enough for this workgroup, which saves a launch per iteration
@@ -132,8 +179,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
     if (scratch_for_fused_ll) {
       ll_sum = (ll_waves[0] + ll_waves[1]) + (ll_waves[2] + ll_waves[3]);
     } else {
-      const double* p = ll_partials + size_t(pair) * ll_blocks_per_pair;
-      for (int b = 0; b < ll_blocks_per_pair; ++b) ll_sum += p[b];
+      for (int b = 0; b < ll_blocks_per_pair; ++b) ll_sum += ll_stage[b];
     }
     rec_index = st.n_iters_total;
     // gn_step addresses levels[n_levels - 1] and iters[n_iters_total]: hand it pointers biased so that those land in LDS
@@ -151,7 +197,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
   if (rec_index < prm.cap_iters) coop_copy(iters + size_t(pair) * prm.cap_iters + rec_index, &rec);
   CLK(5);
 #ifdef DVO_SOLVER_CLOCKS
-  if (threadIdx.x == 0 && blockIdx.x == 0) g_solver_clk[15] += 1;
+  if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicAdd(&g_solver_clk[CLK_ROW + 15], 1ull);
 #endif
 }
 
@@ -216,14 +262,15 @@ void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverPar
 
 void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
                         const float* partials, const double* ll_partials, int ll_blocks_per_pair, const float2* scratch_for_fused_ll,
-                        dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, unsigned long long* step_tally, int* host_status, bool two_waves) {
+                        dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, unsigned long long* step_tally, int* host_status, bool two_waves,
+                        int level_slot_hint) {
   // (two wavefronts: see the kernel; a level of at most 32 tiles -- 160 x 120, 80 x 60 -- of a batch beyond two workgroups per compute unit)
   if (two_waves)
     k_solver_step<2><<<dim3(n_pairs), dim3(128), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
-                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status);
+                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status, level_slot_hint);
   else
     k_solver_step<kWavesPerBlock><<<dim3(n_pairs), dim3(kBlock), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
-                                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status);
+                                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status, level_slot_hint);
 }
 
 void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverParams prm,

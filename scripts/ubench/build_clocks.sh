@@ -10,5 +10,5 @@ mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $FLAGS -DDVO_RESIDENT_CLOCKS -c align_resident.hip -o $OUT/align_resident_clk.o
 /opt/rocm/bin/hipcc $FLAGS -DDVO_SOLVER_CLOCKS -c solver_kernels.hip -o $OUT/solver_kernels_clk.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libdvo_hip_clk.so capi.o pyramid_kernels.o align_kernels.o align_mfma.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libdvo_hip_clk.so capi.o pyramid_kernels.o ingest_strips.o align_kernels.o align_mfma.o align_window.o align_fast.o \
     $OUT/solver_kernels_clk.o $OUT/align_resident_clk.o -L/opt/rocm/lib -lrocprofiler-sdk-roctx

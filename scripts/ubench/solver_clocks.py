@@ -14,7 +14,8 @@ refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)]
 curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)]
 trk = d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0.0), ctx)
 L = C.CDLL(_lib.LIB_PATH)
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 64)()
+ctx.set_option("resident", 0)
 for _ in range(3):
     out = trk.match_batch_arrays(refs, curs)
 L.dvo_hip_debug_solver_clocks(buf, 1)
@@ -24,10 +25,12 @@ for _ in range(R):
     out = trk.match_batch_arrays(refs, curs)
 dt = (time.perf_counter() - t0) / R
 L.dvo_hip_debug_solver_clocks(buf, 0)
-v = np.array(list(buf), dtype=np.float64)
-calls = v[15]
+v = np.array(list(buf), dtype=np.float64).reshape(4, 16)
 names = ["load state", "stage 3 (reduce partials)", "fused LL", "gn_step (lane 0)", "publish", "store state"]
-print("match %.3f ms; %d active solver steps of pair 0 over %d matches (%.1f per match), iterations %s" % (dt * 1e3, calls, R, calls / R, out["n_iterations"][:4]))
-for i, nm in enumerate(names):
-    print("  %-28s %7.2f us per step" % (nm, v[i] / calls * 0.01))
-print("  total %.2f us per step" % (v[:6].sum() / calls * 0.01))
+print("%d pairs: match %.3f ms; iterations %s" % (n, dt * 1e3, out["n_iterations"][:4]))
+for row, width in enumerate((640, 320, 160, 80)):
+    calls = v[row, 15]
+    if calls == 0:
+        continue
+    print("level %d pixels wide: %d active solver steps of the pairs 0, 64, 128, ... over %d matches; us per step: %s; total %.2f"
+          % (width, calls, R, "  ".join("%s %.2f" % (nm, v[row, i] / calls * 0.01) for i, nm in enumerate(names)), v[row, :6].sum() / calls * 0.01))
