@@ -577,7 +577,11 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
 
 bool fast_sweep_takes_width(int w) { return w >= kFastCols && w % 2 == 0; }
 
-bool fast_sweep_supports(const LevelGeom& g) { return !g.linear && fast_sweep_takes_width(g.w) && g.w < 32768 && g.h < 32768 && !g.rcp_table; }
+bool fast_sweep_supports(const LevelGeom& g) {
+  // (a pair's planes and its residual buffer are addressed through 32-bit buffer offsets: 2 GB each at most -- a 16 384 x 16 384 level)
+  const long long plane_bytes = 8ll * g.w * g.h, packed_bytes = 8ll * kCompactTileEntries * g.tiles_x * g.tiles_y;
+  return !g.linear && fast_sweep_takes_width(g.w) && g.w < 32768 && g.h < 32768 && plane_bytes < (1ll << 31) && packed_bytes < (1ll << 31) && !g.rcp_table;
+}
 
 void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                        float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag) {
