@@ -310,6 +310,36 @@ def test_solver_step_in_two_wavefront_workgroups_gives_the_same_records():
                     assert np.array_equal(Ia.EstimateIncrement, Ib.EstimateIncrement, equal_nan=True)
 
 
+def test_contracted_sweep_random_sizes():
+    """Twenty random level sizes for the default schedule as the match runs it -- packed residual pairs, tile grids that hang over the
+    right and the lower edge by any amount (widths 84 ... 330 incl. 64 k + 2: a tile column of two lanes; heights 30 ... 250) -- against
+    the exact schedule: the constraint count (a pixel on a bound may flip: at most 1e-4 of them), and where the counts agree the
+    normal equations to 1e-5 and the log-likelihood to 2e-5."""
+    rng = np.random.default_rng(77)
+    sizes = [(130, 33), (194, 47), (86, 30), (320, 17)] + [(int(rng.integers(42, 166)) * 2, int(rng.integers(30, 251))) for _ in range(16)]
+    worst = [0.0, 0.0, 0]
+    for k, (w, h) in enumerate(sizes):
+        pair = cm.synth(100 + k, w, h)
+        T34 = po.se3_exp(rng.normal(0.0, 0.01, 6))[:3]
+        out = {}
+        for v in (EXACT_VARIANT, DEFAULT_VARIANT):
+            ctx = d.Context(0)
+            ctx.set_option("variant", v)
+            gref, gcur = gpu_pyramids(ctx, pair, 1)
+            trk = d.DenseTracker(d.Config(FirstLevel=0, LastLevel=0), ctx)
+            out[v] = [trk.level_iteration(gref, gcur, 0, T34, P_prev=[900.0, 3.0, 3.0, 400.0], first=f) for f in (True, False)]
+        for a, b in zip(out[EXACT_VARIANT], out[DEFAULT_VARIANT]):
+            assert a["n_selected"] == b["n_selected"], (w, h)
+            assert abs(a["n"] - b["n"]) <= max(1, int(1e-4 * a["n"])), (w, h, a["n"], b["n"])
+            worst[2] = max(worst[2], abs(a["n"] - b["n"]))
+            if a["n"] == b["n"] and a["n"] >= 6:
+                ea = np.abs(a["A"] - b["A"]).max() / np.abs(a["A"]).max()
+                el = abs(a["neg_ll"] - b["neg_ll"]) / abs(a["neg_ll"])
+                worst[0], worst[1] = max(worst[0], ea), max(worst[1], el)
+                assert ea <= 1e-5 and el <= 2e-5, (w, h, ea, el)
+    print("20 random sizes: largest |dA| / |A| %.1e, |d ll| / |ll| %.1e, count difference %d" % tuple(worst))
+
+
 def test_contracted_sweep_at_the_identity():
     """Identical frames, identity transform: every reference pixel projects EXACTLY onto a pixel centre of the current frame -- the
     discontinuity of floor().  Whichever side of it a rounding lands on, the blend is continuous (weight 0 or 1 on the same pixel),
