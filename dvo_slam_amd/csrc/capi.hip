@@ -251,6 +251,7 @@ struct dvo_hip_context {
   long long f16_range_repeats = 0; // batches repeated with the f32 Gram because a Jacobian left the f16 range (counter "f16_range_repeats")
   long long strip_ingests = 0;     // frames ingested by the strip kernel (ingest_strips.hip), counter "strip_ingests"
   int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
+  int opt_tail_speculation = 0;    // 1: always enqueue the step ahead of the poll, also on the tail of a level whose empty step is costly (measurement)
   int opt_solver_waves = 0;        // wavefronts of a solver-step workgroup: 0 = by level and batch size, 2, 4
   int opt_ll_blocks = 0;           // workgroups per pair of the log-likelihood pass (0 = by batch size)
   int opt_compact_residuals = 1;   // the contracted window sweep stores only the residual pairs of constraints, packed (LevelGeom::compact)
@@ -424,6 +425,7 @@ int wait_for_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames) {
 constexpr int kResidentErrorWords = 8;
 
 const int kLlBlocksPerPair = 32;
+const size_t kCostlyEmptyStepWorkgroups = 131072;   // (see run_batch: from here on the step ahead of the poll is held back on a level's tail)
 const int kLlBlocksPerPairBatch = 8;   // (a batch of 256 pairs or more, packed residuals; see run_batch)
 const int kFusedLoglikMaxPixels = 160 * 120;      // any batch
 const int kFusedLoglikMaxPixelsBatch = 320 * 240;  // batches that fill the chip with one solver workgroup per pair
@@ -1362,8 +1364,15 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     int enqueued = std::min(per_sync, per_level);
     enqueue_chunk(enqueued);
     int watched = step - 1;                                  // last step of the chunk whose outcome is awaited
+    // Where an EMPTY step is expensive -- the dispatcher needs 95 us for the 307 200 workgroups of a 1024-pair finest-level sweep
+    // that all exit at once, 114 us with its log-likelihood and solver launches -- the step ahead of the poll is not enqueued once
+    // only a few pairs are left on the level: the host then waits for the outcome first (a bubble of ~15 us if another step is
+    // needed).  Elsewhere the speculative step is cheaper than the bubble.
+    const bool empty_step_is_costly = size_t(g.tiles_x) * g.tiles_y * size_t(n) >= (ctx->opt_tail_speculation >= 2 ? size_t(ctx->opt_tail_speculation) : kCostlyEmptyStepWorkgroups) && ctx->opt_tail_speculation != 1;
+    int last_active = n;
     for (;;) {
-      const int more = std::min(per_sync, per_level - enqueued);
+      const bool hold = empty_step_is_costly && last_active * 8 <= n;
+      int more = hold ? 0 : std::min(per_sync, per_level - enqueued);
       if (more > 0) {
         enqueue_chunk(more);
         enqueued += more;
@@ -1371,6 +1380,14 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       int active = 0;
       rc = wait_for_step(w, watched, &active);
       if (rc != DVO_HIP_OK) return rc;
+      last_active = active;
+      if (hold && active > 0) {                              // (the held-back step is needed after all)
+        more = std::min(per_sync, per_level - enqueued);
+        if (more > 0) {
+          enqueue_chunk(more);
+          enqueued += more;
+        }
+      }
       if (active == 0 || more <= 0) break;                   // every pair left this level (or the iteration cap is reached)
       watched = step - 1;
     }
@@ -1733,6 +1750,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "build_workgroups") == 0) {
     if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "build_workgroups must be >= 0");
     ctx->opt_build_workgroups = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "tail_speculation") == 0) {
+    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "tail_speculation must be >= 0");
+    ctx->opt_tail_speculation = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "solver_waves") == 0) {
