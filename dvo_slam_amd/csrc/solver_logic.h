@@ -223,7 +223,10 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
 
   // contract the Gram sums with W = w P : A = J^T W J, b = -J^T W r (least_squares.cpp:58-64)
   const double p00 = double(P[0]), p01 = double(P[1]), p11 = double(P[3]);
-  double A[36], b[6];
+  // (formed in place in st.A_last, which nothing reads between here and the end of the pass: on the device the state lives in LDS,
+  // a local array of 36 doubles in scratch memory -- three round trips of the serial lane per pass)
+  double* const A = st.A_last;
+  double b[6];
   int o = 0;
   for (int i = 0; i < 6; ++i)
     for (int j = i; j < 6; ++j) {
@@ -256,10 +259,9 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   if (speculate) spec->half_n_logdet = 0.5 * double(n) * log(det);
   for (int i = 0; i < 6; ++i) rec.increment[i] = st.x[i];
   if (spec && spec->defer_information) {
-    for (int i = 0; i < 36; ++i) st.A_last[i] = A[i];
     spec->information_ready = 1;
   } else {
-    for (int i = 0; i < 36; ++i) { rec.information[i] = A[i]; st.A_last[i] = A[i]; }
+    for (int i = 0; i < 36; ++i) rec.information[i] = A[i];
   }
   if (go_on) gn_advance_initial(st);
   DVO_GN_CLK(6);                                             // record, A_last, inverse, product
