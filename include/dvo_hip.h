@@ -266,7 +266,7 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * the same normal equations bit for bit, the log-likelihood the same sum in another order),
  * "ll_blocks" (workgroups per pair of the log-likelihood pass, 1..32; 0 = by batch size),
  * "tail_speculation" (measurement: 1 = the step ahead of the host's poll is always enqueued, also on the tail of a level whose empty
- * step is costly; n >= 2 = "costly" means n workgroups or more per step; 0 = 131072),
+ * step is costly; n >= 2: costly means n workgroups or more per step; 0 = 131072),
  * "solver_waves" (wavefronts of a solver-step workgroup, 2 or 4; 0 = two on the smallest levels of a batch of more than two
  * workgroups per compute unit, four otherwise -- the records do not depend on it),
  * "min_workgroups" (tile-height heuristic: smallest launch that counts as filling the chip; 0 = built-in table),

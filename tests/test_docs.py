@@ -39,3 +39,16 @@ def test_reference_citations_stay_within_the_cited_files():
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "check_citations.py")], text=True)
     head = out.splitlines()[0]
     assert int(head.split()[0]) > 300 and "; 0 out of range" in head, out
+
+
+def test_every_option_and_counter_key_is_documented_in_the_header():
+    """include/dvo_hip.h names every key dvo_hip_set_option and dvo_hip_get_counter accept (the parser in capi.hip is the list)."""
+    src = open(os.path.join(ROOT, "dvo_slam_amd", "csrc", "capi.hip")).read()
+    header = open(os.path.join(ROOT, "include", "dvo_hip.h")).read()
+    documented = set(re.findall(r'"([a-z_0-9]+)"', header))
+    for entry in ("int dvo_hip_set_option(", "int dvo_hip_get_counter("):
+        begin = src.index(entry)
+        body = src[begin:src.index("\n}\n", begin)]
+        keys = set(re.findall(r'std::strcmp\(key, "([a-z_0-9]+)"\) == 0', body))
+        assert len(keys) >= 10, entry
+        assert not (keys - documented), "%s keys missing from include/dvo_hip.h: %s" % (entry, sorted(keys - documented))
