@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--no-from-host", action="store_true", help="skip the PCIe-inclusive leg (raw planes handed over in pinned host memory)")
     ap.add_argument("--no-ref-compat", action="store_true", help="skip the leg that repeats the timed loop with option ref_compat on")
     ap.add_argument("--no-scaling-model", action="store_true", help="skip the one-GPU step times at pairs/2, pairs/4, pairs/8 per step")
+    ap.add_argument("--no-guard-stress", action="store_true", help="skip the leg in which 1 %% of the pairs leave the f16 range of the Gram operands")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--resident-group", type=int, default=0, help="workgroups per pair in the resident match kernel (0 = as many as fit); "
                     "with --rows-per-wave: records that do not depend on the batch size")
@@ -122,6 +123,18 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 record path (process group, pinned staging, asynchronous all-gather, "
                     "drain) even with one rank: exercises the RCCL code path on a one-GPU box")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started as plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on a free
+        # local port -- and pass its exit code on.  Rank 0's JSON line is the only thing the ranks print on stdout.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
@@ -183,9 +196,12 @@ def main():
         ctx.set_option("resident", args.resident)
     if args.resident_rows:
         ctx.set_option("resident_rows", args.resident_rows)
+    base_variant = 8                                                   # the library's default sweep schedule (dvo_hip.h, option "variant")
     for kv in args.option:
         key, _, value = kv.partition("=")
         ctx.set_option(key, int(value))
+        if key == "variant":
+            base_variant = int(value)                                  # ... unless this run asks for another: every leg below runs on it
     if args.iters_per_sync:
         ctx.set_option("iters_per_sync", args.iters_per_sync)
     if not args.no_overlap:
@@ -288,16 +304,14 @@ def main():
     for v in (7, 6):
         ctx.set_option("variant", v)
         k_ms_variants[v] = tracker.time_residual_kernel(refs, curs, 0, reps=ROOFLINE_REPS, warm_iterations=3)
-    ctx.set_option("variant", 8)
+    ctx.set_option("variant", base_variant)                           # (what the run was started with, not a constant)
     stream_ms = tracker.time_stream_mix(refs, curs, 0, reps=10)                       # the same planes streamed in pixel order, read only
     stream_w_ms = tracker.time_stream_mix(refs, curs, 0, reps=10, with_write=True)   # ... plus the 8-B residual pair the sweep writes
     algo_bytes = ALGO_BYTES_PER_PIXEL * W * H * B
     achieved = algo_bytes / (k_ms[0] * 1e-3) / 1e9
     traffic = _pmc_traffic(B)
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                    traffic=traffic, kernel="dvo_hip::k_sweep_fast<2, false> (pyramid level 0, %d pairs per launch; 64 x 16 tiles, the current "
-                                            "frame's {I, Z} window staged in LDS, contracted f32 pixel arithmetic, Gram accumulation on the f16 "
-                                            "matrix pipe from exact hi + lo operand pairs)" % B,
+                    traffic=traffic, kernel=_kernel_label(base_variant, B),
                     kernel_ms=round(k_ms[0], 4), kernel_ms_is="mean of %d back-to-back launches (HIP events on the context stream)" % ROOFLINE_REPS,
                     kernel_ms_exact_arithmetic=round(k_ms_variants[7], 4), kernel_ms_f32_gram=round(k_ms_variants[6], 4),
                     frac_exact_arithmetic=round(algo_bytes / (k_ms_variants[7] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -389,7 +403,7 @@ def main():
         pipe.step(now=None, nxt=counter[0] % n_sets)      # (the sub-pipelines re-ingested some frames of the sets: restore the pipeline's state)
 
     # The reference-compatible mode (option "ref_compat": projection and weights multiply with the host CPU's _mm_rcp_ps like the reference's
-    # SSE path) on the same streaming loop: every level on the launch path, a table lookup per pixel
+    # SSE path) on the same streaming loop: the same schedule, two table lookups per pixel
     ref_compat = None
     if world == 1 and not args.no_ref_compat:
         ctx.set_option("ref_compat", 1)
@@ -405,9 +419,51 @@ def main():
         ref_compat = {"value": round(n_total * args.steps / el_c, 2), "unit": "alignments/s", "ms_per_step": round(el_c / args.steps * 1e3, 3),
                       "max_twist_error_vs_truth": float(np.abs(parallel.twists_of(last["T"]) - pairs_np["xi_true"]).max()),
                       "note": "the same HBM-resident loop with option ref_compat on (the opt-in mode whose trajectories follow the reference's own, "
-                              "DESIGN.md section 2); the finest-level sweep is then dvo_hip::k_sweep_window<true, true, 4>"}
+                              "DESIGN.md section 2); the finest-level sweep is then dvo_hip::k_sweep_fast<2, false, true, true>: the contracted window sweep with the "
+                              "host CPU's _mm_rcp_ps table in projection and weights (round 5; rounds 3-4: k_sweep_window<true, true, 4>, "
+                              "still the bit-exact anchor of the mode under option variant 7)"}
         ctx.set_option("ref_compat", 0)
         pipe.step(now=None, nxt=counter[0] % n_sets)
+
+    # The f16 range guard under load (round 5): 1 % of the pairs carry a depth step that no f16 Gram operand represents (2 mm / 10 m
+    # checkerboard, both frames) -- those pairs, and only those, are repeated with the f32 Gram as a batch of their own
+    guard_stress = None
+    if world == 1 and not args.no_guard_stress and B >= 8:
+        k_bad = max(1, B // 100)
+        bad = [int(round((j + 0.5) * B / k_bad)) for j in range(k_bad)]
+        yy, xx = np.mgrid[0:H, 0:W]
+        step_depth = np.where(((xx // 8) + (yy // 8)) % 2 == 0, 10, 50000).astype(np.uint16).view(np.int16)   # raw counts at 1/5000 m
+        step_dev = torch.from_numpy(step_depth).to(dev)
+        keep = [(i, depth[i].clone(), depth[B + i].clone(), grey[B + i].clone()) for i in bad]
+        for i in bad:
+            depth[i].copy_(step_dev)
+            depth[B + i].copy_(step_dev)
+            grey[B + i].copy_(grey[i])
+        torch.cuda.synchronize()
+        pipe.step(now=None, nxt=counter[0] % n_sets)
+        for j in range(2):
+            step()
+        barrier()
+        r0 = ctx.counter("f16_range_repeats")
+        t1 = time.perf_counter()
+        for j in range(args.steps):
+            step()
+        barrier()
+        el_g = time.perf_counter() - t1
+        guard_stress = {"pairs_out_of_range": k_bad, "ms_per_step": round(el_g / args.steps * 1e3, 3),
+                        "ratio_to_clean_step": round(el_g / elapsed, 4),
+                        "pairs_repeated_per_step": round((ctx.counter("f16_range_repeats") - r0) / args.steps, 2),
+                        "note": "the timed loop with %d of the %d pairs replaced by a 2 mm / 10 m depth checkerboard (Jacobian components beyond +-65504): "
+                                "the sweep raises the pair's word, the library repeats those pairs alone with the f32 Gram" % (k_bad, B)}
+        for i, dr, dc, gc in keep:
+            depth[i].copy_(dr)
+            depth[B + i].copy_(dc)
+            grey[B + i].copy_(gc)
+        torch.cuda.synchronize()
+        pipe.step(now=None, nxt=counter[0] % n_sets)
+        step()                                                          # (both frame sets hold the bench's own pairs again)
+        step()
+        barrier()
 
     # PCIe-inclusive leg (never `value`): the same pipeline, but every step's raw planes are handed over in pinned HOST memory
     # (SURVEY.md 8d config 4 "incl. H2D of 2 planes per frame") -- DMA on the upload stream, build on the build stream, match on
@@ -490,7 +546,10 @@ def main():
                                    "frame (= from_host.value, PCIe-bound, see from_host.roofline); `value` has the raw planes resident in HBM",
             "from_host": from_host,
             "ref_compat": ref_compat,
+            "f16_guard_stress": guard_stress,
             "scaling_model": scaling_model,
+            "config3": ("unmeasured: DVO_TUM_ROOT unset (no TUM RGB-D sequence on this box; tests/test_gpu_replay.py -k real replays one when it is)"
+                        if not os.environ.get("DVO_TUM_ROOT") else "DVO_TUM_ROOT=%s: see tests/test_gpu_replay.py -k real" % os.environ["DVO_TUM_ROOT"]),
             "max_twist_error_vs_truth": twist_err, "nan_results": nan_results,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -502,6 +561,16 @@ def main():
         if out is not None and args.force_gather:
             out["forced_gather"] = {"backend": args.backend, "world_size": world}
         print(json.dumps(out))
+
+
+def _kernel_label(variant, pairs):
+    """Name of the finest-level sweep kernel the schedule `variant` launches (launch_residual_reduce, align_common.h), as rocprofv3 prints it."""
+    names = {8: "dvo_hip::k_sweep_fast<2, false, true, false> (template arguments: operand stores without lane swaps, no partial tile column, "
+                "packed residual pairs, not the ref_compat arithmetic)", 9: "dvo_hip::k_sweep_fast<1, false, true, false>", 7: "dvo_hip::k_sweep_window<true, false, 4>",
+             6: "dvo_hip::k_sweep_window<false, false, 4>", 5: "dvo_hip::k_residual_reduce_mfma", 0: "dvo_hip::k_residual_reduce"}
+    what = ("64 x 16 tiles, the current frame's {I, Z} window staged in LDS, contracted f32 pixel arithmetic, Gram accumulation on the f16 matrix "
+            "pipe from exact hi + lo operand pairs") if variant >= 8 else "option variant=%d, see include/dvo_hip.h" % variant
+    return "%s (pyramid level 0, %d pairs per launch; %s)" % (names.get(variant, "variant %d" % variant), pairs, what)
 
 
 def _pmc_traffic(pairs):

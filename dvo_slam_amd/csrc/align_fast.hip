@@ -90,14 +90,39 @@ struct FastRow {                                        // what phase A leaves f
 __device__ __forceinline__ float fast_lerp(float p, float q, float t) { return fmaf(t, q - p, p); }
 __device__ __forceinline__ f32x2 fast_lerp2(f32x2 p, f32x2 q, f32x2 t) { return __builtin_elementwise_fma(t, q - p, p); }
 
+// The host CPU's _mm_rcp_ps from its table (pixel_math.h::rcp_like_the_host, option "ref_compat"): one 4-byte gather per lane through a
+// buffer resource over the 8-16 KB table (it lives in the vector L1 / L2), the exponent and the sign put back with integer arithmetic.
+__device__ __forceinline__ float fast_rcp_host(__amdgpu_buffer_rsrc_t table, int shift, float x) {
+  const unsigned b = __builtin_bit_cast(unsigned, x);
+  unsigned t = __builtin_amdgcn_raw_buffer_load_b32(table, ((b & 0x7fffffu) >> shift) << 2, 0, 0);     // rcp(1.m), in (0.5, 1]
+  t = (t + (0x3f800000u - (b & 0x7f800000u))) | (b & 0x80000000u);                                     // x 2^-(e - 127), sign of x
+  return __builtin_bit_cast(float, t);
+}
+
 // q = K T (tx z, ty z, z, 1) as z (KT.col0 tx + KT.col1 ty + KT.col2) + KT.col3 and u = qx rcp(qz), v = qy rcp(qz) (v_rcp_f32, 1 ulp).
 // c0..c2: the column's part of the bracket, fmaf(KT[4 i], tx, KT[4 i + 2]).  One instruction sequence for phase A and for the lanes that
 // look their tap corner up again (the checked path): the same bits.
-__device__ __forceinline__ void fast_project(const float* KT, float c0, float c1, float c2, float z, float ty, float& u, float& v, float& qz) {
+// COMPAT (option "ref_compat", the reference's u = x * _mm_rcp_ps(z), dense_tracking_impl.cpp:192): the reciprocal is the host CPU's
+// table value.  That is a STEP function of qz (2^11 - 2^12 steps per binade), so qz is formed in the reference's operation order
+// without contraction -- the very float the exact schedule and the oracle hand to the table, hence the same table entry -- while qx
+// and qy stay contracted: u and v then differ from the exact schedule's by the few ulp they do in the default mode, not by a table step.
+template <bool COMPAT>
+__device__ __forceinline__ void fast_project(const LevelGeom& g, __amdgpu_buffer_rsrc_t table, const float* KT, float c0, float c1, float c2, float z,
+                                             float tx, float ty, float& u, float& v, float& qz) {
   const float qx = fmaf(z, fmaf(KT[1], ty, c0), KT[3]);
   const float qy = fmaf(z, fmaf(KT[5], ty, c1), KT[7]);
-  qz = fmaf(z, fmaf(KT[9], ty, c2), KT[11]);
-  const float r = __builtin_amdgcn_rcpf(qz);
+  float r;
+  if constexpr (COMPAT) {
+    {
+#pragma clang fp contract(off)
+      const float X = tx * z, Y = ty * z;                     // rgbd_image.cpp:258; pixel_math.h::pixel_project_uv_flat
+      qz = (KT[8] * X + KT[9] * Y) + (KT[10] * z + KT[11]);
+    }
+    r = fast_rcp_host(table, g.rcp_shift, qz);
+  } else {
+    qz = fmaf(z, fmaf(KT[9], ty, c2), KT[11]);
+    r = __builtin_amdgcn_rcpf(qz);
+  }
   u = qx * r;
   v = qy * r;
 }
@@ -138,11 +163,14 @@ __device__ __forceinline__ void fast_fill_window(const LevelGeom& g, __amdgpu_bu
     if (interior) {
       // no clamping anywhere: one vector offset per thread, the row group's offset is a scalar
       const int voff = (y0 + rg) * row_bytes + (x0 + 2 * cxp) * 8;
+      // (the last round only has window rows for the first kFastRows - 24 row groups: the others ask past the end of the resource -- the
+      // scalar row offset is not range-checked, and rows y0 + 28, y0 + 29 may lie below the plane)
+      const int voff_last = rg + (kFastLoads - 1) * kFastRowGroups < kFastRows ? voff : 0x7ffffff0;
       f32x4 cell[kFastLoads];
 #pragma unroll
       for (int j = 0; j < kFastLoads; ++j)
         if (j * kFastRowGroups < wh)                                                              // (uniform)
-          cell[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(curC, voff, j * kFastRowGroups * row_bytes, 0));
+          cell[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(curC, j == kFastLoads - 1 ? voff_last : voff, j * kFastRowGroups * row_bytes, 0));
 #pragma unroll
       for (int j = 0; j < kFastLoads; ++j)
         if (j * kFastRowGroups < wh && rg + j * kFastRowGroups < kFastRows) dst[j * kFastRowGroups * (kFastPitch / 2)] = cell[j];
@@ -179,9 +207,10 @@ __device__ __forceinline__ void fast_fill_window(const LevelGeom& g, __amdgpu_bu
 // CHECKED: a tile whose projections spread beyond the window (a depth discontinuity under a large motion): lanes inside read the
 // window, the others fetch their cells from memory, coordinates clamped like the window's -- correct for any motion.  The tap corner
 // is not kept apart from the window index: it is projected again (tx, ty), the same instructions as in phase A.
-template <bool CHECKED>
-__device__ __forceinline__ void fast_fetch_cells(const LevelGeom& g, const float* KT, __amdgpu_buffer_rsrc_t curC, const float2* win, const FastWindow& wnd,
-                                                 int neg_base, const FastRow& r, bool ok, float tx, float ty, f32x2 (&P)[4][4], unsigned& n_fallback) {
+template <bool CHECKED, bool COMPAT>
+__device__ __forceinline__ void fast_fetch_cells(const LevelGeom& g, __amdgpu_buffer_rsrc_t table, const float* KT, __amdgpu_buffer_rsrc_t curC, const float2* win,
+                                                 const FastWindow& wnd, int neg_base, const FastRow& r, bool ok, float tx, float ty, f32x2 (&P)[4][4],
+                                                 unsigned& n_fallback) {
   // (volatile: twelve ds_read_b64, two LDS cycles each; the compiler otherwise pairs them into ds_read2_b64, eight cycles a pair)
   if constexpr (!CHECKED) {
     const int addr = (r.idx << 3) + neg_base;
@@ -193,7 +222,7 @@ __device__ __forceinline__ void fast_fetch_cells(const LevelGeom& g, const float
         if ((rr == 1 || rr == 2) || (cc == 1 || cc == 2)) P[rr][cc] = q[rr * kFastPitch + cc];
   } else {
     float pu, pv, pqz;
-    fast_project(KT, fmaf(KT[0], tx, KT[2]), fmaf(KT[4], tx, KT[6]), fmaf(KT[8], tx, KT[10]), r.z, ty, pu, pv, pqz);
+    fast_project<COMPAT>(g, table, KT, fmaf(KT[0], tx, KT[2]), fmaf(KT[4], tx, KT[6]), fmaf(KT[8], tx, KT[10]), r.z, tx, ty, pu, pv, pqz);
     const int u0 = int(pu), v0 = int(pv);
     const int cx = u0 - wnd.x0 - 1, cy = v0 - wnd.y0 - 1;
     const bool in_win = ok && unsigned(cx) <= unsigned(kFastCols - 4) && unsigned(cy) <= unsigned(kFastRows - 4);
@@ -311,12 +340,16 @@ __device__ __forceinline__ void fast_gram_row(float* my, int lane, const float (
 }
 
 // weights: sqrt(7 / (5 + r^T P r)) = c rsq(k + r^T P r); the first pass of a level (unit weights) rides the same code as 2 rsq(4 + 0)
+// COMPAT (option "ref_compat"): w = 7 * _mm_rcp_ps(5 + r^T P r) with the host CPU's table (dense_tracking_impl.cpp:700), its square
+// root through v_sqrt_f32; the first pass of a level has unit weights: w = 0 * rcp(5 + 0) + 1.
 struct FastWeights {
   float P00, P11, P2x, wk, wc;
+  float wm, wa;                                            // COMPAT: w = wm * rcp_host(arg) + wa
   __device__ __forceinline__ explicit FastWeights(const PairState& st) {
     const bool first = st.first != 0;
     P00 = first ? 0.0f : st.P_prev[0]; P11 = first ? 0.0f : st.P_prev[3]; P2x = first ? 0.0f : st.P_prev[1] + st.P_prev[2];
     wk = first ? 4.0f : 5.0f; wc = first ? 2.0f : 2.6457513110645906f;
+    wm = first ? 0.0f : 7.0f; wa = first ? 1.0f : 0.0f;
   }
 };
 
@@ -324,8 +357,8 @@ struct FastWeights {
 // off_v + scalar offset off_s), validity, weight, Jacobian at the untransformed point, Gram accumulation.  tx, ty, cx = 1 + tx^2:
 // normalised coordinates of the lane's reference pixel.
 // COMPACT (LevelGeom::compact): only a constraint's pair is stored, at the next free entry of the wavefront's slot (off_s: the slot).
-template <int STORE, bool COMPACT>
-__device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const f32x2 (&P)[4][4], const FastRow& r, unsigned long long ok_mask, float tx, float ty,
+template <int STORE, bool COMPACT, bool COMPAT>
+__device__ __forceinline__ void fast_row_tail(const LevelGeom& g, __amdgpu_buffer_rsrc_t table, const f32x2 (&P)[4][4], const FastRow& r, unsigned long long ok_mask, float tx, float ty,
                                               float cx, const FastWeights& wt, __amdgpu_buffer_rsrc_t resid, int off_v, int off_s, float* my, int lane,
                                               f32x4& acc0, f32x4& acc1, int& n_valid) {
   // separable blend (rows first): E_j = row j of the neighbourhood at the tap's column position; intensity / depth, TWICE the
@@ -358,7 +391,14 @@ __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const f32x2 (&
   }
   n_valid += __popcll(valid_mask);
   const float tq = fmaf(wt.P2x, r1, wt.P00 * r0);
-  const float sw_any = wt.wc * fast_rsqrt(fmaf(tq, r0, fmaf(wt.P11 * r1, r1, wt.wk)));
+  float sw_any;
+  if constexpr (COMPAT) {
+    // (a lane without a constraint may hold anything in r0 / r1: the table index is masked to the table by construction, its weight is dropped)
+    const float arg = fmaf(tq, r0, fmaf(wt.P11 * r1, r1, 5.0f));
+    sw_any = __builtin_amdgcn_sqrtf(fmaf(wt.wm, fast_rcp_host(table, g.rcp_shift, arg), wt.wa));
+  } else {
+    sw_any = wt.wc * fast_rsqrt(fmaf(tq, r0, fmaf(wt.P11 * r1, r1, wt.wk)));
+  }
   const float sw = valid ? sw_any : 0.0f;
   // gradient rows scaled by sqrt(w); a lane without a constraint has sw = 0 and every product in which one of its NaN terms meets
   // that zero is a LEGACY multiply (0 x anything = 0): no control flow on validity (an unfilled window cell may hold anything)
@@ -431,7 +471,7 @@ __device__ __forceinline__ void fast_count_fallbacks(unsigned long long* __restr
 // ===================================================================================================================================
 // variants 8 / 9: every pixel of the tile, one wavefront row = one image row of 64 pixels
 // ===================================================================================================================================
-template <int STORE, bool PARTIAL, bool COMPACT>
+template <int STORE, bool PARTIAL, bool COMPACT, bool COMPAT>
 __global__ __launch_bounds__(256, 5) void k_sweep_fast(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count, int* __restrict__ f16_range_flag) {
@@ -453,6 +493,9 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
                                                : __builtin_amdgcn_make_buffer_rsrc(scratch + size_t(pair) * size_t(g.w) * g.h, 0, plane_bytes, 0x00020000);
   // (rows below the image -- a level whose height is no multiple of 16 -- go to a resource of no bytes: no branch around the store)
   const __amdgpu_buffer_rsrc_t resid_none = __builtin_amdgcn_make_buffer_rsrc(scratch, 0, 0, 0x00020000);
+  // (option "ref_compat": the host CPU's reciprocal table, 2^(23 - shift) floats; a resource of no bytes otherwise, never read)
+  const __amdgpu_buffer_rsrc_t rcp_table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(COMPAT ? g.rcp_table : nullptr), 0,
+                                                                             COMPAT ? (4 << (23 - g.rcp_shift)) : 0, 0x00020000);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned gram_entries = kGramEntryTable.e[min(int(threadIdx.x), kNumAcc - 1)];
   // A level whose width is no multiple of 64 (160 x 120): the last tile column hangs over the right edge.  Its lanes beyond the image
@@ -507,7 +550,7 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
       const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ie, ic, 0x138, 0xf, 0xf, false));    // wave_shr:1
       const float z = zv[k];
       float u, v, qz;
-      fast_project(st.KT, c0, c1, c2, z, ty_rows[k], u, v, qz);
+      fast_project<COMPAT>(g, rcp_table, st.KT, c0, c1, c2, z, tx_u, ty_rows[k], u, v, qz);
       // 0 <= u <= w - 2 on the integer image of the float: negative numbers and NaNs (sign or exponent bits) compare above every
       // non-negative bound (Q4; a hole's NaN depth fails here, Q19).  -0.0f fails too -- one float out of 2^32.
       const unsigned long long ok_mask = v_r < g.h ? __builtin_amdgcn_ballot_w64(__builtin_bit_cast(unsigned, u) <= w2_bits) &
@@ -550,11 +593,11 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
     constexpr bool CHECKED = decltype(checked_tag)::value;
     const int v_r = row0 + k * 4;
     f32x2 P[4][4];
-    fast_fetch_cells<CHECKED>(g, st.KT, curC, win, wnd, neg_base, rs[k], __builtin_amdgcn_inverse_ballot_w64(ok_row[k]), tx_u, ty_rows[k], P, n_fallback);
+    fast_fetch_cells<CHECKED, COMPAT>(g, rcp_table, st.KT, curC, win, wnd, neg_base, rs[k], __builtin_amdgcn_inverse_ballot_w64(ok_row[k]), tx_u, ty_rows[k], P, n_fallback);
     if constexpr (COMPACT)
-      fast_row_tail<STORE, true>(g, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, resid, 0, (tile * kCompactTileEntries + wave * kCompactWaveEntries) * 8, my, lane, acc0, acc1, n_valid);
+      fast_row_tail<STORE, true, COMPAT>(g, rcp_table, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, resid, 0, (tile * kCompactTileEntries + wave * kCompactWaveEntries) * 8, my, lane, acc0, acc1, n_valid);
     else
-      fast_row_tail<STORE, false>(g, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_store, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
+      fast_row_tail<STORE, false, COMPAT>(g, rcp_table, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_store, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
   };
   if (wnd.all_in) {                                            // (uniform)
 #pragma unroll
@@ -571,7 +614,7 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
   }
   if (lane == 0) counts[wave] = n_valid;
   __syncthreads();
-  fast_epilogue(slab, counts, gram_entries, partials + (size_t(pair) * tiles + tile) * kAccStride, f16_range_flag);
+  fast_epilogue(slab, counts, gram_entries, partials + (size_t(pair) * tiles + tile) * kAccStride, f16_range_flag ? f16_range_flag + pair : nullptr);   // (one word per pair)
   if (fallback_count && !wnd.all_in) fast_count_fallbacks(fallback_count, n_fallback, lane);
 }
 
@@ -580,7 +623,7 @@ bool fast_sweep_takes_width(int w) { return w >= kFastCols && w % 2 == 0; }
 bool fast_sweep_supports(const LevelGeom& g) {
   // (a pair's planes and its residual buffer are addressed through 32-bit buffer offsets: 2 GB each at most -- a 16 384 x 16 384 level)
   const long long plane_bytes = 8ll * g.w * g.h, packed_bytes = 8ll * kCompactTileEntries * g.tiles_x * g.tiles_y;
-  return !g.linear && fast_sweep_takes_width(g.w) && g.w < 32768 && g.h < 32768 && plane_bytes < (1ll << 31) && packed_bytes < (1ll << 31) && !g.rcp_table;
+  return !g.linear && fast_sweep_takes_width(g.w) && g.w < 32768 && g.h < 32768 && plane_bytes < (1ll << 31) && packed_bytes < (1ll << 31);
 }
 
 void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
@@ -589,20 +632,23 @@ void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const Pai
   const int per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(256);
   const bool partial = g.w % kTileW != 0, compact = g.compact != 0;
-  auto go = [&](auto store_tag, auto partial_tag, auto compact_tag) {
-    k_sweep_fast<decltype(store_tag)::value, decltype(partial_tag)::value, decltype(compact_tag)::value>
+  auto go = [&](auto store_tag, auto partial_tag, auto compact_tag, auto compat_tag) {
+    k_sweep_fast<decltype(store_tag)::value, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value>
         <<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
   };
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
   using T = std::true_type;
   using F = std::false_type;
-  if (variant == 8) {
-    if (compact) { if (partial) go(S2{}, T{}, T{}); else go(S2{}, F{}, T{}); }
-    else { if (partial) go(S2{}, T{}, F{}); else go(S2{}, F{}, F{}); }
+  if (g.rcp_table) {                                           // option "ref_compat": the host's reciprocal table in projection and weights
+    if (compact) { if (partial) go(S2{}, T{}, T{}, T{}); else go(S2{}, F{}, T{}, T{}); }
+    else { if (partial) go(S2{}, T{}, F{}, T{}); else go(S2{}, F{}, F{}, T{}); }
+  } else if (variant == 8) {
+    if (compact) { if (partial) go(S2{}, T{}, T{}, F{}); else go(S2{}, F{}, T{}, F{}); }
+    else { if (partial) go(S2{}, T{}, F{}, F{}); else go(S2{}, F{}, F{}, F{}); }
   } else {
-    if (compact) { if (partial) go(S1{}, T{}, T{}); else go(S1{}, F{}, T{}); }
-    else { if (partial) go(S1{}, T{}, F{}); else go(S1{}, F{}, F{}); }
+    if (compact) { if (partial) go(S1{}, T{}, T{}, F{}); else go(S1{}, F{}, T{}, F{}); }
+    else { if (partial) go(S1{}, T{}, F{}, F{}); else go(S1{}, F{}, F{}, F{}); }
   }
 }
 

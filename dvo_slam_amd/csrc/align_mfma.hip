@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
   // (the wavefront is done with its slab: its Gram matrix goes into the first 256 floats)
   for (int i = 0; i < 4; ++i)
     if (!F16) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
-  if constexpr (F16) gram_f16_finish(my, lane, acc0, acc1, f16_range_flag);
+  if constexpr (F16) gram_f16_finish(my, lane, acc0, acc1, f16_range_flag ? f16_range_flag + pair : nullptr);   // (one word per pair)
   if (lane == 0) counts[wave] = n_valid;
   __syncthreads();
   // fold the four wavefront Gram matrices into the canonical partial row (device_types.h); vector layout:

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
   }
 
   if constexpr (F16) {
-    gram_f16_finish(my, lane, acc0, acc1, f16_range_flag);
+    gram_f16_finish(my, lane, acc0, acc1, f16_range_flag ? f16_range_flag + pair : nullptr);   // (one word per pair)
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) my[((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc0[i] + acc1[i];

@@ -203,7 +203,8 @@ struct Workspace {
   hipStream_t stream = nullptr;
   DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters;
   DevBuf win_fallbacks;          // one 64-bit counter: lanes of the window sweep whose taps were fetched from memory (align_window.hip)
-  int* f16_range_flag = nullptr; // pinned: raised by a workgroup of the f16 Gram schedule whose Jacobian left the f16 range (align_window.hip)
+  int* f16_range_flag = nullptr; // pinned, one word per pair of the batch: raised by a workgroup of the f16 Gram schedule whose Jacobian left the f16 range (gram_f16.h)
+  size_t f16_range_words = 0;
   PinnedRing* tables = nullptr;  // the context's ring for small uploads
   int* host_status = nullptr;    // pinned: one word per Gauss-Newton step of a batch, written by the device (k_solver_step)
   size_t host_status_words = 0;
@@ -379,6 +380,7 @@ void workspace_destroy(Workspace& w) {
   w.host_status_words = 0;
   if (w.f16_range_flag) (void)hipHostFree(w.f16_range_flag);
   w.f16_range_flag = nullptr;
+  w.f16_range_words = 0;
   for (PinnedBuf* b : {&w.direct_results, &w.direct_levels, &w.direct_iters, &w.direct_done}) b->release();
   (void)hipStreamDestroy(w.stream);
   w.created = false;
@@ -499,7 +501,7 @@ void level_tiles(int w, int h, int rows_per_wave, bool linear, int* tiles_x, int
 
 // the contracted window sweep (align_fast.hip, variants 8 / 9) also takes widths that are no multiple of its 64 columns (160 x 120)
 bool level_uses_fast_window(const dvo_hip_context* ctx, int w, int h) {
-  return ctx->opt_variant >= 8 && !ctx->opt_ref_compat && fast_sweep_takes_width(w) && w < 32768 && h < 32768;
+  return ctx->opt_variant >= 8 && fast_sweep_takes_width(w) && w < 32768 && h < 32768;   // (option "ref_compat" included: the COMPAT instantiations)
 }
 
 bool level_is_linear(const dvo_hip_context* ctx, int w) { return ctx->opt_variant >= 5 && w % kTileW != 0 && !level_uses_fast_window(ctx, w, 4); }
@@ -965,9 +967,19 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
     DVO_WS_TRY(w, w.win_fallbacks.reserve(64));
     DVO_WS_TRY(w, hipMemsetAsync(w.win_fallbacks.p, 0, 64, w.stream));
   }
-  if (!w.f16_range_flag) {
-    DVO_WS_TRY(w, hipHostMalloc(reinterpret_cast<void**>(&w.f16_range_flag), 64, hipHostMallocCoherent | hipHostMallocMapped));
-    *w.f16_range_flag = 0;
+  if (w.f16_range_words < size_t(n)) {
+    // (the words are only ever written by sweeps of a batch that is over by the time the next one is prepared: a larger array can
+    // replace the old one here once the stream has drained)
+    if (w.f16_range_flag) {
+      DVO_WS_TRY(w, hipStreamSynchronize(w.stream));
+      (void)hipHostFree(w.f16_range_flag);
+      w.f16_range_flag = nullptr;
+      w.f16_range_words = 0;
+    }
+    const size_t words = std::max<size_t>(64, size_t(n));
+    DVO_WS_TRY(w, hipHostMalloc(reinterpret_cast<void**>(&w.f16_range_flag), words * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset(w.f16_range_flag, 0, words * sizeof(int));
+    w.f16_range_words = words;
   }
   std::vector<PairPtrs>& host = bp.host_ptrs;
   host.assign(size_t(n) * need_levels, PairPtrs());
@@ -1231,22 +1243,12 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     if (!g_trace_ev[0]) { (void)hipEventCreate(&g_trace_ev[0]); (void)hipEventCreate(&g_trace_ev[1]); }
     (void)hipEventRecord(g_trace_ev[0], s);
   }
-  // The Gram schedule of this batch.  The default accumulates on the f16 matrix pipe from exact high + low operand pairs, which cannot
-  // represent a Jacobian component beyond +-65504; a batch that meets one is repeated with the f32 Gram (below).  Two cases take the
-  // f32 Gram from the start: option "deterministic" (a pair's bits must not depend on whether ANOTHER pair of its batch left the f16
-  // range), and the batches right after a repeat (a sequence with a close depth step would otherwise pay twice on every frame).
+  // (the Gram schedule of the batch -- f16 high + low operand pairs or f32 -- was decided by the caller, effective_variant_scope; what
+  // this function changes for a repeat is undone when it returns)
   struct VariantScope {
     dvo_hip_context* c; int keep;
     ~VariantScope() { c->opt_variant = keep; }
   } variant_scope{ctx, ctx->opt_variant};
-  if (ctx->opt_variant >= 7 && (ctx->opt_deterministic || ctx->f32_gram_hold > 0)) {
-    if (ctx->f32_gram_hold > 0) ctx->f32_gram_hold -= 1;
-    ctx->opt_variant = 6;
-    // (the roles were ensured for the schedule the options name: the f32 one reads levels whose width is no multiple of 64 through
-    // the taps A + B where the contracted window sweep reads plane C)
-    const int rc_roles = ensure_batch_roles(ctx, n, refs, curs, cfg);
-    if (rc_roles != DVO_HIP_OK) return rc_roles;
-  }
   BatchPlan bp;
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
   // The coarse levels -- for a small batch every level -- run inside ONE launch (align_resident.hip): no launch per iteration, no
@@ -1450,11 +1452,20 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     ctx->opt_resident = keep;
     return rc;
   }
-  if (*static_cast<volatile int*>(w.f16_range_flag) != 0) {
-    // A Jacobian component of some pixel was beyond +-65504: the f16 high / low split of the Gram operands (variant 7) does not
-    // represent it.  The batch runs again with the f32 Gram of the same sweep (variant 6: same planes, same tiles).
-    *static_cast<volatile int*>(w.f16_range_flag) = 0;
-    ctx->f16_range_repeats += 1;
+  // Pairs in which a Jacobian component of some pixel was beyond +-65504: the f16 high / low split of the Gram operands (variants 7-9)
+  // does not represent it, the sweep's epilogue has raised the pair's word.  Those pairs run again with the f32 Gram of the same sweep
+  // family (variant 6): the whole batch when most of it is concerned (one chain of launches either way; the batches that follow then
+  // start on the f32 Gram, kF32GramHoldBatches), otherwise ONLY the flagged pairs, as a batch of their own, behind the copy-out below
+  // (round 5: a single close depth step used to repeat all 1024 pairs of a batch).
+  std::vector<int> out_of_range;
+  if (ctx->opt_variant >= 7)
+    for (int i = 0; i < n; ++i)
+      if (static_cast<volatile int*>(w.f16_range_flag)[i] != 0) {
+        static_cast<volatile int*>(w.f16_range_flag)[i] = 0;
+        out_of_range.push_back(i);
+      }
+  if (!out_of_range.empty() && out_of_range.size() * 2 >= size_t(n)) {
+    ctx->f16_range_repeats += (long long)out_of_range.size();
     ctx->f32_gram_hold = kF32GramHoldBatches;
     for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, &tinit[size_t(i) * 16], 16 * sizeof(double));
     ctx->opt_variant = 6;                                      // (restored by variant_scope)
@@ -1485,12 +1496,59 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     ctx->host_batches += 1;
   }
   w.needs_drain = false;
+  if (!out_of_range.empty()) {
+    // the flagged pairs again, f32 Gram, as a batch of their own; their records replace the ones just copied out
+    const int m = int(out_of_range.size());
+    ctx->f16_range_repeats += m;
+    std::vector<dvo_hip_frame*> r2(m), c2(m);
+    std::vector<dvo_hip_result> res2(m);
+    for (int k = 0; k < m; ++k) {
+      const int i = out_of_range[k];
+      r2[k] = refs[i];
+      c2[k] = curs[i];
+      res2[k] = results[i];
+      std::memcpy(res2[k].transformation, &tinit[size_t(i) * 16], 16 * sizeof(double));
+    }
+    const bool want_l = levels && cap_levels > 0, want_i = iters && cap_iters > 0;
+    std::vector<dvo_hip_level_stats> l2(want_l ? size_t(m) * cap_levels : 0);
+    std::vector<dvo_hip_iteration_stats> i2(want_i ? size_t(m) * cap_iters : 0);
+    ctx->opt_variant = 6;                                      // (restored by variant_scope)
+    rc = ensure_batch_roles(ctx, m, r2.data(), c2.data(), cfg);
+    if (rc == DVO_HIP_OK)
+      rc = run_batch(ctx, m, r2.data(), c2.data(), cfg, res2.data(), want_l ? l2.data() : nullptr, cap_levels, want_i ? i2.data() : nullptr, cap_iters);
+    if (rc != DVO_HIP_OK && rc != DVO_HIP_ERR_CAPACITY) return rc;
+    truncated |= rc == DVO_HIP_ERR_CAPACITY;
+    for (int k = 0; k < m; ++k) {
+      const int i = out_of_range[k];
+      results[i] = res2[k];
+      if (want_l) std::memcpy(levels + size_t(i) * cap_levels, l2.data() + size_t(k) * cap_levels, size_t(cap_levels) * sizeof(dvo_hip_level_stats));
+      if (want_i) std::memcpy(iters + size_t(i) * cap_iters, i2.data() + size_t(k) * cap_iters, size_t(cap_iters) * sizeof(dvo_hip_iteration_stats));
+    }
+  }
   if (truncated) {
     w.err = "match: statistics arrays too small (results are valid)";
     return DVO_HIP_ERR_CAPACITY;
   }
   return DVO_HIP_OK;
 }
+
+// The Gram schedule of a batch, decided ONCE, before the planes of the roles are prepared for it (round-4 advisor finding: deciding it
+// inside run_batch prepared two flavours of the current role for every new frame).  The default accumulates on the f16 matrix pipe
+// from exact high + low operand pairs, which cannot represent a Jacobian component beyond +-65504; pairs that meet one are repeated
+// with the f32 Gram (run_batch).  Two cases take the f32 Gram from the start: option "deterministic" (a pair's bits must not depend
+// on whether ANOTHER pair of its batch left the f16 range), and the batches right after a batch MOST of whose pairs left it (a
+// tracking sequence with a close depth step would otherwise pay twice on every frame; this makes the arithmetic of those batches
+// depend on the context's history -- documented in dvo_hip.h, reset by option "variant").
+struct EffectiveVariantScope {
+  dvo_hip_context* c; int keep;
+  explicit EffectiveVariantScope(dvo_hip_context* ctx) : c(ctx), keep(ctx->opt_variant) {
+    if (c->opt_variant >= 7 && (c->opt_deterministic || c->f32_gram_hold > 0)) {
+      if (c->f32_gram_hold > 0) c->f32_gram_hold -= 1;
+      c->opt_variant = 6;
+    }
+  }
+  ~EffectiveVariantScope() { c->opt_variant = keep; }
+};
 
 // preparation for the parity / measurement entry points
 int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg, BatchPlan& bp) {
@@ -1703,6 +1761,7 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     if (value != 0 && (value < 5 || value > 9))
       return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0 (all-VALU schedule), 5 (matrix-core schedule), 6 or 7 (current-frame window staged in LDS, residuals bit-identical to the oracle's), 8 or 9 (the same with contracted arithmetic)");
     ctx->opt_variant = value;
+    ctx->f32_gram_hold = 0;                                    // (a schedule asked for by name starts without history)
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "rendezvous") == 0) {
@@ -2145,6 +2204,7 @@ int dvo_hip_match_batch(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const*
           return fail(ctx, DVO_HIP_ERR_INVALID, "match: provided initialization is NaN (dense_tracking.cpp:139)");
   ctx->batch_entry = std::chrono::steady_clock::now();
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  EffectiveVariantScope effective_variant_scope(ctx);
   rc = ensure_batch_roles(ctx, n_pairs, references, currents, cfg);
   if (rc != DVO_HIP_OK) return rc;
 

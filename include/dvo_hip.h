@@ -283,7 +283,10 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * the reference's SSE path does (dvo_core/src/dense_tracking_impl.cpp:192, :700), instead of dividing exactly -- the one quirk of the
  * reference that separates its trajectories from the exact arithmetic's; the instruction is dumped into a table
  * when the option is first switched on; the latency path (option "resident") carries the same arithmetic; also switched on by the environment variable
- * DVO_HIP_REF_COMPAT=1 when a context is created; default 0),
+ * DVO_HIP_REF_COMPAT=1 when a context is created; default 0.  The schedules keep their meaning in this mode: under "variant" 8 (the
+ * default) the contracted window sweep runs with the table in place of v_rcp_f32 -- residuals within 2e-5 of the oracle's MATH + Q1
+ * mode, the same constraints except at pixels on a bound; under "variant" 7 residuals and constraint counts equal that oracle mode
+ * bit for bit),
  * "resident" (-1 default: small batches and coarse levels run in ONE launch per match, each pair owned by a group of resident
  * workgroups -- the latency path; 0: one to three launches per Gauss-Newton step always; 1: every level
  * resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
@@ -303,8 +306,13 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
  * "resident_timeouts" (batches repeated on the launch-per-step path because a workgroup group of the resident kernel waited
  * in vain for its peers -- the device was shared with another such kernel; the results are those of the repeat),
  * "window_fallbacks" (lanes of the window sweep whose bilinear taps fell outside the staged window and were fetched from memory),
- * "f16_range_repeats" (batches that ran a second time with the f32 Gram because a Jacobian component of some pixel was beyond the f16
- * range of the default schedule's matrix operands, +-65504: depth steps of metres right in front of the camera),
+ * "f16_range_repeats" (PAIRS that ran a second time with the f32 Gram because a Jacobian component of some pixel was beyond the f16
+ * range of the default schedule's matrix operands, +-65504: depth steps of metres right in front of the camera.  Only the pairs
+ * concerned are repeated, as a batch of their own -- unless they are half of the batch or more: then the whole batch is, and the 32
+ * batches that follow on this context start on the f32 Gram (a tracking sequence that keeps meeting such a step does not pay twice
+ * per frame).  That hold makes the arithmetic of those batches -- f32 instead of f16 hi + lo Gram operands, 1e-6 apart in the
+ * normal equations -- depend on what the context aligned before; setting option "variant" clears it, option "deterministic" never
+ * enters it),
  * "rendezvous_pairs" (two-pair batches formed from concurrent single matches, see option "rendezvous"),
  * "strip_ingests" (frames whose raw planes went through the strip ingest, one 128 x 8 strip per wavefront -- even-width rows and
  * 4 / 8-byte aligned planes; the others take the tile kernel),

@@ -107,6 +107,88 @@ def test_single_linearisation_against_oracle(gpu_ctx, w, h, level):
     gpu_ctx.set_option("variant", DEFAULT_VARIANT)
 
 
+@pytest.mark.parametrize("w,h,level", [(640, 480, 0), (640, 480, 1), (640, 480, 2), (640, 480, 3), (160, 120, 0), (1280, 960, 0),
+                                       # ragged: a tile column of two lanes and a tile row of two rows; an odd width (gathering sweep
+                                       # with the contracted arithmetic); a level narrower than the window sweep takes
+                                       (258, 194, 0), (131, 97, 0), (200, 64, 0), (80, 60, 0)])
+def test_default_schedule_single_linearisation_against_oracle(gpu_ctx, w, h, level):
+    """The schedule that SHIPS (variant 8: contracted arithmetic, v_rcp_f32 projection, f16 hi + lo Gram, packed residual pairs) against
+    the oracle's MATH mode DIRECTLY -- not through the exact schedule (test_contracted_sweep_against_the_exact_one) -- for one
+    linearisation (dense_tracking.cpp:271-343: residual pass, weights, scale, log-likelihood, normal equations), first pass (unit
+    weights) and a second pass (t-distribution weights of the first pass' precision).  Stated and asserted:
+      * constraints: the same set except at pixels whose tap coordinate sits on a bound (<= 1e-4 of them, at least 1 allowed);
+      * residuals of common constraints: |dr_I| <= 2e-5, |dr_Z| <= 4e-6 m;
+      * P, A, b: 1e-5 relative to the largest entry (+ what the flipped constraints can carry: each at most 20 / n of the sums);
+      * -ll: 2e-5 relative."""
+    pair = cm.synth(23, w, h)
+    levels = level + 1
+    oref, ocur = cm.oracle_pyramids(pair, levels)
+    gref, gcur = gpu_pyramids(gpu_ctx, pair, levels)
+    trk = d.DenseTracker(d.Config(FirstLevel=level, LastLevel=level), gpu_ctx)
+    gpu_ctx.set_option("rows_per_wave", 0)
+    gpu_ctx.set_option("variant", DEFAULT_VARIANT)
+    T34 = po.se3_exp(np.array([0.004, -0.003, 0.002, 0.005, -0.004, 0.003]))[:3]
+    P_prev = None
+    for first in (True, False):
+        o = po.level_iteration(oref, ocur, level, T34, P_prev=P_prev, first=first, mode=po.MATH, want_residuals=True)
+        g = trk.level_iteration(gref, gcur, level, T34, P_prev=P_prev, first=first, want_residuals=True)
+        ro, rg = o["residuals"].reshape(-1, 2), g["residuals"].reshape(-1, 2)
+        vo, vg = ~np.isnan(ro[:, 0]), ~np.isnan(rg[:, 0])
+        flipped = int((vo != vg).sum())
+        both = vo & vg
+        d0 = float(np.abs(ro[both, 0] - rg[both, 0]).max())
+        d1 = float(np.abs(ro[both, 1] - rg[both, 1]).max())
+        relP = np.abs(g["P"] - o["P"]).max() / np.abs(o["P"]).max()
+        relA = np.abs(g["A"] - o["A"]).max() / np.abs(o["A"]).max()
+        relb = np.abs(g["b"] - o["b"]).max() / np.abs(o["b"]).max()
+        rell = abs(g["neg_ll"] - o["neg_ll"]) / abs(o["neg_ll"])
+        print("%dx%d level %d first=%d: n %d vs oracle %d, %d flipped, |dr_I| %.2e |dr_Z| %.2e, P %.1e A %.1e b %.1e -ll %.1e"
+              % (w, h, level, first, g["n"], o["n"], flipped, d0, d1, relP, relA, relb, rell))
+        assert g["n_selected"] == o["n_selected"] and g["n"] == int(vg.sum()) and o["n"] > 0.2 * (w >> level) * (h >> level)
+        assert flipped <= max(1, int(1e-4 * o["n"]))
+        assert d0 <= 2e-5 and d1 <= 4e-6
+        slack = 20.0 * flipped / o["n"]
+        assert relP <= 1e-5 + slack and relA <= 1e-5 + slack and relb <= 1e-5 + slack and rell <= 2e-5 + slack
+        assert np.array_equal(g["A"], g["A"].T)
+        P_prev = o["P"]
+
+
+def test_default_schedule_finest_level_records_against_the_reference(gpu_ctx):
+    """BASELINE config 2 (one 640 x 480 pair, levels 3 -> 0) on the default schedule: EVERY iteration record of the finest level
+    against the records of the reference's own DenseTracker::match() (oracle/_ref: dvo_core's translation units compiled in place)
+    on the same frames.  The two run different arithmetic by design (the reference: _mm_rcp_ps, round-toward-zero, odd-N drop, LL
+    tail), and the level starts from coarser-level results that already differ by that distance, so the bounds
+    are the quirk distance, stated per quantity: constraints within 2 %, precision within 2 %, increments within 3e-4 over the
+    common passes, the level's summed increment within 5e-5, at most 2 passes more or fewer, final transforms within 5e-5."""
+    if po.ref_lib() is None:
+        pytest.skip("oracle/_ref is not built (no /root/reference here and no prebuilt library)")
+    pair = cm.synth(1234, 640, 480)
+    gref, gcur = gpu_pyramids(gpu_ctx, pair, 4)
+    cfg = d.Config(FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7)
+    gpu_ctx.set_option("variant", DEFAULT_VARIANT)
+    g = run_gpu_match(gpu_ctx, gref, gcur, cfg)
+    r = po.ref_match(pair["grey_ref"].astype(np.float32), po.convert_raw_depth(pair["depth_ref"]),
+                     pair["grey_cur"].astype(np.float32), po.convert_raw_depth(pair["depth_cur"]), pair["K"],
+                     cm.oracle_config_from(cfg, po.REF_SSE))
+    Lg, Lr = g["levels"][-1], r["levels"][-1]
+    assert Lg["id"] == 0 and Lr["id"] == 0 and Lg["valid_pixels"] == Lr["valid_pixels"]
+    ig, ir = Lg["iterations"], Lr["iterations"]
+    print("finest level: %d passes on the engine, %d in the reference; terminations %d / %d" % (len(ig), len(ir), Lg["termination"], Lr["termination"]))
+    assert abs(len(ig) - len(ir)) <= 2
+    worst = dict(n=0.0, P=0.0, x=0.0)
+    for a, b in zip(ig, ir):
+        worst["n"] = max(worst["n"], abs(a["n"] - b["n"]) / b["n"])
+        worst["P"] = max(worst["P"], np.abs(a["precision"] - b["precision"]).max() / np.abs(b["precision"]).max())
+        if np.all(np.isfinite(a["x"])) and np.all(np.isfinite(b["x"])):
+            worst["x"] = max(worst["x"], float(np.abs(a["x"] - b["x"]).max()))
+    sum_g = sum(i["x"] for i in ig if np.all(np.isfinite(i["x"])))
+    sum_r = sum(i["x"] for i in ir if np.all(np.isfinite(i["x"])))
+    print("worst over the common passes: n %.2e, P %.2e, x %.2e; summed increments differ by %.2e; final twist distance %.2e"
+          % (worst["n"], worst["P"], worst["x"], np.abs(sum_g - sum_r).max(), cm.twist_matrix_error(g["T"], r["T"])))
+    assert worst["n"] <= 2e-2 and worst["P"] <= 2e-2 and worst["x"] <= 3e-4
+    assert cm.twist_matrix_error(g["T"], r["T"]) < 5e-5
+
+
 @pytest.mark.parametrize("w,h,xi", [(640, 480, [0.004, -0.003, 0.002, 0.006, -0.004, 0.003]), (320, 240, [0.02, 0.01, -0.015, -0.02, 0.025, 0.03]),
                                     (640, 480, [0.05, -0.04, 0.03, 0.05, 0.04, -0.06]), (128, 96, [0, 0, 0, 0, 0, 0]), (64, 48, [0.01, 0, 0, 0, 0.01, 0]),
                                     (640, 480, [0.3, -0.2, 0.1, 0.2, 0.3, -0.4]), (192, 80, [-0.05, 0.08, 0.02, 0.1, -0.1, 0.2])])
@@ -437,6 +519,63 @@ def test_f16_gram_range_guard_repeats_with_the_f32_gram(w, h):
     a, b = cam.create(grey, depth2), cam.create(grey, depth2)
     d.DenseTracker(d.Config(FirstLevel=0, LastLevel=0, MaxIterationsPerLevel=3), ctx).match_batch_arrays([a], [b])
     assert ctx.counter("f16_range_repeats") == 0
+
+
+def test_f16_gram_range_guard_repeats_only_the_pairs_concerned():
+    """Round 5: the guard is per PAIR.  A batch of eight pairs, one of which carries a depth step that leaves the f16 range: only that
+    pair runs again (f32 Gram, a batch of its own) -- the counter moves by one, its record is the f32 schedule's record of that pair bit
+    for bit, the seven others keep the records they have in a batch without it, and the batch that follows starts on the f16 schedule
+    again (no hold: most of the batch was in range).  Statistics travel with the replaced record."""
+    w, h, n, bad = 128, 96, 8, 5
+    b = datagen.synth_batch(11, n, w, h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    step = np.where(((xx // 8) + (yy // 8)) % 2 == 0, 0.002, 10.0).astype(np.float32)
+    cfg = d.Config(FirstLevel=0, LastLevel=0, MaxIterationsPerLevel=3)
+
+    def frames(ctx, with_bad):
+        cam = d.RgbdCameraPyramid(w, h, b["K"], ctx)
+        cam.build(1)
+        refs, curs = [], []
+        for i in range(n):
+            g_r, g_c = b["grey_ref"][i].astype(np.float32), b["grey_cur"][i].astype(np.float32)
+            z_r, z_c = po.convert_raw_depth(b["depth_ref"][i]), po.convert_raw_depth(b["depth_cur"][i])
+            if with_bad and i == bad:
+                g_c, z_r, z_c = g_r, step, step
+            refs.append(cam.create(g_r, z_r))
+            curs.append(cam.create(g_c, z_c))
+        return refs, curs
+
+    ctx = d.Context(0)
+    ctx.set_option("resident", 0)
+    refs, curs = frames(ctx, True)
+    res = [d.Result() for _ in range(n)]
+    trk = d.DenseTracker(cfg, ctx)
+    trk.match_batch(refs, curs, res, with_stats=True)
+    assert ctx.counter("f16_range_repeats") == 1
+    trk.match_batch(refs[:bad], curs[:bad], [d.Result() for _ in range(bad)])          # an ordinary batch next: f16 again, no repeat
+    assert ctx.counter("f16_range_repeats") == 1
+    # the pair concerned, alone, on the f32 schedule
+    c6 = d.Context(0)
+    c6.set_option("resident", 0)
+    c6.set_option("variant", 6)
+    r6, k6 = frames(c6, True)
+    one = d.Result()
+    d.DenseTracker(cfg, c6).match(r6[bad], k6[bad], one)
+    assert np.array_equal(res[bad].Transformation, one.Transformation) and np.array_equal(res[bad].Information, one.Information, equal_nan=True)
+    assert [len(L.Iterations) for L in res[bad].Statistics.Levels] == [len(L.Iterations) for L in one.Statistics.Levels]
+    for Ia, Ib in zip(res[bad].Statistics.Levels[0].Iterations, one.Statistics.Levels[0].Iterations):
+        assert Ia.ValidConstraints == Ib.ValidConstraints and np.array_equal(Ia.EstimateIncrement, Ib.EstimateIncrement, equal_nan=True)
+    # the others: what they are in a batch without the pair
+    c8 = d.Context(0)
+    c8.set_option("resident", 0)
+    r8, k8 = frames(c8, False)
+    clean = [d.Result() for _ in range(n)]
+    d.DenseTracker(cfg, c8).match_batch(r8, k8, clean, with_stats=True)
+    assert c8.counter("f16_range_repeats") == 0
+    for i in range(n):
+        if i != bad:
+            assert np.array_equal(res[i].Transformation, clean[i].Transformation) and np.array_equal(res[i].Information, clean[i].Information)
+            assert res[i].LogLikelihood == clean[i].LogLikelihood
 
 
 def test_window_sweep_whole_matches_and_plane_flavours():

@@ -158,11 +158,29 @@ def test_reference_compatible_mode_single_matches():
                 for level in range(levels):
                     trk = d.DenseTracker(d.Config(FirstLevel=level, LastLevel=level), ctx)
                     P = np.array([900.0, 3.0, 3.0, 400.0], np.float32)
-                    g = trk.level_iteration(gref, gcur, level, T34, P_prev=P, first=False, want_residuals=True)
                     o = po.level_iteration(oref, ocur, level, T34, P_prev=P, first=False, mode=q1, want_residuals=True)
+                    # the bit-exact anchor of the mode: the exact window / gathering sweeps with the table's reciprocal (option variant 7)
+                    ctx.set_option("variant", 7)
+                    g = trk.level_iteration(gref, gcur, level, T34, P_prev=P, first=False, want_residuals=True)
                     assert g["n"] == o["n"], (seed, level, g["n"], o["n"])
                     assert np.array_equal(g["residuals"], o["residuals"], equal_nan=True)
                     assert np.abs(g["A"] - o["A"]).max() <= 2e-5 * np.abs(o["A"]).max()      # (weights: sqrt of the table value vs the value)
+                    # what ships in this mode since round 5: the CONTRACTED window sweep with the same table (k_sweep_fast<.., COMPAT>; qz in the
+                    # reference's operation order, so that both hand the same float to the table -- a step function).  Stated like the default
+                    # schedule's distance to the exact one: the same constraints except at pixels on a bound (<= 1e-4 of them), residuals of
+                    # the common ones within 2e-5 / 4e-6 m, the normal equations within 3e-5 (a residual that moves by 1e-5 moves the weight's
+                    # table entry for ~1 % of the pixels, by 2^-12 of the weight)
+                    ctx.set_option("variant", 8)
+                    c = trk.level_iteration(gref, gcur, level, T34, P_prev=P, first=False, want_residuals=True)
+                    ro, rc = o["residuals"].reshape(-1, 2), c["residuals"].reshape(-1, 2)
+                    vo, vc = ~np.isnan(ro[:, 0]), ~np.isnan(rc[:, 0])
+                    flipped, both = int((vo != vc).sum()), vo & vc
+                    d0, d1 = float(np.abs(ro[both, 0] - rc[both, 0]).max()), float(np.abs(ro[both, 1] - rc[both, 1]).max())
+                    relA = np.abs(c["A"] - o["A"]).max() / np.abs(o["A"]).max()
+                    print("ref_compat, contracted sweep, %dx%d level %d: n %d vs %d, %d flipped, |dr_I| %.2e |dr_Z| %.2e, A %.1e"
+                          % (w, h, level, c["n"], o["n"], flipped, d0, d1, relA))
+                    assert flipped <= max(1, int(1e-4 * o["n"])) and d0 <= 2e-5 and d1 <= 4e-6
+                    assert relA <= 3e-5 + 20.0 * flipped / o["n"]
             for name, kw in (("strict", dict(first_level=levels - 1, last_level=0)),
                              ("yaml", dict(first_level=levels - 1, last_level=1, max_iterations=50, precision=1e-4, mu=0.05))):
                 cfg = d.Config(FirstLevel=kw["first_level"], LastLevel=kw["last_level"], MaxIterationsPerLevel=kw.get("max_iterations", 100),

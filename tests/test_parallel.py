@@ -93,6 +93,20 @@ def _free_port():
     return port
 
 
+def test_bench_without_a_launcher_starts_its_ranks():
+    """CPU tier: `python bench.py --gpus 2` with WORLD_SIZE unset re-executes itself under torch.distributed.run.  Without a GPU the
+    ranks stop at the device check (there is no CPU fallback) -- what matters here is that THEY ran: the message is the ranks', not a
+    refusal to start, and the launcher passes their failure on."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the GPU tier runs the real thing (test_bench_launches_its_own_ranks)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pairs", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert b.returncode != 0
+    assert "needs an MI355X" in b.stderr and "launch with torch.distributed.run" not in b.stderr
+
+
 @pytest.mark.gpu
 def test_two_ranks_gather_the_records_of_one_rank(tmp_path):
     """bench.py's N > 1 path with REAL alignments: two processes (sharing GPU 0, gloo -- the box has one GPU; on an 8-GPU node the
@@ -115,6 +129,24 @@ def test_two_ranks_gather_the_records_of_one_rank(tmp_path):
     assert ra.shape == rb.shape == (12, par.RECORD)
     assert np.array_equal(ra, rb)
     assert ja["nan_results"] == 0 and ja["max_twist_error_vs_truth"] < 1e-4
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` started WITHOUT a launcher (the shape of the driver's single-GPU command, WORLD_SIZE unset): bench.py
+    becomes the launcher itself -- one rank per GPU under torch.distributed.run -- instead of refusing, exits 0 and rank 0 prints
+    exactly one JSON line.  (Two ranks sharing GPU 0 over gloo here; on a multi-GPU node the default backend is RCCL.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = str(tmp_path / "two.npy")
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--pairs", "12",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-from-host", "--records-out", out],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert b.returncode == 0, b.stderr[-2000:]
+    lines = [l for l in b.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["pairs_per_gpu"] == 6 and j["nan_results"] == 0 and j["value"] > 0
+    assert np.load(out).shape == (12, par.RECORD)
 
 
 @pytest.mark.gpu
