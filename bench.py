@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--no-from-host", action="store_true", help="skip the PCIe-inclusive leg (raw planes handed over in pinned host memory)")
     ap.add_argument("--no-ref-compat", action="store_true", help="skip the leg that repeats the timed loop with option ref_compat on")
     ap.add_argument("--no-scaling-model", action="store_true", help="skip the one-GPU step times at pairs/2, pairs/4, pairs/8 per step")
+    ap.add_argument("--loop-only", action="store_true", help="profiling runs: the timed loop and a minimal line, none of the legs behind it")
     ap.add_argument("--no-guard-stress", action="store_true", help="skip the leg in which 1 %% of the pairs leave the f16 range of the Gram operands")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--resident-group", type=int, default=0, help="workgroups per pair in the resident match kernel (0 = as many as fit); "
@@ -282,6 +283,16 @@ def main():
         elapsed = float(t.item())
 
     # ---- everything below is outside the timed region -------------------------------------------------------
+    if args.loop_only:
+        if gathering:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "frame-pair alignments/s (640x480, 4-level pyramid) + finest-level HBM GB/s vs roofline",
+                              "value": round(n_total * args.steps / elapsed, 2), "unit": "alignments/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "loop_only": True,
+                              "config": {"pairs": n_total, "pairs_per_gpu": B}}))
+        return
     twist_err = float(np.abs(parallel.twists_of(last["T"]) - pairs_np["xi_true"]).max())
     if args.records_out and rank == 0:
         full = gathered[0] if gathering else parallel.pack_records(parallel.twists_of(last["T"]), last["information"], last["loglik"])

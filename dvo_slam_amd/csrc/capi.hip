@@ -2265,7 +2265,13 @@ int dvo_hip_match(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame*
     int rc = dvo_hip_match_batch(ctx, 2, r, c, cfg, res, want_levels ? lv.data() : nullptr, cl, want_iters ? it.data() : nullptr, ci);
     Request* both[2] = {partner, &me};
     int rcs[2] = {rc, rc};
-    if (rc != DVO_HIP_OK && rc != DVO_HIP_ERR_CAPACITY) {
+    if (rc != DVO_HIP_OK && rc != DVO_HIP_ERR_CAPACITY && rc != DVO_HIP_ERR_INVALID) {
+      // a HIP or device error: both callers get it at once (two more attempts would only double the time to report a dead device)
+      partner->rc = rc;
+      partner->state.store(2, std::memory_order_release);
+      return rc;
+    }
+    if (rc == DVO_HIP_ERR_INVALID) {
       // the merged batch was refused (one request's initial estimate is not finite, a frame of another context, ...): each request
       // runs alone and gets ITS OWN status -- a valid match does not fail because of the partner it happened to meet
       for (int k = 0; k < 2; ++k) {
@@ -2280,7 +2286,6 @@ int dvo_hip_match(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_hip_frame*
     }
     for (int k = 0; k < 2; ++k) {
       Request* q = both[k];
-      if (rc != DVO_HIP_OK && rc != DVO_HIP_ERR_CAPACITY) continue;
       *q->result = res[k];
       rcs[k] = DVO_HIP_OK;
       if (q->levels && q->cap_levels > 0) {

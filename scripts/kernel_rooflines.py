@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""Per-kernel rooflines of the bench's streaming loop from rocprofv3 passes over ONE command (scripts/r5_rooflines.sh):
+
+  <dir>/trace   --kernel-trace only: in-situ durations (the ingest of batch k + 1 runs beside the match of batch k)
+  <dir>/fetch   --kernel-trace --pmc FETCH_SIZE          (kB; gfx950 reports half of a wide coalesced stream: x 2, MI355X_MICROARCH.md)
+  <dir>/write   --kernel-trace --pmc WRITE_SIZE          (kB)
+  <dir>/sq      --kernel-trace --pmc SQ_* / GRBM_GUI_ACTIVE   (vector-ALU and wait shares)
+
+Kernels are told apart by name AND grid (one kernel serves several pyramid levels).  For every class only the FULL launches count
+(at least half of the class's longest duration / largest traffic: a step enqueued ahead of the host's poll, or the tail of a level
+with a few pairs left, moves next to nothing).  Algorithmic bytes per launch are the DESIGN.md section 4 figures for the bench's
+workload (1024 pairs of 640 x 480, levels 3 -> 0).
+
+usage: kernel_rooflines.py <dir> <pairs> [out.json] > table.md"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+HBM_PEAK = 8000.0  # GB/s
+
+
+def klass(row):
+    name = (row.get("Kernel_Name") or "").replace("void ", "").replace("dvo_hip::", "")
+    name = name.split("(")[0]
+    grid = row.get("Grid_Size") or row.get("Grid_Size_X") or "0"
+    wg = row.get("Workgroup_Size") or row.get("Workgroup_Size_X") or "1"
+    return name, int(grid) // max(int(wg), 1)
+
+
+def load_trace(d):
+    out = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            out[klass(row)].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)   # us
+    return out
+
+
+def load_counters(d):
+    out = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            out[klass(row)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return out
+
+
+def full(values):
+    if not values:
+        return []
+    top = max(values)
+    return [v for v in values if v >= 0.5 * top]
+
+
+def mean(v):
+    return sum(v) / len(v) if v else None
+
+
+def main():
+    d, pairs = sys.argv[1], int(sys.argv[2])
+    out_json = sys.argv[3] if len(sys.argv) > 3 else None
+    W, H = 640, 480
+    px = [W * H >> (2 * l) for l in range(4)]
+    trace = load_trace(os.path.join(d, "trace"))
+    fetch = load_counters(os.path.join(d, "fetch"))
+    write = load_counters(os.path.join(d, "write"))
+    sq = load_counters(os.path.join(d, "sq"))
+    tiles = {0: 300, 1: 75, 2: 24}                          # 64 x 16 tiles of the window sweep per pair (level 2: 3 x 8, last column half empty)
+
+    def algorithmic(name, grid):
+        """(bytes per full launch, what they are), DESIGN.md section 4"""
+        if name.startswith("k_sweep_fast") or name.startswith("k_sweep_window"):
+            for l, t in tiles.items():
+                if grid == t * pairs or grid == ((t * pairs + 7) // 8) * 8:
+                    return 40.0 * px[l] * pairs, "40 B x %d level-%d pixels x %d pairs (SURVEY 8d)" % (px[l], l, pairs)
+        if name.startswith("k_residual_reduce_mfma"):
+            return 40.0 * px[3] * pairs, "40 B x %d level-3 pixels x %d pairs" % (px[3], pairs)
+        if name.startswith("k_loglik"):
+            return 8.0 * px[0] * pairs, "8 B x %d level-0 pixels x %d pairs (one residual pair per pixel; the packed layout holds the constraints only)" % (px[0], pairs)
+        if name.startswith("k_ingest_strips<1"):
+            return 33.0 * px[0] * pairs, "33 B per level-0 pixel of a reference frame x %d frames" % pairs
+        if name.startswith("k_ingest_strips<0"):
+            return None, "current frames: the planes written follow the batch (plane C only for a batch this size): moved bytes are the measure"
+        return None, ""
+
+    rows = []
+    for key in sorted(trace, key=lambda k: -sum(trace[k])):
+        name, grid = key
+        if sum(trace[key]) < 0.005 * sum(sum(v) for v in trace.values()):
+            continue
+        dur = full(trace[key])
+        f = full(fetch.get(key, {}).get("FETCH_SIZE", []))
+        w = full(write.get(key, {}).get("WRITE_SIZE", []))
+        moved = (2.0 * mean(f) + mean(w)) * 1024.0 if f and w else None
+        algo, what = algorithmic(name, grid)
+        ms = mean(dur) * 1e-3
+        s = sq.get(key, {})
+        def share(num, den, scale=1.0):
+            a, b = s.get(num), s.get(den)
+            if not a or not b:
+                return None
+            a, b = full(a), full(b)
+            return scale * mean(a) / mean(b) if mean(b) else None
+        # (the SQ counters of this collection are one XCD's -- 32 compute units, 128 SIMDs: SQ_ACTIVE_INST_VALU x 4 SIMD-cycles per
+        # count against GRBM_GUI_ACTIVE x 128; profiles/r04_pmc3_v8_summary.txt reads 0.83 for the finest sweep the same way)
+        valu = share("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", 4.0 / 128.0)
+        wait = share("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES")
+        rec = dict(kernel=name, workgroups=grid, launches_full=len(dur), launches=len(trace[key]), ms=round(ms, 4),
+                   step_share=round(sum(trace[key]) / sum(sum(v) for v in trace.values()), 4),
+                   algorithmic_bytes=algo, algorithmic_note=what,
+                   achieved_GBps=None if algo is None else round(algo / ms / 1e6, 1),
+                   frac=None if algo is None else round(algo / ms / 1e6 / HBM_PEAK, 4),
+                   moved_bytes=moved, moved_GBps=None if moved is None else round(moved / ms / 1e6, 1),
+                   moved_frac=None if moved is None else round(moved / ms / 1e6 / HBM_PEAK, 4),
+                   valu_active_share=None if valu is None else round(valu, 3), wave_wait_share=None if wait is None else round(wait, 3))
+        if moved is not None and rec["moved_frac"] >= 0.45:
+            rec["limited_by"] = "HBM"
+        elif valu is not None and valu >= 0.6:
+            rec["limited_by"] = "vector-instruction issue"
+        elif ms < 0.1:
+            rec["limited_by"] = "latency (dependent round trips of a short launch)"
+        else:
+            rec["limited_by"] = "latency / issue mix"
+        rows.append(rec)
+    print("| kernel | workgroups | full launches | ms | share of kernel time | achieved GB/s @ algorithmic | frac | moved GB/s (PMC) | moved frac | VALU active | waves waiting | limited by |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    fmt = lambda v, f="%.3g": "-" if v is None else f % v
+    for r in rows:
+        print("| `%s` | %d | %d of %d | %.4f | %.1f %% | %s | %s | %s | %s | %s | %s | %s |" % (
+            r["kernel"][:70], r["workgroups"], r["launches_full"], r["launches"], r["ms"], 100 * r["step_share"], fmt(r["achieved_GBps"], "%.0f"), fmt(r["frac"]),
+            fmt(r["moved_GBps"], "%.0f"), fmt(r["moved_frac"]), fmt(r["valu_active_share"]), fmt(r["wave_wait_share"]), r["limited_by"]))
+    worst = [r for r in rows if r["frac"] is not None]
+    if worst:
+        w = min(worst, key=lambda r: r["frac"])
+        print("\nworst kernel at its algorithmic bytes: `%s` (%d workgroups): %.3f of the HBM roofline" % (w["kernel"], w["workgroups"], w["frac"]))
+    if out_json:
+        json.dump(dict(pairs=pairs, hbm_peak_GBps=HBM_PEAK, kernels=rows,
+                       note="rocprofv3 passes over `bench.py --loop-only` (scripts/r5_rooflines.sh): durations in situ, FETCH_SIZE x 2 + WRITE_SIZE per full launch"),
+                  open(out_json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
