@@ -90,11 +90,24 @@ struct FastRow {                                        // what phase A leaves f
 __device__ __forceinline__ float fast_lerp(float p, float q, float t) { return fmaf(t, q - p, p); }
 __device__ __forceinline__ f32x2 fast_lerp2(f32x2 p, f32x2 q, f32x2 t) { return __builtin_elementwise_fma(t, q - p, p); }
 
-// The host CPU's _mm_rcp_ps from its table (pixel_math.h::rcp_like_the_host, option "ref_compat"): one 4-byte gather per lane through a
-// buffer resource over the 8-16 KB table (it lives in the vector L1 / L2), the exponent and the sign put back with integer arithmetic.
-__device__ __forceinline__ float fast_rcp_host(__amdgpu_buffer_rsrc_t table, int shift, float x) {
+// The host CPU's _mm_rcp_ps from its table (pixel_math.h::rcp_like_the_host, option "ref_compat"), the exponent and the sign put back
+// with integer arithmetic.  COMPAT 2: the table's 16-bit copy in LDS (LevelGeom::rcp_packed; 4-8 KB, filled by every workgroup) -- the
+// weights' operand 5 + r^T P r takes any mantissa, so its 64 lanes ask for 64 different cache lines of a table in memory and the
+// texture addresser, not the vector ALU, paces the sweep (round 5: 17.6 ms per 1024-pair step that way, against 11.6 without the
+// table).  COMPAT 1: a table that does not pack -- one 4-byte gather per lane through a buffer resource.
+struct FastRcpSource {
+  __amdgpu_buffer_rsrc_t table;
+  const unsigned short* lds;
+  int shift;
+};
+
+template <int COMPAT>
+__device__ __forceinline__ float fast_rcp_host(const FastRcpSource& src, float x) {
   const unsigned b = __builtin_bit_cast(unsigned, x);
-  unsigned t = __builtin_amdgcn_raw_buffer_load_b32(table, ((b & 0x7fffffu) >> shift) << 2, 0, 0);     // rcp(1.m), in (0.5, 1]
+  const unsigned idx = (b & 0x7fffffu) >> src.shift;
+  unsigned t;                                                                                          // rcp(1.m), in (0.5, 1]
+  if constexpr (COMPAT == 2) t = 0x3f000000u + (unsigned(src.lds[idx]) << 8);
+  else t = __builtin_amdgcn_raw_buffer_load_b32(src.table, idx << 2, 0, 0);
   t = (t + (0x3f800000u - (b & 0x7f800000u))) | (b & 0x80000000u);                                     // x 2^-(e - 127), sign of x
   return __builtin_bit_cast(float, t);
 }
@@ -106,19 +119,19 @@ __device__ __forceinline__ float fast_rcp_host(__amdgpu_buffer_rsrc_t table, int
 // table value.  That is a STEP function of qz (2^11 - 2^12 steps per binade), so qz is formed in the reference's operation order
 // without contraction -- the very float the exact schedule and the oracle hand to the table, hence the same table entry -- while qx
 // and qy stay contracted: u and v then differ from the exact schedule's by the few ulp they do in the default mode, not by a table step.
-template <bool COMPAT>
-__device__ __forceinline__ void fast_project(const LevelGeom& g, __amdgpu_buffer_rsrc_t table, const float* KT, float c0, float c1, float c2, float z,
+template <int COMPAT>
+__device__ __forceinline__ void fast_project(const LevelGeom& g, const FastRcpSource& table, const float* KT, float c0, float c1, float c2, float z,
                                              float tx, float ty, float& u, float& v, float& qz) {
   const float qx = fmaf(z, fmaf(KT[1], ty, c0), KT[3]);
   const float qy = fmaf(z, fmaf(KT[5], ty, c1), KT[7]);
   float r;
-  if constexpr (COMPAT) {
+  if constexpr (COMPAT != 0) {
     {
 #pragma clang fp contract(off)
       const float X = tx * z, Y = ty * z;                     // rgbd_image.cpp:258; pixel_math.h::pixel_project_uv_flat
       qz = (KT[8] * X + KT[9] * Y) + (KT[10] * z + KT[11]);
     }
-    r = fast_rcp_host(table, g.rcp_shift, qz);
+    r = fast_rcp_host<COMPAT>(table, qz);
   } else {
     qz = fmaf(z, fmaf(KT[9], ty, c2), KT[11]);
     r = __builtin_amdgcn_rcpf(qz);
@@ -207,8 +220,8 @@ __device__ __forceinline__ void fast_fill_window(const LevelGeom& g, __amdgpu_bu
 // CHECKED: a tile whose projections spread beyond the window (a depth discontinuity under a large motion): lanes inside read the
 // window, the others fetch their cells from memory, coordinates clamped like the window's -- correct for any motion.  The tap corner
 // is not kept apart from the window index: it is projected again (tx, ty), the same instructions as in phase A.
-template <bool CHECKED, bool COMPAT>
-__device__ __forceinline__ void fast_fetch_cells(const LevelGeom& g, __amdgpu_buffer_rsrc_t table, const float* KT, __amdgpu_buffer_rsrc_t curC, const float2* win,
+template <bool CHECKED, int COMPAT>
+__device__ __forceinline__ void fast_fetch_cells(const LevelGeom& g, const FastRcpSource& table, const float* KT, __amdgpu_buffer_rsrc_t curC, const float2* win,
                                                  const FastWindow& wnd, int neg_base, const FastRow& r, bool ok, float tx, float ty, f32x2 (&P)[4][4],
                                                  unsigned& n_fallback) {
   // (volatile: twelve ds_read_b64, two LDS cycles each; the compiler otherwise pairs them into ds_read2_b64, eight cycles a pair)
@@ -357,8 +370,8 @@ struct FastWeights {
 // off_v + scalar offset off_s), validity, weight, Jacobian at the untransformed point, Gram accumulation.  tx, ty, cx = 1 + tx^2:
 // normalised coordinates of the lane's reference pixel.
 // COMPACT (LevelGeom::compact): only a constraint's pair is stored, at the next free entry of the wavefront's slot (off_s: the slot).
-template <int STORE, bool COMPACT, bool COMPAT>
-__device__ __forceinline__ void fast_row_tail(const LevelGeom& g, __amdgpu_buffer_rsrc_t table, const f32x2 (&P)[4][4], const FastRow& r, unsigned long long ok_mask, float tx, float ty,
+template <int STORE, bool COMPACT, int COMPAT>
+__device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const FastRcpSource& table, const f32x2 (&P)[4][4], const FastRow& r, unsigned long long ok_mask, float tx, float ty,
                                               float cx, const FastWeights& wt, __amdgpu_buffer_rsrc_t resid, int off_v, int off_s, float* my, int lane,
                                               f32x4& acc0, f32x4& acc1, int& n_valid) {
   // separable blend (rows first): E_j = row j of the neighbourhood at the tap's column position; intensity / depth, TWICE the
@@ -392,10 +405,10 @@ __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, __amdgpu_buffe
   n_valid += __popcll(valid_mask);
   const float tq = fmaf(wt.P2x, r1, wt.P00 * r0);
   float sw_any;
-  if constexpr (COMPAT) {
+  if constexpr (COMPAT != 0) {
     // (a lane without a constraint may hold anything in r0 / r1: the table index is masked to the table by construction, its weight is dropped)
     const float arg = fmaf(tq, r0, fmaf(wt.P11 * r1, r1, 5.0f));
-    sw_any = __builtin_amdgcn_sqrtf(fmaf(wt.wm, fast_rcp_host(table, g.rcp_shift, arg), wt.wa));
+    sw_any = __builtin_amdgcn_sqrtf(fmaf(wt.wm, fast_rcp_host<COMPAT>(table, arg), wt.wa));
   } else {
     sw_any = wt.wc * fast_rsqrt(fmaf(tq, r0, fmaf(wt.P11 * r1, r1, wt.wk)));
   }
@@ -471,8 +484,10 @@ __device__ __forceinline__ void fast_count_fallbacks(unsigned long long* __restr
 // ===================================================================================================================================
 // variants 8 / 9: every pixel of the tile, one wavefront row = one image row of 64 pixels
 // ===================================================================================================================================
-template <int STORE, bool PARTIAL, bool COMPACT, bool COMPAT>
-__global__ __launch_bounds__(256, 5) void k_sweep_fast(
+// COMPAT (option "ref_compat"): 0 = off; 1 = the host's reciprocal table through memory; 2 = its 16-bit copy in LDS (four workgroups
+// per compute unit instead of five)
+template <int STORE, bool PARTIAL, bool COMPACT, int COMPAT>
+__global__ __launch_bounds__(256, COMPAT == 2 ? 4 : 5) void k_sweep_fast(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count, int* __restrict__ f16_range_flag) {
   constexpr int RPW = kFastTileRows / 4;
@@ -494,8 +509,22 @@ __global__ __launch_bounds__(256, 5) void k_sweep_fast(
   // (rows below the image -- a level whose height is no multiple of 16 -- go to a resource of no bytes: no branch around the store)
   const __amdgpu_buffer_rsrc_t resid_none = __builtin_amdgcn_make_buffer_rsrc(scratch, 0, 0, 0x00020000);
   // (option "ref_compat": the host CPU's reciprocal table, 2^(23 - shift) floats; a resource of no bytes otherwise, never read)
-  const __amdgpu_buffer_rsrc_t rcp_table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(COMPAT ? g.rcp_table : nullptr), 0,
-                                                                             COMPAT ? (4 << (23 - g.rcp_shift)) : 0, 0x00020000);
+  __shared__ __attribute__((aligned(16))) unsigned short rcp_lds[COMPAT == 2 ? 4096 : 8];
+  const FastRcpSource rcp_table = {__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(COMPAT ? g.rcp_table : nullptr), 0, COMPAT ? (4 << (23 - g.rcp_shift)) : 0, 0x00020000),
+                                   rcp_lds, g.rcp_shift};
+  if constexpr (COMPAT == 2) {
+    // the table's 16-bit copy (behind its floats) into LDS: 2^(23 - shift) entries of 2 B, 16 bytes per thread and round; the loads
+    // travel with the reference rows' below, the barrier in front of the first lookup is this phase's only addition
+    const int entries = 1 << (23 - g.rcp_shift);
+    const __amdgpu_buffer_rsrc_t packed = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.rcp_table) + entries, 0, entries * 2, 0x00020000);
+    f32x4 chunk[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) chunk[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(packed, (int(threadIdx.x) + j * 256) * 16, 0, 0));
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if ((int(threadIdx.x) + j * 256) * 8 < entries) reinterpret_cast<f32x4*>(rcp_lds)[threadIdx.x + j * 256] = chunk[j];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned gram_entries = kGramEntryTable.e[min(int(threadIdx.x), kNumAcc - 1)];
   // A level whose width is no multiple of 64 (160 x 120): the last tile column hangs over the right edge.  Its lanes beyond the image
@@ -640,15 +669,21 @@ void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const Pai
   using S2 = std::integral_constant<int, 2>;
   using T = std::true_type;
   using F = std::false_type;
-  if (g.rcp_table) {                                           // option "ref_compat": the host's reciprocal table in projection and weights
-    if (compact) { if (partial) go(S2{}, T{}, T{}, T{}); else go(S2{}, F{}, T{}, T{}); }
-    else { if (partial) go(S2{}, T{}, F{}, T{}); else go(S2{}, F{}, F{}, T{}); }
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>;
+  if (g.rcp_table && g.rcp_packed) {                           // option "ref_compat": the host's reciprocal table in projection and weights, from LDS
+    if (compact) { if (partial) go(S2{}, T{}, T{}, C2{}); else go(S2{}, F{}, T{}, C2{}); }
+    else { if (partial) go(S2{}, T{}, F{}, C2{}); else go(S2{}, F{}, F{}, C2{}); }
+  } else if (g.rcp_table) {                                    // ... a table that does not fit a 16-bit copy: from memory
+    if (compact) { if (partial) go(S2{}, T{}, T{}, C1{}); else go(S2{}, F{}, T{}, C1{}); }
+    else { if (partial) go(S2{}, T{}, F{}, C1{}); else go(S2{}, F{}, F{}, C1{}); }
   } else if (variant == 8) {
-    if (compact) { if (partial) go(S2{}, T{}, T{}, F{}); else go(S2{}, F{}, T{}, F{}); }
-    else { if (partial) go(S2{}, T{}, F{}, F{}); else go(S2{}, F{}, F{}, F{}); }
+    if (compact) { if (partial) go(S2{}, T{}, T{}, C0{}); else go(S2{}, F{}, T{}, C0{}); }
+    else { if (partial) go(S2{}, T{}, F{}, C0{}); else go(S2{}, F{}, F{}, C0{}); }
   } else {
-    if (compact) { if (partial) go(S1{}, T{}, T{}, F{}); else go(S1{}, F{}, T{}, F{}); }
-    else { if (partial) go(S1{}, T{}, F{}, F{}); else go(S1{}, F{}, F{}, F{}); }
+    if (compact) { if (partial) go(S1{}, T{}, T{}, C0{}); else go(S1{}, F{}, T{}, C0{}); }
+    else { if (partial) go(S1{}, T{}, F{}, C0{}); else go(S1{}, F{}, F{}, C0{}); }
   }
 }
 

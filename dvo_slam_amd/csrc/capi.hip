@@ -281,6 +281,7 @@ struct dvo_hip_context {
   int opt_ref_compat = 0;          // projection and weights multiply with the HOST CPU's _mm_rcp_ps like the reference does
   DevBuf rcp_table;                // ... from this table, dumped from the instruction itself when the option is first switched on
   int rcp_shift = 0;
+  int rcp_packed = 0;              // a 16-bit copy of the table lies behind it (LevelGeom::rcp_packed)
   int opt_resident_cooperative = 0; // launch groups through hipLaunchCooperativeKernel (a separate hardware queue: +0.1 ms per launch)
   int compute_units = 0;
   std::vector<CameraGeom*> cameras;
@@ -522,6 +523,7 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   level_tiles(g.w, g.h, rows_per_wave, g.linear != 0, &g.tiles_x, &g.tiles_y);
   g.rcp_table = ctx->opt_ref_compat ? ctx->rcp_table.as<float>() : nullptr;
   g.rcp_shift = ctx->rcp_shift;
+  g.rcp_packed = ctx->opt_ref_compat == 1 ? ctx->rcp_packed : 0;   // (2: the table through memory, the path of a table that does not pack)
   g.compact = ctx->opt_compact_residuals && ctx->opt_variant >= 8 && rows_per_wave == 4 && fast_sweep_supports(g) ? 1 : 0;   // (launch_residual_reduce's test)
   return g;
 }
@@ -1625,10 +1627,24 @@ int build_rcp_table(dvo_hip_context* ctx) {
     }
   std::vector<float> table(size_t(1) << k);
   for (unsigned i = 0; i < table.size(); ++i) table[i] = rcp(at(i << shift));
+  // a 16-bit copy for the sweep that keeps the table in LDS: every value is in (0.5, 1], i.e. bits in [0x3f000000, 0x3f800000]; an
+  // instruction with 11-12 bits of precision leaves the low mantissa bits zero (0x3f7ff800 is the OR of all results on the Intel Xeon
+  // this was developed on).  Checked, not assumed; a table that does not pack, or one of more than 2^12 entries, is used from memory.
+  bool packs = k <= 12;
+  std::vector<uint16_t> packed(table.size());
+  for (size_t i = 0; i < table.size() && packs; ++i) {
+    unsigned b;
+    std::memcpy(&b, &table[i], 4);
+    packs = b >= 0x3f000000u && b <= 0x3f800000u && ((b - 0x3f000000u) & 0xffu) == 0;
+    packed[i] = uint16_t((b - 0x3f000000u) >> 8);
+  }
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  DVO_HIP_TRY(ctx, ctx->rcp_table.reserve(table.size() * sizeof(float)));
+  DVO_HIP_TRY(ctx, ctx->rcp_table.reserve(table.size() * (sizeof(float) + sizeof(uint16_t))));
   DVO_HIP_TRY(ctx, hipMemcpy(ctx->rcp_table.p, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (packs)
+    DVO_HIP_TRY(ctx, hipMemcpy(ctx->rcp_table.as<float>() + table.size(), packed.data(), packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   ctx->rcp_shift = shift;
+  ctx->rcp_packed = packs ? 1 : 0;
   return DVO_HIP_OK;
 }
 }  // namespace
@@ -1775,7 +1791,7 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "ref_compat") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "ref_compat must be 0 or 1");
+    if (value < 0 || value > 2) return fail(ctx, DVO_HIP_ERR_INVALID, "ref_compat must be 0, 1 or 2 (2: as 1, the table read through memory by every sweep)");
     if (value && !ctx->rcp_table.p) {
       const int rc = build_rcp_table(ctx);
       if (rc != DVO_HIP_OK) return rc;

@@ -49,6 +49,10 @@ struct LevelGeom {                    // identical for every pair of a batch (on
   // on: rcp(1.m x 2^e) = rcp_table[m >> rcp_shift] x 2^-e (pixel_math.h::rcp_like_the_host).
   const float* rcp_table;
   int rcp_shift;
+  // 1: behind the 2^(23 - rcp_shift) floats of the table lie as many 16-bit entries, (bits(value) - 0x3f000000) >> 8 -- every value is in
+  // (0.5, 1] and the instruction leaves the low mantissa bits zero (checked when the table is dumped), at most 8 KB: the contracted
+  // window sweep keeps that copy in LDS (align_fast.hip, COMPAT 2)
+  int rcp_packed;
   // 1: the sweep stores only the residual pairs of CONSTRAINTS (roughly every second pixel), packed: tile t of the level owns 1024
   // entries of the pair's residual buffer, wavefront q of the tile the entries [256 q, 256 q + count_q), in the order it met them;
   // the four counts ride in the two spare floats of the tile's partial row (kAccCounts).  The log-likelihood pass -- the only reader --

@@ -286,7 +286,8 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * DVO_HIP_REF_COMPAT=1 when a context is created; default 0.  The schedules keep their meaning in this mode: under "variant" 8 (the
  * default) the contracted window sweep runs with the table in place of v_rcp_f32 -- residuals within 2e-5 of the oracle's MATH + Q1
  * mode, the same constraints except at pixels on a bound; under "variant" 7 residuals and constraint counts equal that oracle mode
- * bit for bit),
+ * bit for bit.  2 = as 1 with the table read through memory by every sweep -- the path of a CPU whose table has no 16-bit copy for
+ * the contracted sweep to keep in LDS; test and measurement),
  * "resident" (-1 default: small batches and coarse levels run in ONE launch per match, each pair owned by a group of resident
  * workgroups -- the latency path; 0: one to three launches per Gauss-Newton step always; 1: every level
  * resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per

@@ -23,26 +23,44 @@ HBM_PEAK = 8000.0  # GB/s
 
 
 def klass(row):
+    """(kernel name without arguments, workgroups of the launch): the kernel-trace CSV has the grid per dimension, the counter CSV in total"""
     name = (row.get("Kernel_Name") or "").replace("void ", "").replace("dvo_hip::", "")
     name = name.split("(")[0]
-    grid = row.get("Grid_Size") or row.get("Grid_Size_X") or "0"
-    wg = row.get("Workgroup_Size") or row.get("Workgroup_Size_X") or "1"
-    return name, int(grid) // max(int(wg), 1)
+    if row.get("Grid_Size_X"):
+        grid = int(row["Grid_Size_X"]) * int(row.get("Grid_Size_Y") or 1) * int(row.get("Grid_Size_Z") or 1)
+        wg = int(row["Workgroup_Size_X"]) * int(row.get("Workgroup_Size_Y") or 1) * int(row.get("Workgroup_Size_Z") or 1)
+    else:
+        grid, wg = int(row.get("Grid_Size") or 0), int(row.get("Workgroup_Size") or 1)
+    return name, grid // max(wg, 1)
+
+
+def loop_rows(path):
+    """rows of the streaming loop only: everything before the first batched ingest (frame creation, table uploads of the set-up) is dropped"""
+    rows = list(csv.DictReader(open(path)))
+    starts = [int(r["Start_Timestamp"]) for r in rows if "k_ingest_strips<0" in r["Kernel_Name"] or "k_ingest_strips<1" in r["Kernel_Name"]]
+    t0 = min(starts) if starts else 0
+    return [r for r in rows if int(r["Start_Timestamp"]) >= t0]
 
 
 def load_trace(d):
     out = defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
-        for row in csv.DictReader(open(f)):
+        for row in loop_rows(f):
             out[klass(row)].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)   # us
     return out
 
 
 def load_counters(d):
+    """counter values per class, and under "_us" the durations of the same dispatches: a counter pass runs one kernel at a time, so
+    these are the kernels ALONE (no ingest beside the match)"""
     out = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        for row in csv.DictReader(open(f)):
+        seen = set()
+        for row in loop_rows(f):
             out[klass(row)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            if row["Dispatch_Id"] not in seen:
+                seen.add(row["Dispatch_Id"])
+                out[klass(row)]["_us"].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
     return out
 
 
@@ -95,6 +113,8 @@ def main():
         moved = (2.0 * mean(f) + mean(w)) * 1024.0 if f and w else None
         algo, what = algorithmic(name, grid)
         ms = mean(dur) * 1e-3
+        alone = full(fetch.get(key, {}).get("_us", []))
+        ms_alone = mean(alone) * 1e-3 if alone else None
         s = sq.get(key, {})
         def share(num, den, scale=1.0):
             a, b = s.get(num), s.get(den)
@@ -107,6 +127,8 @@ def main():
         valu = share("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", 4.0 / 128.0)
         wait = share("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES")
         rec = dict(kernel=name, workgroups=grid, launches_full=len(dur), launches=len(trace[key]), ms=round(ms, 4),
+                   ms_alone=None if ms_alone is None else round(ms_alone, 4),
+                   moved_GBps_alone=None if (moved is None or ms_alone is None) else round(moved / ms_alone / 1e6, 1),
                    step_share=round(sum(trace[key]) / sum(sum(v) for v in trace.values()), 4),
                    algorithmic_bytes=algo, algorithmic_note=what,
                    achieved_GBps=None if algo is None else round(algo / ms / 1e6, 1),
@@ -123,13 +145,14 @@ def main():
         else:
             rec["limited_by"] = "latency / issue mix"
         rows.append(rec)
-    print("| kernel | workgroups | full launches | ms | share of kernel time | achieved GB/s @ algorithmic | frac | moved GB/s (PMC) | moved frac | VALU active | waves waiting | limited by |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| kernel | workgroups | full launches | ms in situ | ms alone | share of kernel time | achieved GB/s @ algorithmic | frac | moved GB/s (PMC) | moved frac | moved GB/s alone | VALU active | waves waiting | limited by |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     fmt = lambda v, f="%.3g": "-" if v is None else f % v
     for r in rows:
-        print("| `%s` | %d | %d of %d | %.4f | %.1f %% | %s | %s | %s | %s | %s | %s | %s |" % (
-            r["kernel"][:70], r["workgroups"], r["launches_full"], r["launches"], r["ms"], 100 * r["step_share"], fmt(r["achieved_GBps"], "%.0f"), fmt(r["frac"]),
-            fmt(r["moved_GBps"], "%.0f"), fmt(r["moved_frac"]), fmt(r["valu_active_share"]), fmt(r["wave_wait_share"]), r["limited_by"]))
+        print("| `%s` | %d | %d of %d | %.4f | %s | %.1f %% | %s | %s | %s | %s | %s | %s | %s | %s |" % (
+            r["kernel"][:70], r["workgroups"], r["launches_full"], r["launches"], r["ms"], fmt(r["ms_alone"], "%.4f"), 100 * r["step_share"], fmt(r["achieved_GBps"], "%.0f"),
+            fmt(r["frac"]), fmt(r["moved_GBps"], "%.0f"), fmt(r["moved_frac"]), fmt(r["moved_GBps_alone"], "%.0f"), fmt(r["valu_active_share"]), fmt(r["wave_wait_share"]),
+            r["limited_by"]))
     worst = [r for r in rows if r["frac"] is not None]
     if worst:
         w = min(worst, key=lambda r: r["frac"])

@@ -181,6 +181,12 @@ def test_reference_compatible_mode_single_matches():
                           % (w, h, level, c["n"], o["n"], flipped, d0, d1, relA))
                     assert flipped <= max(1, int(1e-4 * o["n"])) and d0 <= 2e-5 and d1 <= 4e-6
                     assert relA <= 3e-5 + 20.0 * flipped / o["n"]
+                    # (the sweep keeps a 16-bit copy of the table in LDS; value 2 of the option reads the table through memory instead,
+                    # the path of a CPU whose table does not pack: the same numbers, bit for bit)
+                    ctx.set_option("ref_compat", 2)
+                    m = trk.level_iteration(gref, gcur, level, T34, P_prev=P, first=False, want_residuals=True)
+                    ctx.set_option("ref_compat", 1)
+                    assert m["n"] == c["n"] and np.array_equal(m["residuals"], c["residuals"], equal_nan=True) and np.array_equal(m["A"], c["A"])
             for name, kw in (("strict", dict(first_level=levels - 1, last_level=0)),
                              ("yaml", dict(first_level=levels - 1, last_level=1, max_iterations=50, precision=1e-4, mu=0.05))):
                 cfg = d.Config(FirstLevel=kw["first_level"], LastLevel=kw["last_level"], MaxIterationsPerLevel=kw.get("max_iterations", 100),
