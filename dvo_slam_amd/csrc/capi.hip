@@ -32,12 +32,19 @@ namespace {
 
 std::string g_create_error;
 
+// Bumped whenever device memory goes back to the allocator: what the small-table cache (PinnedRing) knows about the contents of
+// device addresses is only good until an address can have been handed out again.
+std::atomic<unsigned long long> g_free_epoch{1};
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
   hipError_t reserve(size_t n) {
     if (n <= bytes) return hipSuccess;
-    if (p) (void)hipFree(p);
+    if (p) {
+      (void)hipFree(p);
+      g_free_epoch.fetch_add(1, std::memory_order_relaxed);
+    }
     p = nullptr;
     bytes = 0;
     hipError_t e = hipMalloc(&p, n);
@@ -45,7 +52,10 @@ struct DevBuf {
     return e;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      (void)hipFree(p);
+      g_free_epoch.fetch_add(1, std::memory_order_relaxed);
+    }
     p = nullptr;
     bytes = 0;
   }
@@ -145,8 +155,69 @@ struct PinnedRing {
   bool in_flight[kSlots] = {};
   unsigned next = 0;
 
+  // A streaming caller hands over the same frame sets step after step: the tables of a step (plane pointers of the frames to build,
+  // of the pairs to align, identity initial guesses) are then the very bytes the device already holds at the very address.  The ring
+  // remembers what it last sent to an address (a host copy) and sends nothing when it is asked for the same bytes again, on the same
+  // stream, with no device memory freed in between (round 5: a 128-pair step of bench.py spent ~150 us of host time on ten such
+  // uploads before its first alignment kernel was enqueued, and two dependent copy kernels at the head of the chain).
+  struct Sent {
+    void* dst = nullptr;
+    hipStream_t stream = nullptr;
+    unsigned long long epoch = 0, used = 0;
+    std::vector<char> bytes;
+  };
+  static const int kSent = 24;
+  Sent sent[kSent];
+  unsigned long long clock = 0;
+  long long skipped = 0;            // uploads answered from the cache (counter "table_uploads_skipped")
+  bool cache = true;
+
   hipError_t upload(hipStream_t stream, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return hipSuccess;
+    Sent* slot = nullptr;
+    if (cache) {
+      const unsigned long long epoch = g_free_epoch.load(std::memory_order_relaxed);
+      Sent* oldest = &sent[0];
+      for (Sent& c : sent) {
+        if (c.dst == dst) { slot = &c; break; }
+        if (c.used < oldest->used) oldest = &c;
+      }
+      if (slot && slot->stream == stream && slot->epoch == epoch && slot->bytes.size() == bytes && std::memcmp(slot->bytes.data(), src, bytes) == 0) {
+        slot->used = ++clock;
+        skipped += 1;
+        return hipSuccess;
+      }
+      if (!slot) slot = oldest;
+      slot->dst = nullptr;                                       // (valid again once the copy below is enqueued)
+    }
+    const hipError_t e_up = upload_now(stream, dst, src, bytes);
+    if (slot && e_up == hipSuccess) {
+      slot->dst = dst;
+      slot->stream = stream;
+      slot->epoch = g_free_epoch.load(std::memory_order_relaxed);
+      slot->used = ++clock;
+      slot->bytes.assign(static_cast<const char*>(src), static_cast<const char*>(src) + bytes);
+    }
+    return e_up;
+  }
+
+  // which of `k` device buffers already holds exactly these bytes (sent on this stream, nothing freed since); -1: none
+  int holder(DevBuf* candidates, int k, hipStream_t stream, const void* src, size_t bytes) const {
+    if (!cache) return -1;
+    const unsigned long long epoch = g_free_epoch.load(std::memory_order_relaxed);
+    for (int i = 0; i < k; ++i)
+      for (const Sent& c : sent)
+        if (c.dst && c.dst == candidates[i].p && c.stream == stream && c.epoch == epoch && c.bytes.size() == bytes && std::memcmp(c.bytes.data(), src, bytes) == 0)
+          return i;
+    return -1;
+  }
+
+  void forget(const void* dst) {                                  // somebody else wrote to this address
+    for (Sent& c : sent)
+      if (c.dst == dst) c.dst = nullptr;
+  }
+
+  hipError_t upload_now(hipStream_t stream, void* dst, const void* src, size_t bytes) {
     if (bytes > slot_bytes) {                      // grow: wait for every copy in flight, then one new block
       hipError_t e = drain();
       if (e != hipSuccess) return e;
@@ -201,7 +272,12 @@ struct PinnedRing {
 // levels are bound by the host's launch rate, which more streams only divide -- profiles/r01_d_groups.txt.)
 struct Workspace {
   hipStream_t stream = nullptr;
-  DevBuf states, pair_ptrs, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters;
+  DevBuf states, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters;
+  // the pairs' plane-pointer table, in one of a few buffers picked by the batch's first frames: a caller that alternates between two
+  // or three frame sets finds each set's table where it left it (PinnedRing's cache of what was sent where)
+  static const int kTableSlots = 4;
+  DevBuf pair_ptrs[kTableSlots];
+  unsigned pair_ptrs_next = 0;
   DevBuf win_fallbacks;          // one 64-bit counter: lanes of the window sweep whose taps were fetched from memory (align_window.hip)
   int* f16_range_flag = nullptr; // pinned, one word per pair of the batch: raised by a workgroup of the f16 Gram schedule whose Jacobian left the f16 range (gram_f16.h)
   size_t f16_range_words = 0;
@@ -295,7 +371,11 @@ struct dvo_hip_context {
   static constexpr size_t kFramePoolMaxBytes = size_t(1) << 30;
   static constexpr size_t kFramePoolMaxBlocks = 64;
   Workspace ws[1];
-  DevBuf misc, build_tbl, role_tbl_cur, role_tbl_ref, prep_tbl_cur, prep_tbl_ref;
+  DevBuf misc, role_tbl_cur, role_tbl_ref, prep_tbl_cur, prep_tbl_ref;
+  static const int kTableSlots = 4;
+  DevBuf build_tbl[kTableSlots];   // (a few, picked by the list's first frame: see Workspace::pair_ptrs)
+  DevBuf* build_tbl_cur = nullptr; // the one that holds the table of build_tbl_frames
+  unsigned build_tbl_next = 0;
   PinnedRing tables;
   // build_tbl holds, in build-stream order, the table of exactly these frames (frames_build): the per-level launches of an
   // eager prepare of the same list reuse it instead of uploading the same bytes again
@@ -373,7 +453,8 @@ int workspace_create(dvo_hip_context* ctx, int g) {
 void workspace_destroy(Workspace& w) {
   if (!w.created) return;
   (void)hipStreamSynchronize(w.stream);
-  for (DevBuf* b : {&w.states, &w.pair_ptrs, &w.partials, &w.scratch, &w.ll_partials, &w.lvl_stats, &w.it_stats, &w.results,
+  for (DevBuf& b : w.pair_ptrs) b.release();
+  for (DevBuf* b : {&w.states, &w.partials, &w.scratch, &w.ll_partials, &w.lvl_stats, &w.it_stats, &w.results,
                     &w.t_init, &w.counters, &w.exchange, &w.win_fallbacks})
     b->release();
   if (w.host_status) (void)hipHostFree(w.host_status);
@@ -431,7 +512,7 @@ const int kLlBlocksPerPair = 32;
 const size_t kCostlyEmptyStepWorkgroups = 131072;   // (see run_batch: from here on the step ahead of the poll is held back on a level's tail)
 const int kLlBlocksPerPairBatch = 8;   // (a batch of 256 pairs or more, packed residuals; see run_batch)
 const int kFusedLoglikMaxPixels = 160 * 120;      // any batch
-const int kFusedLoglikMaxPixelsBatch = 320 * 240;  // batches that fill the chip with one solver workgroup per pair
+const int kFusedLoglikMaxPixelsBatch = 320 * 240;  // batches of 512 pairs and more (run_batch)
 
 // RgbdCameraPyramid::build (rgbd_image.cpp:283-296) + RgbdCamera ctor template (:186-204)
 int get_camera(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, const CameraGeom** out) {
@@ -676,11 +757,17 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
     if (role == 0) f->lv[0].cur_have = flavor0;
     if (role == 1) { f->lv[0].selected = true; f->lv[0].ithr = ithr; f->lv[0].dthr = dthr; }
   }
-  DVO_HIP_TRY(ctx, ctx->build_tbl.reserve(size_t(n) * sizeof(FrameBuildPtrs)));
   hipStream_t bs = ctx->build_stream;
-  DVO_HIP_TRY(ctx, ctx->tables.upload(bs, ctx->build_tbl.p, host.data(), size_t(n) * sizeof(FrameBuildPtrs)));
-  const FrameBuildPtrs* tbl = ctx->build_tbl.as<FrameBuildPtrs>();
+  // (one of a few buffers: the one that already holds this very table -- a streaming caller re-ingests the same frame sets from the same
+  // planes step after step -- else the next in turn)
+  int slot = ctx->tables.holder(ctx->build_tbl, dvo_hip_context::kTableSlots, bs, host.data(), size_t(n) * sizeof(FrameBuildPtrs));
+  if (slot < 0) slot = int(ctx->build_tbl_next++ % dvo_hip_context::kTableSlots);
+  DevBuf& build_tbl = ctx->build_tbl[slot];
+  DVO_HIP_TRY(ctx, build_tbl.reserve(size_t(n) * sizeof(FrameBuildPtrs)));
+  DVO_HIP_TRY(ctx, ctx->tables.upload(bs, build_tbl.p, host.data(), size_t(n) * sizeof(FrameBuildPtrs)));
+  const FrameBuildPtrs* tbl = build_tbl.as<FrameBuildPtrs>();
   ctx->build_tbl_frames.assign(frames, frames + n);
+  ctx->build_tbl_cur = &build_tbl;
   int built = 1;                                       // float ingest: level 0 is already in place
   if (grey) {
     // current frames: the {I, Z} plane of the pyramid levels the window sweep will read comes out of the same pass (no neighbours
@@ -716,9 +803,9 @@ int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int 
   bool launched = false;
   int uploads = 0;                                           // table slices used so far (each launch reads its own)
   auto upload = [&](const std::vector<FrameBuildPtrs>& host, const FrameBuildPtrs** tbl, bool plane_pointers_only = true) -> int {
-    if (plane_pointers_only && eager && int(host.size()) == n && ctx->build_tbl_frames.size() == size_t(n) &&
+    if (plane_pointers_only && eager && ctx->build_tbl_cur && int(host.size()) == n && ctx->build_tbl_frames.size() == size_t(n) &&
         std::equal(frames, frames + n, ctx->build_tbl_frames.begin())) {
-      *tbl = ctx->build_tbl.as<FrameBuildPtrs>();           // the ingest of these very frames left their table on this stream
+      *tbl = ctx->build_tbl_cur->as<FrameBuildPtrs>();      // the ingest of these very frames left their table on this stream
       return DVO_HIP_OK;
     }
     constexpr int kSlices = 4 * kMaxLevels;
@@ -956,7 +1043,7 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
   size_t npx = 0;                                             // residual entries per pair: the largest level's (packed ones own whole tiles)
   for (int l = cfg->last_level; l <= cfg->first_level; ++l) npx = std::max(npx, residual_entries(bp.geom[l]));
   DVO_WS_TRY(w, w.states.reserve(size_t(n) * sizeof(PairState)));
-  DVO_WS_TRY(w, w.pair_ptrs.reserve(size_t(n) * need_levels * sizeof(PairPtrs)));
+
   DVO_WS_TRY(w, w.partials.reserve(size_t(n) * max_tiles * kAccStride * sizeof(float)));
   DVO_WS_TRY(w, w.scratch.reserve(size_t(n) * npx * sizeof(float2)));
   DVO_WS_TRY(w, w.ll_partials.reserve(size_t(n) * kLlBlocksPerPair * sizeof(double)));
@@ -996,8 +1083,12 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
     }
   bp.pair_ptrs = nullptr;
   if (upload_table) {
-    DVO_WS_TRY(w, w.tables->upload(w.stream, w.pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs)));
-    bp.pair_ptrs = w.pair_ptrs.as<PairPtrs>();
+    int slot = w.tables->holder(w.pair_ptrs, Workspace::kTableSlots, w.stream, host.data(), host.size() * sizeof(PairPtrs));
+    if (slot < 0) slot = int(w.pair_ptrs_next++ % Workspace::kTableSlots);
+    DevBuf& pair_ptrs = w.pair_ptrs[slot];
+    DVO_WS_TRY(w, pair_ptrs.reserve(size_t(n) * need_levels * sizeof(PairPtrs)));
+    DVO_WS_TRY(w, w.tables->upload(w.stream, pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs)));
+    bp.pair_ptrs = pair_ptrs.as<PairPtrs>();
   }
   return DVO_HIP_OK;
 }
@@ -1337,7 +1428,9 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // (measured, scripts/ab_match.py fused_ll_pixels: 128 pairs 2.152 -> 2.117 ms with level 1 fused; 16 pairs 0.756 -> 0.799, one
     // pair 0.524 -> 0.547: a lone workgroup per pair is slower than 32 blocks when the chip is empty)
     const int fuse_opt = ctx->opt_fused_ll_pixels;
-    const bool fused_ll = g.w * g.h <= (fuse_opt > 0 ? fuse_opt : (n >= 64 && !ctx->opt_deterministic ? kFusedLoglikMaxPixelsBatch : kFusedLoglikMaxPixels));
+    // (round 5, packed residual pairs, the streaming step beside its ingest, scripts/r5_midsize.py: level 1 in a launch of its own
+    // 64 pairs 1.456 -> 1.378 ms, 128 pairs 1.939 -> 1.908, 256 pairs 3.308 -> 3.286, 512 pairs 5.859 -> 5.880: fused from 512 pairs)
+    const bool fused_ll = g.w * g.h <= (fuse_opt > 0 ? fuse_opt : (n >= 512 && !ctx->opt_deterministic ? kFusedLoglikMaxPixelsBatch : kFusedLoglikMaxPixels));
     // Chunks of `per_sync` iterations are enqueued ONE AHEAD of the poll: while the host waits for the status word of
     // chunk k, chunk k+1 is already queued, so the GPU never idles for a host round trip.  Iterations enqueued past the
     // end of the level are no-ops (workgroups exit on !active).
@@ -1590,6 +1683,7 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
     *value = ctx->rendezvous_pairs;
   }
   else if (std::strcmp(key, "f16_range_repeats") == 0) *value = ctx->f16_range_repeats;
+  else if (std::strcmp(key, "table_uploads_skipped") == 0) *value = ctx->tables.skipped;
   else if (std::strcmp(key, "host_batches") == 0) *value = ctx->host_batches;
   else if (std::strcmp(key, "host_ns_prepare") == 0) *value = ctx->host_ns[0];
   else if (std::strcmp(key, "host_ns_enqueue") == 0) *value = ctx->host_ns[1];
@@ -1742,7 +1836,8 @@ void dvo_hip_context_destroy(dvo_hip_context* ctx) {
   for (hipEvent_t ev : ctx->build_events)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->build_stream) (void)hipStreamDestroy(ctx->build_stream);
-  for (DevBuf* b : {&ctx->misc, &ctx->build_tbl, &ctx->role_tbl_cur, &ctx->role_tbl_ref, &ctx->prep_tbl_cur, &ctx->prep_tbl_ref, &ctx->rcp_table}) b->release();
+  for (DevBuf& b : ctx->build_tbl) b.release();
+  for (DevBuf* b : {&ctx->misc, &ctx->role_tbl_cur, &ctx->role_tbl_ref, &ctx->prep_tbl_cur, &ctx->prep_tbl_ref, &ctx->rcp_table}) b->release();
   for (DevBuf& b : ctx->upload_buf) b.release();
   for (const dvo_hip_context::PooledBlock& b : ctx->frame_pool) (void)hipFree(b.p);
   ctx->frame_pool.clear();
@@ -1855,6 +1950,12 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "condition_number") == 0) {
     if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "condition_number must be 0 or 1");
     ctx->opt_condition_number = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "table_cache") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "table_cache must be 0 or 1");
+    ctx->tables.cache = value != 0;
+    for (PinnedRing::Sent& c : ctx->tables.sent) c.dst = nullptr;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "fused_ll_pixels") == 0) {
@@ -2446,6 +2547,7 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs, dvo_hip_fram
   for (int i = 0; i < bp.n; ++i)
     for (int k = 0; k < 4; ++k) tinit[size_t(i) * 16 + k * 5] = 1.0;
   DVO_HIP_TRY(ctx, hipMemcpyAsync(w.t_init.p, tinit.data(), tinit.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  ctx->tables.forget(w.t_init.p);
   PairState* states = w.states.as<PairState>();
   launch_init_pairs(s, states, bp.n, bp.prm, w.t_init.as<double>());
   launch_level_begin(s, states, bp.n, bp.prm, g, level, pp, w.lvl_stats.as<dvo_hip_level_stats>());

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
       const int tiles = g.tiles_x * g.tiles_y;
       if (g.compact) {                                        // (uniform) the packed residuals of the contracted window sweep
         if constexpr (WAVES == kWavesPerBlock)
-          t[0] = loglik_partial_compact<8>(scratch_for_fused_ll + size_t(pair) * residual_entries(g), partials + size_t(pair) * tiles * kAccStride, tiles * 4, P,
+          t[0] = loglik_partial_compact<16>(scratch_for_fused_ll + size_t(pair) * residual_entries(g), partials + size_t(pair) * tiles * kAccStride, tiles * 4, P,
                                            wave, kWavesPerBlock);
         else
           loglik_partial_compact_played<4, kPlayed>(scratch_for_fused_ll + size_t(pair) * residual_entries(g), partials + size_t(pair) * tiles * kAccStride,

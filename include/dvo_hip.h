@@ -270,8 +270,11 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * "solver_waves" (wavefronts of a solver-step workgroup, 2 or 4; 0 = two on the smallest levels of a batch of more than two
  * workgroups per compute unit, four otherwise -- the records do not depend on it),
  * "min_workgroups" (tile-height heuristic: smallest launch that counts as filling the chip; 0 = built-in table),
+ * "table_cache" (default 1: a small table -- plane pointers of the frames to build or the pairs to align, initial guesses -- is not sent
+ * to the device again when the very bytes were last sent to the very address on the same stream and no device memory was freed since:
+ * a streaming caller hands over the same frame sets step after step; counter "table_uploads_skipped"; 0 for measurement),
  * "fused_ll_pixels" (largest level, in pixels, whose log-likelihood sweep runs inside the solver
- * workgroup instead of a launch of its own; 0 = 160x120, and 320x240 for batches of 64 pairs and more),
+ * workgroup instead of a launch of its own; 0 = 160x120, and 320x240 for batches of 512 pairs and more),
  * "condition_number" (1: results carry the condition number of the information
  * matrix, ~20 us of extra serial work per batch; default 0),
  * "deterministic" (1: a pair's record -- transform, information matrix, log-likelihood, every statistic -- is bit-identical whatever
@@ -314,6 +317,7 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
  * per frame).  That hold makes the arithmetic of those batches -- f32 instead of f16 hi + lo Gram operands, 1e-6 apart in the
  * normal equations -- depend on what the context aligned before; setting option "variant" clears it, option "deterministic" never
  * enters it),
+ * "table_uploads_skipped" (small host-to-device table uploads answered from the cache, see option "table_cache"),
  * "rendezvous_pairs" (two-pair batches formed from concurrent single matches, see option "rendezvous"),
  * "strip_ingests" (frames whose raw planes went through the strip ingest, one 128 x 8 strip per wavefront -- even-width rows and
  * 4 / 8-byte aligned planes; the others take the tile kernel),

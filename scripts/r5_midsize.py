@@ -38,7 +38,7 @@ touched = set()
 def apply(spec):
     opts = dict(DEFAULTS)
     for key in touched:
-        opts.setdefault(key, {"resident": -1}.get(key, 0))
+        opts.setdefault(key, {"resident": -1, "table_cache": 1, "compact_residuals": 1, "rendezvous": 1}.get(key, 0))
     for kv in filter(None, spec.split(",")):
         k, _, v = kv.partition("=")
         opts[k] = int(v)
@@ -47,17 +47,27 @@ def apply(spec):
         ctx.set_option(k, v)
 
 
+KEYS = ("host_batches", "host_ns_prepare", "host_ns_enqueue", "host_ns_wait", "host_ns_finish", "table_uploads_skipped")
+host = {}
+
+
 def run(spec, n):
     apply(spec)
     pipe.step(now=None, nxt=0)
     for j in range(3):
         pipe.step(now=j % 2, nxt=(j + 1) % 2)
     torch.cuda.synchronize()
+    c0 = [ctx.counter(k) for k in KEYS]
     t0 = time.perf_counter()
     for j in range(3, 3 + n):
         res = pipe.step(now=j % 2, nxt=(j + 1) % 2)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
+    c1 = [ctx.counter(k) for k in KEYS]
+    nb = max(c1[0] - c0[0], 1)
+    host[spec] = "host us per match call: prepare %.0f enqueue %.0f wait %.0f finish %.0f; outside the match %.0f; uploads skipped per step %.1f" % (
+        (c1[1] - c0[1]) / nb / 1e3, (c1[2] - c0[2]) / nb / 1e3, (c1[3] - c0[3]) / nb / 1e3, (c1[4] - c0[4]) / nb / 1e3,
+        ms * 1e3 - sum(c1[k] - c0[k] for k in (1, 2, 3, 4)) / nb / 1e3, (c1[5] - c0[5]) / n)
     T = res["transformation"].reshape(B, 4, 4).copy()
     return ms, T
 
@@ -75,3 +85,4 @@ for c in configs:
     ms, T = run(c, 2)
     print("  %-48s %s   median %.3f ms   max |dT| vs first %.1e" % (c or "(defaults)", " ".join("%.3f" % x for x in table[c]), float(np.median(table[c])),
                                                                      float(np.abs(T - base_T).max())))
+    print("      " + host[c])
