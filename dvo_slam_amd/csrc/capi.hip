@@ -600,7 +600,6 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   g.wi_x = 0.5f * g.fx / 255.0f; g.wi_y = 0.5f * g.fy / 255.0f;
   g.half_wi_x = 0.5f * g.wi_x; g.half_wi_y = 0.5f * g.wi_y; g.half_fx = 0.5f * g.fx; g.half_fy = 0.5f * g.fy;
   g.tx = cam->tx[level]; g.ty = cam->ty[level];
-  g.level = level;
   g.linear = level_is_linear(ctx, g.w) ? 1 : 0;
   level_tiles(g.w, g.h, rows_per_wave, g.linear != 0, &g.tiles_x, &g.tiles_y);
   g.rcp_table = ctx->opt_ref_compat ? ctx->rcp_table.as<float>() : nullptr;
@@ -1421,24 +1420,10 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     static const char* const kPrep[kMaxLevels] = {"prep L0", "prep L1", "prep L2", "prep L3", "prep L4", "prep L5", "prep L6", "prep L7"};
     static const char* const kErr[kMaxLevels] = {"err L0", "err L1", "err L2", "err L3", "err L4", "err L5", "err L6", "err L7"};
     static const char* const kLinsys[kMaxLevels] = {"linsys L0", "linsys L1", "linsys L2", "linsys L3", "linsys L4", "linsys L5", "linsys L6", "linsys L7"};
-    if (level == level_from) {
-      // the first level of the launch path (the whole match's first level initialises the pairs too); every later level is begun, pair
-      // by pair, by the solver step that ends the level before it (NextLevel): no launch between two levels
+    {
       Range range(kPrep[level]);
-      launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);
+      launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);   // (first level: initialises the pairs too)
     }
-    NextLevel next;
-    std::memset(&next, 0, sizeof(next));
-    if (level > cfg->last_level) {
-      const LevelGeom& gn = bp.geom[level - 1];
-      next.valid = 1;
-      next.level = level - 1;
-      next.fx = gn.fx; next.fy = gn.fy; next.ox = gn.ox; next.oy = gn.oy;
-      next.pairs = bp.pair_ptrs + size_t(level - 1) * n;
-    } else {
-      next.results = w.results.as<dvo_hip_result>();           // the last level: the step that ends a pair's level writes its result
-    }
-    const int level_slot = cfg->first_level - level;           // (the level record every pair on this level is at: k_solver_step fetches it with the state)
     // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
     // (measured, scripts/ab_match.py fused_ll_pixels: 128 pairs 2.152 -> 2.117 ms with level 1 fused; 16 pairs 0.756 -> 0.799, one
     // pair 0.524 -> 0.547: a lone workgroup per pair is slower than 32 blocks when the chip is empty)
@@ -1470,7 +1455,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
         }
         Range range(kLinsys[level]);
         launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, ll_blocks, fused_ll ? scratch : nullptr, d_levels, d_iters,
-                           tallies + step, w.host_status + step, solver_two_waves, level_slot, &next);
+                           tallies + step, w.host_status + step, solver_two_waves);
       }
     };
     int enqueued = std::min(per_sync, per_level);
@@ -1527,7 +1512,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       DVO_WS_TRY(w, sync_stream(s));                           // every group has to be gone before the batch is repeated
     }
   } else {
-    // (the results are in place: written by the resident launch, or by the solver steps that ended the pairs' last level)
+    if (level_from >= cfg->last_level) launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());   // else: done by the resident launch
     DVO_WS_TRY(w, hipMemcpyAsync(results, w.results.p, size_t(n) * sizeof(dvo_hip_result), hipMemcpyDeviceToHost, s));
     if (levels && cap_levels > 0) {
       hl.resize(size_t(n) * bp.cap_levels);

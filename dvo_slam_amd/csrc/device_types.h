@@ -59,22 +59,6 @@ struct LevelGeom {                    // identical for every pair of a batch (on
   // then moves half the bytes.  Contracted window sweep only (align_fast.hip); 0 = one pair per pixel at its pixel's place, NaN
   // where there is no constraint (every other sweep, and whenever the caller wants the residuals by pixel).
   int compact;
-  // the pyramid level this geometry belongs to: a launch on the launch-per-step path works on the pairs that are ACTIVE ON THIS LEVEL
-  // (PairState::active && PairState::level == level) -- a pair whose solver step has ended the level has already begun the next one
-  // (k_solver_step, NextLevel) and waits there for the rest of the batch
-  int level;
-};
-
-// What the solver step needs to hand a pair that has just ended its level over to the next one without a launch of its own (round 5:
-// k_level_begin used to run between two levels, k_finish after the last).  valid == 0: nothing follows here -- results != null then means the
-// match ends and the pair's result is written (gn_finish).
-struct PairPtrs;
-struct NextLevel {
-  int valid;
-  int level;
-  float fx, fy, ox, oy;                // intrinsics of that level (gn_level_begin forms K T with them)
-  const PairPtrs* pairs;               // that level's plane table (the selection count of the pair's reference frame)
-  dvo_hip_result* results;             // see above
 };
 
 // slot of the tile's partial row that holds count_0 + 512 count_1 (the next one: count_2 + 512 count_3), as exact floats

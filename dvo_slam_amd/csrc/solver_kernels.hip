@@ -71,7 +71,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
                                                         const double* __restrict__ ll_partials, int ll_blocks_per_pair,
                                                         const float2* __restrict__ scratch_for_fused_ll,
                                                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters,
-                                                        unsigned long long* step_tally, int* host_status, int level_slot_hint, NextLevel next) {
+                                                        unsigned long long* step_tally, int* host_status, int level_slot_hint) {
   const int pair = blockIdx.x;
 #ifdef DVO_SOLVER_CLOCKS
   unsigned long long clk_prev_ = wall_clock64();
@@ -81,12 +81,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
   // stored by all 256 lanes at once, touched by lane 0 at LDS latency.
   __shared__ PairState st;
   __shared__ dvo_hip_level_stats lvl;
-  __shared__ dvo_hip_level_stats lvl_next;       // the record of the level a pair begins when this step ends its level (NextLevel)
-  // [1]: the new iteration record; [0]: the one before it, fetched only by a pair whose match ends here (gn_finish reads either)
-  __shared__ dvo_hip_iteration_stats recs[2];
-  __shared__ dvo_hip_result res;                 // ... and its result
-  __shared__ int n_selected_next, handed_over, finished;
-  dvo_hip_iteration_stats& rec = recs[1];
+  __shared__ dvo_hip_iteration_stats rec;
   __shared__ double sh[kWavesPerBlock * kAccStride];
   __shared__ double sums[kAccStride];
   __shared__ double ll_waves[kWavesPerBlock];
@@ -116,9 +111,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
       lvl_w[k] = prm.cap_levels > 0 ? lsrc[i < kLvlWords ? i : 0] : 0u;
     }
   }
-  // (the selection count of the pair's reference frame at the next level, for the hand-over: two dependent loads of one lane, under the
-  // rounds of the reduction below)
-  if (next.valid && threadIdx.x == kThreads - 1) n_selected_next = *next.pairs[pair].n_selected;
   double ll_mine = 0.0;
   if (!scratch_for_fused_ll && threadIdx.x < 32) ll_mine = ll_partials[size_t(pair) * ll_blocks_per_pair + min(int(threadIdx.x), ll_blocks_per_pair - 1)];
   reduce_partials<WAVES>(partials, pair, g.tiles_x * g.tiles_y, sh, sums);   // same routine, same order as k_loglik: identical n, S, P
@@ -138,7 +130,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
     if (threadIdx.x < 32) ll_stage[threadIdx.x] = ll_mine;
   }
   __syncthreads();
-  if (!st.active || st.level != g.level) {   // uniform: the pair has left this level (and, with a level to follow, begun the next)
+  if (!st.active) {                   // uniform
     if (threadIdx.x == 0) publish_step(step_tally, host_status, n_pairs, false);
     return;
   }
@@ -196,36 +188,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
     local.cap_iters = rec_index + 1;
     gn_step(st, local, g, sums, ll_sum, &lvl - level_slot, &rec - rec_index);
     CLK(3);
-    const bool on_level = st.active != 0;
-    publish_step(step_tally, host_status, n_pairs, on_level);
+    publish_step(step_tally, host_status, n_pairs, st.active != 0);
     CLK(4);
-    handed_over = finished = 0;
-    if (!on_level && next.valid) {
-      // the pair has ended this level: it begins the next one here (dense_tracking.cpp:200-238) instead of in a launch between the
-      // levels, and waits there -- active on a level no launch works on yet -- for the rest of the batch
-      LevelGeom gn = g;
-      gn.fx = next.fx; gn.fy = next.fy; gn.ox = next.ox; gn.oy = next.oy;
-      SolverParams begin = prm;
-      begin.cap_levels = st.n_levels < prm.cap_levels ? st.n_levels + 1 : 0;
-      handed_over = begin.cap_levels ? 1 : 2;                   // 1: with a level record to store
-      gn_level_begin(st, begin, gn, next.level, n_selected_next, &lvl_next - st.n_levels);
-    } else if (!on_level && next.results) {
-      finished = 1;                                             // the match ends here: the result below, once the record before this one is in
-    }
   }
   __syncthreads();
-  if (finished) {                                               // uniform
-    // dense_tracking.cpp:368-373 (k_finish used to be a launch of its own): the last iteration with an increment is this step's record
-    // or the one before it -- that one comes from memory (a solver step of an earlier launch wrote it)
-    if (rec_index >= 1 && rec_index - 1 < prm.cap_iters) coop_copy(&recs[0], iters + size_t(pair) * prm.cap_iters + rec_index - 1);
-    __syncthreads();
-    if (threadIdx.x == 0) gn_finish(st, prm, &lvl - level_slot, &recs[1] - rec_index, &res);
-    __syncthreads();
-    coop_copy(next.results + pair, &res);
-  }
   coop_copy(&states[pair], &st);
   if (have_level) coop_copy(lvl_global, &lvl);
-  if (handed_over == 1) coop_copy(lvl_global + 1, &lvl_next);
   if (rec_index < prm.cap_iters) coop_copy(iters + size_t(pair) * prm.cap_iters + rec_index, &rec);
   CLK(5);
 #ifdef DVO_SOLVER_CLOCKS
@@ -250,7 +218,6 @@ __global__ void k_set_fixed_state(PairState* states, LevelGeom g, const float* _
   for (int i = 0; i < 4; ++i) st.P_prev[i] = Pprev[i];
   st.first = first;
   st.active = 1;
-  st.level = g.level;
 }
 
 __global__ __launch_bounds__(kBlock) void k_single_shot_out(LevelGeom g, const float* __restrict__ partials,
@@ -296,17 +263,14 @@ void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverPar
 void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
                         const float* partials, const double* ll_partials, int ll_blocks_per_pair, const float2* scratch_for_fused_ll,
                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, unsigned long long* step_tally, int* host_status, bool two_waves,
-                        int level_slot_hint, const NextLevel* next_or_null) {
-  NextLevel next;
-  next.valid = 0; next.level = 0; next.fx = next.fy = next.ox = next.oy = 0.0f; next.pairs = nullptr; next.results = nullptr;
-  if (next_or_null) next = *next_or_null;
+                        int level_slot_hint) {
   // (two wavefronts: see the kernel; a level of at most 32 tiles -- 160 x 120, 80 x 60 -- of a batch beyond two workgroups per compute unit)
   if (two_waves)
     k_solver_step<2><<<dim3(n_pairs), dim3(128), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
-                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status, level_slot_hint, next);
+                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status, level_slot_hint);
   else
     k_solver_step<kWavesPerBlock><<<dim3(n_pairs), dim3(kBlock), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
-                                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status, level_slot_hint, next);
+                                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status, level_slot_hint);
 }
 
 void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverParams prm,
