@@ -1455,7 +1455,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
         }
         Range range(kLinsys[level]);
         launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, ll_blocks, fused_ll ? scratch : nullptr, d_levels, d_iters,
-                           tallies + step, w.host_status + step, solver_two_waves);
+                           tallies + step, w.host_status + step, solver_two_waves, cfg->first_level - level);   // (the level record every pair on this level is at: fetched with the state)
       }
     };
     int enqueued = std::min(per_sync, per_level);
