@@ -1000,6 +1000,7 @@ void make_plan(const dvo_hip_context* ctx, const CameraGeom* cam, const dvo_hip_
   bp.prm.cap_levels = bp.cap_levels;
   bp.prm.max_points_level0 = cam->w0 * cam->h0;
   bp.prm.want_condition_number = ctx->opt_condition_number;
+  bp.prm.record_prefilled = 0;
   bp.rpw.assign(need_levels, 1);
   bp.geom.resize(need_levels);
   for (int l = cfg->last_level; l <= cfg->first_level; ++l) {

@@ -142,6 +142,9 @@ struct SolverParams {
   int cap_levels;
   int max_points_level0;
   int want_condition_number;          // gn_finish also computes the eigenvalue range of the information matrix
+  // set by a caller of gn_step that has idle lanes next to the solver lane (k_solver_step; 0 from the host): every 8-byte word of the
+  // new iteration record already holds NaN -- 51 stores of one lane off the serial path
+  int record_prefilled;
 };
 
 // ---- the resident match kernel (align_resident.hip): one group of workgroups owns a pair for a whole run of levels ----

@@ -57,10 +57,12 @@ DVO_HD void se3_exp(const double* x, SE3d& T) {
     b = 0.5 - th2 / 24.0;
     c = 1.0 / 6.0 - th2 / 120.0;
   } else {
+    // (one division instead of three: a float64 division is ~150 cycles of one lane's serial time, and this lane is the solver step)
     const double s = sin(th), co = cos(th);
-    a = s / th;
-    b = (1.0 - co) / th2;
-    c = (th - s) / (th2 * th);
+    const double inv2 = 1.0 / th2, inv1 = th * inv2;          // 1 / th^2, 1 / th
+    a = s * inv1;
+    b = (1.0 - co) * inv2;
+    c = (th - s) * (inv2 * inv1);
   }
   double O[9], O2[9];
   hat3(w, O);
@@ -128,7 +130,7 @@ DVO_HD void se3_log(const SE3d& T, double* x) {
 DVO_HD bool solve6_pivoted(const double* Ain, const double* bin, double* x);
 
 DVO_HD bool solve6(const double* A, const double* b, double* x) {
-  double L[6][6], D[6], y[6];
+  double L[6][6], D[6], Dinv[6], y[6];
   bool spd = true;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -138,6 +140,7 @@ DVO_HD bool solve6(const double* A, const double* b, double* x) {
     D[j] = d;
     spd = spd && (d > 0.0);
     const double inv = 1.0 / d;
+    Dinv[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double v = A[i * 6 + j];
@@ -155,7 +158,7 @@ DVO_HD bool solve6(const double* A, const double* b, double* x) {
     y[i] = v;
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) y[i] /= D[i];
+  for (int i = 0; i < 6; ++i) y[i] *= Dinv[i];              // (the pivots' reciprocals of the factorisation: six divisions fewer)
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
     double v = y[i];

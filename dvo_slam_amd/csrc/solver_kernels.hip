@@ -7,6 +7,14 @@
 // device removes the per-iteration D2H/H2D round trip a host-driven loop would need; the host only
 // polls one integer (pairs still active) every few iterations.
 #include "align_common.h"
+#ifdef DVO_SOLVER_CLOCKS
+// experiment build only: the stages of gn_step (solver_logic.h, DVO_GN_CLK) on thread 0 of workgroup 0, 100 MHz wall clock
+namespace dvo_hip {
+__device__ unsigned long long g_gn_clk[16];
+__device__ unsigned long long g_gn_prev;
+}
+#define DVO_GN_CLK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); if ((i) > 0) atomicAdd(&dvo_hip::g_gn_clk[(i)], now_ - dvo_hip::g_gn_prev); else atomicAdd(&dvo_hip::g_gn_clk[0], 1ull); dvo_hip::g_gn_prev = now_; } } while (0)
+#endif
 #include "solver_logic.h"
 
 namespace dvo_hip {
@@ -53,6 +61,11 @@ __device__ unsigned long long g_solver_clk[64];
 #define CLK_ROW (g.w >= 640 ? 0 : g.w >= 320 ? 16 : g.w >= 160 ? 32 : 48)
 // (every 64th workgroup, so that a large batch shows what a step costs with the memory system under load, not only its first workgroup)
 #define CLK(i) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_solver_clk[CLK_ROW + (i)], now_ - clk_prev_); clk_prev_ = now_; } } while (0)
+extern "C" int dvo_hip_debug_gn_clocks(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_gn_clk), sizeof(g_gn_clk)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_gn_clk), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
 extern "C" int dvo_hip_debug_solver_clocks(unsigned long long* out64, int reset) {
   if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_solver_clk), sizeof(g_solver_clk)) != hipSuccess) return -1;
   if (reset) { unsigned long long z[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_solver_clk), z, sizeof(z)) != hipSuccess) return -1; }
@@ -86,6 +99,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
   __shared__ double sums[kAccStride];
   __shared__ double ll_waves[kWavesPerBlock];
   __shared__ double ll_stage[32];
+  __shared__ double Amat[36], bvec[6];         // J^T W J and J^T W r of this pass, contracted by 42 lanes (GnAssist)
+  __shared__ int information_ready;
   __shared__ int rec_index;
   // ONE round trip for everything whose address does not depend on loaded data (round 4; with 1024 workgroups in flight a dependent
   // trip costs 4-5 us and the step was a chain of nine): the pair's state, its level record (the slot every live pair of the batch
@@ -128,6 +143,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
       if (i < kLvlWords) ldst[i] = lvl_w[k];
     }
     if (threadIdx.x < 32) ll_stage[threadIdx.x] = ll_mine;
+    // what the serial lane would otherwise do one store at a time: every word of the new iteration record NaN (SolverParams::record_prefilled)
+    static_assert(sizeof(dvo_hip_iteration_stats) % 8 == 0, "prefilled by 8-byte words");
+    for (int i = threadIdx.x; i < int(sizeof(dvo_hip_iteration_stats) / 8); i += kThreads) reinterpret_cast<double*>(&rec)[i] = dvo_nan();
+    // ... and the contraction of the Gram sums with the pass' precision (the sums are in place since reduce_partials' barrier): lane
+    // i * 6 + j forms A(i, j) from the upper-triangle entry of (min, max), lanes 36..41 J^T W r
+    if (threadIdx.x < 42) {
+      const double d = sums[kAccN] - 3.0;
+      float Cc[3], Pc[4];
+      scale_to_precision(sums[kAccS] / d, sums[kAccS + 1] / d, sums[kAccS + 2] / d, Cc, Pc);
+      const double p00 = double(Pc[0]), p01 = double(Pc[1]), p11 = double(Pc[3]);
+      const int k = threadIdx.x;
+      if (k < 36) {
+        const int i = k / 6, j = k - i * 6, lo = i < j ? i : j, hi = i < j ? j : i;
+        const int o = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);           // index of (lo, hi) in the row-major upper triangle
+        Amat[k] = gn_contract(p00, p01, p11, sums[kAccJ00 + o], sums[kAccJ01 + o], sums[kAccJ11 + o]);
+      } else {
+        bvec[k - 36] = gn_contract(p00, p01, p11, sums[kAccB00 + k - 36], sums[kAccB01 + k - 36], sums[kAccB11 + k - 36]);
+      }
+    }
   }
   __syncthreads();
   if (!st.active) {                   // uniform
@@ -186,11 +220,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
     SolverParams local = prm;
     local.cap_levels = have_level ? level_slot + 1 : 0;
     local.cap_iters = rec_index + 1;
-    gn_step(st, local, g, sums, ll_sum, &lvl - level_slot, &rec - rec_index);
+    local.record_prefilled = 1;
+    GnAssist assist = {Amat, bvec, 1, 0};
+    gn_step(st, local, g, sums, ll_sum, &lvl - level_slot, &rec - rec_index, nullptr, &assist);
+    information_ready = assist.information_ready;
     CLK(3);
     publish_step(step_tally, host_status, n_pairs, st.active != 0);
     CLK(4);
   }
+  __syncthreads();
+  if (information_ready && threadIdx.x < 36) rec.information[threadIdx.x] = Amat[threadIdx.x];   // (uniform; GnAssist::defer_information)
   __syncthreads();
   coop_copy(&states[pair], &st);
   if (have_level) coop_copy(lvl_global, &lvl);

@@ -153,8 +153,24 @@ DVO_HD void gn_release_sweep(GnSpeculation* spec) {
 // sums = the kNumAcc accumulators reduced over all tiles; ll_sum = sum log(1 + 0.2 r^T P r).
 // spec != null, replay_reject == 0: speculative form -- ll_sum is ignored, the pass is treated as accepted, st.error /
 // st.last_error and rec.tdist_loglik are left for gn_commit_loglik.  replay_reject == 1: the full form, taking the revert path.
+// What a caller with idle lanes next to the solver lane takes off the serial path (k_solver_step; the host emulation and the resident
+// kernel pass none):
+//   A, b: the contraction of the Gram sums with the pass' precision, formed with gn_contract (the same expression, the same bits) --
+//     A the full symmetric 6 x 6 WITHOUT the prior's mu on its diagonal, b = J^T W r (not negated); gn_step then works in A itself
+//     instead of PairState::A_last (which it leaves alone);
+//   defer_information: the 36 doubles of rec.information are left to the caller, who copies A when information_ready comes back 1.
+struct GnAssist {
+  double* A;
+  const double* b;
+  int defer_information;
+  int information_ready;
+};
+
+DVO_HD double gn_contract(double p00, double p01, double p11, double s00, double s01, double s11) { return p00 * s00 + p01 * s01 + p11 * s11; }
+
 DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, const double* sums, double ll_sum,
-                    dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, GnSpeculation* spec = nullptr) {
+                    dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, GnSpeculation* spec = nullptr, GnAssist* assist = nullptr) {
+  if (assist) assist->information_ready = 0;
   const bool speculate = spec && !spec->replay_reject;
   if (spec) spec->needs_loglik = spec->information_ready = 0;
   if (!st.active) return;
@@ -168,7 +184,7 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   rec.id = st.iteration;
   rec.valid_constraints = n;
   rec.tdist_mean[0] = rec.tdist_mean[1] = 0.0;              // Q8
-  if (!(spec && spec->record_prefilled)) {
+  if (!(prm.record_prefilled || (spec && spec->record_prefilled))) {
     rec.tdist_loglik = dvo_nan();
     rec.prior_loglik = dvo_nan();
     for (int i = 0; i < 4; ++i) rec.tdist_precision[i] = dvo_nan();
@@ -225,17 +241,21 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   const double p00 = double(P[0]), p01 = double(P[1]), p11 = double(P[3]);
   // (formed in place in st.A_last, which nothing reads between here and the end of the pass: on the device the state lives in LDS,
   // a local array of 36 doubles in scratch memory -- three round trips of the serial lane per pass)
-  double* const A = st.A_last;
+  double* const A = assist ? assist->A : st.A_last;
   double b[6];
-  int o = 0;
-  for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 6; ++j) {
-      const double a = p00 * sums[kAccJ00 + o] + p01 * sums[kAccJ01 + o] + p11 * sums[kAccJ11 + o];
-      A[i * 6 + j] = a;
-      A[j * 6 + i] = a;
-      ++o;
-    }
-  for (int i = 0; i < 6; ++i) b[i] = -(p00 * sums[kAccB00 + i] + p01 * sums[kAccB01 + i] + p11 * sums[kAccB11 + i]);
+  if (assist) {
+    for (int i = 0; i < 6; ++i) b[i] = -assist->b[i];
+  } else {
+    int o = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j) {
+        const double a = gn_contract(p00, p01, p11, sums[kAccJ00 + o], sums[kAccJ01 + o], sums[kAccJ11 + o]);
+        A[i * 6 + j] = a;
+        A[j * 6 + i] = a;
+        ++o;
+      }
+    for (int i = 0; i < 6; ++i) b[i] = -gn_contract(p00, p01, p11, sums[kAccB00 + i], sums[kAccB01 + i], sums[kAccB11 + i]);
+  }
   for (int i = 0; i < 6; ++i) {                              // :345-346
     A[i * 6 + i] += prm.mu;
     b[i] += prm.mu * li[i];
@@ -260,6 +280,8 @@ DVO_HD void gn_step(PairState& st, const SolverParams& prm, const LevelGeom& g, 
   for (int i = 0; i < 6; ++i) rec.increment[i] = st.x[i];
   if (spec && spec->defer_information) {
     spec->information_ready = 1;
+  } else if (assist && assist->defer_information) {
+    assist->information_ready = 1;
   } else {
     for (int i = 0; i < 36; ++i) rec.information[i] = A[i];
   }

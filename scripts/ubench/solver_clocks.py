@@ -19,6 +19,8 @@ ctx.set_option("resident", 0)
 for _ in range(3):
     out = trk.match_batch_arrays(refs, curs)
 L.dvo_hip_debug_solver_clocks(buf, 1)
+gbuf = (C.c_ulonglong * 16)()
+L.dvo_hip_debug_gn_clocks(gbuf, 1)
 t0 = time.perf_counter()
 R = 20
 for _ in range(R):
@@ -34,3 +36,8 @@ for row, width in enumerate((640, 320, 160, 80)):
         continue
     print("level %d pixels wide: %d active solver steps of the pairs 0, 64, 128, ... over %d matches; us per step: %s; total %.2f"
           % (width, calls, R, "  ".join("%s %.2f" % (nm, v[row, i] / calls * 0.01) for i, nm in enumerate(names)), v[row, :6].sum() / calls * 0.01))
+L.dvo_hip_debug_gn_clocks(gbuf, 0)
+g = np.array(list(gbuf), dtype=np.float64)
+if g[0] > 0:
+    stages = ["record initialised", "precision, log det, prior", "contraction", "6x6 solve", "exp, product, K T", "record, A_last, inverse, product"]
+    print("gn_step of pair 0, %d calls, us per call: %s; total %.2f" % (g[0], "  ".join("%s %.2f" % (nm, g[i + 1] / g[0] * 0.01) for i, nm in enumerate(stages)), g[1:7].sum() / g[0] * 0.01))

@@ -195,6 +195,7 @@ int emul_match(const emul_level* levels, const dvo_hip_config* cfg, dvo_hip_resu
   prm.cap_levels = cap_levels;
   prm.max_points_level0 = levels[0].w * levels[0].h;
   prm.want_condition_number = 1;
+  prm.record_prefilled = 0;
   PairState st;
   std::memset(&st, 0, sizeof(st));
   gn_init_pair(st, prm, result->transformation);
@@ -232,6 +233,7 @@ int emul_match_speculative(const emul_level* levels, const dvo_hip_config* cfg, 
   prm.cap_levels = cap_levels;
   prm.max_points_level0 = levels[0].w * levels[0].h;
   prm.want_condition_number = 1;
+  prm.record_prefilled = 0;
   PairState st;
   std::memset(&st, 0, sizeof(st));
   gn_init_pair(st, prm, result->transformation);
