@@ -113,6 +113,7 @@ struct dvo_hip_frame {
   DevBuf pool;
   int* sel_count = nullptr;    // device, one int per level
   unsigned long long built_seq = 0;   // ticket of the last build-stream work that wrote this frame (0 = none pending)
+  int deferred = 0;                   // named by a recorded, not yet executed ingest (option "defer_ingest")
   // Frames ingested from raw sensor planes have no float I / Z planes at level 0 (k_build_from_raw writes the role planes
   // straight from the raw data).  What level 0 can later be derived from: the current-role planes A + B if they exist (they
   // hold everything), else the 3-B copy of the raw planes in the frame's staging area.
@@ -327,6 +328,21 @@ struct dvo_hip_context {
   long long rendezvous_pairs = 0;     // two-pair batches formed (counter "rendezvous_pairs")
   long long f16_range_repeats = 0; // batches repeated with the f32 Gram because a Jacobian left the f16 range (counter "f16_range_repeats")
   long long strip_ingests = 0;     // frames ingested by the strip kernel (ingest_strips.hip), counter "strip_ingests"
+  // Option "defer_ingest": a batched re-ingest (dvo_hip_frames_update_raw_device_as) is only recorded, and carried out by the next
+  // dvo_hip_match_batch right behind the first launches of its first level (or by whatever entry point comes first).  A streaming
+  // caller re-ingests the next batch and then aligns the current one: enqueueing the ingest first keeps the alignment's stream idle
+  // for the ~0.1 ms (128 pairs) to ~0.5 ms (1024 pairs) of host time it takes -- this way the host does that work while the device
+  // is already on the coarsest level.
+  struct DeferredIngest {
+    std::vector<dvo_hip_frame*> frames;
+    std::vector<const void*> grey, raw;
+    float depth_scale;
+    int role;
+    dvo_hip_config cfg;
+  };
+  std::vector<DeferredIngest> deferred;
+  int opt_defer_ingest = 0;
+  long long deferred_ingests = 0;  // ingests carried out behind the first launches of a match (counter "deferred_ingests")
   int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
   int opt_tail_speculation = 0;    // 1: always enqueue the step ahead of the poll, also on the tail of a level whose empty step is costly (measurement)
   int opt_solver_waves = 0;        // wavefronts of a solver-step workgroup: 0 = by level and batch size, 2, 4
@@ -401,6 +417,19 @@ struct dvo_hip_context {
   unsigned upload_next = 0;
   unsigned long long upload_waited_seq = 0;  // newest build ticket the upload stream already waits behind
 };
+
+namespace {
+int flush_deferred(dvo_hip_context* ctx);
+}
+
+// (every entry point that works on frames or streams begins with this, under the context's lock: nothing overtakes a recorded ingest)
+#define DVO_FLUSH_DEFERRED(ctx)                                     \
+  do {                                                              \
+    if ((ctx) && !(ctx)->deferred.empty()) {                        \
+      const int rc_deferred__ = flush_deferred(ctx);                \
+      if (rc_deferred__ != DVO_HIP_OK) return rc_deferred__;        \
+    }                                                               \
+  } while (0)
 
 namespace {
 
@@ -1413,6 +1442,13 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     Range range("resident");
     rc = run_resident(ctx, w, cfg, bp, rp, tinit.data(), want_stats);
     if (rc != DVO_HIP_OK) return rc;
+    if (!ctx->deferred.empty()) {                              // (see the launch path below)
+      const int rc_deferred = flush_deferred(ctx);
+      if (rc_deferred != DVO_HIP_OK) {
+        w.err = ctx->err;
+        return rc_deferred;
+      }
+    }
     level_from = cfg->first_level - rp.levels;
   }
   for (int level = level_from; level >= cfg->last_level; --level) {
@@ -1461,6 +1497,23 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     };
     int enqueued = std::min(per_sync, per_level);
     enqueue_chunk(enqueued);
+    if (!ctx->deferred.empty()) {
+      // A recorded ingest of the caller's next batch (option "defer_ingest") is carried out now, behind the first launches of this
+      // batch.  It is ~0.1-0.5 ms of host time during which nothing more would be enqueued here: where the level's steps are short,
+      // a few more of them go out first (a pair needs more than four passes on its first level; a step too many exits at once).
+      if (size_t(g.tiles_x) * g.tiles_y * size_t(n) < 65536) {
+        const int lead = std::min(3 * per_sync, per_level - enqueued);
+        if (lead > 0) {
+          enqueue_chunk(lead);
+          enqueued += lead;
+        }
+      }
+      const int rc_deferred = flush_deferred(ctx);
+      if (rc_deferred != DVO_HIP_OK) {
+        w.err = ctx->err;
+        return rc_deferred;
+      }
+    }
     int watched = step - 1;                                  // last step of the chunk whose outcome is awaited
     // Where an EMPTY step is expensive -- the dispatcher needs 95 us for the 307 200 workgroups of a 1024-pair finest-level sweep
     // that all exit at once, 114 us with its log-likelihood and solver launches -- the step ahead of the poll is not enqueued once
@@ -1685,6 +1738,7 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
   }
   else if (std::strcmp(key, "f16_range_repeats") == 0) *value = ctx->f16_range_repeats;
   else if (std::strcmp(key, "table_uploads_skipped") == 0) *value = ctx->tables.skipped;
+  else if (std::strcmp(key, "deferred_ingests") == 0) *value = ctx->deferred_ingests;
   else if (std::strcmp(key, "host_batches") == 0) *value = ctx->host_batches;
   else if (std::strcmp(key, "host_ns_prepare") == 0) *value = ctx->host_ns[0];
   else if (std::strcmp(key, "host_ns_enqueue") == 0) *value = ctx->host_ns[1];
@@ -1829,6 +1883,7 @@ int dvo_hip_context_create(int device, dvo_hip_context** out) {
 void dvo_hip_context_destroy(dvo_hip_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  ctx->deferred.clear();                                       // (nobody is left to read what a recorded ingest would build)
   if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
   if (ctx->build_stream) (void)hipStreamSynchronize(ctx->build_stream);
   for (Workspace& w : ctx->ws) workspace_destroy(w);
@@ -1953,6 +2008,12 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     ctx->opt_condition_number = value;
     return DVO_HIP_OK;
   }
+  if (std::strcmp(key, "defer_ingest") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "defer_ingest must be 0 or 1");
+    ctx->opt_defer_ingest = value;
+    if (!value) DVO_FLUSH_DEFERRED(ctx);
+    return DVO_HIP_OK;
+  }
   if (std::strcmp(key, "table_cache") == 0) {
     if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "table_cache must be 0 or 1");
     ctx->tables.cache = value != 0;
@@ -1971,6 +2032,7 @@ int dvo_hip_frame_create_f32(dvo_hip_context* ctx, int width, int height, const 
                              const float* depth, int levels, dvo_hip_frame** out) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
   if (!ctx || !out || !intensity || !depth || !K) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create_f32: null argument");
   size_t raw_off;
   dvo_hip_frame* f = nullptr;
@@ -1997,6 +2059,7 @@ int dvo_hip_frame_create_raw(dvo_hip_context* ctx, int width, int height, const 
                              const uint16_t* raw_depth, float depth_scale, int levels, dvo_hip_frame** out) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
   if (!ctx || !out || !grey || !raw_depth || !K) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create_raw: null argument");
   size_t raw_off;
   dvo_hip_frame* f = nullptr;
@@ -2027,6 +2090,7 @@ int dvo_hip_frame_create_raw_device(dvo_hip_context* ctx, int width, int height,
                                     const void* raw_depth_dev, float depth_scale, int levels, dvo_hip_frame** out) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
   if (!ctx || !out || !grey_dev || !raw_depth_dev || !K) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create_raw_device: null argument");
   size_t raw_off;
   dvo_hip_frame* f = nullptr;
@@ -2096,10 +2160,26 @@ int update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* 
   return rc;
 }
 
+// carry out the recorded ingests (option "defer_ingest"), oldest first; the first failure is returned, the list is empty afterwards
+int flush_deferred(dvo_hip_context* ctx) {
+  if (ctx->deferred.empty()) return DVO_HIP_OK;
+  std::vector<dvo_hip_context::DeferredIngest> list;
+  list.swap(ctx->deferred);
+  int rc = DVO_HIP_OK;
+  for (dvo_hip_context::DeferredIngest& d : list) {
+    for (dvo_hip_frame* f : d.frames) f->deferred = 0;
+    if (rc != DVO_HIP_OK) continue;
+    ctx->deferred_ingests += 1;
+    rc = update_raw_device(ctx, int(d.frames.size()), d.frames.data(), d.grey.data(), d.raw.data(), d.depth_scale, d.role, &d.cfg);
+  }
+  return rc;
+}
+
 }  // namespace
 
 int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
                                      const void* const* raw_depth_dev, float depth_scale) {
+  DVO_FLUSH_DEFERRED(ctx);
   if (!ctx || n_frames < 1 || !frames || !grey_dev || !raw_depth_dev) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device: null argument");
   for (int i = 0; i < n_frames; ++i)
     if (!frames[i] || !grey_dev[i] || !raw_depth_dev[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device: null entry");
@@ -2116,6 +2196,18 @@ int dvo_hip_frames_update_raw_device_as(dvo_hip_context* ctx, int n_frames, dvo_
   if (!grey_dev || !raw_depth_dev) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device_as: null argument");
   for (int i = 0; i < n_frames; ++i)
     if (!grey_dev[i] || !raw_depth_dev[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device_as: null entry");
+  if (ctx->opt_defer_ingest) {
+    dvo_hip_context::DeferredIngest d;
+    d.frames.assign(frames, frames + n_frames);
+    d.grey.assign(grey_dev, grey_dev + n_frames);
+    d.raw.assign(raw_depth_dev, raw_depth_dev + n_frames);
+    d.depth_scale = depth_scale;
+    d.role = role;
+    d.cfg = *cfg;
+    for (int i = 0; i < n_frames; ++i) frames[i]->deferred = 1;
+    ctx->deferred.push_back(std::move(d));
+    return DVO_HIP_OK;
+  }
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   return update_raw_device(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, role, cfg);
 }
@@ -2172,6 +2264,7 @@ static int update_raw_host(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* co
 
 int dvo_hip_frames_update_raw(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const uint8_t* const* grey,
                               const uint16_t* const* raw_depth, float depth_scale) {
+  DVO_FLUSH_DEFERRED(ctx);
   return update_raw_host(ctx, n_frames, frames, grey, raw_depth, depth_scale, -1, nullptr);
 }
 
@@ -2179,6 +2272,7 @@ int dvo_hip_frames_update_raw_as(dvo_hip_context* ctx, int n_frames, dvo_hip_fra
                                  const uint16_t* const* raw_depth, float depth_scale, int role, const dvo_hip_config* cfg) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
   const int rc = check_prepare_args(ctx, n_frames, frames, role, cfg, "frames_update_raw_as: bad argument");
   if (rc != DVO_HIP_OK) return rc;
   return update_raw_host(ctx, n_frames, frames, grey, raw_depth, depth_scale, role, cfg);
@@ -2187,6 +2281,7 @@ int dvo_hip_frames_update_raw_as(dvo_hip_context* ctx, int n_frames, dvo_hip_fra
 int dvo_hip_upload_wait(dvo_hip_context* ctx) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
   if (!ctx) return DVO_HIP_ERR_INVALID;
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   DVO_HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_stream));
@@ -2213,6 +2308,7 @@ void dvo_hip_host_free(dvo_hip_context* ctx, void* p) {
 int dvo_hip_frames_prepare(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, int role, const dvo_hip_config* cfg) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
   const int rc = check_prepare_args(ctx, n_frames, frames, role, cfg, "frames_prepare: bad argument");
   if (rc != DVO_HIP_OK) return rc;
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2231,6 +2327,7 @@ void dvo_hip_frame_destroy(dvo_hip_context* ctx, dvo_hip_frame* frame) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   if (!frame) return;
+  if (ctx && !ctx->deferred.empty()) (void)flush_deferred(ctx);   // (a recorded ingest may name this frame)
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     ctx->build_tbl_frames.clear();   // a later frame may be given the same address
@@ -2261,6 +2358,7 @@ int dvo_hip_frame_info(const dvo_hip_frame* frame, int level, int* width, int* h
 int dvo_hip_frame_download_plane(dvo_hip_context* ctx, dvo_hip_frame* frame, int level, int plane, float* out) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
   if (!ctx || !frame || !out || level < 0 || level >= frame->levels || plane < 0 || plane > 5)
     return fail(ctx, DVO_HIP_ERR_INVALID, "frame_download_plane: bad argument");
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2281,6 +2379,7 @@ int dvo_hip_frame_select(dvo_hip_context* ctx, dvo_hip_frame* frame, int level, 
                          uint8_t* mask_or_null) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
   if (!ctx || !frame || level < 0 || level >= frame->levels) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_select: bad argument");
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t n = size_t(frame->lv[level].w) * frame->lv[level].h;
@@ -2322,12 +2421,22 @@ int dvo_hip_match_batch(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const*
           return fail(ctx, DVO_HIP_ERR_INVALID, "match: provided initialization is NaN (dense_tracking.cpp:139)");
   ctx->batch_entry = std::chrono::steady_clock::now();
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // a recorded ingest (option "defer_ingest") of frames this batch aligns comes first; of other frames: behind the first launches (run_batch)
+  if (!ctx->deferred.empty()) {
+    bool mine = false;
+    for (int i = 0; i < n_pairs && !mine; ++i) mine = references[i]->deferred || currents[i]->deferred;
+    if (mine) DVO_FLUSH_DEFERRED(ctx);
+  }
   EffectiveVariantScope effective_variant_scope(ctx);
   rc = ensure_batch_roles(ctx, n_pairs, references, currents, cfg);
   if (rc != DVO_HIP_OK) return rc;
 
   rc = run_batch(ctx, n_pairs, references, currents, cfg, results, levels, cap_levels, iters, cap_iters);
   if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
+  if (!ctx->deferred.empty()) {                                // (a path without launches to hide it behind, or a batch that ended early)
+    const int rc_deferred = flush_deferred(ctx);
+    if (rc == DVO_HIP_OK) rc = rc_deferred;
+  }
   return rc;
 }
 
@@ -2459,6 +2568,7 @@ int dvo_hip_level_iteration(dvo_hip_context* ctx, dvo_hip_frame* reference, dvo_
                             dvo_hip_iteration_out* out, float* residuals_or_null) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
   if (!ctx || !reference || !current || !T34 || !P_prev || !out) return fail(ctx, DVO_HIP_ERR_INVALID, "level_iteration: null argument");
   dvo_hip_config cfg;
   std::memset(&cfg, 0, sizeof(cfg));
@@ -2528,6 +2638,7 @@ int dvo_hip_time_residual_kernel(dvo_hip_context* ctx, int n_pairs, dvo_hip_fram
                                  int level, int warm_iterations, int reps, float* avg_ms) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
   if (!avg_ms || reps < 1 || warm_iterations < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "time_residual_kernel: bad argument");
   dvo_hip_config cfg;
   std::memset(&cfg, 0, sizeof(cfg));
@@ -2589,6 +2700,7 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* co
                             int level, int with_write, int reps, float* avg_ms) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
   if (!avg_ms || reps < 1) return fail(ctx, DVO_HIP_ERR_INVALID, "time_stream_mix: bad argument");
   dvo_hip_config cfg;
   std::memset(&cfg, 0, sizeof(cfg));

@@ -270,6 +270,11 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * "solver_waves" (wavefronts of a solver-step workgroup, 2 or 4; 0 = two on the smallest levels of a batch of more than two
  * workgroups per compute unit, four otherwise -- the records do not depend on it),
  * "min_workgroups" (tile-height heuristic: smallest launch that counts as filling the chip; 0 = built-in table),
+ * "defer_ingest" (default 0; 1: dvo_hip_frames_update_raw_device_as only RECORDS its request -- the pointer arrays are copied, the
+ * raw planes must stay valid as for any asynchronous ingest -- and the next dvo_hip_match_batch carries it out right behind the first
+ * launches of its first level, so that the host's work for the ingest of batch k + 1 (0.1-0.5 ms) does not keep the alignment of batch k
+ * from starting; any other entry point, a match that aligns the very frames, or switching the option off carries it out at once, and
+ * returns its status if it fails; counter "deferred_ingests".  dvo_slam_amd/apps/stream_pipeline.cpp switches it on around its step),
  * "table_cache" (default 1: a small table -- plane pointers of the frames to build or the pairs to align, initial guesses -- is not sent
  * to the device again when the very bytes were last sent to the very address on the same stream and no device memory was freed since:
  * a streaming caller hands over the same frame sets step after step; counter "table_uploads_skipped"; 0 for measurement),
@@ -317,6 +322,7 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
  * per frame).  That hold makes the arithmetic of those batches -- f32 instead of f16 hi + lo Gram operands, 1e-6 apart in the
  * normal equations -- depend on what the context aligned before; setting option "variant" clears it, option "deterministic" never
  * enters it),
+ * "deferred_ingests" (ingests carried out behind the first launches of a match, see option "defer_ingest"),
  * "table_uploads_skipped" (small host-to-device table uploads answered from the cache, see option "table_cache"),
  * "rendezvous_pairs" (two-pair batches formed from concurrent single matches, see option "rendezvous"),
  * "strip_ingests" (frames whose raw planes went through the strip ingest, one 128 x 8 strip per wavefront -- even-width rows and
