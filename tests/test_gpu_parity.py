@@ -923,6 +923,26 @@ def test_device_ingest_prepare_and_background_build(gpu_ctx):
     d.prepare_roles_batch(sets[1][n:], "current", cfg)
     gpu_ctx.set_option("build_workgroups", 0)
     assert raw(trk.match_batch_arrays(sets[1][:n], sets[1][n:])) == base[0]
+    # option "defer_ingest" (round 5): a role-aware re-ingest is only recorded and carried out by the NEXT match behind its first launches
+    # -- of set 1 (with set 0's data) while set 0 is aligned; a match of the recorded frames themselves, or any other entry point,
+    # carries it out first; switching the option off carries out what is left.  Not a bit of any result changes.
+    k0 = gpu_ctx.counter("deferred_ingests")
+    gpu_ctx.set_option("defer_ingest", 1)
+    d.update_raw_device_batch(sets[1][:n], dev[0][2][:n], dev[0][3][:n], role="reference", config=cfg)
+    d.update_raw_device_batch(sets[1][n:], dev[0][2][n:], dev[0][3][n:], role="current", config=cfg)
+    assert gpu_ctx.counter("deferred_ingests") == k0                                   # recorded, nothing built yet
+    assert raw(trk.match_batch_arrays(sets[0][:n], sets[0][n:])) == base[0]            # ... carried out behind this match's first launches
+    assert gpu_ctx.counter("deferred_ingests") == k0 + 2
+    assert raw(trk.match_batch_arrays(sets[1][:n], sets[1][n:])) == base[0]
+    d.update_raw_device_batch(sets[1][:n], dev[1][2][:n], dev[1][3][:n], role="reference", config=cfg)
+    d.update_raw_device_batch(sets[1][n:], dev[1][2][n:], dev[1][3][n:], role="current", config=cfg)
+    assert raw(trk.match_batch_arrays(sets[1][:n], sets[1][n:])) == base[1]            # the recorded frames themselves: ingested first
+    d.update_raw_device_batch(sets[1][:n], dev[0][2][:n], dev[0][3][:n], role="reference", config=cfg)
+    assert d.PointSelection(sets[1][0]).select(0) == d.PointSelection(sets[0][0]).select(0)   # another entry point: ingested first
+    d.update_raw_device_batch(sets[1][n:], dev[0][2][n:], dev[0][3][n:], role="current", config=cfg)
+    gpu_ctx.set_option("defer_ingest", 0)                                              # carries out the recorded one
+    assert gpu_ctx.counter("deferred_ingests") == k0 + 6
+    assert raw(trk.match_batch_arrays(sets[1][:n], sets[1][n:])) == base[0]
     with pytest.raises(d.DvoHipError):
         d.prepare_roles_batch(sets[0][:n], "reference", d.Config(FirstLevel=5, LastLevel=0))   # more levels than the frames have
     del sets
