@@ -347,7 +347,8 @@ def main():
                                      "pixel order (no window, arithmetic or reduction; the second also writes the 8-B residual pair), timed the same "
                                      "way: what this part's memory system needs for the bytes the sweep moves; bare_stream_frac is that time "
                                      "priced at the 40 algorithmic bytes",
-                    per_level_kernel_ms={str(k): round(v, 4) for k, v in k_ms.items()})
+                    per_level_kernel_ms={str(k): round(v, 4) for k, v in k_ms.items()},
+                    per_kernel=_per_kernel_rooflines(k_ms, B))
 
     # latency of BASELINE config 2: one 640x480 pair, 4 levels
     one = d.Result()
@@ -582,6 +583,38 @@ def _kernel_label(variant, pairs):
     what = ("64 x 16 tiles, the current frame's {I, Z} window staged in LDS, contracted f32 pixel arithmetic, Gram accumulation on the f16 matrix "
             "pipe from exact hi + lo operand pairs") if variant >= 8 else "option variant=%d, see include/dvo_hip.h" % variant
     return "%s (pyramid level 0, %d pairs per launch; %s)" % (names.get(variant, "variant %d" % variant), pairs, what)
+
+
+def _per_kernel_rooflines(k_ms, pairs):
+    """Every kernel that takes 3 % of the step or more, with its roofline: `achieved` / `frac` price a full launch at its ALGORITHMIC bytes
+    (the 40 B per level-pixel of SURVEY.md 8(d) for the sweeps) -- for the four sweep levels from the launch times
+    measured live above (HIP events), for the others from the in-situ rocprofv3 trace; `moved_GBps` / `moved_frac` are the bytes the
+    kernel really moved (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes over the bench loop: scripts/r5_rooflines.sh ->
+    profiles/r05_kernel_rooflines.json, which bench.py cannot collect itself)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r05_kernel_rooflines.json")))
+    except (OSError, ValueError):
+        return None
+    if rec.get("pairs") != pairs:
+        return None
+    level_of = {300 * pairs: 0, 75 * pairs: 1, 24 * pairs: 2}
+    out = []
+    for k in rec["kernels"]:
+        if k["step_share"] < 0.03:
+            continue
+        e = {key: k.get(key) for key in ("kernel", "workgroups", "ms", "ms_alone", "step_share", "achieved_GBps", "frac", "moved_GBps", "moved_frac",
+                                         "valu_active_share", "limited_by")}
+        e["ms_from"] = "rocprofv3 kernel trace of the bench loop (in situ)"
+        lvl = level_of.get(k["workgroups"]) if k["kernel"].startswith("k_sweep_fast") else (3 if k["kernel"].startswith("k_residual_reduce_mfma") else None)
+        if lvl is not None and k.get("algorithmic_bytes"):
+            e["ms_live"] = round(k_ms[lvl], 4)
+            e["achieved_GBps"] = round(k["algorithmic_bytes"] / (k_ms[lvl] * 1e-3) / 1e9, 1)
+            e["frac"] = round(e["achieved_GBps"] / HBM_PEAK_GBPS, 4)
+            e["ms_from"] = "this run (HIP events, mean of back-to-back launches); moved_* from the committed PMC passes"
+        out.append(e)
+    worst = min((e for e in out if e["frac"] is not None), key=lambda e: e["frac"], default=None)
+    return {"kernels": out, "worst_at_algorithmic_bytes": None if worst is None else "%s (%d workgroups): %.3f" % (worst["kernel"], worst["workgroups"], worst["frac"]),
+            "source": "profiles/r05_kernel_rooflines.json + profiles/r05_kernel_rooflines.md"}
 
 
 def _pmc_traffic(pairs):
