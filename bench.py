@@ -316,6 +316,9 @@ def main():
         ctx.set_option("variant", v)
         k_ms_variants[v] = tracker.time_residual_kernel(refs, curs, 0, reps=ROOFLINE_REPS, warm_iterations=3)
     ctx.set_option("variant", base_variant)                           # (what the run was started with, not a constant)
+    ctx.set_option("gram_lo_parts", 1)                                 # ... and the shipped schedule with every operand's low part kept
+    k_ms_lo_parts = tracker.time_residual_kernel(refs, curs, 0, reps=ROOFLINE_REPS, warm_iterations=3)
+    ctx.set_option("gram_lo_parts", 0)
     stream_ms = tracker.time_stream_mix(refs, curs, 0, reps=10)                       # the same planes streamed in pixel order, read only
     stream_w_ms = tracker.time_stream_mix(refs, curs, 0, reps=10, with_write=True)   # ... plus the 8-B residual pair the sweep writes
     algo_bytes = ALGO_BYTES_PER_PIXEL * W * H * B
@@ -324,11 +327,14 @@ def main():
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
                     traffic=traffic, kernel=_kernel_label(base_variant, B),
                     kernel_ms=round(k_ms[0], 4), kernel_ms_is="mean of %d back-to-back launches (HIP events on the context stream)" % ROOFLINE_REPS,
+                    kernel_ms_all_lo_parts=round(k_ms_lo_parts, 4), frac_all_lo_parts=round(algo_bytes / (k_ms_lo_parts * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     kernel_ms_exact_arithmetic=round(k_ms_variants[7], 4), kernel_ms_f32_gram=round(k_ms_variants[6], 4),
                     frac_exact_arithmetic=round(algo_bytes / (k_ms_variants[7] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     frac_f32_gram=round(algo_bytes / (k_ms_variants[6] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     schedules_note="kernel_ms: the shipped schedule (variant 8: fused multiply-adds, v_rcp_f32 in the projection; residuals within "
-                                   "2e-5 of the oracle's, tests/test_gpu_parity.py::test_contracted_sweep_against_the_exact_one); "
+                                   "2e-5 of the oracle's, tests/test_gpu_parity.py::test_contracted_sweep_against_the_exact_one; at this level the "
+                                   "Jacobian components enter the matrix pipe as f16 high parts); kernel_ms_all_lo_parts: the same with every "
+                                   "operand's low part kept (option gram_lo_parts 1: what the smaller levels run); "
                                    "kernel_ms_exact_arithmetic: variant 7, residuals and constraint counts bit-identical to the oracle's MATH mode, "
                                    "f16 hi + lo Gram operands; kernel_ms_f32_gram: variant 6, the same with the f32 matrix instruction (no f16 anywhere)",
                     algorithmic_bytes_per_launch=algo_bytes,
@@ -431,7 +437,7 @@ def main():
         ref_compat = {"value": round(n_total * args.steps / el_c, 2), "unit": "alignments/s", "ms_per_step": round(el_c / args.steps * 1e3, 3),
                       "max_twist_error_vs_truth": float(np.abs(parallel.twists_of(last["T"]) - pairs_np["xi_true"]).max()),
                       "note": "the same HBM-resident loop with option ref_compat on (the opt-in mode whose trajectories follow the reference's own, "
-                              "DESIGN.md section 2); the finest-level sweep is then dvo_hip::k_sweep_fast<2, false, true, true>: the contracted window sweep with the "
+                              "DESIGN.md section 2); the finest-level sweep is then dvo_hip::k_sweep_fast<2, false, true, 2, true>: the contracted window sweep with the "
                               "host CPU's _mm_rcp_ps table in projection and weights (round 5; rounds 3-4: k_sweep_window<true, true, 4>, "
                               "still the bit-exact anchor of the mode under option variant 7)"}
         ctx.set_option("ref_compat", 0)
@@ -539,7 +545,8 @@ def main():
             "metric": "frame-pair alignments/s (640x480, 4-level pyramid) + finest-level HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (Gram operands f16 hi+lo, f32 accumulate)", "data": "synthetic",
+            "dtype": "f32 (Gram operands f16 -- residual components hi + lo, Jacobian components hi + lo below 150 000 pixels per level and hi "
+                     "alone at the finest level -- f32 accumulate)", "data": "synthetic",
             "config": {"workload": "%d pairs (BASELINE config 4): independent 640x480 RGB-D frame pairs, seeds 0..%d, pair i on rank i mod %d, "
                                    "4-level pyramid, FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0; "
                                    "step = every rank re-ingests the raw planes of its shard from HBM (pyramids, sampling planes, point "
@@ -577,11 +584,11 @@ def main():
 
 def _kernel_label(variant, pairs):
     """Name of the finest-level sweep kernel the schedule `variant` launches (launch_residual_reduce, align_common.h), as rocprofv3 prints it."""
-    names = {8: "dvo_hip::k_sweep_fast<2, false, true, false> (template arguments: operand stores without lane swaps, no partial tile column, "
-                "packed residual pairs, not the ref_compat arithmetic)", 9: "dvo_hip::k_sweep_fast<1, false, true, false>", 7: "dvo_hip::k_sweep_window<true, false, 4>",
+    names = {8: "dvo_hip::k_sweep_fast<2, false, true, 0, true> (template arguments: operand stores without lane swaps, no partial tile column, "
+                "packed residual pairs, not the ref_compat arithmetic, Jacobian operands as f16 high parts)", 9: "dvo_hip::k_sweep_fast<1, false, true, 0, false>", 7: "dvo_hip::k_sweep_window<true, false, 4>",
              6: "dvo_hip::k_sweep_window<false, false, 4>", 5: "dvo_hip::k_residual_reduce_mfma", 0: "dvo_hip::k_residual_reduce"}
     what = ("64 x 16 tiles, the current frame's {I, Z} window staged in LDS, contracted f32 pixel arithmetic, Gram accumulation on the f16 matrix "
-            "pipe from exact hi + lo operand pairs") if variant >= 8 else "option variant=%d, see include/dvo_hip.h" % variant
+            "pipe: the residual components as exact hi + lo pairs, the Jacobian components as their high parts (levels of 150 000 pixels and more)") if variant >= 8 else "option variant=%d, see include/dvo_hip.h" % variant
     return "%s (pyramid level 0, %d pairs per launch; %s)" % (names.get(variant, "variant %d" % variant), pairs, what)
 
 

@@ -271,11 +271,31 @@ __device__ __forceinline__ void fast_fetch_cells(const LevelGeom& g, const FastR
 //     every eighth row, or the halves of every other 16 rows exchanged, give the same conflict count and the same time +-1 %.)
 //   STORE 1 (variant 9): high and low blocks side by side (80-byte rows, gram_f16.h), 32 pixels at a time; v_permlane32_swap_b32 moves
 //     half of every row to the idle half of the wavefront -- 8 swaps per row at 8.3 issue cycles each (scripts/ubench/issue_rate.hip).
-template <int STORE>
+// HI_J (round 5; levels of 150 000 pixels and more, LevelGeom::gram_hi_j): the twelve JACOBIAN components enter the matrix pipe as
+// their f16 high parts alone, only the two residual components keep a low part -- 18 of a row's ~186 vector instructions less
+// (finest level 2.041 -> 1.974 ms per 1024-pair launch, builds alternated on one box).  A component is then off by <= 2^-12 of itself,
+// at random: the sums over N constraints by ~5 x 2^-12 / sqrt(N) -- measured against the oracle 1.5e-5 of |A| at N = 6 500 (a
+// 160 x 120 level: NOT taken there), 2.7e-6 expected at the 190 000 constraints of a 640 x 480 level, where the measured distance to
+// the oracle does not move (3.2e-5 / 2.1e-5 for A / b with one constraint flipped, either way); the residual components, whose
+// products form b and the scale matrix, stay exact.
+template <int STORE, bool HI_J>
 __device__ __forceinline__ void fast_gram_row(float* my, int lane, const float (&comps)[14], f32x4& acc0, f32x4& acc1) {
   typedef volatile __attribute__((address_space(3))) u32x4* LdsQuadPtr;
   unsigned hh[7], ll[7];
-  split_pairs(comps, hh, ll);
+  if constexpr (HI_J) {
+    typedef float __attribute__((ext_vector_type(2))) f32pair;
+    typedef _Float16 __attribute__((ext_vector_type(2))) f16pair;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) hh[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32pair{comps[2 * k], comps[2 * k + 1]}, f16pair));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ll[k] = 0u;
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(comps[12]), "v"(hh[6]));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(comps[13]), "v"(hh[6]));
+    ll[6] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32pair{ra, rb}, f16pair));
+  } else {
+    split_pairs(comps, hh, ll);
+  }
   // the padding components (14, 15) may hold anything: they only reach rows / columns 14, 15 of the Gram matrix, which nobody reads
   unsigned pad;
   asm volatile("" : "=v"(pad));                           // (defined by nothing: no instruction, any register)
@@ -370,7 +390,7 @@ struct FastWeights {
 // off_v + scalar offset off_s), validity, weight, Jacobian at the untransformed point, Gram accumulation.  tx, ty, cx = 1 + tx^2:
 // normalised coordinates of the lane's reference pixel.
 // COMPACT (LevelGeom::compact): only a constraint's pair is stored, at the next free entry of the wavefront's slot (off_s: the slot).
-template <int STORE, bool COMPACT, int COMPAT>
+template <int STORE, bool COMPACT, int COMPAT, bool HI_J>
 __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const FastRcpSource& table, const f32x2 (&P)[4][4], const FastRow& r, unsigned long long ok_mask, float tx, float ty,
                                               float cx, const FastWeights& wt, __amdgpu_buffer_rsrc_t resid, int off_v, int off_s, float* my, int lane,
                                               f32x4& acc0, f32x4& acc1, int& n_valid) {
@@ -436,7 +456,7 @@ __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const FastRcpS
   const float sr = sw * kResidualScale;
   c[12] = mul_legacy(sr, r0);
   c[13] = mul_legacy(sr, r1);
-  fast_gram_row<STORE>(my, lane, c, acc0, acc1);
+  fast_gram_row<STORE, HI_J>(my, lane, c, acc0, acc1);
 }
 
 // epilogue: G = H H^T + S + S^T summed over the four wavefronts by the 85 threads that own an accumulator (slab[w]: H H^T at [0, 256),
@@ -486,7 +506,7 @@ __device__ __forceinline__ void fast_count_fallbacks(unsigned long long* __restr
 // ===================================================================================================================================
 // COMPAT (option "ref_compat"): 0 = off; 1 = the host's reciprocal table through memory; 2 = its 16-bit copy in LDS (four workgroups
 // per compute unit instead of five)
-template <int STORE, bool PARTIAL, bool COMPACT, int COMPAT>
+template <int STORE, bool PARTIAL, bool COMPACT, int COMPAT, bool HI_J>
 __global__ __launch_bounds__(256, COMPAT == 2 ? 4 : 5) void k_sweep_fast(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count, int* __restrict__ f16_range_flag) {
@@ -624,9 +644,9 @@ __global__ __launch_bounds__(256, COMPAT == 2 ? 4 : 5) void k_sweep_fast(
     f32x2 P[4][4];
     fast_fetch_cells<CHECKED, COMPAT>(g, rcp_table, st.KT, curC, win, wnd, neg_base, rs[k], __builtin_amdgcn_inverse_ballot_w64(ok_row[k]), tx_u, ty_rows[k], P, n_fallback);
     if constexpr (COMPACT)
-      fast_row_tail<STORE, true, COMPAT>(g, rcp_table, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, resid, 0, (tile * kCompactTileEntries + wave * kCompactWaveEntries) * 8, my, lane, acc0, acc1, n_valid);
+      fast_row_tail<STORE, true, COMPAT, HI_J>(g, rcp_table, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, resid, 0, (tile * kCompactTileEntries + wave * kCompactWaveEntries) * 8, my, lane, acc0, acc1, n_valid);
     else
-      fast_row_tail<STORE, false, COMPAT>(g, rcp_table, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_store, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
+      fast_row_tail<STORE, false, COMPAT, HI_J>(g, rcp_table, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_store, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
   };
   if (wnd.all_in) {                                            // (uniform)
 #pragma unroll
@@ -662,8 +682,13 @@ void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const Pai
   const dim3 grid(per_xcd * 8), block(256);
   const bool partial = g.w % kTileW != 0, compact = g.compact != 0;
   auto go = [&](auto store_tag, auto partial_tag, auto compact_tag, auto compat_tag) {
-    k_sweep_fast<decltype(store_tag)::value, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value>
-        <<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+    constexpr int kStore = decltype(store_tag)::value;
+    if (g.gram_hi_j && kStore == 2)
+      k_sweep_fast<2, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value, true>
+          <<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+    else
+      k_sweep_fast<kStore, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value, false>
+          <<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
   };
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;

@@ -348,6 +348,7 @@ struct dvo_hip_context {
   int opt_solver_waves = 0;        // wavefronts of a solver-step workgroup: 0 = by level and batch size, 2, 4
   int opt_ll_blocks = 0;           // workgroups per pair of the log-likelihood pass (0 = by batch size)
   int opt_compact_residuals = 1;   // the contracted window sweep stores only the residual pairs of constraints, packed (LevelGeom::compact)
+  int opt_gram_lo_parts = 0;       // 1: every Gram operand keeps its f16 low part on every level (0: LevelGeom::gram_hi_j on the large ones)
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
   int opt_fused_ll_pixels = 0;     // largest level (pixels) whose log-likelihood sweep runs inside the solver workgroup (0 = by batch size)
@@ -634,6 +635,7 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   g.rcp_table = ctx->opt_ref_compat ? ctx->rcp_table.as<float>() : nullptr;
   g.rcp_shift = ctx->rcp_shift;
   g.rcp_packed = ctx->opt_ref_compat == 1 ? ctx->rcp_packed : 0;   // (2: the table through memory, the path of a table that does not pack)
+  g.gram_hi_j = !ctx->opt_gram_lo_parts && !ctx->opt_deterministic && ctx->opt_variant == 8 && size_t(g.w) * g.h >= 150000 ? 1 : 0;
   g.compact = ctx->opt_compact_residuals && ctx->opt_variant >= 8 && rows_per_wave == 4 && fast_sweep_supports(g) ? 1 : 0;   // (launch_residual_reduce's test)
   return g;
 }
@@ -1991,6 +1993,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "ll_blocks") == 0) {
     if (value < 0 || value > kLlBlocksPerPair) return fail(ctx, DVO_HIP_ERR_INVALID, "ll_blocks must be 0..32");
     ctx->opt_ll_blocks = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "gram_lo_parts") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "gram_lo_parts must be 0 or 1");
+    ctx->opt_gram_lo_parts = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "compact_residuals") == 0) {

@@ -59,6 +59,10 @@ struct LevelGeom {                    // identical for every pair of a batch (on
   // then moves half the bytes.  Contracted window sweep only (align_fast.hip); 0 = one pair per pixel at its pixel's place, NaN
   // where there is no constraint (every other sweep, and whenever the caller wants the residuals by pixel).
   int compact;
+  // 1: the contracted window sweep forms its Gram operands from the f16 HIGH parts of the twelve Jacobian components alone (the two
+  // residual components keep high + low parts): levels of 150 000 pixels and more, where the rounding of a component (2^-12, at random)
+  // averages out over the constraints -- align_fast.hip, fast_gram_row; option "gram_lo_parts" 1 keeps every low part
+  int gram_hi_j;
 };
 
 // slot of the tile's partial row that holds count_0 + 512 count_1 (the next one: count_2 + 512 count_3), as exact floats

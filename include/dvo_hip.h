@@ -261,6 +261,11 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * whose residuals and constraint counts equal the oracle's MATH mode BIT FOR BIT (no contraction, correctly rounded divisions), f16
  * Gram; 6 = the same with the f32 Gram (bit-identical to 5); 5 = gathered taps, f32 Gram accumulation on the matrix cores; 0 =
  * all-VALU with the DPP + LDS reduction),
+ * "gram_lo_parts" (default 0: on levels of 150 000 pixels and more the default schedule forms its matrix operands from the f16 HIGH parts
+ * of the twelve Jacobian components alone -- the two residual components keep high + low parts everywhere -- which is 3.5 % of the
+ * finest-level sweep; a component is then off by <= 2^-12 of itself, at random, and the normal equations by ~3e-6 of their largest
+ * entry at 190 000 constraints; 1: every operand keeps its low part on every level, as on the smaller levels and
+ * under options "deterministic" and "variant" 9),
  * "compact_residuals" (default 1: the contracted window sweep stores only the residual pairs of constraints, packed per wavefront
  * slot, for the log-likelihood pass to read half the bytes; 0: one pair per pixel at its pixel's place like every other schedule --
  * the same normal equations bit for bit, the log-likelihood the same sum in another order),

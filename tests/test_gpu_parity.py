@@ -118,7 +118,8 @@ def test_default_schedule_single_linearisation_against_oracle(gpu_ctx, w, h, lev
     weights) and a second pass (t-distribution weights of the first pass' precision).  Stated and asserted:
       * constraints: the same set except at pixels whose tap coordinate sits on a bound (<= 1e-4 of them, at least 1 allowed);
       * residuals of common constraints: |dr_I| <= 2e-5, |dr_Z| <= 4e-6 m;
-      * P, A, b: 1e-5 relative to the largest entry (+ what the flipped constraints can carry: each at most 20 / n of the sums);
+      * P, A, b: 1e-5 relative to the largest entry (+ what the flipped constraints can carry: each at most 20 / n of the sums); b 3e-5 on
+        a level of 150 000 pixels and more, where the Jacobian components enter the matrix pipe as f16 high parts (option gram_lo_parts);
       * -ll: 2e-5 relative."""
     pair = cm.synth(23, w, h)
     levels = level + 1
@@ -148,7 +149,8 @@ def test_default_schedule_single_linearisation_against_oracle(gpu_ctx, w, h, lev
         assert flipped <= max(1, int(1e-4 * o["n"]))
         assert d0 <= 2e-5 and d1 <= 4e-6
         slack = 20.0 * flipped / o["n"]
-        assert relP <= 1e-5 + slack and relA <= 1e-5 + slack and relb <= 1e-5 + slack and rell <= 2e-5 + slack
+        hi_j = (w >> level) * (h >> level) >= 150000                 # the Jacobian as f16 high parts: b (a cancelling sum) to 3e-5
+        assert relP <= 1e-5 + slack and relA <= 1e-5 + slack and relb <= (3e-5 if hi_j else 1e-5) + slack and rell <= 2e-5 + slack
         assert np.array_equal(g["A"], g["A"].T)
         P_prev = o["P"]
 
@@ -247,9 +249,12 @@ def test_contracted_sweep_against_the_exact_one(w, h, xi):
     pair = cm.synth(31, w, h)
     T34 = po.se3_exp(np.array(xi, np.float64))[:3]
     out = {}
-    for v in (EXACT_VARIANT, 8, 9):
+    # (8 as it ships: on levels of 150 000 pixels and more the Jacobian components enter the matrix pipe as f16 high parts -- "8 lo" keeps
+    # every low part like variant 9 does, option gram_lo_parts)
+    for v in (EXACT_VARIANT, 8, 9, "8 lo"):
         ctx = d.Context(0)
-        ctx.set_option("variant", v)
+        ctx.set_option("variant", 8 if v == "8 lo" else v)
+        ctx.set_option("gram_lo_parts", 1 if v == "8 lo" else 0)
         ctx.set_option("rows_per_wave", 4)
         gref, gcur = gpu_pyramids(ctx, pair, 1)
         trk = d.DenseTracker(d.Config(FirstLevel=0, LastLevel=0), ctx)
@@ -277,12 +282,19 @@ def test_contracted_sweep_against_the_exact_one(w, h, xi):
             assert flipped <= max(1, int(1e-4 * a["n"]))
             assert d0 <= 2e-5 and d1 <= 4e-6
             if flipped == 0:
+                # (b is a sum of cancelling terms: where the Jacobian enters the matrix pipe as f16 high parts -- variant 8 on a level of
+                # 150 000 pixels and more -- its bound is 3e-5 of its largest entry: measured 1.1e-5 with 27 000 constraints, 4e-6 with 190 000)
+                hi_j = v == 8 and w * h >= 150000
                 assert np.abs(a["A"] - b["A"]).max() <= 1e-5 * np.abs(a["A"]).max()
-                assert np.abs(a["b"] - b["b"]).max() <= 1e-5 * np.abs(a["b"]).max() + 1e-9 * np.abs(a["A"]).max()
+                assert np.abs(a["b"] - b["b"]).max() <= (3e-5 if hi_j else 1e-5) * np.abs(a["b"]).max() + 1e-9 * np.abs(a["A"]).max()
                 assert abs(a["neg_ll"] - b["neg_ll"]) <= 2e-5 * abs(a["neg_ll"])
         # the two operand-store schemes of the contracted sweep feed the same numbers to the matrix pipe
         assert np.array_equal(out[8][k]["residuals"], out[9][k]["residuals"], equal_nan=True) and out[8][k]["n"] == out[9][k]["n"]
-        assert np.abs(out[8][k]["A"] - out[9][k]["A"]).max() <= 1e-6 * np.abs(out[8][k]["A"]).max()
+        assert np.abs(out["8 lo"][k]["A"] - out[9][k]["A"]).max() <= 1e-6 * np.abs(out[9][k]["A"]).max()
+        # ... and the Jacobian's high parts alone, where the level is large enough for it, stay inside the schedule's bound
+        assert np.array_equal(out[8][k]["residuals"], out["8 lo"][k]["residuals"], equal_nan=True)
+        assert np.abs(out[8][k]["A"] - out["8 lo"][k]["A"]).max() <= (6e-6 if w * h >= 150000 else 0.0) * np.abs(out[9][k]["A"]).max()
+        assert np.abs(out[8][k]["b"] - out["8 lo"][k]["b"]).max() <= (3e-5 if w * h >= 150000 else 0.0) * np.abs(out[9][k]["b"]).max() + 1e-9 * np.abs(out[9][k]["A"]).max()
 
 
 @pytest.mark.parametrize("w,h,rpw,xi", [(160, 120, 2, [0.01, -0.008, 0.006, 0.012, -0.01, 0.008]), (80, 60, 2, [0.02, 0.01, -0.015, -0.02, 0.025, 0.03]),
