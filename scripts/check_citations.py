@@ -12,7 +12,7 @@ own = set()
 for d,_,fs in os.walk(ROOT):
     if '.git' in d or 'gpurun_out' in d: continue
     for f in fs: own.add(f)
-srcs = glob.glob(ROOT+'/include/**/*.h', recursive=True)+glob.glob(ROOT+'/dvo_slam_amd/csrc/*')+glob.glob(ROOT+'/oracle/*.cpp')+glob.glob(ROOT+'/oracle/*.h')+glob.glob(ROOT+'/oracle/*.py')+glob.glob(ROOT+'/dvo_slam_amd/*.py')+[ROOT+'/DESIGN.md',ROOT+'/INTEGRATION.md',ROOT+'/README.md']+glob.glob(ROOT+'/tests/*.py')
+srcs = glob.glob(ROOT+'/include/**/*.h', recursive=True)+glob.glob(ROOT+'/dvo_slam_amd/csrc/*')+glob.glob(ROOT+'/oracle/*.cpp')+glob.glob(ROOT+'/oracle/*.h')+glob.glob(ROOT+'/oracle/*.py')+glob.glob(ROOT+'/dvo_slam_amd/*.py')+[ROOT+'/DESIGN.md',ROOT+'/HISTORY.md',ROOT+'/INTEGRATION.md',ROOT+'/README.md']+glob.glob(ROOT+'/tests/*.py')
 pat = re.compile(r'([A-Za-z0-9_./]+\.(?:cpp|h|hpp|cfg|yaml)):(\d+)(?:-(\d+))?')
 bad=[]; n=0
 for s in srcs:

@@ -4,7 +4,7 @@ import re
 
 from common import ROOT
 
-DOCS = ["DESIGN.md", "INTEGRATION.md", "README.md", os.path.join("profiles", "README.md")]
+DOCS = ["DESIGN.md", "HISTORY.md", "INTEGRATION.md", "README.md", os.path.join("profiles", "README.md")]
 PREFIXES = ("profiles/", "scripts/", "tests/", "dvo_slam_amd/", "oracle/", "include/")
 
 
