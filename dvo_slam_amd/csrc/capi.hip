@@ -1503,8 +1503,11 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       // A recorded ingest of the caller's next batch (option "defer_ingest") is carried out now, behind the first launches of this
       // batch.  It is ~0.1-0.5 ms of host time during which nothing more would be enqueued here: where the level's steps are short,
       // a few more of them go out first (a pair needs more than four passes on its first level; a step too many exits at once).
+      // (how many: the ingest of 2 n frames is ~0.3 us of host time per frame, a step of a small level ~20 us -- measured, builds
+      // alternated on one box: seven instead of three more 256 pairs 3.288 -> 3.216 ms per step, 128 pairs 1.837 -> 1.856, 64 pairs
+      // 1.199 -> 1.210)
       if (size_t(g.tiles_x) * g.tiles_y * size_t(n) < 65536) {
-        const int lead = std::min(3 * per_sync, per_level - enqueued);
+        const int lead = std::min((n >= 192 ? 7 : 3) * per_sync, per_level - enqueued);
         if (lead > 0) {
           enqueue_chunk(lead);
           enqueued += lead;
