@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256, COMPAT == 2 ? 4 : 5) void k_sweep_fast(
   const int pair = item / tiles, tile = item - pair * tiles;
   const int tile_x = tile % g.tiles_x, tile_y = tile / g.tiles_x;
   const PairState& st = states[pair];
-  if (!st.active) return;
+  if (!st.active || st.level != g.level) return;          // (not on this level: finished it, and maybe begun the next)
   const PairPtrs pp = pairs[pair];
   const int plane_bytes = g.w * g.h * 8;
   const __amdgpu_buffer_rsrc_t refR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.refR), 0, plane_bytes, 0x00020000);

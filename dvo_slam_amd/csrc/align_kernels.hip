@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce(
   const int pair = item / tiles, tile = item - pair * tiles;
 
   const PairState& st = states[pair];
-  if (!st.active) return;                            // wave-uniform: pair finished on this level
+  if (!st.active || st.level != g.level) return;     // wave-uniform: pair finished on this level (and maybe begun the next)
   const PairPtrs pp = pairs[pair];
   // pointers loaded from memory are generic; tell the compiler they are global so it emits global_load
   const GlobalLoad2 refR{(GlobalVec2)pp.refR};
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const Pair
                                                    const float* __restrict__ partials, const float2* __restrict__ scratch,
                                                    double* __restrict__ ll_partials, int blocks_per_pair) {
   const int pair = blockIdx.y;
-  if (!states[pair].active) return;
+  if (!states[pair].active || states[pair].level != g.level) return;
   __shared__ double sh[16];
   __shared__ double sums[4];
   __shared__ float stage[kScaleStageFloats];

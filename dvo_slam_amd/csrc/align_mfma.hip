@@ -58,11 +58,11 @@ __global__ __launch_bounds__(kBlock) void k_residual_reduce_mfma(
     // instead of as a chain of dependent round trips (the compiler otherwise sinks each to its first use).  Tall tiles run
     // measurably better with the lazy order.
     const PairPtrs early = pairs[pair];
-    const int active = st.active;
+    const int active = st.active && st.level == g.level;
     asm volatile("" ::"s"(early.refR), "s"(early.curA), "s"(early.curB), "s"(active));
     if (!active) return;
   } else {
-    if (!st.active) return;
+    if (!st.active || st.level != g.level) return;
   }
   const PairPtrs pp = pairs[pair];
   float KT[12], Pp[4];

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 6 : (F16 ? 5 : 4)) void k_
   const PairState& st = states[pair];
   // (Measured and dropped: requesting the pair's plane pointers together with its activity flag and pinning both above the branch,
   // which helps the gathering sweep's short tiles -- here it cost 10 %.)
-  if (!st.active) return;
+  if (!st.active || st.level != g.level) return;
   const PairPtrs pp = pairs[pair];
   const int plane_bytes = g.w * g.h * 8;
   const __amdgpu_buffer_rsrc_t refR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.refR), 0, plane_bytes, 0x00020000);

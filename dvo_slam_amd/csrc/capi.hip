@@ -630,6 +630,7 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   g.wi_x = 0.5f * g.fx / 255.0f; g.wi_y = 0.5f * g.fy / 255.0f;
   g.half_wi_x = 0.5f * g.wi_x; g.half_wi_y = 0.5f * g.wi_y; g.half_fx = 0.5f * g.fx; g.half_fy = 0.5f * g.fy;
   g.tx = cam->tx[level]; g.ty = cam->ty[level];
+  g.level = level;
   g.linear = level_is_linear(ctx, g.w) ? 1 : 0;
   level_tiles(g.w, g.h, rows_per_wave, g.linear != 0, &g.tiles_x, &g.tiles_y);
   g.rcp_table = ctx->opt_ref_compat ? ctx->rcp_table.as<float>() : nullptr;
@@ -1459,9 +1460,26 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     static const char* const kPrep[kMaxLevels] = {"prep L0", "prep L1", "prep L2", "prep L3", "prep L4", "prep L5", "prep L6", "prep L7"};
     static const char* const kErr[kMaxLevels] = {"err L0", "err L1", "err L2", "err L3", "err L4", "err L5", "err L6", "err L7"};
     static const char* const kLinsys[kMaxLevels] = {"linsys L0", "linsys L1", "linsys L2", "linsys L3", "linsys L4", "linsys L5", "linsys L6", "linsys L7"};
-    {
+    // Batches of up to 256 pairs: every level but the launch path's first is begun pair by pair by the solver steps of the level before
+    // it, and the results are written by the steps behind the last level (NextLevel) -- no launch between two levels, none at the end:
+    // builds alternated on one box, 16 / 64 / 128 pairs 0.558 -> 0.553 / 1.196 -> 1.187 / 1.825 -> 1.807 ms per step; 256 and 1024
+    // pairs level, 512 pairs 5.79 -> 5.88 (the launches k_level_begin / k_finish stay there)
+    const bool hand_over = n <= 256;
+    if (level == level_from || !hand_over) {
       Range range(kPrep[level]);
-      launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);   // (first level: initialises the pairs too)
+      launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);
+    }
+    NextLevel next;
+    std::memset(&next, 0, sizeof(next));
+    if (!hand_over) {
+    } else if (level > cfg->last_level) {
+      const LevelGeom& gn = bp.geom[level - 1];
+      next.valid = 1;
+      next.level = level - 1;
+      next.fx = gn.fx; next.fy = gn.fy; next.ox = gn.ox; next.oy = gn.oy;
+      next.pairs = bp.pair_ptrs + size_t(level - 1) * n;
+    } else {
+      next.results = w.results.as<dvo_hip_result>();           // the last level: a pair that has left it gets its result written
     }
     // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
     // (measured, scripts/ab_match.py fused_ll_pixels: 128 pairs 2.152 -> 2.117 ms with level 1 fused; 16 pairs 0.756 -> 0.799, one
@@ -1494,7 +1512,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
         }
         Range range(kLinsys[level]);
         launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, ll_blocks, fused_ll ? scratch : nullptr, d_levels, d_iters,
-                           tallies + step, w.host_status + step, solver_two_waves, cfg->first_level - level);   // (the level record every pair on this level is at: fetched with the state)
+                           tallies + step, w.host_status + step, solver_two_waves, cfg->first_level - level, &next);   // (the level record every pair on this level is at: fetched with the state)
       }
     };
     int enqueued = std::min(per_sync, per_level);
@@ -1547,6 +1565,14 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       if (active == 0 || more <= 0) break;                   // every pair left this level (or the iteration cap is reached)
       watched = step - 1;
     }
+    // The pairs that ended the level in the step just awaited are handed over (NextLevel) by the step that was enqueued ahead of the poll.
+    // If there is none -- the step was held back, or the iteration cap is reached -- one solver launch does nothing else.
+    if (hand_over && step - 1 <= watched) {
+      Range range(kLinsys[level]);
+      launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, ll_blocks, nullptr, d_levels, d_iters, tallies + step, w.host_status + step,
+                         solver_two_waves, cfg->first_level - level, &next);
+      ++step;
+    }
   }
 
   const bool resident_used = rp.levels > 0;
@@ -1571,7 +1597,8 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       DVO_WS_TRY(w, sync_stream(s));                           // every group has to be gone before the batch is repeated
     }
   } else {
-    if (level_from >= cfg->last_level) launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());   // else: done by the resident launch
+    if (level_from >= cfg->last_level && n > 256) launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());
+    // (else the results are in place: written by the resident launch, or by the solver steps behind the pairs' last level)
     DVO_WS_TRY(w, hipMemcpyAsync(results, w.results.p, size_t(n) * sizeof(dvo_hip_result), hipMemcpyDeviceToHost, s));
     if (levels && cap_levels > 0) {
       hl.resize(size_t(n) * bp.cap_levels);

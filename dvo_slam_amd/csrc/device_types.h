@@ -63,6 +63,24 @@ struct LevelGeom {                    // identical for every pair of a batch (on
   // residual components keep high + low parts): levels of 150 000 pixels and more, where the rounding of a component (2^-12, at random)
   // averages out over the constraints -- align_fast.hip, fast_gram_row; option "gram_lo_parts" 1 keeps every low part
   int gram_hi_j;
+  // the pyramid level this geometry belongs to: a launch on the launch-per-step path works on the pairs that are ACTIVE ON THIS LEVEL
+  // (PairState::active && PairState::level == level) -- a pair that has left the level may already have begun the next one
+  // (k_solver_step, NextLevel) and waits there for the rest of the batch
+  int level;
+};
+
+// What a solver step needs to hand the pairs that have LEFT its level over to the next one without a launch between the levels
+// (round 5): a pair that is no longer active when the step begins -- it ended the level in an earlier step -- begins the next level
+// there, in the shadow of the workgroups that still iterate (dense_tracking.cpp:200-238); a pair that has left the LAST level gets its
+// result written (dense_tracking.cpp:368-373).  The step the host enqueues ahead of its poll does it for the pairs that ended last.
+// valid == 0 and results == null: nothing of the kind (the parity and measurement entry points).
+struct PairPtrs;
+struct NextLevel {
+  int valid;
+  int level;
+  float fx, fy, ox, oy;                // intrinsics of that level (gn_level_begin forms K T with them)
+  const PairPtrs* pairs;               // that level's plane table (the selection count of the pair's reference frame)
+  dvo_hip_result* results;             // non-null (with valid == 0): the match ends on this level
 };
 
 // slot of the tile's partial row that holds count_0 + 512 count_1 (the next one: count_2 + 512 count_3), as exact floats
@@ -130,7 +148,7 @@ struct PairState {
   int n_iters_total;                  // iteration records written so far
   int n_levels;                       // level records written so far
   int level_first_iter;               // index of the first iteration record of the current level
-  int pad;
+  int finished;                       // the pair's result has been written (k_solver_step, NextLevel::results)
 };
 
 // a step's word in the pinned status array: kStepDoneFlag | number of pairs still active on the level

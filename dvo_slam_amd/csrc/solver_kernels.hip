@@ -84,7 +84,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
                                                         const double* __restrict__ ll_partials, int ll_blocks_per_pair,
                                                         const float2* __restrict__ scratch_for_fused_ll,
                                                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters,
-                                                        unsigned long long* step_tally, int* host_status, int level_slot_hint) {
+                                                        unsigned long long* step_tally, int* host_status, int level_slot_hint, NextLevel next) {
   const int pair = blockIdx.x;
 #ifdef DVO_SOLVER_CLOCKS
   unsigned long long clk_prev_ = wall_clock64();
@@ -94,7 +94,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
   // stored by all 256 lanes at once, touched by lane 0 at LDS latency.
   __shared__ PairState st;
   __shared__ dvo_hip_level_stats lvl;
-  __shared__ dvo_hip_iteration_stats rec;
+  // [1]: the new iteration record; [0]: the one before it, fetched only for a pair whose result is written here (gn_finish reads either)
+  __shared__ dvo_hip_iteration_stats recs[2];
+  __shared__ dvo_hip_result res;
+  dvo_hip_iteration_stats& rec = recs[1];
   __shared__ double sh[kWavesPerBlock * kAccStride];
   __shared__ double sums[kAccStride];
   __shared__ double ll_waves[kWavesPerBlock];
@@ -164,8 +167,44 @@ __global__ __launch_bounds__(WAVES * 64) void k_solver_step(PairState* states, i
     }
   }
   __syncthreads();
-  if (!st.active) {                   // uniform
+  if (!st.active || st.level != g.level) {   // uniform: the pair is not (or no longer) on this level
     if (threadIdx.x == 0) publish_step(step_tally, host_status, n_pairs, false);
+    // The hand-over (NextLevel): a pair that ENDED this level in an earlier step begins the next level here -- or, on the last level,
+    // has its result written -- in the shadow of the workgroups that still iterate: no launch between two levels, none behind the
+    // last.  (Doing it in the very step that ends the level was measured and dropped: that workgroup is the launch's slowest.)
+    if (st.level != g.level || st.finished) return;
+    const int slot_now = st.n_levels - 1;
+    const bool have_now = slot_now >= 0 && slot_now < prm.cap_levels;
+    if (next.valid) {
+      __shared__ dvo_hip_level_stats lvl_next;
+      __shared__ int stored;
+      if (threadIdx.x == 0) {
+        const int n_selected_next = *next.pairs[pair].n_selected;
+        LevelGeom gn = g;
+        gn.fx = next.fx; gn.fy = next.fy; gn.ox = next.ox; gn.oy = next.oy;
+        SolverParams begin = prm;
+        begin.cap_levels = st.n_levels < prm.cap_levels ? st.n_levels + 1 : 0;
+        stored = begin.cap_levels ? st.n_levels : -1;
+        gn_level_begin(st, begin, gn, next.level, n_selected_next, &lvl_next - st.n_levels);   // (dense_tracking.cpp:200-238)
+      }
+      __syncthreads();
+      coop_copy(&states[pair], &st);
+      if (stored >= 0) coop_copy(levels + size_t(pair) * prm.cap_levels + stored, &lvl_next);
+    } else if (next.results) {
+      // dense_tracking.cpp:368-373: the last iteration with an increment is the level's last record or the one before it
+      const int last = st.n_iters_total - 1;
+      if (have_now && !(hint_ok && slot_now == level_slot_hint)) coop_copy(&lvl, levels + size_t(pair) * prm.cap_levels + slot_now);
+      if (last >= 0 && last < prm.cap_iters) coop_copy(&recs[1], iters + size_t(pair) * prm.cap_iters + last);
+      if (last >= 1 && last - 1 < prm.cap_iters) coop_copy(&recs[0], iters + size_t(pair) * prm.cap_iters + last - 1);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        gn_finish(st, prm, &lvl - slot_now, &recs[1] - last, &res);
+        st.finished = 1;
+      }
+      __syncthreads();
+      coop_copy(next.results + pair, &res);
+      if (threadIdx.x == 0) states[pair].finished = 1;
+    }
     return;
   }
   CLK(0);
@@ -257,6 +296,7 @@ __global__ void k_set_fixed_state(PairState* states, LevelGeom g, const float* _
   for (int i = 0; i < 4; ++i) st.P_prev[i] = Pprev[i];
   st.first = first;
   st.active = 1;
+  st.level = g.level;
 }
 
 __global__ __launch_bounds__(kBlock) void k_single_shot_out(LevelGeom g, const float* __restrict__ partials,
@@ -302,14 +342,17 @@ void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverPar
 void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
                         const float* partials, const double* ll_partials, int ll_blocks_per_pair, const float2* scratch_for_fused_ll,
                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, unsigned long long* step_tally, int* host_status, bool two_waves,
-                        int level_slot_hint) {
+                        int level_slot_hint, const NextLevel* next_or_null) {
+  NextLevel next;
+  next.valid = 0; next.level = 0; next.fx = next.fy = next.ox = next.oy = 0.0f; next.pairs = nullptr; next.results = nullptr;
+  if (next_or_null) next = *next_or_null;
   // (two wavefronts: see the kernel; a level of at most 32 tiles -- 160 x 120, 80 x 60 -- of a batch beyond two workgroups per compute unit)
   if (two_waves)
     k_solver_step<2><<<dim3(n_pairs), dim3(128), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
-                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status, level_slot_hint);
+                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status, level_slot_hint, next);
   else
     k_solver_step<kWavesPerBlock><<<dim3(n_pairs), dim3(kBlock), 0, s>>>(states, n_pairs, prm, g, partials, ll_partials, ll_blocks_per_pair,
-                                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status, level_slot_hint);
+                                                                         scratch_for_fused_ll, levels, iters, step_tally, host_status, level_slot_hint, next);
 }
 
 void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverParams prm,

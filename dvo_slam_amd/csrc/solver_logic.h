@@ -82,6 +82,7 @@ DVO_HD void gn_init_pair(PairState& st, const SolverParams& prm, const double* T
   st.n_iters_total = 0;
   st.n_levels = 0;
   st.level_first_iter = 0;
+  st.finished = 0;
   for (int i = 0; i < 4; ++i) st.P_prev[i] = 0.0f;
   for (int i = 0; i < 12; ++i) st.KT[i] = 0.0f;
 }
