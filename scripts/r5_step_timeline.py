@@ -16,8 +16,8 @@ for r in rows:
     wg = int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y") or 1) * int(r.get("Workgroup_Size_Z") or 1)
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, grid // max(wg, 1), r.get("Stream_Id") or r.get("Queue_Id") or "?"))
 ev.sort()
-# a step's match begins with k_level_begin of the coarsest level (the launch that also initialises the pairs): the first one after a k_finish
-begins = [i for i, e in enumerate(ev) if e[2] == "k_finish"]
+# a step's match ends with the copy of its results to the host (batches up to 256 pairs have no k_finish launch any more)
+begins = [i for i, e in enumerate(ev) if e[2] == "__amd_rocclr_copyBuffer"]
 lo = begins[-back - 1] + 1 if len(begins) > back else 0
 hi = begins[-back] + 1
 win = ev[lo:hi]
