@@ -1471,14 +1471,13 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     }
     NextLevel next;
     std::memset(&next, 0, sizeof(next));
-    if (!hand_over) {
-    } else if (level > cfg->last_level) {
+    if (hand_over && level > cfg->last_level) {
       const LevelGeom& gn = bp.geom[level - 1];
       next.valid = 1;
       next.level = level - 1;
       next.fx = gn.fx; next.fy = gn.fy; next.ox = gn.ox; next.oy = gn.oy;
       next.pairs = bp.pair_ptrs + size_t(level - 1) * n;
-    } else {
+    } else if (hand_over) {
       next.results = w.results.as<dvo_hip_result>();           // the last level: a pair that has left it gets its result written
     }
     // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
