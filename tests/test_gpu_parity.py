@@ -964,6 +964,44 @@ def test_device_ingest_prepare_and_background_build(gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_table_cache_never_serves_a_stale_table():
+    """Round 5: the small tables of a batch (plane pointers of its frames and pairs, initial guesses) are not sent to the device again
+    when the very bytes are already there (option table_cache, counter table_uploads_skipped).  The cache compares CONTENTS: a frame
+    that is destroyed and replaced -- its device block is pooled, so the new frame has the old one's addresses -- by a frame with other
+    pixels gives the other pixels' result, and every result equals the one of a context without the cache, bit for bit."""
+    n, w, h = 6, 320, 240
+    b = datagen.synth_batch(300, n + 1, w, h)
+    cfg = d.Config(FirstLevel=2, LastLevel=0)
+
+    def raw(out):
+        return b"".join(np.ascontiguousarray(out[k]).tobytes() for k in ("T", "information", "loglik", "n_iterations"))
+
+    runs = {}
+    for cache in (1, 0):
+        ctx = d.Context(0)
+        ctx.set_option("table_cache", cache)
+        ctx.set_option("resident", 0)
+        cam = d.RgbdCameraPyramid(w, h, b["K"], ctx)
+        cam.build(3)
+        refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)]
+        curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)]
+        trk = d.DenseTracker(cfg, ctx)
+        first = raw(trk.match_batch_arrays(refs, curs))
+        k0 = ctx.counter("table_uploads_skipped")
+        again = raw(trk.match_batch_arrays(refs, curs))                       # the same tables: nothing is sent
+        assert again == first
+        assert (ctx.counter("table_uploads_skipped") > k0) == bool(cache)
+        # pair 2 gets another current frame: the old one is destroyed first, the new one takes over its pooled device block
+        curs[2] = None
+        curs[2] = cam.create_raw(b["grey_cur"][n], b["depth_cur"][n])
+        swapped = trk.match_batch_arrays(refs, curs)
+        assert not np.array_equal(swapped["T"][2], np.frombuffer(first[:n * 128], np.float64).reshape(n, 4, 4)[2])
+        runs[cache] = (first, raw(swapped), raw(trk.match_batch_arrays(refs, curs)))
+        assert runs[cache][1] == runs[cache][2]
+    assert runs[1] == runs[0]
+
+
+@pytest.mark.gpu
 def test_streaming_upload_from_host_memory(gpu_ctx):
     """dvo_hip_frames_update_raw: raw planes handed over in host memory (pinned block in the frame layout, pinned but separate
     planes, plain pageable numpy arrays) and DMA-ed on the upload stream while OTHER frames are aligned -- bit-identical results
