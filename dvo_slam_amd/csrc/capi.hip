@@ -1492,8 +1492,10 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // end of the level are no-ops (workgroups exit on !active).
     // workgroups per pair of the log-likelihood pass: each begins by reducing the pair's scale sums (a latency chain of ~10 us), which
     // a batch that fills the device anyway pays once per workgroup for nothing -- fewer, longer ones then (option ll_blocks to override)
+    // (round 5, mid-size batches, scripts/r5_midsize.py: 16 instead of 32 workgroups per pair 64 / 128 / 200 pairs 1.179 -> 1.173 /
+    // 1.775 -> 1.760 / 2.558 -> 2.538 ms per step; 8: 1.183 / 1.760 / 2.546)
     const int ll_blocks = ctx->opt_ll_blocks > 0 ? std::min(ctx->opt_ll_blocks, kLlBlocksPerPair)
-                                                 : (g.compact && n >= 256 && !ctx->opt_deterministic ? kLlBlocksPerPairBatch : kLlBlocksPerPair);
+                          : (!g.compact || ctx->opt_deterministic ? kLlBlocksPerPair : n >= 256 ? kLlBlocksPerPairBatch : n >= 48 ? 16 : kLlBlocksPerPair);
     // the solver step of the smallest levels in two-wavefront workgroups (four per compute unit instead of two): a batch that otherwise
     // needs two goes of 512 resident workgroups (option solver_waves 2 / 4 to force; the records do not depend on it).  Measured at
     // 1024 pairs (scripts/r4_trace.sh): 80 x 60 46 -> 36 us per step; 160 x 120 with packed residuals 77 -> 90 (two wavefronts walk

@@ -269,7 +269,7 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * "compact_residuals" (default 1: the contracted window sweep stores only the residual pairs of constraints, packed per wavefront
  * slot, for the log-likelihood pass to read half the bytes; 0: one pair per pixel at its pixel's place like every other schedule --
  * the same normal equations bit for bit, the log-likelihood the same sum in another order),
- * "ll_blocks" (workgroups per pair of the log-likelihood pass, 1..32; 0 = by batch size),
+ * "ll_blocks" (workgroups per pair of the log-likelihood pass, 1..32; 0 = by batch size: 32, 16 from 48 pairs, 8 from 256),
  * "tail_speculation" (measurement: 1 = the step ahead of the host's poll is always enqueued, also on the tail of a level whose empty
  * step is costly; n >= 2: costly means n workgroups or more per step; 0 = 131072),
  * "solver_waves" (wavefronts of a solver-step workgroup, 2 or 4; 0 = two on the smallest levels of a batch of more than two
