@@ -1261,17 +1261,26 @@ ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg
   // pairs <= compute units / 4.  Measured at the end of round 3, 96 / 128 pairs with ONE workgroup each: full match 1.63 / 1.93 ms
   // resident against 1.61 / 1.90 on the launch path, levels 3 -> 1 0.60 / 0.67 against 0.57 / 0.65, and a streaming step of 128 pairs
   // beside its background ingest 2.50 against 2.41 ms; at 64 pairs (two workgroups each) resident still wins, 1.19 against 1.26.)
-  if (ctx->opt_resident < 0 && ctx->opt_resident_group == 0 && bp.n * 4 > cus) return rp;
+  // (round 5: up to 7/16 as many pairs as compute units the FIRST level alone -- 18 of a streaming step's 34 iterations in BASELINE
+  // config 4, each a sweep and a solver launch of 11 + 12 us -- is still quicker resident with two workgroups per pair, which leave
+  // an eighth of the chip to the background ingest: streaming step of 72 / 80 / 96 / 112 pairs 1.215 / 1.283 / 1.440 / 1.634 ->
+  // 1.172 / 1.232 / 1.378 / 1.587 ms.  128 pairs: two workgroups each 1.808 against 1.776, one 1.748 on one box and level on two
+  // others -- left on the launch path; with the second level resident as well 1.59 at 96 pairs.  Only a level the launch path
+  // reads through the taps too: its planes exist.)
+  const bool first_level_only = ctx->opt_resident < 0 && ctx->opt_resident_group == 0 && bp.n * 4 > cus;
+  if (first_level_only && (bp.n * 2 * 8 > cus * 7 || level_uses_window(ctx, bp.cam->w[cfg->first_level], bp.cam->h[cfg->first_level]))) return rp;
   // all workgroups of a launch with groups must be resident at once: one workgroup (8 wavefronts, up to 256 registers) per compute unit
   int group = 1;
   while (group * 2 <= kResidentMaxGroup && bp.n * group * 2 <= cus) group *= 2;
   if (ctx->opt_resident_group > 0) group = std::min(group, ctx->opt_resident_group);
+  if (first_level_only) group = 2;
   rp.group = group;
   const int rows_max = ctx->opt_resident_rows > 0 ? ctx->opt_resident_rows : kResidentRowsDefault;
   for (int level = cfg->first_level; level >= cfg->last_level; --level) {
     const int segments = (bp.cam->w[level] * bp.cam->h[level] + kTileW - 1) / kTileW;
     const int rows = (segments + group * kResidentSweepers - 1) / (group * kResidentSweepers);
     if (ctx->opt_resident != 1 && rows > rows_max) break;
+    if (first_level_only && rp.levels == 1) break;
     if (size_t(bp.cam->w[level]) * bp.cam->h[level] >= (size_t(1) << 24)) break;   // the kernel locates a pixel with one float multiply
     rp.levels += 1;
   }

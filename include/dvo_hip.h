@@ -302,8 +302,8 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * bit for bit.  2 = as 1 with the table read through memory by every sweep -- the path of a CPU whose table has no 16-bit copy for
  * the contracted sweep to keep in LDS; test and measurement),
  * "resident" (-1 default: small batches and coarse levels run in ONE launch per match, each pair owned by a group of resident
- * workgroups -- the latency path; 0: one to three launches per Gauss-Newton step always; 1: every level
- * resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
+ * workgroups -- the latency path, DESIGN.md section 4: up to compute units / 4 pairs the coarse levels, up to 7/16 of the compute
+ * units the coarsest one; 0: one to three launches per Gauss-Newton step always; 1: every level resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
  * pass; default 24), "resident_group" (workgroups per pair, a power of two <= 64; 0 = as many as fit the device),
  * "resident_cooperative" (1: groups are launched with hipLaunchCooperativeKernel), "resident_flags" (measurement / test hooks). 
  * "rendezvous" (default 1): two dvo_hip_match calls from two host threads with the SAME current frame and configuration -- the

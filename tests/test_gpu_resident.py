@@ -163,6 +163,29 @@ def test_default_policy_uses_the_resident_kernel_for_small_batches_only(ctx):
         assert np.array_equal(a.Transformation, bb.Transformation) and np.array_equal(a.Information, bb.Information)
 
 
+def test_default_policy_runs_the_first_level_of_a_mid_size_batch_resident(ctx):
+    """Between 1/4 and 7/16 as many pairs as compute units (65 ... 112 on an MI355X) the first level alone runs in the resident
+    kernel, two workgroups per pair (they leave an eighth of the chip free), and the launch path takes over from the second level;
+    above that no resident launch at all (plan_resident, capi.hip).  Same passes and results as the launch path."""
+    n_all = 136
+    b = datagen.synth_batch(5, n_all, 160, 120)
+    cam = d.RgbdCameraPyramid(160, 120, b["K"], ctx)
+    cam.build(3)
+    refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n_all)]
+    curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n_all)]
+    cfg = d.Config(FirstLevel=2, LastLevel=0, Precision=5e-7)
+    ctx.set_option("resident", 0)
+    base = stats_of(ctx, cfg, refs, curs)
+    ctx.set_option("resident", -1)
+    for n, launches in ((72, 1), (112, 1), (128, 0), (n_all, 0)):
+        before = ctx.counter("resident_launches")
+        res = stats_of(ctx, cfg, refs[:n], curs[:n])
+        assert ctx.counter("resident_launches") == before + launches and ctx.counter("resident_timeouts") == 0, n
+        for a, bb in zip(res, base):                 # (a pass more or less where an increment sits on the stopping rule's threshold)
+            assert same_structure(a, bb) or abs(sum(len(L.Iterations) for L in a.Statistics.Levels) - sum(len(L.Iterations) for L in bb.Statistics.Levels)) <= 4
+            assert cm.twist_matrix_error(a.Transformation, bb.Transformation) < 5e-6
+
+
 def test_resident_edge_cases_follow_the_state_machine(ctx):
     """No constraints at all, the iteration cap, and a level that ends on its first pass: the same records as the launch path."""
     h, w = 120, 160
