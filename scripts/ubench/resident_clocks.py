@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where an iteration of the resident match kernel spends its time (experiment build with -DDVO_RESIDENT_CLOCKS; run with
-DVO_HIP_LIBRARY=scripts/ubench/_build/libdvo_hip_clk.so).  usage: resident_clocks.py [pairs [group]]"""
+DVO_HIP_LIBRARY=scripts/ubench/_build/libdvo_hip_clk.so).  usage: resident_clocks.py [pairs [group [last_level]]]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -8,6 +8,7 @@ import dvo_slam_amd as d
 from dvo_slam_amd import datagen, _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 group = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+last = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = d.default_context()
 ctx.set_option("resident", 1)
 ctx.set_option("resident_group", group)
@@ -15,7 +16,7 @@ b = datagen.synth_batch(0, n, 640, 480)
 cam = d.RgbdCameraPyramid(640, 480, b["K"], ctx); cam.build(4)
 refs = [cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)]
 curs = [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)]
-trk = d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0.0), ctx)
+trk = d.DenseTracker(d.Config(FirstLevel=3, LastLevel=last, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0.0), ctx)
 L = C.CDLL(_lib.LIB_PATH)
 buf = (C.c_ulonglong * 32)()
 for _ in range(3):
