@@ -16,7 +16,8 @@
 extern "C" {
 
 // One step on frame sets `next` (to be re-ingested: n reference frames from (grey_ref, raw_ref), n current frames from
-// (grey_cur, raw_cur), device pointers) and `now` (to be aligned: results[n], identity initial guess).
+// (grey_cur, raw_cur), device pointers) and `now` (to be aligned: results[n], identity initial guess).  The frames of `next_refs` are
+// good for the reference role with this configuration's thresholds until they are ingested again (they keep no copy of their raw planes).
 int dvo_stream_step(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next_refs, dvo_hip_frame* const* next_curs,
                     const void* const* grey_ref, const void* const* raw_ref, const void* const* grey_cur, const void* const* raw_cur,
                     float depth_scale, dvo_hip_frame* const* now_refs, dvo_hip_frame* const* now_curs, const dvo_hip_config* cfg,
@@ -31,7 +32,11 @@ int dvo_stream_step(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next_refs
   const bool deferring = n <= defer_max && next_refs && now_refs;
   if (deferring) (void)dvo_hip_set_option(ctx, "defer_ingest", 1);
   if (next_refs) {
+    // a frame this loop ingests as a reference is ingested again before it plays any other part: no copy of its raw planes (option
+    // "keep_raw_copy": 3 of the 16 bytes per pixel a reference frame's ingest moves; 1024-pair step 11.48 -> 11.37 ms)
+    (void)dvo_hip_set_option(ctx, "keep_raw_copy", 0);
     rc = dvo_hip_frames_update_raw_device_as(ctx, n, next_refs, grey_ref, raw_ref, depth_scale, DVO_HIP_ROLE_REFERENCE, cfg);
+    (void)dvo_hip_set_option(ctx, "keep_raw_copy", 1);
     if (rc == DVO_HIP_OK) rc = dvo_hip_frames_update_raw_device_as(ctx, n, next_curs, grey_cur, raw_cur, depth_scale, DVO_HIP_ROLE_CURRENT, cfg);
   }
   if (rc == DVO_HIP_OK && now_refs) {
@@ -97,7 +102,9 @@ int dvo_stream_step_host(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next
   const auto t0 = std::chrono::steady_clock::now();
   int rc = DVO_HIP_OK;
   if (next_refs) {
+    (void)dvo_hip_set_option(ctx, "keep_raw_copy", 0);           // (as in dvo_stream_step)
     rc = dvo_hip_frames_update_raw_as(ctx, n, next_refs, grey_ref, raw_ref, depth_scale, DVO_HIP_ROLE_REFERENCE, cfg);
+    (void)dvo_hip_set_option(ctx, "keep_raw_copy", 1);
     if (rc != DVO_HIP_OK) return rc;
     rc = dvo_hip_frames_update_raw_as(ctx, n, next_curs, grey_cur, raw_cur, depth_scale, DVO_HIP_ROLE_CURRENT, cfg);
     if (rc != DVO_HIP_OK) return rc;

@@ -339,9 +339,11 @@ struct dvo_hip_context {
     float depth_scale;
     int role;
     dvo_hip_config cfg;
+    bool keep_raw_copy;
   };
   std::vector<DeferredIngest> deferred;
   int opt_defer_ingest = 0;
+  int opt_keep_raw_copy = 1;       // 0: a frame ingested straight into the reference role keeps no copy of its raw planes (option "keep_raw_copy")
   long long deferred_ingests = 0;  // ingests carried out behind the first launches of a match (counter "deferred_ingests")
   int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
   int opt_tail_speculation = 0;    // 1: always enqueue the step ahead of the poll, also on the tail of a level whose empty step is costly (measurement)
@@ -756,7 +758,7 @@ int eager_current_flavor(const dvo_hip_context* ctx, const CameraGeom* cam, int 
 }
 
 int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, const void* const* grey, const void* const* raw,
-                 float depth_scale, int role = -1, float ithr = 0.0f, float dthr = 0.0f) {
+                 float depth_scale, int role = -1, float ithr = 0.0f, float dthr = 0.0f, bool keep_raw_copy = true) {
   Range range("build");
   const CameraGeom* cam = frames[0]->cam;
   const int levels = frames[0]->levels;
@@ -780,7 +782,7 @@ int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, cons
     const bool in_place = host[i].raw == staging_depth(f) && host[i].grey == staging_grey(f);
     if (in_place) {
       f->raw_copy = true;
-    } else if (role != 0) {
+    } else if (role < 0 || (role == 1 && keep_raw_copy)) {
       host[i].keep_grey = staging_grey(f);
       host[i].keep_raw = staging_depth(f);
       f->raw_copy = true;
@@ -2061,6 +2063,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     if (!value) DVO_FLUSH_DEFERRED(ctx);
     return DVO_HIP_OK;
   }
+  if (std::strcmp(key, "keep_raw_copy") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "keep_raw_copy must be 0 or 1");
+    ctx->opt_keep_raw_copy = value;
+    return DVO_HIP_OK;
+  }
   if (std::strcmp(key, "table_cache") == 0) {
     if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "table_cache must be 0 or 1");
     ctx->tables.cache = value != 0;
@@ -2198,11 +2205,11 @@ int prepare_roles(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* fram
 
 // ingest of device-resident raw planes, optionally straight into a role (role < 0: none)
 int update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
-                      const void* const* raw_depth_dev, float depth_scale, int role, const dvo_hip_config* cfg) {
+                      const void* const* raw_depth_dev, float depth_scale, int role, const dvo_hip_config* cfg, bool keep_raw_copy = true) {
   const bool ref = role == DVO_HIP_ROLE_REFERENCE;
   const int fused = role >= 0 && cfg->last_level == 0 ? (ref ? 1 : 0) : -1;   // level 0 is built in the same pass if it is used at all
   int rc = frames_build(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, fused, ref ? cfg->intensity_derivative_threshold : 0.0f,
-                        ref ? cfg->depth_derivative_threshold : 0.0f);
+                        ref ? cfg->depth_derivative_threshold : 0.0f, keep_raw_copy);
   if (rc == DVO_HIP_OK && role >= 0) rc = prepare_roles(ctx, n_frames, frames, role, cfg);
   return rc;
 }
@@ -2217,7 +2224,7 @@ int flush_deferred(dvo_hip_context* ctx) {
     for (dvo_hip_frame* f : d.frames) f->deferred = 0;
     if (rc != DVO_HIP_OK) continue;
     ctx->deferred_ingests += 1;
-    rc = update_raw_device(ctx, int(d.frames.size()), d.frames.data(), d.grey.data(), d.raw.data(), d.depth_scale, d.role, &d.cfg);
+    rc = update_raw_device(ctx, int(d.frames.size()), d.frames.data(), d.grey.data(), d.raw.data(), d.depth_scale, d.role, &d.cfg, d.keep_raw_copy);
   }
   return rc;
 }
@@ -2251,12 +2258,13 @@ int dvo_hip_frames_update_raw_device_as(dvo_hip_context* ctx, int n_frames, dvo_
     d.depth_scale = depth_scale;
     d.role = role;
     d.cfg = *cfg;
+    d.keep_raw_copy = ctx->opt_keep_raw_copy != 0;
     for (int i = 0; i < n_frames; ++i) frames[i]->deferred = 1;
     ctx->deferred.push_back(std::move(d));
     return DVO_HIP_OK;
   }
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return update_raw_device(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, role, cfg);
+  return update_raw_device(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, role, cfg, ctx->opt_keep_raw_copy != 0);
 }
 
 // Streaming ingest from HOST memory: DMA of the raw planes into a transfer buffer on the upload stream, then the batched
@@ -2304,7 +2312,7 @@ static int update_raw_host(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* co
   }
   DVO_HIP_TRY(ctx, hipEventRecord(ctx->upload_done, ctx->upload_stream));
   DVO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->build_stream, ctx->upload_done, 0));
-  rc = update_raw_device(ctx, n_frames, frames, g.data(), r.data(), depth_scale, role, cfg);
+  rc = update_raw_device(ctx, n_frames, frames, g.data(), r.data(), depth_scale, role, cfg, ctx->opt_keep_raw_copy != 0);
   ctx->upload_buf_seq[b] = ctx->build_seq;          // the newest ticket is behind every reader of the buffer
   return rc;
 }

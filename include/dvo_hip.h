@@ -280,6 +280,10 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * launches of its first level, so that the host's work for the ingest of batch k + 1 (0.1-0.5 ms) does not keep the alignment of batch k
  * from starting; any other entry point, a match that aligns the very frames, or switching the option off carries it out at once, and
  * returns its status if it fails; counter "deferred_ingests".  dvo_slam_amd/apps/stream_pipeline.cpp switches it on around its step),
+ * "keep_raw_copy" (default 1: a frame ingested from raw planes straight into the REFERENCE role keeps a copy of them, 3 bytes per
+ * pixel, from which its other role -- or a selection with other thresholds -- is derived later; 0: no copy: such a frame serves as a
+ * reference with the thresholds it was ingested for until it is ingested again, anything else fails with DVO_HIP_ERR_INVALID.  The
+ * value in effect when the ingest is requested counts; dvo_slam_amd/apps/stream_pipeline.cpp switches it off for its reference frames),
  * "table_cache" (default 1: a small table -- plane pointers of the frames to build or the pairs to align, initial guesses -- is not sent
  * to the device again when the very bytes were last sent to the very address on the same stream and no device memory was freed since:
  * a streaming caller hands over the same frame sets step after step; counter "table_uploads_skipped"; 0 for measurement),

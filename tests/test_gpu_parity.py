@@ -955,6 +955,21 @@ def test_device_ingest_prepare_and_background_build(gpu_ctx):
     gpu_ctx.set_option("defer_ingest", 0)                                              # carries out the recorded one
     assert gpu_ctx.counter("deferred_ingests") == k0 + 6
     assert raw(trk.match_batch_arrays(sets[1][:n], sets[1][n:])) == base[0]
+    # option "keep_raw_copy" = 0 (round 5; the streaming loop's reference frames): the frame serves in the role and with the thresholds
+    # it was ingested for -- the same bits -- and says so when asked for anything else, until it is ingested again
+    gpu_ctx.set_option("keep_raw_copy", 0)
+    d.update_raw_device_batch(sets[1][:n], dev[1][2][:n], dev[1][3][:n], role="reference", config=cfg)
+    gpu_ctx.set_option("keep_raw_copy", 1)
+    d.update_raw_device_batch(sets[1][n:], dev[1][2][n:], dev[1][3][n:], role="current", config=cfg)
+    assert raw(trk.match_batch_arrays(sets[1][:n], sets[1][n:])) == base[1]
+    with pytest.raises(d.DvoHipError):
+        d.prepare_roles_batch(sets[1][:n], "current", cfg)
+    with pytest.raises(d.DvoHipError):
+        d.prepare_roles_batch(sets[1][:n], "reference", d.Config(FirstLevel=2, LastLevel=0, IntensityDerivativeThreshold=3.0))
+    assert raw(trk.match_batch_arrays(sets[1][:n], sets[1][n:])) == base[1]            # (the failed requests left the frames alone)
+    d.update_raw_device_batch(sets[1][:n], dev[1][2][:n], dev[1][3][:n], role="reference", config=cfg)   # with the copy again
+    d.prepare_roles_batch(sets[1][:n], "current", cfg)
+    assert np.isfinite(trk.match_batch_arrays(sets[1][n:], sets[1][:n])["T"]).all()
     with pytest.raises(d.DvoHipError):
         d.prepare_roles_batch(sets[0][:n], "reference", d.Config(FirstLevel=5, LastLevel=0))   # more levels than the frames have
     del sets
