@@ -342,8 +342,8 @@ def main():
                     moved_bytes_per_pixel=None if traffic is None else round(traffic / (W * H * B), 2),
                     moved_GBps=None if traffic is None else round(traffic / (k_ms[0] * 1e-3) / 1e9, 1),
                     moved_frac=None if traffic is None else round(traffic / (k_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                    limited_by="vector-instruction issue (profiles/r04_pmc3_v8_summary.txt: the vector ALU issues during ~90 % of the kernel's cycles, "
-                               "the LDS array is busy ~50 %); `achieved` / `frac` price the launch at SURVEY.md 8(d)'s 40 ALGORITHMIC bytes per pixel -- a "
+                    limited_by="vector-instruction issue (profiles/r05_pmc3_v8_summary.txt: 170 vector instructions per 64-pixel row, the vector ALU active ~79 % "
+                               "of the kernel's cycles, the LDS array ~68 %); `achieved` / `frac` price the launch at SURVEY.md 8(d)'s 40 ALGORITHMIC bytes per pixel -- a "
                                "derived rate, the contract's definition -- while the bytes the kernel really moves (`traffic`, PMC) give `moved_GBps` / "
                                "`moved_frac`: the kernel is not near any memory limit",
                     timed_at="converged transform, t-distribution weights on (3 warm-up Gauss-Newton steps on the level)",

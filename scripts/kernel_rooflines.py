@@ -97,7 +97,9 @@ def main():
         if name.startswith("k_loglik"):
             return 8.0 * px[0] * pairs, "8 B x %d level-0 pixels x %d pairs (one residual pair per pixel; the packed layout holds the constraints only)" % (px[0], pairs)
         if name.startswith("k_ingest_strips<1"):
-            return 33.0 * px[0] * pairs, "33 B per level-0 pixel of a reference frame x %d frames" % pairs
+            # (33 B per level-0 pixel of a reference frame with the 3-B copy of its raw planes; the streaming loop's
+            #  reference frames keep none, option keep_raw_copy)
+            return 30.0 * px[0] * pairs, "30 B per level-0 pixel of a reference frame that keeps no copy of its raw planes x %d frames" % pairs
         if name.startswith("k_ingest_strips<0"):
             return None, "current frames: the planes written follow the batch (plane C only for a batch this size): moved bytes are the measure"
         return None, ""

@@ -10,7 +10,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05
 mkdir -p $O
 cd $R
-rocminfo 2>/dev/null | grep -m2 -E "gfx|Marketing" > $O/device.txt; lscpu | grep -m1 "Model name" >> $O/device.txt
+rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9" | grep -m2 -iE "instinct|MI3|gfx9" > $O/device.txt; lscpu | grep -m1 "Model name" >> $O/device.txt
 PMC_PAIRS=1024 bash scripts/pmc.sh > $O/pmc.log 2>&1; tail -2 $O/pmc.log | cut -c1-300
 cp gpurun_out/pmc/pmc_finest_kernel.json profiles/pmc_finest_kernel.json 2>/dev/null; cp gpurun_out/pmc/pmc_finest_kernel.json $O/ 2>/dev/null
 bash scripts/r5_rooflines.sh > $O/rooflines.log 2>&1; tail -16 $O/rooflines.log | cut -c1-260
