@@ -366,6 +366,7 @@ struct dvo_hip_context {
   int opt_resident_group = 0;      // workgroups per pair (0 = as many as fit, up to kResidentMaxGroup)
   int resident_timeouts = 0;       // batches that had to be repeated because a group timed out (see run_batch)
   long long resident_launches = 0;
+  long long resident_levels = 0;   // pyramid levels those launches ran (counter "resident_levels")
   // where the host thread's time of dvo_hip_match_batch goes (ns, accumulated): before the first launch of the batch, enqueueing,
   // waiting for the device, after the device is done
   long long host_ns[4] = {0, 0, 0, 0};
@@ -754,7 +755,10 @@ bool aligned_to(const void* p, size_t a) { return reinterpret_cast<uintptr_t>(p)
 // derived then (ensure_roles).
 int eager_current_flavor(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_frames) {
   if (!level_uses_window(ctx, cam->w[level], cam->h[level])) return kCurAB;
-  return n_frames * 4 > (ctx->compute_units > 0 ? ctx->compute_units : 256) ? kCurC : (kCurAB | kCurC);   // (plan_resident's limit)
+  // (round 5: from an eighth as many frames as compute units on, plane C alone -- the taps cost three times the bytes to write, and a
+  // streaming step of 32 / 48 / 64 pairs that re-ingests them every step is 0.885 / 0.98 / 1.24 -> 0.783 / 0.93 / 1.09 ms without them and
+  // with the first level alone resident: plan_resident looks at what the frames hold)
+  return n_frames * 8 >= (ctx->compute_units > 0 ? ctx->compute_units : 256) ? kCurC : (kCurAB | kCurC);
 }
 
 int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, const void* const* grey, const void* const* raw,
@@ -1046,7 +1050,8 @@ void make_plan(const dvo_hip_context* ctx, const CameraGeom* cam, const dvo_hip_
 // buildAccelerationStructure for the current frames, PointSelection::select for the reference frames (both cached per
 // frame and level); enqueued on the context's main stream
 // `launch_path_only`: the caller runs every level on the launch-per-step path (the parity / measurement entry points)
-int resident_levels_of(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const CameraGeom* cam, int n);
+int resident_levels_of(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const CameraGeom* cam, int n, bool taps_missing);
+bool window_taps_missing(const dvo_hip_context* ctx, const dvo_hip_config* cfg, int n, dvo_hip_frame* const* curs);
 
 int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
                        bool launch_path_only = false) {
@@ -1059,7 +1064,7 @@ int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, 
   // the flavour of the current role each level is read in: the resident kernel and the gathering sweep read the taps A + B, the
   // window sweep the 8-byte plane C
   const CameraGeom* cam = curs[0]->cam;
-  const int resident = launch_path_only ? 0 : resident_levels_of(ctx, cfg, cam, n);
+  const int resident = launch_path_only ? 0 : resident_levels_of(ctx, cfg, cam, n, window_taps_missing(ctx, cfg, n, curs));
   int want[kMaxLevels];
   for (int l = 0; l < kMaxLevels; ++l)
     want[l] = l > cfg->first_level - resident || l >= cam->levels || !level_uses_window(ctx, cam->w[l], cam->h[l]) ? kCurAB : kCurC;
@@ -1250,7 +1255,20 @@ struct ResidentPlan {
 constexpr int kResidentDirectPairs = 16;
 constexpr size_t kResidentDirectStatsBytes = size_t(64) << 20;
 
-ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const BatchPlan& bp) {
+// `taps_missing`: current frames of the batch hold plane C but not the taps A + B on the level below the first one (they were ingested
+// straight into their role in a batch of an eighth as many frames as compute units or more, eager_current_flavor): the resident kernel
+// would have to have the taps derived for it first
+bool window_taps_missing(const dvo_hip_context* ctx, const dvo_hip_config* cfg, int n, dvo_hip_frame* const* curs) {
+  const int level = cfg->first_level - 1;
+  if (level < cfg->last_level || level >= curs[0]->levels || !level_uses_window(ctx, curs[0]->cam->w[level], curs[0]->cam->h[level])) return false;
+  for (int i = 0; i < n; ++i) {
+    const int have = curs[i]->lv[level].cur_have;
+    if ((have & kCurC) && !(have & kCurAB)) return true;
+  }
+  return false;
+}
+
+ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const BatchPlan& bp, bool taps_missing) {
   ResidentPlan rp;
   if (ctx->opt_resident == 0 || ctx->opt_deterministic) return rp;   // (deterministic: one path whatever the batch size, and that is the launch path)
   const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
@@ -1269,13 +1287,19 @@ ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg
   // 1.172 / 1.232 / 1.378 / 1.587 ms.  128 pairs: two workgroups each 1.808 against 1.776, one 1.748 on one box and level on two
   // others -- left on the launch path; with the second level resident as well 1.59 at 96 pairs.  Only a level the launch path
   // reads through the taps too: its planes exist.)
-  const bool first_level_only = ctx->opt_resident < 0 && ctx->opt_resident_group == 0 && bp.n * 4 > cus;
+  // (the same from an eighth of the compute units on when the batch came from a streaming ingest that left the taps out -- see
+  // eager_current_flavor; frames that hold them, or nothing yet, get the coarse levels resident as before: a match of 64 prepared pairs
+  // 0.96 ms against 1.02 with the first level alone)
+  const bool first_level_only = ctx->opt_resident < 0 && ctx->opt_resident_group == 0 && (bp.n * 4 > cus || (bp.n * 8 >= cus && taps_missing));
   if (first_level_only && (bp.n * 2 * 8 > cus * 7 || level_uses_window(ctx, bp.cam->w[cfg->first_level], bp.cam->h[cfg->first_level]))) return rp;
   // all workgroups of a launch with groups must be resident at once: one workgroup (8 wavefronts, up to 256 registers) per compute unit
   int group = 1;
   while (group * 2 <= kResidentMaxGroup && bp.n * group * 2 <= cus) group *= 2;
   if (ctx->opt_resident_group > 0) group = std::min(group, ctx->opt_resident_group);
-  if (first_level_only) group = 2;
+  if (first_level_only) {                                       // the groups leave an eighth of the chip free
+    group = 1;
+    while (group * 2 <= kResidentMaxGroup && bp.n * group * 2 * 8 <= cus * 7) group *= 2;
+  }
   rp.group = group;
   const int rows_max = ctx->opt_resident_rows > 0 ? ctx->opt_resident_rows : kResidentRowsDefault;
   for (int level = cfg->first_level; level >= cfg->last_level; --level) {
@@ -1286,15 +1310,19 @@ ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg
     if (size_t(bp.cam->w[level]) * bp.cam->h[level] >= (size_t(1) << 24)) break;   // the kernel locates a pixel with one float multiply
     rp.levels += 1;
   }
+  static const bool trace_plan = std::getenv("DVO_HIP_TRACE_PLAN") != nullptr;     // (stderr: which plan a batch got)
+  if (trace_plan)
+    std::fprintf(stderr, "plan_resident: %d pairs, taps missing %d -> %s, %d workgroup(s) per pair, %d level(s) resident\n", bp.n, int(taps_missing),
+                 first_level_only ? "first level only" : "coarse levels", rp.group, rp.levels);
   rp.direct = rp.levels == cfg->first_level - cfg->last_level + 1 && bp.n <= kResidentDirectPairs &&
               size_t(bp.n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats) <= kResidentDirectStatsBytes;   // (pinned, if asked for)
   return rp;
 }
 
-int resident_levels_of(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const CameraGeom* cam, int n) {
+int resident_levels_of(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const CameraGeom* cam, int n, bool taps_missing) {
   BatchPlan bp;
   make_plan(ctx, cam, cfg, n, bp);
-  return plan_resident(ctx, cfg, bp).levels;
+  return plan_resident(ctx, cfg, bp, taps_missing).levels;
 }
 
 int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, const BatchPlan& bp, const ResidentPlan& rp,
@@ -1337,6 +1365,7 @@ int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, 
     }
   }
   ctx->resident_launches += 1;
+  ctx->resident_levels += rp.levels;
   if (rp.group > 1) {
     // the rows of every group, and behind them one heartbeat word per workgroup (align_resident.hip, "Flow control")
     const size_t bytes = size_t(bp.n) * rp.group * kResidentRing * kResidentSlots * sizeof(unsigned long long) + align_up(size_t(bp.n) * rp.group * sizeof(unsigned), 256);
@@ -1390,7 +1419,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
   // The coarse levels -- for a small batch every level -- run inside ONE launch (align_resident.hip): no launch per iteration, no
   // host poll, the pairs of a batch do not wait for each other.
-  const ResidentPlan rp = plan_resident(ctx, cfg, bp);
+  const ResidentPlan rp = plan_resident(ctx, cfg, bp, window_taps_missing(ctx, cfg, n, curs));
   const bool tables_inline = rp.direct && n <= kResidentInline;   // plane pointers and initial guesses travel as kernel arguments
   int rc = prepare_buffers(w, cfg, refs, curs, bp, !tables_inline);
   if (rc != DVO_HIP_OK) return rc;
@@ -1765,6 +1794,7 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
   if (!ctx || !key || !value) return DVO_HIP_ERR_INVALID;
   std::unique_lock<std::recursive_mutex> guard(ctx->mutex);
   if (std::strcmp(key, "resident_launches") == 0) *value = ctx->resident_launches;
+  else if (std::strcmp(key, "resident_levels") == 0) *value = ctx->resident_levels;
   else if (std::strcmp(key, "resident_timeouts") == 0) *value = ctx->resident_timeouts;
   else if (std::strcmp(key, "window_fallbacks") == 0) {
     unsigned long long v = 0;

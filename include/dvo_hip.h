@@ -307,7 +307,8 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * the contracted sweep to keep in LDS; test and measurement),
  * "resident" (-1 default: small batches and coarse levels run in ONE launch per match, each pair owned by a group of resident
  * workgroups -- the latency path, DESIGN.md section 4: up to compute units / 4 pairs the coarse levels, up to 7/16 of the compute
- * units the coarsest one; 0: one to three launches per Gauss-Newton step always; 1: every level resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
+ * units -- and from compute units / 8 pairs on when the current frames hold plane C without the taps, as a role-aware ingest of that
+ * many frames leaves them -- the coarsest one (DVO_HIP_TRACE_PLAN in the environment prints the plan of every batch to stderr); 0: one to three launches per Gauss-Newton step always; 1: every level resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
  * pass; default 24), "resident_group" (workgroups per pair, a power of two <= 64; 0 = as many as fit the device),
  * "resident_cooperative" (1: groups are launched with hipLaunchCooperativeKernel), "resident_flags" (measurement / test hooks). 
  * "rendezvous" (default 1): two dvo_hip_match calls from two host threads with the SAME current frame and configuration -- the
@@ -321,6 +322,7 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 
 /* Event counters of a context.  key: "resident_launches" (matches, or coarse-level runs, done by the resident kernel),
+ * "resident_levels" (pyramid levels those launches ran, summed),
  * "resident_timeouts" (batches repeated on the launch-per-step path because a workgroup group of the resident kernel waited
  * in vain for its peers -- the device was shared with another such kernel; the results are those of the repeat),
  * "window_fallbacks" (lanes of the window sweep whose bilinear taps fell outside the staged window and were fetched from memory),

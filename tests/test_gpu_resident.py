@@ -186,6 +186,56 @@ def test_default_policy_runs_the_first_level_of_a_mid_size_batch_resident(ctx):
             assert cm.twist_matrix_error(a.Transformation, bb.Transformation) < 5e-6
 
 
+def test_frames_streamed_without_their_taps_get_the_first_level_resident_only(gpu_ctx):
+    """Round 5: a role-aware ingest of an eighth as many frames as compute units or more (32 on an MI355X) writes plane C alone on the
+    levels the window sweep reads (eager_current_flavor) -- and the match of such frames runs the FIRST level in the resident kernel
+    and the others on the launch path instead of having the taps derived (plan_resident looks at what the frames hold).  Frames that
+    were created without a role get the coarse levels resident as before.  Same passes, same results either way.  (The default
+    schedule, variant 8: under the fixture's variant 6 a 160-pixel level is not the window sweep's.)"""
+    ctx = gpu_ctx
+    n, w, h = 40, 640, 480
+    b = datagen.synth_batch(9, n, w, h, nthreads=8)
+    cam = d.RgbdCameraPyramid(w, h, b["K"], ctx)
+    cam.build(4)
+    cfg = d.Config(FirstLevel=3, LastLevel=1, Precision=5e-7)
+    fresh = lambda: ([cam.create_raw(b["grey_ref"][i], b["depth_ref"][i]) for i in range(n)],
+                     [cam.create_raw(b["grey_cur"][i], b["depth_cur"][i]) for i in range(n)])
+    ctx.set_option("resident", 0)
+    base = stats_of(ctx, cfg, *fresh())
+    ctx.set_option("resident", -1)
+    lazy_refs, lazy_curs = fresh()                                    # (no role planes yet: the match has built what its plan reads)
+    k0 = ctx.counter("resident_launches"), ctx.counter("resident_levels")
+    lazy = stats_of(ctx, cfg, lazy_refs, lazy_curs)
+    assert (ctx.counter("resident_launches"), ctx.counter("resident_levels")) == (k0[0] + 1, k0[1] + 2)     # levels 3 and 2
+    streamed_refs, streamed_curs = fresh()
+    d.update_raw_host_batch(streamed_refs, list(b["grey_ref"]), list(b["depth_ref"]), role="reference", config=cfg)
+    d.update_raw_host_batch(streamed_curs, list(b["grey_cur"]), list(b["depth_cur"]), role="current", config=cfg)
+    d.upload_wait(ctx)
+    k1 = ctx.counter("resident_launches"), ctx.counter("resident_levels")
+    streamed = stats_of(ctx, cfg, streamed_refs, streamed_curs)
+    assert (ctx.counter("resident_launches"), ctx.counter("resident_levels")) == (k1[0] + 1, k1[1] + 1)     # level 3 alone
+    assert ctx.counter("resident_timeouts") == 0
+    # (the default schedule's f16 Gram on the launch path beside the resident kernel's f32 one: a stopping rule on the edge falls
+    # either way, the iteration counts are not compared here -- the fixture's variant 6 tests above do that)
+    worst = 0.0
+    for res in (lazy, streamed):
+        for a, bb in zip(res, base):
+            assert [L.Id for L in a.Statistics.Levels] == [L.Id for L in bb.Statistics.Levels]
+            worst = max(worst, cm.twist_matrix_error(a.Transformation, bb.Transformation))
+    print("40 pairs, coarse levels / first level resident against the launch path: twist distance at most %.1e" % worst)
+    assert worst < 1e-5
+    # a small streamed batch (below an eighth of the compute units) carries both flavours: the coarse levels resident, as ever
+    few = 8
+    d.update_raw_host_batch(streamed_curs[:few], list(b["grey_cur"][:few]), list(b["depth_cur"][:few]), role="current", config=cfg)
+    d.upload_wait(ctx)
+    k2 = ctx.counter("resident_levels")
+    small = stats_of(ctx, cfg, streamed_refs[:few], streamed_curs[:few])
+    assert ctx.counter("resident_levels") >= k2 + 2
+    for a, bb in zip(small, base):
+        assert cm.twist_matrix_error(a.Transformation, bb.Transformation) < 1e-5
+    ctx.set_option("resident", -1)
+
+
 def test_resident_edge_cases_follow_the_state_machine(ctx):
     """No constraints at all, the iteration cap, and a level that ends on its first pass: the same records as the launch path."""
     h, w = 120, 160
