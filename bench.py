@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--resident", type=int, default=-1, help="library option resident (-1 default policy, 0 launch path only, 1 every level resident)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses GPU 0 (with --backend gloo)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "native", "torch"], help="who runs the record all-gather: native = the C-ABI's "
+                    "own RCCL call (dvo_hip_gather_records_*, csrc/gather_rccl.hip: what a C++ host uses), torch = torch.distributed.all_gather "
+                    "(dvo_slam_amd/parallel.py::RecordGatherer); auto = native with --backend nccl, torch otherwise (gloo dry runs)")
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 record path (process group, pinned staging, asynchronous all-gather, "
                     "drain) even with one rank: exercises the RCCL code path on a one-GPU box")
     args = ap.parse_args()
@@ -253,7 +256,17 @@ def main():
         return None
 
     pending, gathered = [None], [None]
-    gatherer = parallel.RecordGatherer(n_total, rank, world, device=comm_dev) if gathering else None
+    gather_kind = ("native" if args.backend == "nccl" else "torch") if args.gather == "auto" else args.gather
+    gatherer = None
+    if gathering and gather_kind == "native":
+        # the communicator's 128-byte id travels once through the launcher's process group; every gather after that is the library's own
+        uid = torch.zeros(128, dtype=torch.uint8, device=comm_dev)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(parallel.NativeRecordGatherer.unique_id(ctx)), dtype=torch.uint8).to(comm_dev)
+        dist.broadcast(uid, src=0)
+        gatherer = parallel.NativeRecordGatherer(ctx, bytes(uid.cpu().numpy().tobytes()), n_total, rank, world)
+    elif gathering:
+        gatherer = parallel.RecordGatherer(n_total, rank, world, device=comm_dev)
 
     def drain():
         if pending[0] is not None:
@@ -316,9 +329,9 @@ def main():
         ctx.set_option("variant", v)
         k_ms_variants[v] = tracker.time_residual_kernel(refs, curs, 0, reps=ROOFLINE_REPS, warm_iterations=3)
     ctx.set_option("variant", base_variant)                           # (what the run was started with, not a constant)
-    ctx.set_option("gram_lo_parts", 1)                                 # ... and the shipped schedule with every operand's low part kept
-    k_ms_lo_parts = tracker.time_residual_kernel(refs, curs, 0, reps=ROOFLINE_REPS, warm_iterations=3)
-    ctx.set_option("gram_lo_parts", 0)
+    ctx.set_option("gram_lo_parts", 0)                                 # ... and round 5's default: the Jacobian components as f16 high parts alone
+    k_ms_hi_j = tracker.time_residual_kernel(refs, curs, 0, reps=ROOFLINE_REPS, warm_iterations=3)
+    ctx.set_option("gram_lo_parts", 1)
     stream_ms = tracker.time_stream_mix(refs, curs, 0, reps=10)                       # the same planes streamed in pixel order, read only
     stream_w_ms = tracker.time_stream_mix(refs, curs, 0, reps=10, with_write=True)   # ... plus the 8-B residual pair the sweep writes
     algo_bytes = ALGO_BYTES_PER_PIXEL * W * H * B
@@ -327,14 +340,15 @@ def main():
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
                     traffic=traffic, kernel=_kernel_label(base_variant, B),
                     kernel_ms=round(k_ms[0], 4), kernel_ms_is="mean of %d back-to-back launches (HIP events on the context stream)" % ROOFLINE_REPS,
-                    kernel_ms_all_lo_parts=round(k_ms_lo_parts, 4), frac_all_lo_parts=round(algo_bytes / (k_ms_lo_parts * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    kernel_ms_hi_j=round(k_ms_hi_j, 4), frac_hi_j=round(algo_bytes / (k_ms_hi_j * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     kernel_ms_exact_arithmetic=round(k_ms_variants[7], 4), kernel_ms_f32_gram=round(k_ms_variants[6], 4),
                     frac_exact_arithmetic=round(algo_bytes / (k_ms_variants[7] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     frac_f32_gram=round(algo_bytes / (k_ms_variants[6] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                    schedules_note="kernel_ms: the shipped schedule (variant 8: fused multiply-adds, v_rcp_f32 in the projection; residuals within "
-                                   "2e-5 of the oracle's, tests/test_gpu_parity.py::test_contracted_sweep_against_the_exact_one; at this level the "
-                                   "Jacobian components enter the matrix pipe as f16 high parts); kernel_ms_all_lo_parts: the same with every "
-                                   "operand's low part kept (option gram_lo_parts 1: what the smaller levels run); "
+                    schedules_note="kernel_ms / frac: the shipped schedule (variant 8: fused multiply-adds, v_rcp_f32 in the projection; residuals within "
+                                   "2e-5 of the oracle's, tests/test_gpu_parity.py::test_contracted_sweep_against_the_exact_one; every Gram operand an "
+                                   "exact f16 high + low pair, f32 accumulation: 22-bit operands, the precision class of the reference's f32 sums); "
+                                   "kernel_ms_hi_j / frac_hi_j: option gram_lo_parts 0, round 5's default -- the twelve Jacobian components as f16 high "
+                                   "parts alone (11-bit operands) at this level: faster, and NOT the number to credit; "
                                    "kernel_ms_exact_arithmetic: variant 7, residuals and constraint counts bit-identical to the oracle's MATH mode, "
                                    "f16 hi + lo Gram operands; kernel_ms_f32_gram: variant 6, the same with the f32 matrix instruction (no f16 anywhere)",
                     algorithmic_bytes_per_launch=algo_bytes,
@@ -545,8 +559,7 @@ def main():
             "metric": "frame-pair alignments/s (640x480, 4-level pyramid) + finest-level HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (Gram operands f16 -- residual components hi + lo, Jacobian components hi + lo below 150 000 pixels per level and hi "
-                     "alone at the finest level -- f32 accumulate)", "data": "synthetic",
+            "dtype": "f32 (Gram operands exact f16 hi + lo pairs on every level, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "%d pairs (BASELINE config 4): independent 640x480 RGB-D frame pairs, seeds 0..%d, pair i on rank i mod %d, "
                                    "4-level pyramid, FirstLevel=3, LastLevel=0, MaxIterationsPerLevel=100, Precision=5e-7, Mu=0; "
                                    "step = every rank re-ingests the raw planes of its shard from HBM (pyramids, sampling planes, point "
@@ -555,7 +568,12 @@ def main():
                                        "; the build of step k+1 (build stream) overlaps the match of step k, every step does one full build and one full match"),
                        "pairs": n_total, "pairs_per_gpu": B, "width": W, "height": H,
                        "parallelism": "independent pairs sharded round-robin over %d GPU(s) (fixed total: strong scaling), one all-gather of "
-                                      "256-B records per step" % world},
+                                      "256-B records per step%s" % (world, "" if not gathering else
+                                                                    " (ncclAllGather called by the C-ABI: dvo_hip_gather_records_*)" if gather_kind == "native"
+                                                                    else " (torch.distributed.all_gather)"),
+                       # (what the first keys of this line do NOT say by themselves -- SURVEY.md 8d quotes config 4 "incl. H2D": that is contract_value)
+                       "ingest": "hbm-resident raw planes (u8 grey + u16 depth per frame already in HBM when the timed region starts; the same loop "
+                                 "fed from pinned host memory, PCIe-inclusive, is contract_value)"},
             "roofline": roofline,
             "match_only_ms_per_batch": round(match_only_ms, 3),
             "single_pair_ms": round(single_pair_ms, 3),
@@ -578,17 +596,17 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         if out is not None and args.force_gather:
-            out["forced_gather"] = {"backend": args.backend, "world_size": world}
+            out["forced_gather"] = {"backend": args.backend, "world_size": world, "gather": gather_kind}
         print(json.dumps(out))
 
 
 def _kernel_label(variant, pairs):
     """Name of the finest-level sweep kernel the schedule `variant` launches (launch_residual_reduce, align_common.h), as rocprofv3 prints it."""
-    names = {8: "dvo_hip::k_sweep_fast<2, false, true, 0, true> (template arguments: operand stores without lane swaps, no partial tile column, "
-                "packed residual pairs, not the ref_compat arithmetic, Jacobian operands as f16 high parts)", 9: "dvo_hip::k_sweep_fast<1, false, true, 0, false>", 7: "dvo_hip::k_sweep_window<true, false, 4>",
+    names = {8: "dvo_hip::k_sweep_fast<2, false, true, 0, false> (template arguments: operand stores without lane swaps, no partial tile column, "
+                "packed residual pairs, not the ref_compat arithmetic, every operand an f16 high + low pair)", 9: "dvo_hip::k_sweep_fast<1, false, true, 0, false>", 7: "dvo_hip::k_sweep_window<true, false, 4>",
              6: "dvo_hip::k_sweep_window<false, false, 4>", 5: "dvo_hip::k_residual_reduce_mfma", 0: "dvo_hip::k_residual_reduce"}
     what = ("64 x 16 tiles, the current frame's {I, Z} window staged in LDS, contracted f32 pixel arithmetic, Gram accumulation on the f16 matrix "
-            "pipe: the residual components as exact hi + lo pairs, the Jacobian components as their high parts (levels of 150 000 pixels and more)") if variant >= 8 else "option variant=%d, see include/dvo_hip.h" % variant
+            "pipe: every component as an exact hi + lo pair") if variant >= 8 else "option variant=%d, see include/dvo_hip.h" % variant
     return "%s (pyramid level 0, %d pairs per launch; %s)" % (names.get(variant, "variant %d" % variant), pairs, what)
 
 

@@ -65,7 +65,14 @@ EXPORTS = [
     "dvo_hip_host_alloc", "dvo_hip_host_free", "dvo_hip_frames_prepare", "dvo_hip_frame_destroy", "dvo_hip_frame_info", "dvo_hip_frame_download_plane", "dvo_hip_frame_select",
     "dvo_hip_match", "dvo_hip_match_batch", "dvo_hip_level_iteration", "dvo_hip_time_residual_kernel", "dvo_hip_time_stream_mix",
     "dvo_hip_set_option", "dvo_hip_get_counter", "dvo_hip_version",
+    "dvo_hip_frames_update_raw_device_as_ex", "dvo_hip_frames_update_raw_as_ex", "dvo_hip_flush_deferred", "dvo_hip_context_device",
+    "dvo_hip_comm_get_unique_id", "dvo_hip_comm_create", "dvo_hip_comm_destroy", "dvo_hip_comm_rank", "dvo_hip_comm_size",
+    "dvo_hip_comm_last_error", "dvo_hip_gather_records_begin", "dvo_hip_gather_records_end", "dvo_hip_gather_records",
 ]
+
+ROLE_CURRENT, ROLE_REFERENCE = 0, 1
+INGEST_DEFER, INGEST_NO_RAW_COPY = 1, 2
+COMM_ID_BYTES = 128
 
 
 def build(force=False):
@@ -129,5 +136,20 @@ def lib():
     L.dvo_hip_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.dvo_hip_get_counter.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
     L.dvo_hip_version.restype = C.c_char_p
+    L.dvo_hip_frames_update_raw_device_as_ex.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_float, C.c_int, C.POINTER(Config), C.c_uint]
+    L.dvo_hip_frames_update_raw_as_ex.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_float, C.c_int, C.POINTER(Config), C.c_uint]
+    L.dvo_hip_flush_deferred.argtypes = [vp]
+    L.dvo_hip_context_device.argtypes = [vp]
+    L.dvo_hip_comm_get_unique_id.argtypes = [vp]
+    L.dvo_hip_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.dvo_hip_comm_destroy.argtypes = [vp]
+    L.dvo_hip_comm_destroy.restype = None
+    L.dvo_hip_comm_rank.argtypes = [vp]
+    L.dvo_hip_comm_size.argtypes = [vp]
+    L.dvo_hip_comm_last_error.argtypes = [vp]
+    L.dvo_hip_comm_last_error.restype = C.c_char_p
+    L.dvo_hip_gather_records_begin.argtypes = [vp, vp, C.c_size_t, C.c_size_t, ip]
+    L.dvo_hip_gather_records_end.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.dvo_hip_gather_records.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t]
     _lib = L
     return L

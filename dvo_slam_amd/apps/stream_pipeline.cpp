@@ -29,15 +29,17 @@ int dvo_stream_step(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next_refs
   // 1024-pair step is better off with the early ingest, 11.57 vs 11.74 ms -- it hides beside the latency-bound coarse levels, and half a
   // millisecond later there is less of them left)
   static const int defer_max = std::getenv("DVO_STREAM_DEFER_MAX") ? std::atoi(std::getenv("DVO_STREAM_DEFER_MAX")) : 256;
+  // (per-call flags, not the context's options: the caller's own settings stay what they were, and another thread on the context
+  // never sees a toggled option -- round-5 advisor finding)
   const bool deferring = n <= defer_max && next_refs && now_refs;
-  if (deferring) (void)dvo_hip_set_option(ctx, "defer_ingest", 1);
+  const unsigned defer_flag = deferring ? DVO_HIP_INGEST_DEFER : 0u;
   if (next_refs) {
-    // a frame this loop ingests as a reference is ingested again before it plays any other part: no copy of its raw planes (option
-    // "keep_raw_copy": 3 of the 16 bytes per pixel a reference frame's ingest moves; 1024-pair step 11.48 -> 11.37 ms)
-    (void)dvo_hip_set_option(ctx, "keep_raw_copy", 0);
-    rc = dvo_hip_frames_update_raw_device_as(ctx, n, next_refs, grey_ref, raw_ref, depth_scale, DVO_HIP_ROLE_REFERENCE, cfg);
-    (void)dvo_hip_set_option(ctx, "keep_raw_copy", 1);
-    if (rc == DVO_HIP_OK) rc = dvo_hip_frames_update_raw_device_as(ctx, n, next_curs, grey_cur, raw_cur, depth_scale, DVO_HIP_ROLE_CURRENT, cfg);
+    // a frame this loop ingests as a reference is ingested again before it plays any other part: no copy of its raw planes (3 of
+    // the 16 bytes per pixel a reference frame's ingest moves; 1024-pair step 11.48 -> 11.37 ms)
+    rc = dvo_hip_frames_update_raw_device_as_ex(ctx, n, next_refs, grey_ref, raw_ref, depth_scale, DVO_HIP_ROLE_REFERENCE, cfg,
+                                                defer_flag | DVO_HIP_INGEST_NO_RAW_COPY);
+    if (rc == DVO_HIP_OK)
+      rc = dvo_hip_frames_update_raw_device_as_ex(ctx, n, next_curs, grey_cur, raw_cur, depth_scale, DVO_HIP_ROLE_CURRENT, cfg, defer_flag);
   }
   if (rc == DVO_HIP_OK && now_refs) {
     static const double identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -45,7 +47,7 @@ int dvo_stream_step(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next_refs
     rc = dvo_hip_match_batch(ctx, n, now_refs, now_curs, cfg, results, nullptr, 0, nullptr, 0);
   }
   if (deferring) {
-    const int rc_off = dvo_hip_set_option(ctx, "defer_ingest", 0);   // (carries out whatever is still recorded)
+    const int rc_off = dvo_hip_flush_deferred(ctx);              // (carries out whatever is still recorded)
     if (rc == DVO_HIP_OK) rc = rc_off;
   }
   return rc;
@@ -102,11 +104,9 @@ int dvo_stream_step_host(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next
   const auto t0 = std::chrono::steady_clock::now();
   int rc = DVO_HIP_OK;
   if (next_refs) {
-    (void)dvo_hip_set_option(ctx, "keep_raw_copy", 0);           // (as in dvo_stream_step)
-    rc = dvo_hip_frames_update_raw_as(ctx, n, next_refs, grey_ref, raw_ref, depth_scale, DVO_HIP_ROLE_REFERENCE, cfg);
-    (void)dvo_hip_set_option(ctx, "keep_raw_copy", 1);
+    rc = dvo_hip_frames_update_raw_as_ex(ctx, n, next_refs, grey_ref, raw_ref, depth_scale, DVO_HIP_ROLE_REFERENCE, cfg, DVO_HIP_INGEST_NO_RAW_COPY);   // (as in dvo_stream_step)
     if (rc != DVO_HIP_OK) return rc;
-    rc = dvo_hip_frames_update_raw_as(ctx, n, next_curs, grey_cur, raw_cur, depth_scale, DVO_HIP_ROLE_CURRENT, cfg);
+    rc = dvo_hip_frames_update_raw_as_ex(ctx, n, next_curs, grey_cur, raw_cur, depth_scale, DVO_HIP_ROLE_CURRENT, cfg, 0u);
     if (rc != DVO_HIP_OK) return rc;
   }
   const auto t1 = std::chrono::steady_clock::now();

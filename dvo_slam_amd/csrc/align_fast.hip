@@ -697,6 +697,9 @@ void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const Pai
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
   using C2 = std::integral_constant<int, 2>;
+  // Option "ref_compat" VALUE 1 -> template COMPAT 2 (the table's 16-bit copy in LDS) when the table packs, else COMPAT 1; option VALUE 2
+  // -> COMPAT 1 (the table through memory) always: the numbers run the other way round on purpose of history, not of meaning.  Under
+  // "ref_compat" the operand store is STORE 2 whatever the variant: "variant" 9 (STORE 1, a measurement schedule) is the same as 8 there.
   if (g.rcp_table && g.rcp_packed) {                           // option "ref_compat": the host's reciprocal table in projection and weights, from LDS
     if (compact) { if (partial) go(S2{}, T{}, T{}, C2{}); else go(S2{}, F{}, T{}, C2{}); }
     else { if (partial) go(S2{}, T{}, F{}, C2{}); else go(S2{}, F{}, F{}, C2{}); }

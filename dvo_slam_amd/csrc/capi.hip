@@ -190,6 +190,13 @@ struct PinnedRing {
       }
       if (!slot) slot = oldest;
       slot->dst = nullptr;                                       // (valid again once the copy below is enqueued)
+      // Whatever else the cache believes about bytes of [dst, dst + bytes) is about to be overwritten: the slices of one table buffer
+      // (ensure_roles) lie at offsets that depend on the batch size, so uploads of different batches overlap without sharing a start
+      // address (round-5 advisor finding: batches of 3, 2, 3 pairs with a re-ingest between them left the 3-pair slice's entry alive
+      // over the 2-pair slices' bytes, and the third upload was skipped).
+      const char* lo = static_cast<const char*>(dst);
+      for (Sent& c : sent)
+        if (c.dst && static_cast<const char*>(c.dst) < lo + bytes && lo < static_cast<const char*>(c.dst) + c.bytes.size()) c.dst = nullptr;
     }
     const hipError_t e_up = upload_now(stream, dst, src, bytes);
     if (slot && e_up == hipSuccess) {
@@ -350,7 +357,7 @@ struct dvo_hip_context {
   int opt_solver_waves = 0;        // wavefronts of a solver-step workgroup: 0 = by level and batch size, 2, 4
   int opt_ll_blocks = 0;           // workgroups per pair of the log-likelihood pass (0 = by batch size)
   int opt_compact_residuals = 1;   // the contracted window sweep stores only the residual pairs of constraints, packed (LevelGeom::compact)
-  int opt_gram_lo_parts = 0;       // 1: every Gram operand keeps its f16 low part on every level (0: LevelGeom::gram_hi_j on the large ones)
+  int opt_gram_lo_parts = 1;       // 1 (default since round 6): every Gram operand keeps its f16 low part on every level; 0: LevelGeom::gram_hi_j on the large ones
   int opt_min_workgroups = 0;      // tile-height heuristic: smallest launch that still counts as filling the chip
   int opt_condition_number = 0;    // results carry |lambda_max / lambda_min| of the information matrix
   int opt_fused_ll_pixels = 0;     // largest level (pixels) whose log-likelihood sweep runs inside the solver workgroup (0 = by batch size)
@@ -639,7 +646,8 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   g.rcp_table = ctx->opt_ref_compat ? ctx->rcp_table.as<float>() : nullptr;
   g.rcp_shift = ctx->rcp_shift;
   g.rcp_packed = ctx->opt_ref_compat == 1 ? ctx->rcp_packed : 0;   // (2: the table through memory, the path of a table that does not pack)
-  g.gram_hi_j = !ctx->opt_gram_lo_parts && !ctx->opt_deterministic && ctx->opt_variant == 8 && size_t(g.w) * g.h >= 150000 ? 1 : 0;
+  // (not under "ref_compat": a run that is compared with the reference's own numbers keeps every low part -- round-5 advisor finding)
+  g.gram_hi_j = !ctx->opt_gram_lo_parts && !ctx->opt_deterministic && !ctx->opt_ref_compat && ctx->opt_variant == 8 && size_t(g.w) * g.h >= 150000 ? 1 : 0;
   g.compact = ctx->opt_compact_residuals && ctx->opt_variant >= 8 && rows_per_wave == 4 && fast_sweep_supports(g) ? 1 : 0;   // (launch_residual_reduce's test)
   return g;
 }
@@ -838,6 +846,19 @@ int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int 
   DevBuf& table = eager ? (role == 0 ? ctx->prep_tbl_cur : ctx->prep_tbl_ref) : (role == 0 ? ctx->role_tbl_cur : ctx->role_tbl_ref);
   hipStream_t stream = eager ? ctx->build_stream : ctx->stream;
   const int cap = eager ? ctx->opt_build_workgroups : 0;   // planes needed right now are built at full width
+  // Every frame is checked before the state of any is touched: a frame ingested straight into a role without a copy of its raw planes
+  // (option "keep_raw_copy" 0) has nothing its level 0 could be derived from in another role, and the marks below -- planes "built" --
+  // are set while the launches are still being gathered (round-5 advisor finding: the error used to leave earlier frames of the list
+  // marked as built without their launches, and a retry aligned against stale planes).
+  if (l0 == 0)
+    for (int i = 0; i < n; ++i) {
+      const dvo_hip_frame* f = frames[i];
+      const FrameLevel& L = f->lv[0];
+      if (!f->raw0 || L.cur_have != 0 || f->raw_copy) continue;
+      const int want0 = role == 0 ? (cur_want ? cur_want[0] : kCurAB) & (L.C ? (kCurAB | kCurC) : kCurAB) : 0;
+      const bool need = role == 0 ? want0 != 0 : !(L.selected && L.ithr == ithr && L.dthr == dthr);
+      if (need) return fail(ctx, DVO_HIP_ERR_INVALID, "frame has neither sampling planes nor a raw copy at level 0");
+    }
   bool launched = false;
   int uploads = 0;                                           // table slices used so far (each launch reads its own)
   auto upload = [&](const std::vector<FrameBuildPtrs>& host, const FrameBuildPtrs** tbl, bool plane_pointers_only = true) -> int {
@@ -1433,7 +1454,12 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   const size_t n_steps = size_t(bp.cap_iters) + 8 + kResidentErrorWords;
   // a batch that ended early (time-out, HIP error) may have left steps queued: nothing of it may still be running when the
   // status words and tallies are reset
-  if (w.needs_drain) DVO_WS_TRY(w, sync_stream(s));
+  if (w.needs_drain) {
+    DVO_WS_TRY(w, sync_stream(s));
+    // ... and the f16 range words it may have raised are nobody's business any more (they are cleared where they are read, at a batch's
+    // regular end: left standing, the next batch would repeat unrelated pairs at the same indices -- round-5 advisor finding)
+    if (w.f16_range_flag) std::memset(w.f16_range_flag, 0, w.f16_range_words * sizeof(int));
+  }
   w.needs_drain = true;                                        // until this batch has come to its regular end
   mark(2);
   rc = ensure_host_status(w, n_steps);
@@ -1983,6 +2009,8 @@ const char* dvo_hip_last_error(const dvo_hip_context* ctx) { return ctx ? ctx->e
 
 void* dvo_hip_context_stream(dvo_hip_context* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
 
+int dvo_hip_context_device(const dvo_hip_context* ctx) { return ctx ? ctx->device : -1; }
+
 int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
@@ -2263,6 +2291,8 @@ int flush_deferred(dvo_hip_context* ctx) {
 
 int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
                                      const void* const* raw_depth_dev, float depth_scale) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   DVO_FLUSH_DEFERRED(ctx);
   if (!ctx || n_frames < 1 || !frames || !grey_dev || !raw_depth_dev) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device: null argument");
   for (int i = 0; i < n_frames; ++i)
@@ -2271,8 +2301,9 @@ int dvo_hip_frames_update_raw_device(dvo_hip_context* ctx, int n_frames, dvo_hip
   return update_raw_device(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, -1, nullptr);
 }
 
-int dvo_hip_frames_update_raw_device_as(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
-                                        const void* const* raw_depth_dev, float depth_scale, int role, const dvo_hip_config* cfg) {
+// defer / keep_raw_copy: -1 = what the context's options say ("defer_ingest", "keep_raw_copy"), 0 / 1 = for this call only
+static int update_raw_device_as(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
+                                const void* const* raw_depth_dev, float depth_scale, int role, const dvo_hip_config* cfg, int defer, int keep_raw_copy) {
   std::unique_lock<std::recursive_mutex> guard;
   if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   int rc = check_prepare_args(ctx, n_frames, frames, role, cfg, "frames_update_raw_device_as: bad argument");
@@ -2280,7 +2311,8 @@ int dvo_hip_frames_update_raw_device_as(dvo_hip_context* ctx, int n_frames, dvo_
   if (!grey_dev || !raw_depth_dev) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device_as: null argument");
   for (int i = 0; i < n_frames; ++i)
     if (!grey_dev[i] || !raw_depth_dev[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw_device_as: null entry");
-  if (ctx->opt_defer_ingest) {
+  const bool keep = keep_raw_copy < 0 ? ctx->opt_keep_raw_copy != 0 : keep_raw_copy != 0;
+  if (defer < 0 ? ctx->opt_defer_ingest != 0 : defer != 0) {
     dvo_hip_context::DeferredIngest d;
     d.frames.assign(frames, frames + n_frames);
     d.grey.assign(grey_dev, grey_dev + n_frames);
@@ -2288,20 +2320,39 @@ int dvo_hip_frames_update_raw_device_as(dvo_hip_context* ctx, int n_frames, dvo_
     d.depth_scale = depth_scale;
     d.role = role;
     d.cfg = *cfg;
-    d.keep_raw_copy = ctx->opt_keep_raw_copy != 0;
+    d.keep_raw_copy = keep;
     for (int i = 0; i < n_frames; ++i) frames[i]->deferred = 1;
     ctx->deferred.push_back(std::move(d));
     return DVO_HIP_OK;
   }
+  DVO_FLUSH_DEFERRED(ctx);                                     // (nothing overtakes a recorded ingest)
   DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return update_raw_device(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, role, cfg, ctx->opt_keep_raw_copy != 0);
+  return update_raw_device(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, role, cfg, keep);
+}
+
+int dvo_hip_frames_update_raw_device_as(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
+                                        const void* const* raw_depth_dev, float depth_scale, int role, const dvo_hip_config* cfg) {
+  return update_raw_device_as(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, role, cfg, -1, -1);
+}
+
+int dvo_hip_frames_update_raw_device_as_ex(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const void* const* grey_dev,
+                                           const void* const* raw_depth_dev, float depth_scale, int role, const dvo_hip_config* cfg, unsigned flags) {
+  return update_raw_device_as(ctx, n_frames, frames, grey_dev, raw_depth_dev, depth_scale, role, cfg, (flags & DVO_HIP_INGEST_DEFER) ? 1 : 0,
+                              (flags & DVO_HIP_INGEST_NO_RAW_COPY) ? 0 : 1);
+}
+
+int dvo_hip_flush_deferred(dvo_hip_context* ctx) {
+  if (!ctx) return DVO_HIP_ERR_INVALID;
+  std::unique_lock<std::recursive_mutex> guard(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
+  return DVO_HIP_OK;
 }
 
 // Streaming ingest from HOST memory: DMA of the raw planes into a transfer buffer on the upload stream, then the batched
 // build on the build stream.  Returns at once; from pinned memory (dvo_hip_host_alloc) the transfers are truly asynchronous,
 // from pageable memory the runtime stages them (correct, but the call then blocks for most of the copy).
 static int update_raw_host(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const uint8_t* const* grey,
-                           const uint16_t* const* raw_depth, float depth_scale, int role, const dvo_hip_config* cfg) {
+                           const uint16_t* const* raw_depth, float depth_scale, int role, const dvo_hip_config* cfg, int keep_raw_copy = -1) {
   if (!ctx || n_frames < 1 || !frames || !grey || !raw_depth) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw: null argument");
   for (int i = 0; i < n_frames; ++i) {
     if (!frames[i] || !grey[i] || !raw_depth[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "frames_update_raw: null entry");
@@ -2342,13 +2393,15 @@ static int update_raw_host(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* co
   }
   DVO_HIP_TRY(ctx, hipEventRecord(ctx->upload_done, ctx->upload_stream));
   DVO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->build_stream, ctx->upload_done, 0));
-  rc = update_raw_device(ctx, n_frames, frames, g.data(), r.data(), depth_scale, role, cfg, ctx->opt_keep_raw_copy != 0);
+  rc = update_raw_device(ctx, n_frames, frames, g.data(), r.data(), depth_scale, role, cfg, keep_raw_copy < 0 ? ctx->opt_keep_raw_copy != 0 : keep_raw_copy != 0);
   ctx->upload_buf_seq[b] = ctx->build_seq;          // the newest ticket is behind every reader of the buffer
   return rc;
 }
 
 int dvo_hip_frames_update_raw(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const uint8_t* const* grey,
                               const uint16_t* const* raw_depth, float depth_scale) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
   DVO_FLUSH_DEFERRED(ctx);
   return update_raw_host(ctx, n_frames, frames, grey, raw_depth, depth_scale, -1, nullptr);
 }
@@ -2361,6 +2414,16 @@ int dvo_hip_frames_update_raw_as(dvo_hip_context* ctx, int n_frames, dvo_hip_fra
   const int rc = check_prepare_args(ctx, n_frames, frames, role, cfg, "frames_update_raw_as: bad argument");
   if (rc != DVO_HIP_OK) return rc;
   return update_raw_host(ctx, n_frames, frames, grey, raw_depth, depth_scale, role, cfg);
+}
+
+int dvo_hip_frames_update_raw_as_ex(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames, const uint8_t* const* grey,
+                                    const uint16_t* const* raw_depth, float depth_scale, int role, const dvo_hip_config* cfg, unsigned flags) {
+  std::unique_lock<std::recursive_mutex> guard;
+  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
+  DVO_FLUSH_DEFERRED(ctx);
+  const int rc = check_prepare_args(ctx, n_frames, frames, role, cfg, "frames_update_raw_as_ex: bad argument");
+  if (rc != DVO_HIP_OK) return rc;
+  return update_raw_host(ctx, n_frames, frames, grey, raw_depth, depth_scale, role, cfg, (flags & DVO_HIP_INGEST_NO_RAW_COPY) ? 0 : 1);
 }
 
 int dvo_hip_upload_wait(dvo_hip_context* ctx) {

@@ -72,11 +72,8 @@ class PendingGather:
         g = self.gatherer
         if self.work is not None:
             self.work.wait()
-        full = np.zeros((g.n_pairs, RECORD), np.float64)
-        for r in range(g.world_size):
-            idx = g.owners[r]
-            full[idx] = g.out[self.slot][r][: len(idx)].cpu().numpy()
-        return full
+        blocks = np.stack([g.out[self.slot][r].cpu().numpy() for r in range(g.world_size)])
+        return blocks_to_pair_order(blocks, g.n_pairs, g.world_size)
 
 
 class RecordGatherer:
@@ -105,6 +102,77 @@ class RecordGatherer:
         self.buf[slot].copy_(self.stage[slot], non_blocking=True)
         work = dist.all_gather(self.out[slot], self.buf[slot], async_op=True)
         return PendingGather(self, slot, work)
+
+
+def blocks_to_pair_order(blocks, n_pairs, world_size):
+    """[world_size, per_rank, RECORD] blocks in rank order (a rank's block padded to the largest share) -> [n_pairs, RECORD] in global
+    pair order (pair i was aligned by rank i mod world_size as its (i // world_size)-th pair).  Shared by both gatherers and by the CPU
+    test of the record layout."""
+    blocks = np.asarray(blocks, np.float64).reshape(world_size, -1, RECORD)
+    full = np.zeros((n_pairs, RECORD), np.float64)
+    for r in range(world_size):
+        idx = shard_indices(n_pairs, r, world_size)
+        full[idx] = blocks[r][: len(idx)]
+    return full
+
+
+class NativePendingGather:
+    def __init__(self, gatherer, ticket):
+        self.gatherer, self.ticket = gatherer, ticket
+
+    def result(self):
+        import ctypes as C
+        g = self.gatherer
+        out = np.empty((g.world_size, g.per_rank, RECORD), np.float64)
+        rc = g.lib.dvo_hip_gather_records_end(g.comm, self.ticket, C.c_void_p(out.ctypes.data), out.nbytes)
+        if rc != 0:
+            raise RuntimeError("dvo_hip_gather_records_end: %s" % g.lib.dvo_hip_comm_last_error(g.comm).decode())
+        return blocks_to_pair_order(out, g.n_pairs, g.world_size)
+
+
+class NativeRecordGatherer:
+    """The same all-gather through the C-ABI (include/dvo_hip.h: dvo_hip_comm_*, dvo_hip_gather_records_*; csrc/gather_rccl.hip calls
+    ncclAllGather itself, on a stream of its own): the path a C++ host of the engine uses, and since round 6 the one bench.py times for
+    N > 1.  `unique_id`: the 128 bytes rank 0 obtained from unique_id() and the caller carried to every rank (bench.py: one
+    torch.distributed broadcast, the launcher's rendezvous being there anyway)."""
+
+    def __init__(self, ctx, unique_id, n_pairs, rank, world_size):
+        import ctypes as C
+        from . import _lib
+        self.lib = ctx._lib
+        self.n_pairs, self.rank, self.world_size = n_pairs, rank, world_size
+        self.per_rank = (n_pairs + world_size - 1) // world_size
+        assert len(unique_id) == _lib.COMM_ID_BYTES
+        buf = (C.c_char * _lib.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        comm = C.c_void_p()
+        rc = self.lib.dvo_hip_comm_create(ctx.ptr, C.cast(buf, C.c_void_p), rank, world_size, C.byref(comm))
+        if rc != 0:
+            raise RuntimeError("dvo_hip_comm_create: %s" % self.lib.dvo_hip_comm_last_error(None).decode())
+        self.comm = comm
+
+    @staticmethod
+    def unique_id(ctx):
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_char * _lib.COMM_ID_BYTES)()
+        rc = ctx._lib.dvo_hip_comm_get_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise RuntimeError("dvo_hip_comm_get_unique_id: %s" % ctx._lib.dvo_hip_comm_last_error(None).decode())
+        return bytes(buf)
+
+    def start(self, local_records):
+        import ctypes as C
+        loc = np.ascontiguousarray(local_records, dtype=np.float64).reshape(-1, RECORD)
+        ticket = C.c_int(-1)
+        rc = self.lib.dvo_hip_gather_records_begin(self.comm, C.c_void_p(loc.ctypes.data), loc.nbytes, self.per_rank * RECORD * 8, C.byref(ticket))
+        if rc != 0:
+            raise RuntimeError("dvo_hip_gather_records_begin: %s" % self.lib.dvo_hip_comm_last_error(self.comm).decode())
+        return NativePendingGather(self, ticket.value)
+
+    def close(self):
+        if self.comm is not None:
+            self.lib.dvo_hip_comm_destroy(self.comm)
+            self.comm = None
 
 
 def gather_records_start(local_records, n_pairs, rank, world_size, device=None):

@@ -114,6 +114,8 @@ void dvo_hip_context_destroy(dvo_hip_context* ctx);
 const char* dvo_hip_last_error(const dvo_hip_context* ctx);
 /* the hipStream_t all work of this context is enqueued on (for HIP-event timing by the caller) */
 void* dvo_hip_context_stream(dvo_hip_context* ctx);
+/* the device index the context was created on (-1 for a null context) */
+int dvo_hip_context_device(const dvo_hip_context* ctx);
 int dvo_hip_device_count(void);
 
 /* ---- frames: RgbdCameraPyramid::create + RgbdImagePyramid::build + buildAccelerationStructure --
@@ -163,6 +165,23 @@ int dvo_hip_frames_update_raw(dvo_hip_context* ctx, int n_frames, dvo_hip_frame*
 int dvo_hip_frames_update_raw_as(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames,
                                  const uint8_t* const* grey, const uint16_t* const* raw_depth, float depth_scale,
                                  int role, const dvo_hip_config* cfg);
+/* The two role-aware ingests with PER-CALL behaviour instead of the context-wide options "defer_ingest" / "keep_raw_copy" (a caller
+ * that shares its context with other host threads must not toggle options around a call): flags = DVO_HIP_INGEST_DEFER (device
+ * planes only: the request is recorded -- pointer arrays copied, the raw planes must stay valid -- and carried out right behind the
+ * first launches of the next dvo_hip_match_batch, or by whatever entry point comes first, or by dvo_hip_flush_deferred) |
+ * DVO_HIP_INGEST_NO_RAW_COPY (a frame ingested into the REFERENCE role keeps no copy of its raw planes: it serves as a reference with
+ * cfg's thresholds until it is ingested again, anything else fails with DVO_HIP_ERR_INVALID and leaves every frame as it was).
+ * dvo_slam_amd/apps/stream_pipeline.cpp (the loop bench.py times) uses these. */
+#define DVO_HIP_INGEST_DEFER 1u
+#define DVO_HIP_INGEST_NO_RAW_COPY 2u
+int dvo_hip_frames_update_raw_device_as_ex(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames,
+                                           const void* const* grey_dev, const void* const* raw_depth_dev, float depth_scale,
+                                           int role, const dvo_hip_config* cfg, unsigned flags);
+int dvo_hip_frames_update_raw_as_ex(dvo_hip_context* ctx, int n_frames, dvo_hip_frame* const* frames,
+                                    const uint8_t* const* grey, const uint16_t* const* raw_depth, float depth_scale,
+                                    int role, const dvo_hip_config* cfg, unsigned flags);
+/* carries out every recorded ingest now; returns the first failure */
+int dvo_hip_flush_deferred(dvo_hip_context* ctx);
 int dvo_hip_upload_wait(dvo_hip_context* ctx);
 /* pinned (page-locked) host memory for raw planes: decoders / camera drivers write here, uploads from it are asynchronous */
 int dvo_hip_host_alloc(dvo_hip_context* ctx, size_t bytes, void** out);
@@ -261,11 +280,12 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * whose residuals and constraint counts equal the oracle's MATH mode BIT FOR BIT (no contraction, correctly rounded divisions), f16
  * Gram; 6 = the same with the f32 Gram (bit-identical to 5); 5 = gathered taps, f32 Gram accumulation on the matrix cores; 0 =
  * all-VALU with the DPP + LDS reduction),
- * "gram_lo_parts" (default 0: on levels of 150 000 pixels and more the default schedule forms its matrix operands from the f16 HIGH parts
- * of the twelve Jacobian components alone -- the two residual components keep high + low parts everywhere -- which is 3.5 % of the
- * finest-level sweep; a component is then off by <= 2^-12 of itself, at random, and the normal equations by ~3e-6 of their largest
- * entry at 190 000 constraints; 1: every operand keeps its low part on every level, as on the smaller levels and
- * under options "deterministic" and "variant" 9),
+ * "gram_lo_parts" (default 1 since round 6: every matrix operand is an exact f16 high + low pair on every level -- 22-bit operands, f32
+ * accumulation: what the reference's f32 accumulation, dvo_core/src/core/math_sse.cpp:82-178, is compared with at 1e-5; 0: on levels of
+ * 150 000 pixels and more the default schedule forms its operands from the f16 HIGH parts of the twelve Jacobian components alone -- the
+ * two residual components keep both parts -- which is 3.5 % of the finest-level sweep; a component is then off by <= 2^-12 of itself,
+ * at random, the normal equations by ~3e-6 of their largest entry at 190 000 constraints and `b` by up to 3e-5.
+ * Never under options "deterministic", "ref_compat" and "variant" 9),
  * "compact_residuals" (default 1: the contracted window sweep stores only the residual pairs of constraints, packed per wavefront
  * slot, for the log-likelihood pass to read half the bytes; 0: one pair per pixel at its pixel's place like every other schedule --
  * the same normal equations bit for bit, the log-likelihood the same sum in another order),
@@ -343,6 +363,37 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
  * "host_batches" and "host_ns_prepare" / "host_ns_enqueue" / "host_ns_wait" / "host_ns_finish" (nanoseconds the calling thread spent
  * in dvo_hip_match_batch before its first launch, enqueueing, waiting for the device and afterwards; accumulated). */
 int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value);
+
+/* ---- multi-GPU: one process per GPU, the records of a sharded batch gathered over RCCL (xGMI) --------------------------------
+ * The reference runs independent match() calls on the workers of a tbb::parallel_reduce and concatenates their results
+ * (dvo_slam/src/keyframe_graph.cpp:576-593; dvo_slam/src/local_tracker.cpp:180-184).  Spread over the GPUs of a node -- pair i on rank
+ * i mod N, no communication while aligning -- the only exchange is an all-gather of fixed-size result records
+ * afterwards.  These entry points are that exchange for a C++ host (inside ONE process dvo::DenseTracker::matchBatch over several
+ * contexts needs none).  RCCL is loaded when the first of them is called (librccl.so.1; DVO_HIP_RCCL_LIBRARY overrides the name):
+ * without it they return DVO_HIP_ERR_NO_DEVICE and nothing else in this header is affected.
+ *   rank 0: dvo_hip_comm_get_unique_id(id) -> the caller carries the DVO_HIP_COMM_ID_BYTES bytes to every rank (a file, a socket, MPI,
+ *           torch.distributed's store: the reference has no process launcher of its own, so none is prescribed here);
+ *   every rank: dvo_hip_comm_create(ctx, id, rank, n_ranks, &comm)   -- collective (ncclCommInitRank) on the context's device;
+ *   per batch:  dvo_hip_gather_records_begin(comm, mine, bytes_mine, bytes_per_rank, &ticket)   -- returns at once: the block is staged
+ *               in pinned memory, copied to the device, ncclAllGather and the copy back are enqueued on the communicator's OWN stream
+ *               (the context's stream is busy aligning the next batch by then); bytes_per_rank, a multiple of 8, is the same on every
+ *               rank -- a rank with a smaller share is padded with zeros;
+ *               dvo_hip_gather_records_end(comm, ticket, all, all_bytes)   -- waits for that gather: n_ranks blocks in rank order.
+ *               Two gathers may be in flight (the records of step k travel while step k + 1 is aligned).
+ *   dvo_hip_gather_records = begin + end.  Every rank must make the same sequence of calls (a collective).
+ * The record layout a batch of alignments travels in -- 32 doubles per pair: twist (6) | upper triangle of the information matrix (21) |
+ * log-likelihood | flag | padding (3) -- is dvo_stream_pack_records' (dvo_slam_amd/apps/stream_pipeline.cpp). */
+typedef struct dvo_hip_comm dvo_hip_comm;
+#define DVO_HIP_COMM_ID_BYTES 128
+int dvo_hip_comm_get_unique_id(void* id /* DVO_HIP_COMM_ID_BYTES bytes */);
+int dvo_hip_comm_create(dvo_hip_context* ctx, const void* id, int rank, int n_ranks, dvo_hip_comm** out);
+void dvo_hip_comm_destroy(dvo_hip_comm* comm);
+int dvo_hip_comm_rank(const dvo_hip_comm* comm);
+int dvo_hip_comm_size(const dvo_hip_comm* comm);
+const char* dvo_hip_comm_last_error(const dvo_hip_comm* comm /* null: the calling thread's last failed comm call */);
+int dvo_hip_gather_records_begin(dvo_hip_comm* comm, const void* mine, size_t bytes_mine, size_t bytes_per_rank, int* ticket);
+int dvo_hip_gather_records_end(dvo_hip_comm* comm, int ticket, void* all, size_t all_bytes);
+int dvo_hip_gather_records(dvo_hip_comm* comm, const void* mine, size_t bytes_mine, size_t bytes_per_rank, void* all, size_t all_bytes);
 
 const char* dvo_hip_version(void);
 

@@ -102,7 +102,7 @@ def test_stream_pipeline_object_builds_and_binds_only_the_c_abi():
     assert "dvo_stream_step" in defined
     ours = [u for u in undefined if u.startswith("dvo_hip_")]
     assert "dvo_stream_step_host" in defined
-    assert sorted(ours) == ["dvo_hip_frames_update_raw_as", "dvo_hip_frames_update_raw_device_as", "dvo_hip_match_batch", "dvo_hip_set_option"]
+    assert sorted(ours) == ["dvo_hip_flush_deferred", "dvo_hip_frames_update_raw_as_ex", "dvo_hip_frames_update_raw_device_as_ex", "dvo_hip_match_batch"]
     assert all(u.startswith("dvo_hip_") or "GLIBC" in u or u.startswith(("mem", "__")) for u in undefined), undefined
 
 

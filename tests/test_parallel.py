@@ -161,15 +161,82 @@ def test_rccl_record_path_on_one_gpu(tmp_path):
     a = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--records-out", plain] + common,
                        capture_output=True, text=True, timeout=600)
     assert a.returncode == 0, a.stderr[-2000:]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--backend", "nccl", "--records-out", forced] + common,
-                       capture_output=True, text=True, timeout=600, env=env)
-    assert b.returncode == 0, b.stderr[-2000:]
-    jb = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
-    assert jb["forced_gather"] == {"backend": "nccl", "world_size": 1} and jb["n_gpus"] == 1 and jb["nan_results"] == 0
-    ra, rb = np.load(plain), np.load(forced)
-    assert ra.shape == rb.shape == (12, par.RECORD)
-    assert np.array_equal(ra, rb)
+    ra = np.load(plain)
+    # both gatherers: "native" = ncclAllGather called by the C-ABI itself (dvo_hip_gather_records_*, the default with --backend nccl since
+    # round 6: what a C++ host uses), "torch" = torch.distributed.all_gather
+    for kind in ("native", "torch"):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--backend", "nccl", "--gather", kind,
+                            "--records-out", forced] + common, capture_output=True, text=True, timeout=600, env=env)
+        assert b.returncode == 0, b.stderr[-2000:]
+        jb = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
+        assert jb["forced_gather"] == {"backend": "nccl", "world_size": 1, "gather": kind} and jb["n_gpus"] == 1 and jb["nan_results"] == 0
+        rb = np.load(forced)
+        assert ra.shape == rb.shape == (12, par.RECORD)
+        assert np.array_equal(ra, rb), kind
+
+
+@pytest.mark.gpu
+def test_native_gather_through_the_c_abi_world_of_one():
+    """dvo_hip_comm_* / dvo_hip_gather_records_* called directly (no torch.distributed anywhere): a communicator of one rank on GPU 0, two
+    gathers in flight at once (the double buffering a streaming caller relies on), a smaller share padded with zeros, and the error
+    behaviour of the entry points."""
+    import ctypes as C
+    import dvo_slam_amd as d
+    from dvo_slam_amd import _lib
+    ctx = d.Context(0)
+    L = ctx._lib
+    assert L.dvo_hip_context_device(ctx.ptr) == 0
+    uid = par.NativeRecordGatherer.unique_id(ctx)
+    assert len(uid) == _lib.COMM_ID_BYTES
+    g = par.NativeRecordGatherer(ctx, uid, 10, 0, 1)
+    assert L.dvo_hip_comm_rank(g.comm) == 0 and L.dvo_hip_comm_size(g.comm) == 1
+    rng = np.random.default_rng(3)
+    a, b = rng.normal(size=(10, par.RECORD)), rng.normal(size=(7, par.RECORD))
+    pa, pb = g.start(a), g.start(b)                                     # both slots in flight
+    with pytest.raises(RuntimeError):
+        g.start(a)                                                      # a third is refused, not queued
+    assert np.array_equal(pa.result(), a)
+    got = pb.result()
+    assert np.array_equal(got[:7], b) and not got[7:].any()             # the smaller share: padded with zeros
+    assert np.array_equal(g.start(b[:3]).result()[:3], b[:3])           # slots are reusable
+    t = C.c_int()
+    assert L.dvo_hip_gather_records_begin(g.comm, None, 8, 8, C.byref(t)) == _lib.ERR_INVALID
+    assert L.dvo_hip_gather_records_begin(g.comm, C.c_void_p(a.ctypes.data), 24, 16, C.byref(t)) == _lib.ERR_INVALID    # more than a block
+    assert L.dvo_hip_gather_records_begin(g.comm, C.c_void_p(a.ctypes.data), 4, 12, C.byref(t)) == _lib.ERR_INVALID     # not a multiple of 8
+    assert L.dvo_hip_gather_records_end(g.comm, 0, C.c_void_p(a.ctypes.data), 8) == _lib.ERR_INVALID                    # nothing in flight
+    g.close()
+
+
+def test_record_blocks_restore_pair_order():
+    """CPU tier: the layout both gatherers deliver -- one block per rank, a rank's pairs in the order it aligned them (pair i on rank
+    i mod N as its (i // N)-th), blocks padded to the largest share -- put back into global pair order."""
+    for n_pairs, world in ((12, 1), (12, 2), (13, 4), (5, 8), (1024, 8)):
+        rec = np.arange(n_pairs * par.RECORD, dtype=np.float64).reshape(n_pairs, par.RECORD) + 1.0
+        per_rank = (n_pairs + world - 1) // world
+        blocks = np.zeros((world, per_rank, par.RECORD))
+        for r in range(world):
+            mine = rec[par.shard_indices(n_pairs, r, world)]
+            blocks[r, : len(mine)] = mine
+        assert np.array_equal(par.blocks_to_pair_order(blocks, n_pairs, world), rec)
+        assert np.array_equal(par.blocks_to_pair_order(blocks.reshape(-1), n_pairs, world), rec)
+
+
+def test_comm_entry_points_refuse_bad_arguments_without_a_device():
+    """CPU tier (no compute): the gather entry points of the C-ABI exist and fail cleanly on null arguments."""
+    import ctypes as C
+    import dvo_slam_amd as d
+    from dvo_slam_amd import _lib
+    L = d.lib()
+    out = C.c_void_p()
+    assert L.dvo_hip_comm_create(None, None, 0, 1, C.byref(out)) == _lib.ERR_INVALID and not out.value
+    assert L.dvo_hip_comm_get_unique_id(None) == _lib.ERR_INVALID
+    assert L.dvo_hip_comm_rank(None) == -1 and L.dvo_hip_comm_size(None) == 0
+    t = C.c_int()
+    assert L.dvo_hip_gather_records_begin(None, None, 0, 8, C.byref(t)) == _lib.ERR_INVALID
+    assert L.dvo_hip_gather_records_end(None, 0, None, 0) == _lib.ERR_INVALID
+    L.dvo_hip_comm_destroy(None)
+    assert L.dvo_hip_context_device(None) == -1
 
 
 def test_pipeline_object_packs_the_same_records():
