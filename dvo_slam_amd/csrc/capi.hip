@@ -380,6 +380,10 @@ struct dvo_hip_context {
   long long host_batches = 0;
   std::chrono::steady_clock::time_point batch_entry;
   int opt_resident_flags = 0;      // kResidentFlag* (measurement and test hooks)
+  int opt_coarse = 0;              // the fused coarse-level kernel (align_coarse.hip): 0 = off (default: measured and lost), 1 = whenever the levels admit it
+  int opt_coarse_pixels = 0;       // levels of up to this many pixels run in it (0 = kCoarseMaxPixels)
+  int opt_coarse_wgs = 0;          // its workgroups per compute unit: 0 / 4 (128 registers) or 3 (168)
+  long long coarse_launches = 0, coarse_levels = 0;
   int opt_deterministic = 0;       // a pair's record does not depend on the batch it is aligned in (see dvo_hip.h, option "deterministic")
   int opt_ref_compat = 0;          // projection and weights multiply with the HOST CPU's _mm_rcp_ps like the reference does
   DevBuf rcp_table;                // ... from this table, dumped from the instruction itself when the option is first switched on
@@ -1023,6 +1027,7 @@ struct BatchPlan {
   std::vector<LevelGeom> geom;   // per absolute level
   PairPtrs* pair_ptrs = nullptr; // device [levels][n] (null when the table only travels in kernel arguments)
   std::vector<PairPtrs> host_ptrs;   // the same table on the host
+  int coarse_levels = 0;         // leading levels (first_level, first_level - 1, ...) the fused coarse-level kernel runs (plan_coarse)
 };
 
 int validate_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg) {
@@ -1340,10 +1345,52 @@ ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg
   return rp;
 }
 
+// ---- the fused coarse-level kernel (align_coarse.hip): which levels -----------------------------------------------------------------
+// One workgroup per pair runs the leading levels of the match to their termination in ONE launch (sweep over all tiles, reduction,
+// log-likelihood, loop body), with the launch path's device functions on the launch path's data layout: the records are the launch
+// path's bit for bit.  The levels: from the first one down, as long as the level is small (kCoarseMaxPixels) and the kernel has an
+// instantiation for it (coarse_kernel_takes).  OPT-IN (option "coarse" 1): measured in round 6 against the launch path at 128 / 256 /
+// 512 / 1024 pairs per step and slower at every size (1.80 -> 3.08, 3.16 -> 4.43, 6.0 -> 7.2, 11.5 -> 12.5 ms per streaming step): a
+// workgroup walks the 10 + 34 tiles of levels 3 and 2 one after the other -- 60 / 200 us per iteration where the launch path, which
+// spreads the tiles of an iteration over the chip, needs 25 / 40 -- and with as many pairs as workgroup slots (1024 = 256 compute units x
+// 4) the launch lasts as long as its slowest pair (15 + 9 iterations against a mean of 8 + 5).  It pays where pairs outnumber the slots
+// several times over; kept for that case and as the bit-exact cross-check of the launch path's hand-over logic.
+constexpr int kCoarseMaxPixels = 160 * 120;
+
+void plan_coarse(const dvo_hip_context* ctx, const dvo_hip_config* cfg, BatchPlan& bp, const ResidentPlan& rp) {
+  bp.coarse_levels = 0;
+  if (ctx->opt_coarse == 0 || rp.levels > 0 || ctx->opt_variant != 8) return;
+  const int max_pixels = ctx->opt_coarse_pixels > 0 ? ctx->opt_coarse_pixels : kCoarseMaxPixels;
+  for (int level = cfg->first_level; level >= cfg->last_level; --level) {
+    if (bp.cam->w[level] * bp.cam->h[level] > max_pixels) break;
+    const bool window_level = level_uses_window(ctx, bp.cam->w[level], bp.cam->h[level]);
+    const int rpw = window_level ? 4 : kCoarseRowsPerWave;
+    if (!window_level && ctx->opt_rows_per_wave > 0 && ctx->opt_rows_per_wave != rpw) break;   // (a tile height asked for by name stays)
+    const LevelGeom g = make_geom(ctx, bp.cam, level, rpw);
+    if (!coarse_kernel_takes(g, window_level)) break;
+    bp.rpw[level] = rpw;
+    bp.geom[level] = g;
+    bp.coarse_levels += 1;
+  }
+}
+
+// which of the two one-launch kernels takes the leading levels of a batch, if any
+ResidentPlan plan_paths(const dvo_hip_context* ctx, const dvo_hip_config* cfg, BatchPlan& bp, bool taps_missing) {
+  ResidentPlan rp = plan_resident(ctx, cfg, bp, taps_missing);
+  if (ctx->opt_coarse == 1) {                                  // (option "coarse" 1: the fused coarse-level kernel wherever the levels admit it)
+    const ResidentPlan none;
+    plan_coarse(ctx, cfg, bp, none);
+    if (bp.coarse_levels > 0) rp = none;
+  } else {
+    plan_coarse(ctx, cfg, bp, rp);
+  }
+  return rp;
+}
+
 int resident_levels_of(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const CameraGeom* cam, int n, bool taps_missing) {
   BatchPlan bp;
   make_plan(ctx, cam, cfg, n, bp);
-  return plan_resident(ctx, cfg, bp, taps_missing).levels;
+  return plan_paths(ctx, cfg, bp, taps_missing).levels;
 }
 
 int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, const BatchPlan& bp, const ResidentPlan& rp,
@@ -1412,6 +1459,30 @@ int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, 
   return DVO_HIP_OK;
 }
 
+int run_coarse(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, const BatchPlan& bp) {
+  CoarseArgs args;
+  std::memset(&args, 0, sizeof(args));
+  for (int l = cfg->last_level; l <= cfg->first_level; ++l) args.geom[l] = bp.geom[l];
+  args.pair_ptrs = bp.pair_ptrs;
+  args.states = w.states.as<PairState>();
+  args.levels = w.lvl_stats.as<dvo_hip_level_stats>();
+  args.iters = w.it_stats.as<dvo_hip_iteration_stats>();
+  args.T_init = w.t_init.as<double>();
+  args.partials = w.partials.as<float>();
+  args.scratch = w.scratch.as<float2>();
+  args.fallback_count = w.win_fallbacks.as<unsigned long long>();
+  args.f16_range_flag = w.f16_range_flag;
+  args.prm = bp.prm;
+  args.n_pairs = bp.n;
+  args.first_level = cfg->first_level;
+  args.last_level = cfg->first_level - bp.coarse_levels + 1;
+  args.results = args.last_level == cfg->last_level ? w.results.as<dvo_hip_result>() : nullptr;
+  ctx->coarse_launches += 1;
+  ctx->coarse_levels += bp.coarse_levels;
+  DVO_WS_TRY(w, launch_match_coarse(w.stream, args, ctx->opt_coarse_wgs == 3 ? 3 : 4));
+  return DVO_HIP_OK;
+}
+
 constexpr int kF32GramHoldBatches = 32;   // after a batch left the f16 range of the Gram operands: this many batches go straight to the f32 Gram
 
 hipEvent_t g_trace_ev[2] = {nullptr, nullptr};   // DVO_HIP_TRACE_SLOW: device time stamps around a batch's preparation
@@ -1440,7 +1511,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
   // The coarse levels -- for a small batch every level -- run inside ONE launch (align_resident.hip): no launch per iteration, no
   // host poll, the pairs of a batch do not wait for each other.
-  const ResidentPlan rp = plan_resident(ctx, cfg, bp, window_taps_missing(ctx, cfg, n, curs));
+  const ResidentPlan rp = plan_paths(ctx, cfg, bp, window_taps_missing(ctx, cfg, n, curs));
   const bool tables_inline = rp.direct && n <= kResidentInline;   // plane pointers and initial guesses travel as kernel arguments
   int rc = prepare_buffers(w, cfg, refs, curs, bp, !tables_inline);
   if (rc != DVO_HIP_OK) return rc;
@@ -1519,6 +1590,21 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       }
     }
     level_from = cfg->first_level - rp.levels;
+  }
+  if (bp.coarse_levels > 0) {
+    // the coarse levels of every pair in ONE launch, a workgroup per pair (align_coarse.hip): nothing to poll -- the host goes on to
+    // enqueue the first steps of the level behind them
+    Range range("coarse");
+    rc = run_coarse(ctx, w, cfg, bp);
+    if (rc != DVO_HIP_OK) return rc;
+    if (!ctx->deferred.empty()) {
+      const int rc_deferred = flush_deferred(ctx);
+      if (rc_deferred != DVO_HIP_OK) {
+        w.err = ctx->err;
+        return rc_deferred;
+      }
+    }
+    level_from = cfg->first_level - bp.coarse_levels;
   }
   for (int level = level_from; level >= cfg->last_level; --level) {
     const LevelGeom& g = bp.geom[level];
@@ -1822,6 +1908,8 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
   if (std::strcmp(key, "resident_launches") == 0) *value = ctx->resident_launches;
   else if (std::strcmp(key, "resident_levels") == 0) *value = ctx->resident_levels;
   else if (std::strcmp(key, "resident_timeouts") == 0) *value = ctx->resident_timeouts;
+  else if (std::strcmp(key, "coarse_launches") == 0) *value = ctx->coarse_launches;
+  else if (std::strcmp(key, "coarse_levels") == 0) *value = ctx->coarse_levels;
   else if (std::strcmp(key, "window_fallbacks") == 0) {
     unsigned long long v = 0;
     if (ctx->ws[0].win_fallbacks.p) {
@@ -2055,6 +2143,21 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "resident") == 0) {
     if (value < -1 || value > 1) return fail(ctx, DVO_HIP_ERR_INVALID, "resident must be -1 (automatic), 0 (off) or 1 (every level)");
     ctx->opt_resident = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "coarse") == 0) {
+    if (value < 0 || value > 1) return fail(ctx, DVO_HIP_ERR_INVALID, "coarse must be 0 (off) or 1 (whenever the levels admit it)");
+    ctx->opt_coarse = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "coarse_pixels") == 0) {
+    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "coarse_pixels must be >= 0");
+    ctx->opt_coarse_pixels = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "coarse_workgroups") == 0) {
+    if (value != 0 && value != 3 && value != 4) return fail(ctx, DVO_HIP_ERR_INVALID, "coarse_workgroups must be 0, 3 or 4");
+    ctx->opt_coarse_wgs = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "resident_flags") == 0) {

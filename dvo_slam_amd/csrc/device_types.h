@@ -214,4 +214,26 @@ struct ResidentArgs {
   int flags;                                          // kResidentFlag*
 };
 
+// ---- the fused coarse-level kernel (align_coarse.hip): ONE workgroup runs the coarse levels of a pair from gn_level_begin to the level's
+// termination -- sweep over all tiles, stage 3 of the reduction, log-likelihood, loop body -- with the device functions the launch path's
+// kernels are made of (fast_sweep_tile, mfma_sweep_tile, reduce_partials, loglik_partial*, gn_step): the records are the launch path's
+// bit for bit.  No workgroup waits for another: no residency requirement, any batch size.
+constexpr int kCoarseRowsPerWave = 2;                // tile height of the gathering sweep inside the fused kernel (levels the window sweep does not take)
+struct CoarseArgs {
+  LevelGeom geom[kMaxLevels];                         // per absolute level (rows_per_wave 4 on window levels, kCoarseRowsPerWave elsewhere)
+  const PairPtrs* pair_ptrs;                          // device [levels][n_pairs]
+  PairState* states;
+  dvo_hip_level_stats* levels;
+  dvo_hip_iteration_stats* iters;
+  const double* T_init;                               // non-null: the pairs are initialised here (the launch starts the match)
+  float* partials;                                    // per-tile partial rows, [pair][tiles of the level][kAccStride]
+  float2* scratch;                                    // residual pairs, [pair][residual_entries(level)]
+  unsigned long long* fallback_count;                 // window sweep: lanes whose taps were fetched from memory (may be null)
+  int* f16_range_flag;                                // one word per pair (pinned host memory; may be null)
+  SolverParams prm;
+  int n_pairs;
+  int first_level, last_level;                        // the levels this launch runs, coarse to fine
+  dvo_hip_result* results;                            // non-null: the launch ends the match and writes the results (gn_finish)
+};
+
 }  // namespace dvo_hip

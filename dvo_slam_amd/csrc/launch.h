@@ -71,6 +71,11 @@ void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, i
 // device at once when group > 1 (one per compute unit); `cooperative` launches them through hipLaunchCooperativeKernel.
 hipError_t launch_match_resident(hipStream_t s, const ResidentArgs& args, bool cooperative);
 
+// align_coarse.hip: levels first_level..last_level of every pair in one launch, one workgroup per pair (no workgroup waits for another).
+// workgroups_per_cu: 4 (128 registers; default) or 3 (168)
+bool coarse_kernel_takes(const LevelGeom& g, bool window_level);
+hipError_t launch_match_coarse(hipStream_t s, const CoarseArgs& args, int workgroups_per_cu);
+
 // solver_kernels.hip
 void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, const double* T_init);
 void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,

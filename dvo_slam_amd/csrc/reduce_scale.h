@@ -23,11 +23,13 @@ constexpr int kReduceInFlight = 32;
 // WAVES: wavefronts the workgroup really has (4, or 2: the solver step of a small level, so that four of them fit a compute unit).
 // The additions do not depend on it: a real wavefront plays the "virtual" wavefronts w, w + WAVES, ... of a four-wavefront
 // workgroup, each with its own accumulators.
-template <int WAVES = kWavesPerBlock>
+// IN_FLIGHT: row loads in flight per lane and round (registers against round trips; a caller whose levels have few tiles and whose
+// registers are scarce -- the fused coarse-level kernel -- asks for fewer); like WAVES it does not touch the order of the additions.
+template <int WAVES = kWavesPerBlock, int IN_FLIGHT = kReduceInFlight>
 __device__ inline void reduce_partials(const float* __restrict__ partials, int pair, int tiles, double* sh, double* sums) {
   static_assert(WAVES == 2 || WAVES == 4, "two or four wavefronts");
   constexpr int kPlayed = kWavesPerBlock / WAVES;           // virtual wavefronts per real one
-  constexpr int kInFlight = kReduceInFlight / kPlayed;
+  constexpr int kInFlight = IN_FLIGHT / kPlayed;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* base = partials + size_t(pair) * tiles * kAccStride;
   const bool hi = lane < kAccStride - 64;

@@ -330,7 +330,18 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * units -- and from compute units / 8 pairs on when the current frames hold plane C without the taps, as a role-aware ingest of that
  * many frames leaves them -- the coarsest one (DVO_HIP_TRACE_PLAN in the environment prints the plan of every batch to stderr); 0: one to three launches per Gauss-Newton step always; 1: every level resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
  * pass; default 24), "resident_group" (workgroups per pair, a power of two <= 64; 0 = as many as fit the device),
- * "resident_cooperative" (1: groups are launched with hipLaunchCooperativeKernel), "resident_flags" (measurement / test hooks). 
+ * "resident_cooperative" (1: groups are launched with hipLaunchCooperativeKernel), "resident_flags" (measurement / test hooks).
+ * "coarse" (default 0; 1: wherever the levels admit it -- the default schedule, no "ref_compat", levels of up to 160 x 120 pixels --
+ * the leading pyramid levels run in ONE launch, a workgroup per pair from the level's begin to its termination, level after level,
+ * like one thread runs one match() in the reference (dvo_core/src/dense_tracking.cpp:200-357, dvo_slam/src/keyframe_graph.cpp:576-593):
+ * dvo_slam_amd/csrc/align_coarse.hip, in place of the resident kernel too.  No workgroup waits for another one: no residency
+ * requirement, no time-out, any batch size; built from the launch path's own device functions on its data layout, so the records are
+ * the launch path's bit for bit at the tile height 2 the kernel sweeps gathering levels with ("rows_per_wave" 2 on the launch path).
+ * Off by default: slower than the launch path up to 1024 pairs per batch -- a workgroup walks the tiles of an iteration one after the
+ * other, and with no more pairs than workgroup slots the launch lasts as long as its slowest pair),
+ * "coarse_pixels" (the largest level it takes, in pixels; 0 = 160 x 120.  Above that the launch path's log-likelihood schedule differs
+ * and the records agree to the stopping rule's precision only), "coarse_workgroups" (its workgroups per compute unit: 4 with 128
+ * registers, the default, or 3 with 168).
  * "rendezvous" (default 1): two dvo_hip_match calls from two host threads with the SAME current frame and configuration -- the
  * reference's LocalTracker, dvo_slam/src/local_tracker.cpp:180-184 -- leave as one two-pair batch: the second caller's thread runs
  * it, the first waits at most 60 microseconds for a partner, and only on a context where concurrent callers have been seen
@@ -343,6 +354,7 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 
 /* Event counters of a context.  key: "resident_launches" (matches, or coarse-level runs, done by the resident kernel),
  * "resident_levels" (pyramid levels those launches ran, summed),
+ * "coarse_launches" / "coarse_levels" (the same for the fused coarse-level kernel, option "coarse"),
  * "resident_timeouts" (batches repeated on the launch-per-step path because a workgroup group of the resident kernel waited
  * in vain for its peers -- the device was shared with another such kernel; the results are those of the repeat),
  * "window_fallbacks" (lanes of the window sweep whose bilinear taps fell outside the staged window and were fetched from memory),
