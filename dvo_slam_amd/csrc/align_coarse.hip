@@ -94,8 +94,12 @@ __global__ __launch_bounds__(kBlock, WG_PER_CU) void k_match_coarse(const Coarse
     __syncthreads();
     const int tiles = g.tiles_x * g.tiles_y;
     const bool window_level = !g.linear && g.compact;           // (uniform; what launch_residual_reduce sends to the contracted window sweep)
-    float* my_partials = a.partials + size_t(pair) * tiles * kAccStride;
-    const float2* my_residuals = a.scratch + size_t(pair) * residual_entries(g);
+    // (the pair's OWN region of the two buffers, whatever level it is on: the pairs of a launch are on different levels at the same
+    // time, and the launch path's [pair][tiles of the level] layout would let a pair on level 2 write over its neighbours on level 3.
+    // The shared device functions address "pair 0" of the pre-offset pointers.)
+    float* my_partials = a.partials + size_t(pair) * a.max_tiles * kAccStride;
+    float2* my_residuals = a.scratch + size_t(pair) * a.max_entries;
+    int* my_flag = a.f16_range_flag ? a.f16_range_flag + pair : nullptr;
 
     for (;;) {
       // ---- the sweep: the pose and the weights' precision out of LDS into scalar registers, then tile after tile ----------------
@@ -110,29 +114,29 @@ __global__ __launch_bounds__(kBlock, WG_PER_CU) void k_match_coarse(const Coarse
         if (g.w % kTileW != 0) {
 #pragma unroll 1
           for (int tile = 0; tile < tiles; ++tile)
-            fast_sweep_tile<2, true, true, 0, false>(g, KT, wt, pp, pair, tile, a.partials, a.scratch, lds, no_table, a.fallback_count, a.f16_range_flag);
+            fast_sweep_tile<2, true, true, 0, false>(g, KT, wt, pp, 0, tile, my_partials, my_residuals, lds, no_table, a.fallback_count, my_flag);
         } else {
 #pragma unroll 1
           for (int tile = 0; tile < tiles; ++tile)
-            fast_sweep_tile<2, false, true, 0, false>(g, KT, wt, pp, pair, tile, a.partials, a.scratch, lds, no_table, a.fallback_count, a.f16_range_flag);
+            fast_sweep_tile<2, false, true, 0, false>(g, KT, wt, pp, 0, tile, my_partials, my_residuals, lds, no_table, a.fallback_count, my_flag);
         }
       } else if (g.linear) {
 #pragma unroll 1
         for (int tile = 0; tile < tiles; ++tile) {
-          mfma_sweep_tile<kCoarseRowsPerWave, true, 2>(g, KT, Pp, first, pp, pair, tile, a.partials, a.scratch, &slab[0][0], counts, a.f16_range_flag);
+          mfma_sweep_tile<kCoarseRowsPerWave, true, 2>(g, KT, Pp, first, pp, 0, tile, my_partials, my_residuals, &slab[0][0], counts, my_flag);
           __syncthreads();                                     // (the fold reads every wavefront's slab)
         }
       } else {
 #pragma unroll 1
         for (int tile = 0; tile < tiles; ++tile) {
-          mfma_sweep_tile<kCoarseRowsPerWave, false, 2>(g, KT, Pp, first, pp, pair, tile, a.partials, a.scratch, &slab[0][0], counts, a.f16_range_flag);
+          mfma_sweep_tile<kCoarseRowsPerWave, false, 2>(g, KT, Pp, first, pp, 0, tile, my_partials, my_residuals, &slab[0][0], counts, my_flag);
           __syncthreads();
         }
       }
       __syncthreads();                                         // partial rows and residual pairs of every tile are in memory (one compute unit: one L1)
 
       // ---- the solver step (solver_kernels.hip::k_solver_step with the fused log-likelihood, four wavefronts) -------------------
-      reduce_partials<kWavesPerBlock, kCoarseReduceInFlight>(a.partials, pair, tiles, sh, sums);
+      reduce_partials<kWavesPerBlock, kCoarseReduceInFlight>(my_partials, 0, tiles, sh, sums);
       for (int i = tid; i < int(sizeof(dvo_hip_iteration_stats) / 8); i += kBlock) reinterpret_cast<double*>(&rec)[i] = dvo_nan();
       if (tid < 42) {                                          // A = J^T W J, b = J^T W r: the Gram sums contracted with the pass' precision (GnAssist)
         const double d = sums[kAccN] - 3.0;

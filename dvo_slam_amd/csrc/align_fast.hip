@@ -40,6 +40,7 @@
 // differences of a few ulp in u, v and the blends (tests/test_gpu_parity.py::test_contracted_sweep_against_the_exact_one states and
 // checks the bounds); variants 6 / 7 stay in the tree as the bit-exact anchors.
 #include "fast_sweep.h"
+#include "solver_step.h"
 
 namespace dvo_hip {
 
@@ -48,10 +49,14 @@ namespace dvo_hip {
 // ===================================================================================================================================
 // COMPAT (option "ref_compat"): 0 = off; 1 = the host's reciprocal table through memory; 2 = its 16-bit copy in LDS (four workgroups
 // per compute unit instead of five)
-template <int STORE, bool PARTIAL, bool COMPACT, int COMPAT, bool HI_J>
+// TAIL (round 6; levels whose log-likelihood pass fits the solver step): the workgroup that completes the last tile of a pair runs the
+// pair's Gauss-Newton step right here (solver_step.h) -- one launch per iteration instead of two.  Every workgroup of such a launch
+// ends in sweep_tail, also those of a pair that is not on the level; partial rows and residual pairs are stored write-through.
+template <int STORE, bool PARTIAL, bool COMPACT, int COMPAT, bool HI_J, bool TAIL>
 __global__ __launch_bounds__(256, COMPAT == 2 ? 4 : 5) void k_sweep_fast(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
-    float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count, int* __restrict__ f16_range_flag) {
+    float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count, int* __restrict__ f16_range_flag,
+    const SolverStepArgs tail) {
   const int tiles = g.tiles_x * g.tiles_y;
   const int total = tiles * n_pairs;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -59,12 +64,16 @@ __global__ __launch_bounds__(256, COMPAT == 2 ? 4 : 5) void k_sweep_fast(
   if (item >= total) return;
   const int pair = item / tiles, tile = item - pair * tiles;
   const PairState& st = states[pair];
-  if (!st.active || st.level != g.level) return;          // (not on this level: finished it, and maybe begun the next)
-  const PairPtrs pp = pairs[pair];
   __shared__ __attribute__((aligned(16))) float slab[4][kSlabFloatsF16];
   __shared__ __attribute__((aligned(16))) float2 win[kFastCells];
   __shared__ __attribute__((aligned(16))) int bbox[4][2];
   __shared__ int counts[4];
+  static_assert(!TAIL || sizeof(SweepTailLds) + 16 <= sizeof(win), "the step's LDS lies over the window");
+  if (!st.active || st.level != g.level) {                  // (not on this level: finished it, and maybe begun the next)
+    if constexpr (TAIL) sweep_tail(g, tail, pair, reinterpret_cast<char*>(win));
+    return;
+  }
+  const PairPtrs pp = pairs[pair];
   // (option "ref_compat": the host CPU's reciprocal table, 2^(23 - shift) floats; a resource of no bytes otherwise, never read)
   __shared__ __attribute__((aligned(16))) unsigned short rcp_lds[COMPAT == 2 ? 4096 : 8];
   const FastRcpSource rcp_table = {__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(COMPAT ? g.rcp_table : nullptr), 0, COMPAT ? (4 << (23 - g.rcp_shift)) : 0, 0x00020000),
@@ -84,8 +93,12 @@ __global__ __launch_bounds__(256, COMPAT == 2 ? 4 : 5) void k_sweep_fast(
   }
   const FastLds lds = {slab, win, bbox, counts};
   const FastWeights wt(st);
-  fast_sweep_tile<STORE, PARTIAL, COMPACT, COMPAT, HI_J>(g, st.KT, wt, pp, pair, tile, partials, scratch, lds, rcp_table, fallback_count, f16_range_flag);
+  fast_sweep_tile<STORE, PARTIAL, COMPACT, COMPAT, HI_J, TAIL>(g, st.KT, wt, pp, pair, tile, partials, scratch, lds, rcp_table, fallback_count, f16_range_flag);
+  if constexpr (TAIL) sweep_tail(g, tail, pair, reinterpret_cast<char*>(win));
 }
+
+// the instantiations with a tail: the default schedule (variant 8, every low part of the Gram operands, no "ref_compat")
+bool sweep_fast_has_tail(int variant, const LevelGeom& g) { return variant == 8 && !g.rcp_table && !g.gram_hi_j && fast_sweep_supports(g); }
 
 bool fast_sweep_takes_width(int w) { return w >= kFastCols && w % 2 == 0; }
 
@@ -96,19 +109,30 @@ bool fast_sweep_supports(const LevelGeom& g) {
 }
 
 void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
-                       float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag) {
+                       float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag, const SolverStepArgs* tail) {
   const int total = g.tiles_x * g.tiles_y * n_pairs;
   const int per_xcd = (total + 7) / 8;
   const dim3 grid(per_xcd * 8), block(256);
   const bool partial = g.w % kTileW != 0, compact = g.compact != 0;
+  const SolverStepArgs no_tail = {};
+  if (tail) {                                                // (the default schedule only: sweep_fast_has_tail)
+    if (compact) {
+      if (partial) k_sweep_fast<2, true, true, 0, false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, *tail);
+      else k_sweep_fast<2, false, true, 0, false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, *tail);
+    } else {
+      if (partial) k_sweep_fast<2, true, false, 0, false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, *tail);
+      else k_sweep_fast<2, false, false, 0, false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, *tail);
+    }
+    return;
+  }
   auto go = [&](auto store_tag, auto partial_tag, auto compact_tag, auto compat_tag) {
     constexpr int kStore = decltype(store_tag)::value;
     if (g.gram_hi_j && kStore == 2)
-      k_sweep_fast<2, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value, true>
-          <<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+      k_sweep_fast<2, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value, true, false>
+          <<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, no_tail);
     else
-      k_sweep_fast<kStore, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value, false>
-          <<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag);
+      k_sweep_fast<kStore, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value, false, false>
+          <<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, no_tail);
   };
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;

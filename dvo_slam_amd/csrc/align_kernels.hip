@@ -155,10 +155,18 @@ static void launch_rr(hipStream_t s, bool finest, const LevelGeom& g, const Pair
     k_residual_reduce<RPW, false><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd);
 }
 
+// the sweep of this level has an instantiation that ends with the pairs' solver steps (launch_residual_reduce's own dispatch)
+bool sweep_has_tail(int variant, int rows_per_wave, const LevelGeom& g) {
+  if (variant >= 8 && rows_per_wave == 4 && fast_sweep_supports(g)) return sweep_fast_has_tail(variant, g);
+  if (variant >= 6 && rows_per_wave == 4 && window_sweep_supports(g)) return false;
+  return variant >= 5 && mfma_sweep_has_tail(variant, rows_per_wave, g);
+}
+
 void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
-                            const PairState* states, int n_pairs, float* partials, float2* scratch, unsigned long long* window_fallbacks, int* f16_range_flag) {
+                            const PairState* states, int n_pairs, float* partials, float2* scratch, unsigned long long* window_fallbacks, int* f16_range_flag,
+                            const SolverStepArgs* tail) {
   if (variant >= 8 && rows_per_wave == 4 && fast_sweep_supports(g)) {
-    launch_sweep_fast(s, variant, g, pairs, states, n_pairs, partials, scratch, window_fallbacks, f16_range_flag);
+    launch_sweep_fast(s, variant, g, pairs, states, n_pairs, partials, scratch, window_fallbacks, f16_range_flag, tail);
     return;
   }
   if (variant >= 6 && rows_per_wave == 4 && window_sweep_supports(g)) {
@@ -166,7 +174,7 @@ void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool 
     return;
   }
   if (variant >= 5) {
-    launch_residual_reduce_mfma(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, variant >= 8 ? 2 : variant >= 7 ? 1 : 0, f16_range_flag);
+    launch_residual_reduce_mfma(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, variant >= 8 ? 2 : variant >= 7 ? 1 : 0, f16_range_flag, tail);
     return;
   }
   switch (rows_per_wave) {

@@ -380,6 +380,11 @@ struct dvo_hip_context {
   long long host_batches = 0;
   std::chrono::steady_clock::time_point batch_entry;
   int opt_resident_flags = 0;      // kResidentFlag* (measurement and test hooks)
+  // 1: on the levels whose log-likelihood pass fits the solver step, the step runs in the sweep's launch (solver_step.h).  Default 0:
+  // measured slower in round 6 (profiles/r06_sweep_tail.txt) -- the step's serial float64 lane needs ~180 registers, the sweep it rides
+  // in is built for 96 (five workgroups per compute unit), and the spilled step takes 40-50 us instead of 15
+  int opt_sweep_tail = 0;
+  long long tail_steps = 0;        // Gauss-Newton steps enqueued as ONE launch (sweep with a tail)
   int opt_coarse = 0;              // the fused coarse-level kernel (align_coarse.hip): 0 = off (default: measured and lost), 1 = whenever the levels admit it
   int opt_coarse_pixels = 0;       // levels of up to this many pixels run in it (0 = kCoarseMaxPixels)
   int opt_coarse_wgs = 0;          // its workgroups per compute unit: 0 / 4 (128 registers) or 3 (168)
@@ -1117,7 +1122,8 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
   DVO_WS_TRY(w, w.it_stats.reserve(size_t(n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats)));
   DVO_WS_TRY(w, w.results.reserve(size_t(n) * sizeof(dvo_hip_result)));
   DVO_WS_TRY(w, w.t_init.reserve(size_t(n) * 16 * sizeof(double)));
-  DVO_WS_TRY(w, w.counters.reserve(size_t(bp.cap_iters + 8 + kResidentErrorWords) * sizeof(unsigned long long)));
+  // per-step tallies, and behind them one arrival word per pair (the sweeps' tail, solver_step.h): cleared together at the start of a batch
+  DVO_WS_TRY(w, w.counters.reserve(size_t(bp.cap_iters + 8 + kResidentErrorWords) * sizeof(unsigned long long) + align_up(size_t(n) * sizeof(int), 8)));
   if (!w.win_fallbacks.p) {
     DVO_WS_TRY(w, w.win_fallbacks.reserve(64));
     DVO_WS_TRY(w, hipMemsetAsync(w.win_fallbacks.p, 0, 64, w.stream));
@@ -1476,6 +1482,10 @@ int run_coarse(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, co
   args.n_pairs = bp.n;
   args.first_level = cfg->first_level;
   args.last_level = cfg->first_level - bp.coarse_levels + 1;
+  for (int l = args.last_level; l <= args.first_level; ++l) {   // (prepare_buffers sized both buffers for the largest level of the match)
+    args.max_tiles = std::max(args.max_tiles, bp.geom[l].tiles_x * bp.geom[l].tiles_y);
+    args.max_entries = std::max(args.max_entries, residual_entries(bp.geom[l]));
+  }
   args.results = args.last_level == cfg->last_level ? w.results.as<dvo_hip_result>() : nullptr;
   ctx->coarse_launches += 1;
   ctx->coarse_levels += bp.coarse_levels;
@@ -1555,7 +1565,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
                      mark_ms[4] - mark_ms[3], gpu_ms);
     }
     std::memset(w.host_status, 0, n_steps * sizeof(int));
-    DVO_WS_TRY(w, hipMemsetAsync(w.counters.p, 0, n_steps * sizeof(unsigned long long), s));
+    DVO_WS_TRY(w, hipMemsetAsync(w.counters.p, 0, n_steps * sizeof(unsigned long long) + align_up(size_t(n) * sizeof(int), 8), s));
   }
 
   PairState* states = w.states.as<PairState>();
@@ -1565,6 +1575,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   float2* scratch = w.scratch.as<float2>();
   double* ll_partials = w.ll_partials.as<double>();
   unsigned long long* tallies = w.counters.as<unsigned long long>();
+  int* arrivals = reinterpret_cast<int*>(tallies + n_steps);
   const int per_level = cfg->max_iterations_per_level;
   const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 1;
   int step = kResidentErrorWords;                           // the first status words belong to the resident kernel's launches
@@ -1655,8 +1666,20 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     const bool solver_two_waves = ctx->opt_solver_waves == 2 ||
                                   (ctx->opt_solver_waves == 0 && fused_ll && !g.compact && g.tiles_x * g.tiles_y <= 32 &&
                                    n > 2 * (ctx->compute_units > 0 ? ctx->compute_units : 256));
+    // The step in the sweep's launch (round 6): where the log-likelihood pass runs inside the solver step anyway and the level's sweep
+    // has the instantiation, the workgroup that completes a pair's last tile runs the pair's step -- ONE launch per iteration
+    const bool tail = ctx->opt_sweep_tail != 0 && fused_ll && sweep_has_tail(ctx->opt_variant, bp.rpw[level], g);
     auto enqueue_chunk = [&](int count) {
       for (int c = 0; c < count; ++c, ++step) {
+        if (tail) {
+          Range range(kErr[level]);
+          const SolverStepArgs a = make_solver_step_args(states, n, bp.prm, partials, ll_partials, ll_blocks, scratch, d_levels, d_iters, tallies + step, w.host_status + step,
+                                                         cfg->first_level - level, &next, arrivals);
+          launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch, w.win_fallbacks.as<unsigned long long>(),
+                                 w.f16_range_flag, &a);
+          ctx->tail_steps += 1;
+          continue;
+        }
         {
           Range range(kErr[level]);
           launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch, w.win_fallbacks.as<unsigned long long>(),
@@ -1908,6 +1931,7 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
   if (std::strcmp(key, "resident_launches") == 0) *value = ctx->resident_launches;
   else if (std::strcmp(key, "resident_levels") == 0) *value = ctx->resident_levels;
   else if (std::strcmp(key, "resident_timeouts") == 0) *value = ctx->resident_timeouts;
+  else if (std::strcmp(key, "tail_steps") == 0) *value = ctx->tail_steps;
   else if (std::strcmp(key, "coarse_launches") == 0) *value = ctx->coarse_launches;
   else if (std::strcmp(key, "coarse_levels") == 0) *value = ctx->coarse_levels;
   else if (std::strcmp(key, "window_fallbacks") == 0) {
@@ -2143,6 +2167,16 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "resident") == 0) {
     if (value < -1 || value > 1) return fail(ctx, DVO_HIP_ERR_INVALID, "resident must be -1 (automatic), 0 (off) or 1 (every level)");
     ctx->opt_resident = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "solver_occupancy") == 0) {
+    if (value != 0 && value != 3 && value != 4) return fail(ctx, DVO_HIP_ERR_INVALID, "solver_occupancy must be 0, 3 or 4");
+    g_solver_occupancy = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "sweep_tail") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "sweep_tail must be 0 or 1");
+    ctx->opt_sweep_tail = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "coarse") == 0) {

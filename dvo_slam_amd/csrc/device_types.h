@@ -169,6 +169,38 @@ struct SolverParams {
   int record_prefilled;
 };
 
+// what a step needs besides the level's geometry (kernel arguments of both callers)
+struct SolverStepArgs {
+  PairState* states;
+  int n_pairs;
+  SolverParams prm;
+  const float* partials;
+  const double* ll_partials;             // sums of k_loglik's workgroups (when the log-likelihood ran in a launch of its own)
+  int ll_blocks_per_pair;
+  const float2* scratch_for_fused_ll;    // non-null: the log-likelihood sweep runs inside the step (small levels)
+  dvo_hip_level_stats* levels;
+  dvo_hip_iteration_stats* iters;
+  unsigned long long* step_tally;        // publish_step
+  int* host_status;
+  int level_slot_hint;
+  NextLevel next;
+  int* arrivals;                         // the sweeps' tail: one word per pair, the tiles of the pair that are through (self-resetting)
+};
+
+__host__ inline SolverStepArgs make_solver_step_args(PairState* states, int n_pairs, const SolverParams& prm, const float* partials, const double* ll_partials,
+                                            int ll_blocks_per_pair, const float2* scratch_for_fused_ll, dvo_hip_level_stats* levels,
+                                            dvo_hip_iteration_stats* iters, unsigned long long* step_tally, int* host_status, int level_slot_hint,
+                                            const NextLevel* next_or_null, int* arrivals) {
+  SolverStepArgs a;
+  a.states = states; a.n_pairs = n_pairs; a.prm = prm; a.partials = partials; a.ll_partials = ll_partials; a.ll_blocks_per_pair = ll_blocks_per_pair;
+  a.scratch_for_fused_ll = scratch_for_fused_ll; a.levels = levels; a.iters = iters; a.step_tally = step_tally; a.host_status = host_status;
+  a.level_slot_hint = level_slot_hint;
+  a.next.valid = 0; a.next.level = 0; a.next.fx = a.next.fy = a.next.ox = a.next.oy = 0.0f; a.next.pairs = nullptr; a.next.results = nullptr;
+  if (next_or_null) a.next = *next_or_null;
+  a.arrivals = arrivals;
+  return a;
+}
+
 // ---- the resident match kernel (align_resident.hip): one group of workgroups owns a pair for a whole run of levels ----
 constexpr int kResidentWaves = 8;                    // wavefronts per workgroup (512 threads: the solver lane needs > 128 registers)
 constexpr int kResidentSweepers = kResidentWaves - 1;  // wavefront 0 is the workgroup's solver
@@ -226,8 +258,10 @@ struct CoarseArgs {
   dvo_hip_level_stats* levels;
   dvo_hip_iteration_stats* iters;
   const double* T_init;                               // non-null: the pairs are initialised here (the launch starts the match)
-  float* partials;                                    // per-tile partial rows, [pair][tiles of the level][kAccStride]
-  float2* scratch;                                    // residual pairs, [pair][residual_entries(level)]
+  float* partials;                                    // per-tile partial rows, [pair][max_tiles][kAccStride]: a pair's own region on every level
+  float2* scratch;                                    // residual pairs, [pair][max_entries]
+  int max_tiles;                                      // largest tile count among the launch's levels
+  size_t max_entries;                                 // largest residual_entries among them
   unsigned long long* fallback_count;                 // window sweep: lanes whose taps were fetched from memory (may be null)
   int* f16_range_flag;                                // one word per pair (pinned host memory; may be null)
   SolverParams prm;

@@ -353,7 +353,8 @@ struct FastWeights {
 // off_v + scalar offset off_s), validity, weight, Jacobian at the untransformed point, Gram accumulation.  tx, ty, cx = 1 + tx^2:
 // normalised coordinates of the lane's reference pixel.
 // COMPACT (LevelGeom::compact): only a constraint's pair is stored, at the next free entry of the wavefront's slot (off_s: the slot).
-template <int STORE, bool COMPACT, int COMPAT, bool HI_J>
+// AUX: cache policy of the residual store (0; 16 = sc1, write-through: the pair's step runs in this very launch, solver_step.h)
+template <int STORE, bool COMPACT, int COMPAT, bool HI_J, int AUX = 0>
 __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const FastRcpSource& table, const f32x2 (&P)[4][4], const FastRow& r, unsigned long long ok_mask, float tx, float ty,
                                               float cx, const FastWeights& wt, __amdgpu_buffer_rsrc_t resid, int off_v, int off_s, float* my, int lane,
                                               f32x4& acc0, f32x4& acc1, int& n_valid) {
@@ -380,10 +381,10 @@ __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const FastRcpS
     // a constraint's place: the wavefront's constraints so far (scalar) + those in the lanes below; the others store past the resource
     const int below = __builtin_amdgcn_mbcnt_hi(unsigned(valid_mask >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(valid_mask), 0));
     const f32x2 rr2 = {r0, r1};
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fast_u32v2, rr2), resid, valid ? below * 8 : 0x7ffffff8, off_s + n_valid * 8, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fast_u32v2, rr2), resid, valid ? below * 8 : 0x7ffffff8, off_s + n_valid * 8, AUX);
   } else {
     const f32x2 rr2 = {valid ? r0 : __builtin_nanf(""), r1};  // (the log-likelihood pass tests the first component)
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fast_u32v2, rr2), resid, off_v, off_s, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fast_u32v2, rr2), resid, off_v, off_s, AUX);
   }
   n_valid += __popcll(valid_mask);
   const float tq = fmaf(wt.P2x, r1, wt.P00 * r0);
@@ -424,8 +425,14 @@ __device__ __forceinline__ void fast_row_tail(const LevelGeom& g, const FastRcpS
 
 // epilogue: G = H H^T + S + S^T summed over the four wavefronts by the 85 threads that own an accumulator (slab[w]: H H^T at [0, 256),
 // S at [256, 512), entry row * 16 + col)
+// WT: the row is stored write-through (agent-scope stores, sc1) -- see fast_row_tail
+template <bool WT = false>
 __device__ __forceinline__ void fast_epilogue(float (*slab)[kSlabFloatsF16], const int* counts, unsigned gram_entries, float* __restrict__ out_row,
                                               int* __restrict__ f16_range_flag) {
+  auto put = [&](int i, float v) {
+    if constexpr (WT) __hip_atomic_store(out_row + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else out_row[i] = v;
+  };
   const int kk = threadIdx.x;
   if (kk < kNumAcc) {
     auto G = [&](int e) {                                      // entry e of the tile's Gram matrix, residual scale removed
@@ -447,11 +454,11 @@ __device__ __forceinline__ void fast_epilogue(float (*slab)[kSlabFloatsF16], con
       // and every sum it enters is infinite or not-a-number: the caller repeats the work with the f32 Gram
       if (f16_range_flag && !(__builtin_fabsf(v) < __builtin_inff())) __hip_atomic_store(f16_range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    out_row[kk] = v;
+    put(kk, v);
   } else if (kk < kNumAcc + 2) {
     // the wavefronts' counts, two per spare float of the row: where their packed residual pairs end (LevelGeom::compact)
     const int q = (kk - kNumAcc) * 2;
-    out_row[kAccCounts + (kk - kNumAcc)] = float(counts[q] + 512 * counts[q + 1]);
+    put(kAccCounts + (kk - kNumAcc), float(counts[q] + 512 * counts[q + 1]));
   }
 }
 
@@ -479,7 +486,7 @@ struct FastLds {
   int* counts;                                          // [4]
 };
 
-template <int STORE, bool PARTIAL, bool COMPACT, int COMPAT, bool HI_J>
+template <int STORE, bool PARTIAL, bool COMPACT, int COMPAT, bool HI_J, bool WT = false>
 __device__ __forceinline__ void fast_sweep_tile(const LevelGeom& g, const float* KT, const FastWeights& wt, const PairPtrs& pp, int pair, int tile,
                                                 float* __restrict__ partials, float2* __restrict__ scratch, const FastLds& lds,
                                                 const FastRcpSource& rcp_table, unsigned long long* __restrict__ fallback_count,
@@ -592,9 +599,9 @@ __device__ __forceinline__ void fast_sweep_tile(const LevelGeom& g, const float*
     f32x2 P[4][4];
     fast_fetch_cells<CHECKED, COMPAT>(g, rcp_table, KT, curC, win, wnd, neg_base, rs[k], __builtin_amdgcn_inverse_ballot_w64(ok_row[k]), tx_u, ty_rows[k], P, n_fallback);
     if constexpr (COMPACT)
-      fast_row_tail<STORE, true, COMPAT, HI_J>(g, rcp_table, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, resid, 0, (tile * kCompactTileEntries + wave * kCompactWaveEntries) * 8, my, lane, acc0, acc1, n_valid);
+      fast_row_tail<STORE, true, COMPAT, HI_J, WT ? 16 : 0>(g, rcp_table, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, resid, 0, (tile * kCompactTileEntries + wave * kCompactWaveEntries) * 8, my, lane, acc0, acc1, n_valid);
     else
-      fast_row_tail<STORE, false, COMPAT, HI_J>(g, rcp_table, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_store, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
+      fast_row_tail<STORE, false, COMPAT, HI_J, WT ? 16 : 0>(g, rcp_table, P, rs[k], ok_row[k], tx_u, ty_rows[k], cx_u, wt, v_r < g.h ? resid : resid_none, off_store, v_r * row_bytes, my, lane, acc0, acc1, n_valid);
   };
   if (wnd.all_in) {                                            // (uniform)
 #pragma unroll
@@ -611,7 +618,7 @@ __device__ __forceinline__ void fast_sweep_tile(const LevelGeom& g, const float*
   }
   if (lane == 0) counts[wave] = n_valid;
   __syncthreads();
-  fast_epilogue(slab, counts, gram_entries, partials + (size_t(pair) * tiles + tile) * kAccStride, f16_range_flag ? f16_range_flag + pair : nullptr);   // (one word per pair)
+  fast_epilogue<WT>(slab, counts, gram_entries, partials + (size_t(pair) * tiles + tile) * kAccStride, f16_range_flag ? f16_range_flag + pair : nullptr);   // (one word per pair)
   if (fallback_count && !wnd.all_in) fast_count_fallbacks(fallback_count, n_fallback, lane);
 }
 

@@ -42,12 +42,17 @@ void launch_unpack_plane(hipStream_t s, const float4* A, const float2* B, int n,
 // two-stage reduction (align_kernels.hip).  Same outputs.
 void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
                             const PairState* states, int n_pairs, float* partials, float2* scratch, unsigned long long* window_fallbacks = nullptr,
-                            int* f16_range_flag = nullptr);
+                            int* f16_range_flag = nullptr, const SolverStepArgs* tail = nullptr);
+// `tail` (non-null; only where sweep_has_tail says so): the workgroup that completes the last tile of a pair runs the pair's solver step
+// in the sweep's launch (solver_step.h) -- no launch_solver_step behind it
+bool sweep_has_tail(int variant, int rows_per_wave, const LevelGeom& g);
+bool sweep_fast_has_tail(int variant, const LevelGeom& g);
+bool mfma_sweep_has_tail(int variant, int rows_per_wave, const LevelGeom& g);
 // mode 0: f32 Gram (the f32 matrix instruction); 1: Gram accumulation on the f16 matrix pipe (gram_f16.h; variant 7); 2: 1 with the contracted
 // per-pixel arithmetic of align_fast.hip (variants 8 / 9 on the levels the window sweep does not take)
 void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest_level, const LevelGeom& g, const PairPtrs* pairs,
                                  const PairState* states, int n_pairs, float* partials, float2* scratch, int mode = 0,
-                                 int* f16_range_flag = nullptr);
+                                 int* f16_range_flag = nullptr, const SolverStepArgs* tail = nullptr);
 // align_window.hip: variants 6 (f32 Gram) and 7 (f16 hi/lo Gram) -- the current frame's {I, Z} window staged in LDS; tiled levels whose
 // width is a multiple of 64 only (window_sweep_supports), tile height 16 (rows_per_wave 4).  fallback_count (may be null): lanes
 // whose taps fell outside the staged window and were fetched from memory.  f16_range_flag (may be null; pinned host memory): set
@@ -60,7 +65,8 @@ void launch_sweep_window(hipStream_t s, bool f16, const LevelGeom& g, const Pair
 bool fast_sweep_takes_width(int w);   // (64-column tiles; a width that is no multiple of 64 leaves the last tile column partly empty)
 bool fast_sweep_supports(const LevelGeom& g);
 void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
-                       float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag = nullptr);
+                       float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag = nullptr,
+                       const SolverStepArgs* tail = nullptr);
 // scratch == null: read-only (one float per workgroup goes to `sink`, which must hold a float per (8 * 256)-pixel block)
 // window_planes: the planes the window sweep reads (reference 8 B + current {I, Z} 8 B) instead of the gathering sweep's 8 + 16 + 8 B
 void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch, float* sink, bool window_planes = false);
@@ -77,6 +83,7 @@ bool coarse_kernel_takes(const LevelGeom& g, bool window_level);
 hipError_t launch_match_coarse(hipStream_t s, const CoarseArgs& args, int workgroups_per_cu);
 
 // solver_kernels.hip
+extern int g_solver_occupancy;   // experiment (option "solver_occupancy"): 3 / 4 = the four-wavefront solver step built for that many workgroups per compute unit
 void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, const double* T_init);
 void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
                         const PairPtrs* pairs, dvo_hip_level_stats* levels, const double* T_init_or_null = nullptr);

@@ -30,7 +30,9 @@ struct RefRow {
 template <int MODE>
 __host__ __device__ constexpr int mfma_slab_floats() { return MODE >= 1 ? kSlabFloatsF16 : kSlabFloats; }
 
-template <int RPW, bool LINEAR, int MODE>
+// WT: partial row and residual pairs are stored write-through (agent-scope stores, sc1): the pair's step runs in this very launch
+// (solver_step.h, the sweeps' tail)
+template <int RPW, bool LINEAR, int MODE, bool WT = false>
 __device__ __forceinline__ void mfma_sweep_tile(const LevelGeom& g, const float* KT_src, const float* P_prev_src, bool first, const PairPtrs& pp, int pair,
                                                 int tile, float* __restrict__ partials, float2* __restrict__ scratch, float* slab_mem, int* counts,
                                                 int* __restrict__ f16_range_flag) {
@@ -201,7 +203,11 @@ __device__ __forceinline__ void mfma_sweep_tile(const LevelGeom& g, const float*
       valid = pixel_finish_flat(g, ref, p, t, o) && p.ok;
     }
     n_valid += __popcll(__ballot(valid));                     // exact count on the scalar unit
-    if (in_image) scratch[pix_base + pix] = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);   // one full-width store
+    if (in_image) {                                           // one full-width store
+      const float2 rr = valid ? make_float2(o.r0, o.r1) : make_float2(nanv, nanv);
+      if constexpr (WT) __hip_atomic_store(reinterpret_cast<unsigned long long*>(scratch + pix_base + pix), __builtin_bit_cast(unsigned long long, rr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else scratch[pix_base + pix] = rr;
+    }
     if constexpr (F16) {
       // (no branch on `valid`: zero weight and legacy multiplies, gram_f16.h)
       const float sw_any = first ? 1.0f : g.rcp_table ? tdist_weight_sqrt_compat(g.rcp_table, g.rcp_shift, o.r0, o.r1, Pp)
@@ -277,7 +283,8 @@ __device__ __forceinline__ void mfma_sweep_tile(const LevelGeom& g, const float*
       v = G(e1);
       if (e2 >= 0) v += G(e2);
     }
-    partials[(size_t(pair) * tiles + tile) * kAccStride + k] = v;
+    if constexpr (WT) __hip_atomic_store(partials + (size_t(pair) * tiles + tile) * kAccStride + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else partials[(size_t(pair) * tiles + tile) * kAccStride + k] = v;
   }
 }
 

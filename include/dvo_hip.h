@@ -331,6 +331,13 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * many frames leaves them -- the coarsest one (DVO_HIP_TRACE_PLAN in the environment prints the plan of every batch to stderr); 0: one to three launches per Gauss-Newton step always; 1: every level resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
  * pass; default 24), "resident_group" (workgroups per pair, a power of two <= 64; 0 = as many as fit the device),
  * "resident_cooperative" (1: groups are launched with hipLaunchCooperativeKernel), "resident_flags" (measurement / test hooks).
+ * "sweep_tail" (default 0; 1: on the levels whose log-likelihood pass runs inside the solver step -- up to 160 x 120 pixels, 320 x 240
+ * in batches of 512 pairs and more -- under the default schedule, the workgroup of the sweep that completes the LAST tile of a pair
+ * runs the pair's Gauss-Newton step right there: one launch per iteration instead of two (dvo_slam_amd/csrc/solver_step.h; the
+ * reference's loop body follows its residual pass without leaving the thread either, dvo_core/src/dense_tracking.cpp:240-357).  The
+ * records are the two-launch form's bit for bit.  Off by default: measured slower (128 pairs 1.82 -> 2.20 ms per step, 1024 pairs
+ * 11.8 -> 14.4): the step's serial float64 lane wants ~180 registers and the sweep it rides in is built for 96 -- DESIGN.md section 10;
+ * counter "tail_steps"),
  * "coarse" (default 0; 1: wherever the levels admit it -- the default schedule, no "ref_compat", levels of up to 160 x 120 pixels --
  * the leading pyramid levels run in ONE launch, a workgroup per pair from the level's begin to its termination, level after level,
  * like one thread runs one match() in the reference (dvo_core/src/dense_tracking.cpp:200-357, dvo_slam/src/keyframe_graph.cpp:576-593):
@@ -354,6 +361,7 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 
 /* Event counters of a context.  key: "resident_launches" (matches, or coarse-level runs, done by the resident kernel),
  * "resident_levels" (pyramid levels those launches ran, summed),
+ * "tail_steps" (Gauss-Newton steps of a batch enqueued as ONE launch, the sweep with the solver step in its tail, option "sweep_tail"),
  * "coarse_launches" / "coarse_levels" (the same for the fused coarse-level kernel, option "coarse"),
  * "resident_timeouts" (batches repeated on the launch-per-step path because a workgroup group of the resident kernel waited
  * in vain for its peers -- the device was shared with another such kernel; the results are those of the repeat),
