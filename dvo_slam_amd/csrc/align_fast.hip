@@ -52,7 +52,8 @@ namespace dvo_hip {
 // TAIL (round 6; levels whose log-likelihood pass fits the solver step): the workgroup that completes the last tile of a pair runs the
 // pair's Gauss-Newton step right here (solver_step.h) -- one launch per iteration instead of two.  Every workgroup of such a launch
 // ends in sweep_tail, also those of a pair that is not on the level; partial rows and residual pairs are stored write-through.
-template <int STORE, bool PARTIAL, bool COMPACT, int COMPAT, bool HI_J, bool TAIL>
+// TAIL 2: the WIDE half of the step only (reduction + log-likelihood, sweep_tail_wide); the serial half follows in k_solver_serial.
+template <int STORE, bool PARTIAL, bool COMPACT, int COMPAT, bool HI_J, int TAIL>
 __global__ __launch_bounds__(256, COMPAT == 2 ? 4 : 5) void k_sweep_fast(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, unsigned long long* __restrict__ fallback_count, int* __restrict__ f16_range_flag,
@@ -68,9 +69,9 @@ __global__ __launch_bounds__(256, COMPAT == 2 ? 4 : 5) void k_sweep_fast(
   __shared__ __attribute__((aligned(16))) float2 win[kFastCells];
   __shared__ __attribute__((aligned(16))) int bbox[4][2];
   __shared__ int counts[4];
-  static_assert(!TAIL || sizeof(SweepTailLds) + 16 <= sizeof(win), "the step's LDS lies over the window");
+  static_assert(TAIL == 0 || sizeof(SweepTailLds) + 16 <= sizeof(win), "the step's LDS lies over the window");
   if (!st.active || st.level != g.level) {                  // (not on this level: finished it, and maybe begun the next)
-    if constexpr (TAIL) sweep_tail(g, tail, pair, reinterpret_cast<char*>(win));
+    if constexpr (TAIL == 1) sweep_tail(g, tail, pair, reinterpret_cast<char*>(win));
     return;
   }
   const PairPtrs pp = pairs[pair];
@@ -93,8 +94,9 @@ __global__ __launch_bounds__(256, COMPAT == 2 ? 4 : 5) void k_sweep_fast(
   }
   const FastLds lds = {slab, win, bbox, counts};
   const FastWeights wt(st);
-  fast_sweep_tile<STORE, PARTIAL, COMPACT, COMPAT, HI_J, TAIL>(g, st.KT, wt, pp, pair, tile, partials, scratch, lds, rcp_table, fallback_count, f16_range_flag);
-  if constexpr (TAIL) sweep_tail(g, tail, pair, reinterpret_cast<char*>(win));
+  fast_sweep_tile<STORE, PARTIAL, COMPACT, COMPAT, HI_J, TAIL != 0>(g, st.KT, wt, pp, pair, tile, partials, scratch, lds, rcp_table, fallback_count, f16_range_flag);
+  if constexpr (TAIL == 1) sweep_tail(g, tail, pair, reinterpret_cast<char*>(win));
+  if constexpr (TAIL == 2) sweep_tail_wide(g, tail, pair, reinterpret_cast<char*>(win));
 }
 
 // the instantiations with a tail: the default schedule (variant 8, every low part of the Gram operands, no "ref_compat")
@@ -116,22 +118,22 @@ void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const Pai
   const bool partial = g.w % kTileW != 0, compact = g.compact != 0;
   const SolverStepArgs no_tail = {};
   if (tail) {                                                // (the default schedule only: sweep_fast_has_tail)
-    if (compact) {
-      if (partial) k_sweep_fast<2, true, true, 0, false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, *tail);
-      else k_sweep_fast<2, false, true, 0, false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, *tail);
-    } else {
-      if (partial) k_sweep_fast<2, true, false, 0, false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, *tail);
-      else k_sweep_fast<2, false, false, 0, false, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, *tail);
-    }
+    auto with = [&](auto partial_tag, auto compact_tag) {
+      constexpr bool kP = decltype(partial_tag)::value, kC = decltype(compact_tag)::value;
+      if (tail->pair_sums) k_sweep_fast<2, kP, kC, 0, false, 2><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, *tail);
+      else k_sweep_fast<2, kP, kC, 0, false, 1><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, *tail);
+    };
+    if (compact) { if (partial) with(std::true_type{}, std::true_type{}); else with(std::false_type{}, std::true_type{}); }
+    else { if (partial) with(std::true_type{}, std::false_type{}); else with(std::false_type{}, std::false_type{}); }
     return;
   }
   auto go = [&](auto store_tag, auto partial_tag, auto compact_tag, auto compat_tag) {
     constexpr int kStore = decltype(store_tag)::value;
     if (g.gram_hi_j && kStore == 2)
-      k_sweep_fast<2, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value, true, false>
+      k_sweep_fast<2, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value, true, 0>
           <<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, no_tail);
     else
-      k_sweep_fast<kStore, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value, false, false>
+      k_sweep_fast<kStore, decltype(partial_tag)::value, decltype(compact_tag)::value, decltype(compat_tag)::value, false, 0>
           <<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, fallback_count, f16_range_flag, no_tail);
   };
   using S1 = std::integral_constant<int, 1>;

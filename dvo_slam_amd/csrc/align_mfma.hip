@@ -27,7 +27,7 @@ namespace dvo_hip {
 // k_sweep_fast) -- one launch per iteration instead of two on the levels whose log-likelihood pass fits the step.
 // (with a tail the kernel is built for five workgroups per compute unit: the out-of-line step gets the kernel's register budget,
 // and left alone -- 248 registers -- it would leave the sweep two)
-template <int RPW, bool FINEST, bool LINEAR, int MODE, bool TAIL>
+template <int RPW, bool FINEST, bool LINEAR, int MODE, int TAIL>
 __global__ __launch_bounds__(kBlock, TAIL ? 5 : 1) void k_residual_reduce_mfma(
     const LevelGeom g, const PairPtrs* __restrict__ pairs, const PairState* __restrict__ states, int n_pairs,
     float* __restrict__ partials, float2* __restrict__ scratch, int blocks_per_xcd, int* __restrict__ f16_range_flag, const SolverStepArgs tail) {
@@ -52,20 +52,23 @@ __global__ __launch_bounds__(kBlock, TAIL ? 5 : 1) void k_residual_reduce_mfma(
     const int active = st.active && st.level == g.level;
     asm volatile("" ::"s"(early.refR), "s"(early.curA), "s"(early.curB), "s"(active));
     if (!active) {
-      if constexpr (TAIL) sweep_tail(g, tail, pair, reinterpret_cast<char*>(slab_mem));
+      if constexpr (TAIL == 1) sweep_tail(g, tail, pair, reinterpret_cast<char*>(slab_mem));
       return;
     }
   } else {
     if (!st.active || st.level != g.level) {
-      if constexpr (TAIL) sweep_tail(g, tail, pair, reinterpret_cast<char*>(slab_mem));
+      if constexpr (TAIL == 1) sweep_tail(g, tail, pair, reinterpret_cast<char*>(slab_mem));
       return;
     }
   }
   const PairPtrs pp = pairs[pair];
-  mfma_sweep_tile<RPW, LINEAR, MODE, TAIL>(g, st.KT, st.P_prev, st.first != 0, pp, pair, tile, partials, scratch, slab_mem, counts, f16_range_flag);
+  DVO_TCLK_START(tc0);
+  mfma_sweep_tile<RPW, LINEAR, MODE, TAIL != 0>(g, st.KT, st.P_prev, st.first != 0, pp, pair, tile, partials, scratch, slab_mem, counts, f16_range_flag);
   if constexpr (TAIL) {
     __syncthreads();                                           // (the fold has read every wavefront's slab)
-    sweep_tail(g, tail, pair, reinterpret_cast<char*>(slab_mem));
+    DVO_TCLK(0, tc0);                                          // the tile
+    if constexpr (TAIL == 1) sweep_tail(g, tail, pair, reinterpret_cast<char*>(slab_mem));
+    else sweep_tail_wide(g, tail, pair, reinterpret_cast<char*>(slab_mem));
   }
 }
 
@@ -78,17 +81,22 @@ static void launch_m(hipStream_t s, bool finest, const LevelGeom& g, const PairP
   const SolverStepArgs no_tail = {};
   if constexpr (F16 == 2 && RPW <= 8) {
     if (tail) {                                                // (the default schedule's gathering sweep, never the finest level: mfma_sweep_has_tail)
-      if (g.linear) k_residual_reduce_mfma<RPW, false, true, 2, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, *tail);
-      else k_residual_reduce_mfma<RPW, false, false, 2, true><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, *tail);
+      if (tail->pair_sums) {
+        if (g.linear) k_residual_reduce_mfma<RPW, false, true, 2, 2><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, *tail);
+        else k_residual_reduce_mfma<RPW, false, false, 2, 2><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, *tail);
+      } else {
+        if (g.linear) k_residual_reduce_mfma<RPW, false, true, 2, 1><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, *tail);
+        else k_residual_reduce_mfma<RPW, false, false, 2, 1><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, *tail);
+      }
       return;
     }
   }
   if (g.linear) {
-    if (finest) k_residual_reduce_mfma<RPW, true, true, F16, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, no_tail);
-    else k_residual_reduce_mfma<RPW, false, true, F16, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, no_tail);
+    if (finest) k_residual_reduce_mfma<RPW, true, true, F16, 0><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, no_tail);
+    else k_residual_reduce_mfma<RPW, false, true, F16, 0><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, no_tail);
   } else {
-    if (finest) k_residual_reduce_mfma<RPW, true, false, F16, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, no_tail);
-    else k_residual_reduce_mfma<RPW, false, false, F16, false><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, no_tail);
+    if (finest) k_residual_reduce_mfma<RPW, true, false, F16, 0><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, no_tail);
+    else k_residual_reduce_mfma<RPW, false, false, F16, 0><<<grid, block, 0, s>>>(g, pairs, states, n_pairs, partials, scratch, per_xcd, f16_range_flag, no_tail);
   }
 }
 
@@ -116,5 +124,13 @@ void launch_residual_reduce_mfma(hipStream_t s, int rows_per_wave, bool finest, 
   else if (mode == 1) launch_rpw<1>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, f16_range_flag, nullptr);
   else launch_rpw<0>(s, rows_per_wave, finest, g, pairs, states, n_pairs, partials, scratch, nullptr, nullptr);
 }
+
+#ifdef DVO_TAIL_CLOCKS
+extern "C" int dvo_hip_debug_tail_clocks(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tail_clk), sizeof(g_tail_clk)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tail_clk), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 }  // namespace dvo_hip

@@ -280,7 +280,7 @@ struct PinnedRing {
 // levels are bound by the host's launch rate, which more streams only divide -- profiles/r01_d_groups.txt.)
 struct Workspace {
   hipStream_t stream = nullptr;
-  DevBuf states, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters;
+  DevBuf states, partials, scratch, ll_partials, lvl_stats, it_stats, results, t_init, counters, pair_sums;
   // the pairs' plane-pointer table, in one of a few buffers picked by the batch's first frames: a caller that alternates between two
   // or three frame sets finds each set's table where it left it (PinnedRing's cache of what was sent where)
   static const int kTableSlots = 4;
@@ -504,7 +504,7 @@ void workspace_destroy(Workspace& w) {
   (void)hipStreamSynchronize(w.stream);
   for (DevBuf& b : w.pair_ptrs) b.release();
   for (DevBuf* b : {&w.states, &w.partials, &w.scratch, &w.ll_partials, &w.lvl_stats, &w.it_stats, &w.results,
-                    &w.t_init, &w.counters, &w.exchange, &w.win_fallbacks})
+                    &w.t_init, &w.counters, &w.exchange, &w.win_fallbacks, &w.pair_sums})
     b->release();
   if (w.host_status) (void)hipHostFree(w.host_status);
   w.host_status = nullptr;
@@ -1121,6 +1121,7 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
   DVO_WS_TRY(w, w.lvl_stats.reserve(size_t(n) * bp.cap_levels * sizeof(dvo_hip_level_stats)));
   DVO_WS_TRY(w, w.it_stats.reserve(size_t(n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats)));
   DVO_WS_TRY(w, w.results.reserve(size_t(n) * sizeof(dvo_hip_result)));
+  DVO_WS_TRY(w, w.pair_sums.reserve(size_t(n) * kPairSumsStride * sizeof(double)));
   DVO_WS_TRY(w, w.t_init.reserve(size_t(n) * 16 * sizeof(double)));
   // per-step tallies, and behind them one arrival word per pair (the sweeps' tail, solver_step.h): cleared together at the start of a batch
   DVO_WS_TRY(w, w.counters.reserve(size_t(bp.cap_iters + 8 + kResidentErrorWords) * sizeof(unsigned long long) + align_up(size_t(n) * sizeof(int), 8)));
@@ -1669,14 +1670,21 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // The step in the sweep's launch (round 6): where the log-likelihood pass runs inside the solver step anyway and the level's sweep
     // has the instantiation, the workgroup that completes a pair's last tile runs the pair's step -- ONE launch per iteration
     const bool tail = ctx->opt_sweep_tail != 0 && fused_ll && sweep_has_tail(ctx->opt_variant, bp.rpw[level], g);
+    // (option 2: the WIDE half of the step -- reduction and log-likelihood, its memory round trips -- in the sweep's tail, the serial half
+    // in a one-wavefront launch behind it)
+    double* pair_sums = tail && ctx->opt_sweep_tail == 2 ? w.pair_sums.as<double>() : nullptr;
     auto enqueue_chunk = [&](int count) {
       for (int c = 0; c < count; ++c, ++step) {
         if (tail) {
           Range range(kErr[level]);
           const SolverStepArgs a = make_solver_step_args(states, n, bp.prm, partials, ll_partials, ll_blocks, scratch, d_levels, d_iters, tallies + step, w.host_status + step,
-                                                         cfg->first_level - level, &next, arrivals);
+                                                         cfg->first_level - level, &next, arrivals, pair_sums);
           launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch, w.win_fallbacks.as<unsigned long long>(),
                                  w.f16_range_flag, &a);
+          if (pair_sums) {
+            Range range2(kLinsys[level]);
+            launch_solver_serial(s, n, g, a);
+          }
           ctx->tail_steps += 1;
           continue;
         }
@@ -2170,12 +2178,12 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "solver_occupancy") == 0) {
-    if (value != 0 && value != 3 && value != 4) return fail(ctx, DVO_HIP_ERR_INVALID, "solver_occupancy must be 0, 3 or 4");
+    if (value != 0 && value != 3) return fail(ctx, DVO_HIP_ERR_INVALID, "solver_occupancy must be 0 or 3");
     g_solver_occupancy = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "sweep_tail") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "sweep_tail must be 0 or 1");
+    if (value < 0 || value > 2) return fail(ctx, DVO_HIP_ERR_INVALID, "sweep_tail must be 0, 1 (the whole step in the sweep's tail) or 2 (its wide half; the serial half in a launch behind it)");
     ctx->opt_sweep_tail = value;
     return DVO_HIP_OK;
   }

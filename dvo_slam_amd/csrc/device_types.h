@@ -185,12 +185,16 @@ struct SolverStepArgs {
   int level_slot_hint;
   NextLevel next;
   int* arrivals;                         // the sweeps' tail: one word per pair, the tiles of the pair that are through (self-resetting)
+  // the WIDE half of the step in the sweep's tail (reduction + log-likelihood), the serial half in a one-wavefront launch behind it:
+  // kPairSumsStride doubles per pair -- the kAccStride reduced sums, then the four wavefronts' log-likelihood sums
+  double* pair_sums;
 };
+constexpr int kPairSumsStride = 96;
 
 __host__ inline SolverStepArgs make_solver_step_args(PairState* states, int n_pairs, const SolverParams& prm, const float* partials, const double* ll_partials,
                                             int ll_blocks_per_pair, const float2* scratch_for_fused_ll, dvo_hip_level_stats* levels,
                                             dvo_hip_iteration_stats* iters, unsigned long long* step_tally, int* host_status, int level_slot_hint,
-                                            const NextLevel* next_or_null, int* arrivals) {
+                                            const NextLevel* next_or_null, int* arrivals, double* pair_sums = nullptr) {
   SolverStepArgs a;
   a.states = states; a.n_pairs = n_pairs; a.prm = prm; a.partials = partials; a.ll_partials = ll_partials; a.ll_blocks_per_pair = ll_blocks_per_pair;
   a.scratch_for_fused_ll = scratch_for_fused_ll; a.levels = levels; a.iters = iters; a.step_tally = step_tally; a.host_status = host_status;
@@ -198,6 +202,7 @@ __host__ inline SolverStepArgs make_solver_step_args(PairState* states, int n_pa
   a.next.valid = 0; a.next.level = 0; a.next.fx = a.next.fy = a.next.ox = a.next.oy = 0.0f; a.next.pairs = nullptr; a.next.results = nullptr;
   if (next_or_null) a.next = *next_or_null;
   a.arrivals = arrivals;
+  a.pair_sums = pair_sums;
   return a;
 }
 

@@ -91,6 +91,8 @@ void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverPar
                         const float* partials, const double* ll_partials, int ll_blocks_per_pair, const float2* scratch_for_fused_ll,
                         dvo_hip_level_stats* levels, dvo_hip_iteration_stats* iters, unsigned long long* step_tally,
                         int* host_status, bool two_waves = false, int level_slot_hint = -1, const NextLevel* next_or_null = nullptr);
+// the serial half of a step whose wide half ran in the sweep's tail (a.pair_sums)
+void launch_solver_serial(hipStream_t s, int n_pairs, LevelGeom g, const SolverStepArgs& a);
 void launch_finish(hipStream_t s, const PairState* states, int n_pairs, SolverParams prm,
                    const dvo_hip_level_stats* levels, const dvo_hip_iteration_stats* iters, dvo_hip_result* results);
 // single-shot linearisation for parity tests: fixed T34 / P_prev, no state machine

@@ -43,12 +43,20 @@ extern "C" int dvo_hip_debug_gn_clocks(unsigned long long* out16, int reset) {
 #endif
 
 // the step of one pair (solver_step.h::solver_step_body -- shared with the sweeps' tail, align_fast.hip / align_mfma.hip)
-// MIN_WG: workgroups per compute unit the kernel is built for (1: the compiler's choice, 184 registers = two four-wavefront workgroups;
-// 3 / 4: 168 / 128 registers, the serial lane's float64 state partly in scratch -- experiment, option "solver_occupancy")
+// MIN_WG: workgroups per compute unit the kernel is built for (1: the compiler's choice -- 168 registers = three four-wavefront workgroups
+// since the pivoted 6 x 6 solve, a path of singular systems, is out of line (round 6: 184 before, two workgroups; 1024-pair step 11.6 ->
+// 11.4 ms); 3: the same asked for by name -- option "solver_occupancy")
 template <int WAVES, int MIN_WG = 1>
 __global__ __launch_bounds__(WAVES * 64, MIN_WG) void k_solver_step(LevelGeom g, SolverStepArgs a) {
   __shared__ SolverLds L;
   solver_step_body<WAVES>(L, g, a, blockIdx.x);
+}
+
+// the serial half of the step, one wavefront per pair: the sums and log-likelihood terms of the pass come from the sweep's tail
+// (sweep_tail_wide, SolverStepArgs::pair_sums)
+__global__ __launch_bounds__(64) void k_solver_serial(LevelGeom g, SolverStepArgs a) {
+  __shared__ SolverLds L;
+  solver_step_body<1, kReduceInFlight, 16, 16, true>(L, g, a, blockIdx.x);
 }
 
 __global__ void k_finish(const PairState* states, int n_pairs, SolverParams prm, const dvo_hip_level_stats* levels,
@@ -111,6 +119,10 @@ void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverPar
   k_level_begin<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, g, level, pairs, levels, T_init_or_null);
 }
 
+void launch_solver_serial(hipStream_t s, int n_pairs, LevelGeom g, const SolverStepArgs& a) {
+  k_solver_serial<<<dim3(n_pairs), dim3(64), 0, s>>>(g, a);
+}
+
 int g_solver_occupancy = 0;   // (experiment: option "solver_occupancy")
 
 void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g,
@@ -122,7 +134,6 @@ void launch_solver_step(hipStream_t s, PairState* states, int n_pairs, SolverPar
   // (two wavefronts: see solver_step_body; a level of at most 32 tiles -- 160 x 120, 80 x 60 -- of a batch beyond two workgroups per compute unit)
   if (two_waves) k_solver_step<2><<<dim3(n_pairs), dim3(128), 0, s>>>(g, a);
   else if (g_solver_occupancy == 3) k_solver_step<kWavesPerBlock, 3><<<dim3(n_pairs), dim3(kBlock), 0, s>>>(g, a);
-  else if (g_solver_occupancy == 4) k_solver_step<kWavesPerBlock, 4><<<dim3(n_pairs), dim3(kBlock), 0, s>>>(g, a);
   else k_solver_step<kWavesPerBlock><<<dim3(n_pairs), dim3(kBlock), 0, s>>>(g, a);
 }
 

@@ -12,6 +12,17 @@
 #include "align_common.h"
 #include "solver_logic.h"
 
+// DVO_TAIL_CLOCKS (experiment build of one translation unit, scripts/r6_tailclk.sh): where the time of a sweep's tail goes -- 100 MHz wall
+// clock, thread 0 of every workgroup (arrival) / of the pair's last workgroup (the rest); g_tail_clk[k] sums, g_tail_clk[8 + k] counts
+#ifdef DVO_TAIL_CLOCKS
+namespace dvo_hip { __device__ unsigned long long g_tail_clk[16]; }
+#define DVO_TCLK(k, t_from) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&dvo_hip::g_tail_clk[(k)], now_ - (t_from)); atomicAdd(&dvo_hip::g_tail_clk[8 + (k)], 1ull); (t_from) = now_; } } while (0)
+#define DVO_TCLK_START(t) unsigned long long t = wall_clock64()
+#else
+#define DVO_TCLK(k, t_from) ((void)0)
+#define DVO_TCLK_START(t) ((void)0)
+#endif
+
 namespace dvo_hip {
 
 // the step's LDS (k_solver_step declares one; the sweeps' tail lays it over their window, idle by then)
@@ -57,7 +68,9 @@ __device__ __forceinline__ void publish_step(unsigned long long* step_tally, int
 // serial float64 work.  A two-wavefront workgroup plays the four (reduce_scale.h, loglik_partial_played): the records are the same bits.
 // REDUCE_IN_FLIGHT / LL_SLOTS / LL_LOADS: loads in flight of the reduction and of the fused log-likelihood (registers against round
 // trips; the order of the additions and products does not depend on them).
-template <int WAVES, int REDUCE_IN_FLIGHT = kReduceInFlight, int LL_SLOTS = 16, int LL_LOADS = 16>
+// PRE (round 6, k_solver_serial): the reduced sums and the four wavefronts' log-likelihood sums of the pass were formed in the sweep's
+// tail (sweep_tail_wide) and are read from SolverStepArgs::pair_sums -- the step is its serial half, any number of wavefronts.
+template <int WAVES, int REDUCE_IN_FLIGHT = kReduceInFlight, int LL_SLOTS = 16, int LL_LOADS = 16, bool PRE = false>
 __device__ __forceinline__ void solver_step_body(SolverLds& L, const LevelGeom& g, const SolverStepArgs& a, int pair) {
   PairState& st = L.st;
   dvo_hip_level_stats& lvl = L.lvl;
@@ -91,8 +104,15 @@ __device__ __forceinline__ void solver_step_body(SolverLds& L, const LevelGeom& 
     }
   }
   double ll_mine = 0.0;
-  if (!a.scratch_for_fused_ll && threadIdx.x < 32) ll_mine = a.ll_partials[size_t(pair) * a.ll_blocks_per_pair + min(int(threadIdx.x), a.ll_blocks_per_pair - 1)];
-  reduce_partials<WAVES, REDUCE_IN_FLIGHT>(a.partials, pair, g.tiles_x * g.tiles_y, L.sh, L.sums);   // same routine, same order as k_loglik: identical n, S, P
+  if constexpr (PRE) {
+    const double* mine = a.pair_sums + size_t(pair) * kPairSumsStride;
+    for (int i = threadIdx.x; i < kAccStride; i += kThreads) L.sums[i] = mine[i];
+    if (threadIdx.x < kWavesPerBlock) L.ll_waves[threadIdx.x] = mine[kAccStride + threadIdx.x];
+    __syncthreads();
+  } else {
+    if (!a.scratch_for_fused_ll && threadIdx.x < 32) ll_mine = a.ll_partials[size_t(pair) * a.ll_blocks_per_pair + min(int(threadIdx.x), a.ll_blocks_per_pair - 1)];
+    reduce_partials<WAVES, REDUCE_IN_FLIGHT>(a.partials, pair, g.tiles_x * g.tiles_y, L.sh, L.sums);   // same routine, same order as k_loglik: identical n, S, P
+  }
   {
     unsigned* dst = reinterpret_cast<unsigned*>(&st);
 #pragma unroll
@@ -112,12 +132,11 @@ __device__ __forceinline__ void solver_step_body(SolverLds& L, const LevelGeom& 
     for (int i = threadIdx.x; i < int(sizeof(dvo_hip_iteration_stats) / 8); i += kThreads) reinterpret_cast<double*>(&rec)[i] = dvo_nan();
     // ... and the contraction of the Gram sums with the pass' precision (the sums are in place since reduce_partials' barrier): lane
     // i * 6 + j forms A(i, j) from the upper-triangle entry of (min, max), lanes 36..41 J^T W r
-    if (threadIdx.x < 42) {
+    for (int k = threadIdx.x; k < 42; k += kThreads) {
       const double d = L.sums[kAccN] - 3.0;
       float Cc[3], Pc[4];
       scale_to_precision(L.sums[kAccS] / d, L.sums[kAccS + 1] / d, L.sums[kAccS + 2] / d, Cc, Pc);
       const double p00 = double(Pc[0]), p01 = double(Pc[1]), p11 = double(Pc[3]);
-      const int k = threadIdx.x;
       if (k < 36) {
         const int i = k / 6, j = k - i * 6, lo = i < j ? i : j, hi = i < j ? j : i;
         const int o = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);           // index of (lo, hi) in the row-major upper triangle
@@ -173,7 +192,9 @@ __device__ __forceinline__ void solver_step_body(SolverLds& L, const LevelGeom& 
     coop_copy<kThreads>(&lvl, lvl_global);
     __syncthreads();
   }
-  if (a.scratch_for_fused_ll) {
+  if constexpr (PRE) {
+    // (the four wavefronts' sums are in place)
+  } else if (a.scratch_for_fused_ll) {
     // coarse levels: the log-likelihood sweep is small enough for this workgroup, which saves a launch per iteration
     float C[3], P[4];
     const int n = scale_from_sums(L.sums, C, P);
@@ -205,7 +226,7 @@ __device__ __forceinline__ void solver_step_body(SolverLds& L, const LevelGeom& 
   }
   if (threadIdx.x == 0) {
     double ll_sum = 0.0;
-    if (a.scratch_for_fused_ll) {
+    if (PRE || a.scratch_for_fused_ll) {
       ll_sum = (L.ll_waves[0] + L.ll_waves[1]) + (L.ll_waves[2] + L.ll_waves[3]);
     } else {
       for (int b = 0; b < a.ll_blocks_per_pair; ++b) ll_sum += L.ll_stage[b];
@@ -222,7 +243,8 @@ __device__ __forceinline__ void solver_step_body(SolverLds& L, const LevelGeom& 
     publish_step(a.step_tally, a.host_status, a.n_pairs, st.active != 0);
   }
   __syncthreads();
-  if (L.information_ready && threadIdx.x < 36) rec.information[threadIdx.x] = L.Amat[threadIdx.x];   // (uniform; GnAssist::defer_information)
+  if (L.information_ready)                                    // (uniform; GnAssist::defer_information)
+    for (int i = threadIdx.x; i < 36; i += kThreads) rec.information[i] = L.Amat[i];
   __syncthreads();
   coop_copy<kThreads>(&a.states[pair], &st);
   if (have_level) coop_copy<kThreads>(lvl_global, &lvl);
@@ -266,6 +288,34 @@ __device__ __attribute__((noinline)) static void sweep_tail_step(__attribute__((
   solver_step_body<kWavesPerBlock, 8, 4, 4>(T.step, T.g, T.a, pair);
 }
 
+// The WIDE half of the step in the tail (TAIL = 2): the last workgroup of a pair sums the pair's partial rows (stage 3 of the reduction)
+// and, with the pass' precision, the log-likelihood terms of its residual pairs -- the step's memory round trips -- and leaves the
+// kAccStride sums and the four wavefronts' log-likelihood sums in SolverStepArgs::pair_sums; the serial half (k_solver_serial, one
+// wavefront per pair) follows in a launch of its own.  What this half needs fits the sweep's register budget.
+__device__ __attribute__((noinline)) static void sweep_tail_wide_step(__attribute__((address_space(3))) char* lds, int pair) {
+  SweepTailLds& T = *reinterpret_cast<SweepTailLds*>((char*)lds);
+  const LevelGeom& g = T.g;
+  const SolverStepArgs& a = T.a;
+  const int tiles = g.tiles_x * g.tiles_y;
+  DVO_TCLK_START(tc);
+  reduce_partials<kWavesPerBlock, 8>(a.partials, pair, tiles, T.step.sh, T.step.sums);
+  DVO_TCLK(3, tc);
+  float C[3], P[4];
+  const int n = scale_from_sums(T.step.sums, C, P);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double t = 0.0;
+  if (n >= 6) {
+    if (g.compact) t = loglik_partial_compact<4>(a.scratch_for_fused_ll + size_t(pair) * residual_entries(g), a.partials + size_t(pair) * tiles * kAccStride, tiles * 4, P, wave, kWavesPerBlock);
+    else t = loglik_partial<4>(a.scratch_for_fused_ll + size_t(pair) * g.w * g.h, g.w * g.h, P, 0, 1);
+  }
+  const double total = wave_sum_double(t);
+  DVO_TCLK(4, tc);
+  double* out = a.pair_sums + size_t(pair) * kPairSumsStride;
+  if ((threadIdx.x & 63) == 0) out[kAccStride + wave] = total;
+  if (threadIdx.x < kAccStride) out[threadIdx.x] = T.step.sums[threadIdx.x];
+  DVO_TCLK(5, tc);
+}
+
 // the whole tail behind a tile: arrive; the last workgroup of the pair stages the arguments and runs the step.  `lds`: the workgroup's
 // idle LDS, at least sizeof(SweepTailLds) + 16 bytes, 16-byte aligned.
 __device__ __forceinline__ void sweep_tail(const LevelGeom& g, const SolverStepArgs& a, int pair, char* lds) {
@@ -278,6 +328,24 @@ __device__ __forceinline__ void sweep_tail(const LevelGeom& g, const SolverStepA
   }
   __syncthreads();
   sweep_tail_step((__attribute__((address_space(3))) char*)lds, pair);
+}
+
+// ... and with the wide half only (only the workgroups of pairs that ARE on the level come here: nothing of the pair's state changes)
+__device__ __forceinline__ void sweep_tail_wide(const LevelGeom& g, const SolverStepArgs& a, int pair, char* lds) {
+  SweepTailLds* T = reinterpret_cast<SweepTailLds*>(lds);
+  int* ticket = reinterpret_cast<int*>(lds + sizeof(SweepTailLds));
+  DVO_TCLK_START(tc);
+  const bool last = sweep_tail_arrive(a.arrivals, pair, g.tiles_x * g.tiles_y, ticket);
+  DVO_TCLK(1, tc);                                           // arrival: the stores' completion, two barriers, the ticket
+  if (!last) return;
+  if (threadIdx.x == 0) {
+    T->g = g;
+    T->a = a;
+  }
+  __syncthreads();
+  DVO_TCLK(2, tc);                                           // arguments staged
+  sweep_tail_wide_step((__attribute__((address_space(3))) char*)lds, pair);
+  DVO_TCLK(6, tc);                                           // the whole wide half
 }
 
 }  // namespace dvo_hip

@@ -44,13 +44,14 @@ def test_step_in_the_sweep_s_launch_gives_the_two_launch_records_bit_for_bit(ctx
     before = ctx.counter("tail_steps")
     base = raw_match(ctx, cfg, refs, curs, T0)
     assert ctx.counter("tail_steps") == before
-    ctx.set_option("sweep_tail", 1)
-    for rep in range(3 if copies > 1 else 1):              # (a hand-off that is stale one time in a hundred shows up in a few hundred pairs x iterations)
-        tail = raw_match(ctx, cfg, refs, curs, T0)
-        assert ctx.counter("tail_steps") > before
-        assert tail[0] == base[0], "results differ"
-        assert tail[1] == base[1], "level records differ"
-        assert tail[2] == base[2], "iteration records differ"
+    for mode in (1, 2):                                     # 1: the whole step in the tail; 2: its wide half, the serial half in a launch behind it
+        ctx.set_option("sweep_tail", mode)
+        for rep in range(3 if copies > 1 else 1):          # (a hand-off that is stale one time in a hundred shows up in a few hundred pairs x iterations)
+            tail = raw_match(ctx, cfg, refs, curs, T0)
+            assert ctx.counter("tail_steps") > before
+            assert tail[0] == base[0], "results differ (mode %d)" % mode
+            assert tail[1] == base[1], "level records differ (mode %d)" % mode
+            assert tail[2] == base[2], "iteration records differ (mode %d)" % mode
 
 
 def test_pairs_that_leave_their_levels_at_different_times(ctx):
@@ -70,9 +71,10 @@ def test_pairs_that_leave_their_levels_at_different_times(ctx):
     cfg = d.Config(FirstLevel=3, LastLevel=0)
     ctx.set_option("sweep_tail", 0)
     base = raw_match(ctx, cfg, refs, curs)
-    ctx.set_option("sweep_tail", 1)
-    for rep in range(3):
-        assert raw_match(ctx, cfg, refs, curs)[:3] == base[:3]
+    for mode in (1, 2):
+        ctx.set_option("sweep_tail", mode)
+        for rep in range(3):
+            assert raw_match(ctx, cfg, refs, curs)[:3] == base[:3]
     # a pair's record does not depend on the batch's other pairs' tails: alone (launch path forced) it is the same bytes
     ctx.set_option("resident", 0)
     size = C.sizeof(_lib.Result)
