@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--resident-group", type=int, default=0, help="workgroups per pair in the resident match kernel (0 = as many as fit); "
                     "with --rows-per-wave: records that do not depend on the batch size")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes of the streaming loop on one GPU (contexts + host threads that run their shards' steps out of "
+                    "phase, dvo_stream_lanes_*): 0 = by the pairs per GPU (two from three and a half pairs per compute unit on), 1 = one")
     ap.add_argument("--option", action="append", default=[], help="library option key=value (dvo_hip_set_option), for experiments")
     ap.add_argument("--resident-rows", type=int, default=0, help="library option resident_rows (0 = default 24)")
     ap.add_argument("--iters-per-sync", type=int, default=0)
@@ -278,18 +280,92 @@ def main():
         if gathering:
             dist.barrier()
 
+    # Lanes (round 6): with two pairs per compute unit and more the rank's pairs are dealt to 2-3 lanes -- a context and a host thread
+    # each, running their shards' steps without waiting for one another (dvo_slam_amd/apps/stream_pipeline.cpp, dvo_stream_lanes_*): one
+    # lane's latency-bound phases pass beside another's sweeps.  A step is still one full ingest + alignment of EVERY pair of the rank;
+    # its results are collected in submission order, at most LANE_DEPTH steps behind.
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    # (measured on 256 compute units, builds alternated on one box: 1024 pairs 11.3 -> 10.8 ms per step with two lanes, 10.9-11.2 with three, 11.1
+    # with four; 512 pairs 5.80 -> 5.72, 768 pairs level: two lanes from three and a half pairs per compute unit on)
+    n_lanes = args.lanes if args.lanes > 0 else (1 if args.no_overlap else 2 if 2 * B >= 7 * cus else 1)
+    n_lanes = max(1, min(n_lanes, B // 64 if B >= 128 else 1))
+    LANE_DEPTH = 2
+    lanes = None
+    if n_lanes > 1:
+        from dvo_slam_amd.stream import StreamLanes
+        lane_cap = {2: 192, 3: 96}.get(n_lanes, max(64, 384 // n_lanes)) if args.build_workgroups < 0 else args.build_workgroups
+        lane_ctx, lane_cam = [], {}
+        for _ in range(n_lanes):
+            c = d.Context(local_rank)
+            for kv in args.option:
+                key, _, value = kv.partition("=")
+                c.set_option(key, int(value))
+            c.set_option("build_workgroups", lane_cap)
+            lane_ctx.append(c)
+            lane_cam[id(c)] = d.RgbdCameraPyramid(W, H, pairs_np["K"], c)
+            lane_cam[id(c)].build(4)
+
+        def make_frames(c, idx):
+            cam_l = lane_cam[id(c)]
+            return ([cam_l.create_raw_device(grey_ptrs[i], depth_ptrs[i]) for i in idx],
+                    [cam_l.create_raw_device(grey_ptrs[B + i], depth_ptrs[B + i]) for i in idx])
+        lanes = StreamLanes(lane_ctx, cfg, B, make_frames, grey_ptrs[:B], depth_ptrs[:B], grey_ptrs[B:], depth_ptrs[B:], depth=LANE_DEPTH)
+
+    def lanes_collect():
+        res = lanes.collect()
+        last["T"] = res["transformation"].reshape(B, 4, 4).copy()
+        last["information"] = res["information"].reshape(B, 6, 6).copy()
+        last["loglik"] = res["loglik"].copy()
+        if gathering:
+            rec = lanes.records()
+            if pending[0] is not None:
+                gathered[0] = pending[0].result()
+            pending[0] = gatherer.start(rec)
+
+    def lanes_loop(k_steps):
+        for _ in range(k_steps):
+            lanes.submit()
+            if lanes.outstanding >= LANE_DEPTH:
+                lanes_collect()
+        while lanes.outstanding:
+            lanes_collect()
+
     if n_sets > 1:
         build(0)                                                        # prime the pipeline: step k aligns set k % 2 and builds the other
-    for _ in range(args.warmup):
-        step()
-    drain()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()                                                             # the last batch's records have arrived on every rank
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_one_lane = None
+    if lanes is not None:
+        # the one-lane loop first (its step time is reported beside the lanes'; its results are what the lanes' are compared with)
+        for _ in range(max(2, args.warmup)):
+            step()
+        drain()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()
+        barrier()
+        elapsed_one_lane = time.perf_counter() - t0
+        one_lane_T = last["T"].copy()
+        lanes_loop(args.warmup)
+        drain()
+        barrier()
+        t0 = time.perf_counter()
+        lanes_loop(args.steps)                                          # EXACTLY args.steps steps: submitted, aligned and collected inside the timed region
+        drain()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        lanes_vs_one = float(np.abs(parallel.twists_of(last["T"]) - parallel.twists_of(one_lane_T)).max())
+    else:
+        for _ in range(args.warmup):
+            step()
+        drain()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()                                                         # the last batch's records have arrived on every rank
+        barrier()
+        elapsed = time.perf_counter() - t0
     if gathering:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -304,7 +380,8 @@ def main():
             print(json.dumps({"metric": "frame-pair alignments/s (640x480, 4-level pyramid) + finest-level HBM GB/s vs roofline",
                               "value": round(n_total * args.steps / elapsed, 2), "unit": "alignments/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "loop_only": True,
-                              "config": {"pairs": n_total, "pairs_per_gpu": B}}))
+                              "config": {"pairs": n_total, "pairs_per_gpu": B, "lanes": n_lanes},
+                              "ms_per_step_one_lane": None if elapsed_one_lane is None else round(elapsed_one_lane / args.steps * 1e3, 3)}))
         return
     twist_err = float(np.abs(parallel.twists_of(last["T"]) - pairs_np["xi_true"]).max())
     if args.records_out and rank == 0:
@@ -483,7 +560,7 @@ def main():
         barrier()
         el_g = time.perf_counter() - t1
         guard_stress = {"pairs_out_of_range": k_bad, "ms_per_step": round(el_g / args.steps * 1e3, 3),
-                        "ratio_to_clean_step": round(el_g / elapsed, 4),
+                        "ratio_to_clean_step": round(el_g / (elapsed_one_lane if elapsed_one_lane is not None else elapsed), 4),
                         "pairs_repeated_per_step": round((ctx.counter("f16_range_repeats") - r0) / args.steps, 2),
                         "note": "the timed loop with %d of the %d pairs replaced by a 2 mm / 10 m depth checkerboard (Jacobian components beyond +-65504): "
                                 "the sweep raises the pair's word, the library repeats those pairs alone with the f32 Gram" % (k_bad, B)}
@@ -567,6 +644,9 @@ def main():
                                        n_total, n_total - 1, world, "; build and match run back to back" if args.no_overlap else
                                        "; the build of step k+1 (build stream) overlaps the match of step k, every step does one full build and one full match"),
                        "pairs": n_total, "pairs_per_gpu": B, "width": W, "height": H,
+                       "lanes": ("%d lanes per GPU: the rank's pairs dealt to %d contexts of its GPU, a host thread each, that run their shards' steps out of phase "
+                                 "(dvo_stream_lanes_*, dvo_slam_amd/apps/stream_pipeline.cpp); a step = one full ingest + alignment of every pair, collected in "
+                                 "submission order at most %d steps behind" % (n_lanes, n_lanes, LANE_DEPTH)) if n_lanes > 1 else "1 lane",
                        "parallelism": "independent pairs sharded round-robin over %d GPU(s) (fixed total: strong scaling), one all-gather of "
                                       "256-B records per step%s" % (world, "" if not gathering else
                                                                     " (ncclAllGather called by the C-ABI: dvo_hip_gather_records_*)" if gather_kind == "native"
@@ -575,6 +655,13 @@ def main():
                        "ingest": "hbm-resident raw planes (u8 grey + u16 depth per frame already in HBM when the timed region starts; the same loop "
                                  "fed from pinned host memory, PCIe-inclusive, is contract_value)"},
             "roofline": roofline,
+            "lanes": None if elapsed_one_lane is None else {
+                "lanes": n_lanes, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_one_lane": round(elapsed_one_lane / args.steps * 1e3, 3),
+                "value_one_lane": round(n_total * args.steps / elapsed_one_lane, 2), "build_workgroups_per_lane": lane_cap,
+                "max_twist_difference_to_one_lane": lanes_vs_one,
+                "note": "value / ms_per_step are the loop over the lanes; the same loop on one context and one host thread (rounds 1-5) is "
+                        "ms_per_step_one_lane.  A pair's record in a lane's shard agrees with its record in the one-lane batch to the precision "
+                        "of the stopping rule (another batch-size class of the schedule)"},
             "match_only_ms_per_batch": round(match_only_ms, 3),
             "single_pair_ms": round(single_pair_ms, 3),
             "latency_ms": latency,

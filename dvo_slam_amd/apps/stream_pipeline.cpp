@@ -5,6 +5,8 @@
 //
 // Reference call pattern it stands for: dvo_benchmark/src/benchmark_slam.cpp:327-383 (load pair -> create pyramid -> track),
 // with the proposals of dvo_slam/src/keyframe_graph.cpp:576-593 as the source of independent pairs.
+#include <pthread.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -120,6 +122,157 @@ int dvo_stream_step_host(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next
                  std::chrono::duration<double, std::milli>(t2 - t1).count());
   }
   return rc;
+}
+
+// ---- several LANES on one GPU (round 6) ---------------------------------------------------------------------------------------------
+// The steady state of a streaming consumer with enough independent pairs per step (two per compute unit and more): the pairs are dealt
+// to G lanes -- lane l takes the pairs l, l + G, ... -- each with a context of its own on the SAME device (own streams, own scratch) and
+// a host thread that runs dvo_stream_step on the lane's shard, step after step, WITHOUT waiting for the other lanes: they drift out of
+// phase, and one lane's latency-bound phases (coarse sweeps, solver steps, the host's share of a step) pass beside another's sweeps.
+// This is the reference's own model for independent pairs -- the workers of a tbb::parallel_reduce each run whole match() calls
+// (dvo_slam/src/keyframe_graph.cpp:576-593) -- with the GPU's queues in place of the cores.  Measured (scripts/r6_groups.py, MI355X,
+// 1024 pairs of 640 x 480 per step): 1 lane 11.5-11.7 ms per step, 2 lanes 10.9, 3 lanes 10.8-10.9; lanes that meet after every step
+// keep about half of it.  A step's results are collected in submission order, up to `depth` steps behind the submission.
+// (pthreads and malloc rather than <thread> / new: the object binds the C-ABI and libc only, tests/test_capi.py.)
+struct dvo_stream_lane {
+  dvo_hip_context* ctx;
+  int n;
+  dvo_hip_frame* const* refs[2];                 // the lane's two frame sets (double buffer), n frames each
+  dvo_hip_frame* const* curs[2];
+  const void* const* grey_ref; const void* const* raw_ref; const void* const* grey_cur; const void* const* raw_cur;   // n device pointers each
+};
+
+struct dvo_stream_lanes {
+  int n_lanes, depth;
+  float depth_scale;
+  dvo_hip_config cfg;
+  struct Lane {
+    dvo_stream_lane d;
+    dvo_stream_lanes* owner;
+    pthread_t thread;
+    dvo_hip_result* slots;                       // depth x n results
+    long long done;                              // steps finished (guarded by owner->m)
+    int rc;                                      // first failure of the lane
+  }* lanes;
+  pthread_mutex_t m;
+  pthread_cond_t cv;
+  long long submitted, collected;
+  int quit;
+};
+
+static void* dvo_stream_lane_main(void* arg) {
+  dvo_stream_lanes::Lane* lane = static_cast<dvo_stream_lanes::Lane*>(arg);
+  dvo_stream_lanes* L = lane->owner;
+  for (;;) {
+    pthread_mutex_lock(&L->m);
+    while (!L->quit && lane->done >= L->submitted) pthread_cond_wait(&L->cv, &L->m);
+    if (L->quit) {
+      pthread_mutex_unlock(&L->m);
+      return nullptr;
+    }
+    const long long k = lane->done;
+    pthread_mutex_unlock(&L->m);
+    const int now = int(k & 1), nxt = int((k + 1) & 1);        // step k aligns set k % 2 and re-ingests the other for step k + 1
+    const int rc = dvo_stream_step(lane->d.ctx, lane->d.n, lane->d.refs[nxt], lane->d.curs[nxt], lane->d.grey_ref, lane->d.raw_ref, lane->d.grey_cur,
+                                   lane->d.raw_cur, L->depth_scale, lane->d.refs[now], lane->d.curs[now], &L->cfg,
+                                   lane->slots + size_t(k % L->depth) * lane->d.n);
+    pthread_mutex_lock(&L->m);
+    if (rc != DVO_HIP_OK && lane->rc == DVO_HIP_OK) lane->rc = rc;
+    lane->done = k + 1;
+    pthread_cond_broadcast(&L->cv);
+    pthread_mutex_unlock(&L->m);
+  }
+}
+
+// depth: steps that may be submitted ahead of their collection (>= 1; 2 lets the lanes drift a step apart).  The frame set 0 of every
+// lane is ingested here (the pipeline is primed); returns null on failure.
+dvo_stream_lanes* dvo_stream_lanes_create(int n_lanes, const dvo_stream_lane* lanes, float depth_scale, const dvo_hip_config* cfg, int depth) {
+  if (n_lanes < 1 || !lanes || !cfg || depth < 1) return nullptr;
+  dvo_stream_lanes* L = static_cast<dvo_stream_lanes*>(std::calloc(1, sizeof(dvo_stream_lanes)));
+  if (!L) return nullptr;
+  L->n_lanes = n_lanes; L->depth = depth; L->depth_scale = depth_scale; L->cfg = *cfg;
+  L->lanes = static_cast<dvo_stream_lanes::Lane*>(std::calloc(size_t(n_lanes), sizeof(dvo_stream_lanes::Lane)));
+  pthread_mutex_init(&L->m, nullptr);
+  pthread_cond_init(&L->cv, nullptr);
+  bool ok = L->lanes != nullptr;
+  for (int l = 0; ok && l < n_lanes; ++l) {
+    dvo_stream_lanes::Lane& lane = L->lanes[l];
+    lane.d = lanes[l];
+    lane.owner = L;
+    lane.slots = static_cast<dvo_hip_result*>(std::calloc(size_t(depth) * size_t(lanes[l].n), sizeof(dvo_hip_result)));
+    ok = lane.slots != nullptr &&
+         dvo_stream_step(lane.d.ctx, lane.d.n, lane.d.refs[0], lane.d.curs[0], lane.d.grey_ref, lane.d.raw_ref, lane.d.grey_cur, lane.d.raw_cur, depth_scale,
+                         nullptr, nullptr, cfg, nullptr) == DVO_HIP_OK;
+  }
+  int started = 0;
+  for (; ok && started < n_lanes; ++started) ok = pthread_create(&L->lanes[started].thread, nullptr, dvo_stream_lane_main, &L->lanes[started]) == 0;
+  if (!ok) {
+    pthread_mutex_lock(&L->m);
+    L->quit = 1;
+    pthread_cond_broadcast(&L->cv);
+    pthread_mutex_unlock(&L->m);
+    for (int l = 0; l < started - 1; ++l) pthread_join(L->lanes[l].thread, nullptr);
+    for (int l = 0; L->lanes && l < n_lanes; ++l) std::free(L->lanes[l].slots);
+    std::free(L->lanes);
+    std::free(L);
+    return nullptr;
+  }
+  return L;
+}
+
+// one more step for every lane; DVO_HIP_ERR_CAPACITY when `depth` steps are already waiting to be collected
+int dvo_stream_lanes_submit(dvo_stream_lanes* L) {
+  if (!L) return DVO_HIP_ERR_INVALID;
+  pthread_mutex_lock(&L->m);
+  const bool room = L->submitted - L->collected < L->depth;
+  if (room) {
+    L->submitted += 1;
+    pthread_cond_broadcast(&L->cv);
+  }
+  pthread_mutex_unlock(&L->m);
+  return room ? DVO_HIP_OK : DVO_HIP_ERR_CAPACITY;
+}
+
+// waits for the oldest submitted step on every lane; out[l + j * n_lanes] = result j of lane l (the order the pairs were dealt in).
+// Returns the first failure of any lane's steps (the error text: dvo_hip_last_error of that lane's context).
+int dvo_stream_lanes_collect(dvo_stream_lanes* L, dvo_hip_result* out) {
+  if (!L || !out) return DVO_HIP_ERR_INVALID;
+  pthread_mutex_lock(&L->m);
+  if (L->collected >= L->submitted) {
+    pthread_mutex_unlock(&L->m);
+    return DVO_HIP_ERR_INVALID;                                 // nothing outstanding
+  }
+  const long long k = L->collected;
+  int rc = DVO_HIP_OK;
+  for (int l = 0; l < L->n_lanes; ++l) {
+    while (L->lanes[l].done <= k) pthread_cond_wait(&L->cv, &L->m);
+    if (rc == DVO_HIP_OK) rc = L->lanes[l].rc;
+  }
+  pthread_mutex_unlock(&L->m);                                  // (slot k % depth of a lane is not written again before `collected` moves)
+  for (int l = 0; l < L->n_lanes; ++l) {
+    const dvo_hip_result* src = L->lanes[l].slots + size_t(k % L->depth) * L->lanes[l].d.n;
+    for (int j = 0; j < L->lanes[l].d.n; ++j) out[size_t(l) + size_t(j) * L->n_lanes] = src[j];
+  }
+  pthread_mutex_lock(&L->m);
+  L->collected = k + 1;
+  pthread_mutex_unlock(&L->m);
+  return rc;
+}
+
+void dvo_stream_lanes_destroy(dvo_stream_lanes* L) {
+  if (!L) return;
+  pthread_mutex_lock(&L->m);
+  L->quit = 1;
+  pthread_cond_broadcast(&L->cv);
+  pthread_mutex_unlock(&L->m);
+  for (int l = 0; l < L->n_lanes; ++l) {
+    pthread_join(L->lanes[l].thread, nullptr);
+    std::free(L->lanes[l].slots);
+  }
+  pthread_mutex_destroy(&L->m);
+  pthread_cond_destroy(&L->cv);
+  std::free(L->lanes);
+  std::free(L);
 }
 
 }  // extern "C"

@@ -307,6 +307,27 @@ struct Workspace {
   unsigned resident_launch_counter = 0;
 };
 
+// a helper thread of the concurrent pair groups (dvo_hip_context::opt_batch_groups) and the slice of the caller's batch it aligns
+struct GroupWorker {
+  dvo_hip_context* twin = nullptr;
+  std::thread thread;
+  std::mutex m;
+  std::condition_variable cv;
+  bool has_job = false, done = false, quit = false;
+  // the job: a slice of the caller's batch
+  int n = 0;
+  dvo_hip_frame* const* refs = nullptr;
+  dvo_hip_frame* const* curs = nullptr;
+  const dvo_hip_config* cfg = nullptr;
+  dvo_hip_result* results = nullptr;
+  dvo_hip_level_stats* levels = nullptr;
+  dvo_hip_iteration_stats* iters = nullptr;
+  int cap_levels = 0, cap_iters = 0;
+  hipEvent_t after = nullptr;                                  // the twin's stream waits for it (the role planes are ready)
+  int rc = DVO_HIP_OK;
+};
+
+
 struct dvo_hip_context {
   // The reference hands one current pyramid to two trackers on two threads (dvo_slam/src/local_tracker.cpp:180-184) and runs
   // thread-local validators over shared keyframes (keyframe_graph.cpp:576-593): calls on one context from several host threads
@@ -385,6 +406,15 @@ struct dvo_hip_context {
   // in is built for 96 (five workgroups per compute unit), and the spilled step takes 40-50 us instead of 15
   int opt_sweep_tail = 0;
   long long tail_steps = 0;        // Gauss-Newton steps enqueued as ONE launch (sweep with a tail)
+  // Concurrent pair groups (round 6): a large batch is aligned as two or three sub-batches at once -- the caller's thread runs the first
+  // on this context, helper threads the others on TWIN contexts (same device, own stream, own scratch), like the reference spreads
+  // independent match() calls over the workers of a tbb::parallel_reduce (dvo_slam/src/keyframe_graph.cpp:576-593).  Option
+  // "batch_groups": 0 / 1 = one group (the default: see batch_groups_of for what was measured), 2 .. 4 = that many.
+  int opt_batch_groups = 0;
+  bool is_twin = false;            // a helper's context: never splits, never owns frames
+  std::vector<GroupWorker*> group_workers;
+  hipEvent_t roles_ready = nullptr;   // recorded behind ensure_batch_roles: the twins' streams wait for it
+  long long grouped_batches = 0;
   int opt_coarse = 0;              // the fused coarse-level kernel (align_coarse.hip): 0 = off (default: measured and lost), 1 = whenever the levels admit it
   int opt_coarse_pixels = 0;       // levels of up to this many pixels run in it (0 = kCoarseMaxPixels)
   int opt_coarse_wgs = 0;          // its workgroups per compute unit: 0 / 4 (128 registers) or 3 (168)
@@ -1494,6 +1524,8 @@ int run_coarse(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, co
   return DVO_HIP_OK;
 }
 
+std::mutex g_rare_path_mutex;   // (see run_batch: the repeat of pairs that left the f16 range)
+
 constexpr int kF32GramHoldBatches = 32;   // after a batch left the f16 range of the Gram operands: this many batches go straight to the f32 Gram
 
 hipEvent_t g_trace_ev[2] = {nullptr, nullptr};   // DVO_HIP_TRACE_SLOW: device time stamps around a batch's preparation
@@ -1829,6 +1861,9 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
         static_cast<volatile int*>(w.f16_range_flag)[i] = 0;
         out_of_range.push_back(i);
       }
+  // (the repeats below prepare role planes and run another batch: two groups of one batch -- dvo_hip_match_batch -- do not do that at once)
+  std::unique_lock<std::mutex> rare_path;
+  if (!out_of_range.empty()) rare_path = std::unique_lock<std::mutex>(g_rare_path_mutex);
   if (!out_of_range.empty() && out_of_range.size() * 2 >= size_t(n)) {
     ctx->f16_range_repeats += (long long)out_of_range.size();
     ctx->f32_gram_hold = kF32GramHoldBatches;
@@ -1915,6 +1950,131 @@ struct EffectiveVariantScope {
   ~EffectiveVariantScope() { c->opt_variant = keep; }
 };
 
+// ---- concurrent pair groups (dvo_hip_context::opt_batch_groups) -----------------------------------------------------------------------
+// the options a group's twin context aligns with: the owner's, as they are in effect for this batch
+void mirror_options(const dvo_hip_context* from, dvo_hip_context* to) {
+#define DVO_MIRROR(f) to->f = from->f
+  DVO_MIRROR(opt_rows_per_wave); DVO_MIRROR(opt_iters_per_sync); DVO_MIRROR(opt_tail_speculation); DVO_MIRROR(opt_solver_waves);
+  DVO_MIRROR(opt_ll_blocks); DVO_MIRROR(opt_compact_residuals); DVO_MIRROR(opt_gram_lo_parts); DVO_MIRROR(opt_min_workgroups);
+  DVO_MIRROR(opt_condition_number); DVO_MIRROR(opt_fused_ll_pixels); DVO_MIRROR(opt_variant); DVO_MIRROR(opt_resident);
+  DVO_MIRROR(opt_resident_rows); DVO_MIRROR(opt_resident_group); DVO_MIRROR(opt_resident_flags); DVO_MIRROR(opt_resident_cooperative);
+  DVO_MIRROR(opt_sweep_tail); DVO_MIRROR(opt_coarse); DVO_MIRROR(opt_coarse_pixels); DVO_MIRROR(opt_coarse_wgs);
+  DVO_MIRROR(opt_deterministic); DVO_MIRROR(compute_units);
+#undef DVO_MIRROR
+}
+
+void group_worker_main(GroupWorker* gw) {
+  (void)hipSetDevice(gw->twin->device);
+  for (;;) {
+    std::unique_lock<std::mutex> lock(gw->m);
+    gw->cv.wait(lock, [&] { return gw->has_job || gw->quit; });
+    if (gw->quit) return;
+    gw->has_job = false;
+    lock.unlock();
+    dvo_hip_context* t = gw->twin;
+    t->batch_entry = std::chrono::steady_clock::now();
+    int rc = DVO_HIP_OK;
+    if (hipStreamWaitEvent(t->stream, gw->after, 0) != hipSuccess) {
+      t->err = "match: a pair group could not wait for the batch's role planes";
+      rc = DVO_HIP_ERR_HIP;
+    }
+    if (rc == DVO_HIP_OK) {
+      rc = run_batch(t, gw->n, gw->refs, gw->curs, gw->cfg, gw->results, gw->levels, gw->cap_levels, gw->iters, gw->cap_iters);
+      if (rc != DVO_HIP_OK) t->err = t->ws[0].err;
+    }
+    lock.lock();
+    gw->rc = rc;
+    gw->done = true;
+    lock.unlock();
+    gw->cv.notify_all();
+  }
+}
+
+// how many groups a batch of n pairs is aligned in
+int batch_groups_of(const dvo_hip_context* ctx, int n) {
+  if (ctx->is_twin || ctx->opt_ref_compat || ctx->opt_deterministic) return 1;   // (the reciprocal table lives in the owner; one schedule per pair)
+  // Asked for by name only.  Measured (round 6, streaming loop, one box): 1024 pairs 11.75 -> 11.1-11.9 ms per step with two groups,
+  // 11.4-12.0 with three -- groups that start together stay in phase, and two sweeps of the same level side by side gain nothing; the
+  // gain of several contexts on one GPU comes from running OUT of phase, which a streaming caller gets from lanes
+  // (dvo_slam_amd/apps/stream_pipeline.cpp, dvo_stream_lanes_*: 11.3 -> 10.8).
+  return ctx->opt_batch_groups > 1 ? std::min(ctx->opt_batch_groups, std::max(1, n / 64)) : 1;
+}
+
+int ensure_group_workers(dvo_hip_context* ctx, int groups) {
+  while (int(ctx->group_workers.size()) < groups - 1) {
+    dvo_hip_context* twin = nullptr;
+    const int rc = dvo_hip_context_create(ctx->device, &twin);
+    if (rc != DVO_HIP_OK) return fail(ctx, rc, "match: could not create a pair group's context");
+    twin->is_twin = true;
+    GroupWorker* gw = new GroupWorker();
+    gw->twin = twin;
+    gw->thread = std::thread(group_worker_main, gw);
+    ctx->group_workers.push_back(gw);
+  }
+  if (!ctx->roles_ready) DVO_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->roles_ready, hipEventDisableTiming));
+  return DVO_HIP_OK;
+}
+
+void destroy_group_workers(dvo_hip_context* ctx) {
+  for (GroupWorker* gw : ctx->group_workers) {
+    {
+      std::lock_guard<std::mutex> lock(gw->m);
+      gw->quit = true;
+    }
+    gw->cv.notify_all();
+    if (gw->thread.joinable()) gw->thread.join();
+    dvo_hip_context_destroy(gw->twin);
+    delete gw;
+  }
+  ctx->group_workers.clear();
+  if (ctx->roles_ready) (void)hipEventDestroy(ctx->roles_ready);
+  ctx->roles_ready = nullptr;
+}
+
+// the batch as `groups` sub-batches at once: pairs [0, n_0) on the caller's thread and context, the other slices on the helpers
+int run_batch_grouped(dvo_hip_context* ctx, int groups, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
+                      dvo_hip_result* results, dvo_hip_level_stats* levels, int cap_levels, dvo_hip_iteration_stats* iters, int cap_iters) {
+  int rc = ensure_group_workers(ctx, groups);
+  if (rc != DVO_HIP_OK) return rc;
+  DVO_HIP_TRY(ctx, hipEventRecord(ctx->roles_ready, ctx->stream));
+  const int base = n / groups, extra = n % groups;             // slice g: base pairs, the first `extra` slices one more
+  const int n0 = base + (extra > 0 ? 1 : 0);
+  int at = n0;
+  for (int g = 1; g < groups; ++g) {
+    GroupWorker* gw = ctx->group_workers[g - 1];
+    const int m = base + (g < extra ? 1 : 0);
+    mirror_options(ctx, gw->twin);
+    {
+      std::lock_guard<std::mutex> lock(gw->m);
+      gw->n = m;
+      gw->refs = refs + at; gw->curs = curs + at; gw->cfg = cfg; gw->results = results + at;
+      gw->levels = levels && cap_levels > 0 ? levels + size_t(at) * cap_levels : nullptr;
+      gw->iters = iters && cap_iters > 0 ? iters + size_t(at) * cap_iters : nullptr;
+      gw->cap_levels = cap_levels; gw->cap_iters = cap_iters;
+      gw->after = ctx->roles_ready;
+      gw->done = false;
+      gw->has_job = true;
+    }
+    gw->cv.notify_all();
+    at += m;
+  }
+  ctx->grouped_batches += 1;
+  rc = run_batch(ctx, n0, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
+  if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
+  for (int g = 1; g < groups; ++g) {                          // every helper is awaited whatever the outcome: its slice of the caller's arrays is in use
+    GroupWorker* gw = ctx->group_workers[g - 1];
+    std::unique_lock<std::mutex> lock(gw->m);
+    gw->cv.wait(lock, [&] { return gw->done; });
+    if (gw->rc != DVO_HIP_OK && (rc == DVO_HIP_OK || rc == DVO_HIP_ERR_CAPACITY)) {
+      rc = gw->rc;
+      ctx->err = gw->twin->err;
+    }
+    ctx->f16_range_repeats += gw->twin->f16_range_repeats;
+    gw->twin->f16_range_repeats = 0;
+  }
+  return rc;
+}
+
 // preparation for the parity / measurement entry points
 int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg, BatchPlan& bp) {
   int rc = validate_batch(ctx, n, refs, curs, cfg);
@@ -1939,7 +2099,11 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
   if (std::strcmp(key, "resident_launches") == 0) *value = ctx->resident_launches;
   else if (std::strcmp(key, "resident_levels") == 0) *value = ctx->resident_levels;
   else if (std::strcmp(key, "resident_timeouts") == 0) *value = ctx->resident_timeouts;
-  else if (std::strcmp(key, "tail_steps") == 0) *value = ctx->tail_steps;
+  else if (std::strcmp(key, "grouped_batches") == 0) *value = ctx->grouped_batches;
+  else if (std::strcmp(key, "tail_steps") == 0) {
+    *value = ctx->tail_steps;
+    for (const GroupWorker* gw : ctx->group_workers) *value += gw->twin->tail_steps;
+  }
   else if (std::strcmp(key, "coarse_launches") == 0) *value = ctx->coarse_launches;
   else if (std::strcmp(key, "coarse_levels") == 0) *value = ctx->coarse_levels;
   else if (std::strcmp(key, "window_fallbacks") == 0) {
@@ -2104,6 +2268,7 @@ void dvo_hip_context_destroy(dvo_hip_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   ctx->deferred.clear();                                       // (nobody is left to read what a recorded ingest would build)
+  destroy_group_workers(ctx);
   if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
   if (ctx->build_stream) (void)hipStreamSynchronize(ctx->build_stream);
   for (Workspace& w : ctx->ws) workspace_destroy(w);
@@ -2175,6 +2340,11 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "resident") == 0) {
     if (value < -1 || value > 1) return fail(ctx, DVO_HIP_ERR_INVALID, "resident must be -1 (automatic), 0 (off) or 1 (every level)");
     ctx->opt_resident = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "batch_groups") == 0) {
+    if (value < 0 || value > 4) return fail(ctx, DVO_HIP_ERR_INVALID, "batch_groups must be 0 or 1 (one group) .. 4");
+    ctx->opt_batch_groups = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "solver_occupancy") == 0) {
@@ -2724,8 +2894,13 @@ int dvo_hip_match_batch(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* const*
   rc = ensure_batch_roles(ctx, n_pairs, references, currents, cfg);
   if (rc != DVO_HIP_OK) return rc;
 
-  rc = run_batch(ctx, n_pairs, references, currents, cfg, results, levels, cap_levels, iters, cap_iters);
-  if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
+  const int groups = batch_groups_of(ctx, n_pairs);
+  if (groups > 1) {
+    rc = run_batch_grouped(ctx, groups, n_pairs, references, currents, cfg, results, levels, cap_levels, iters, cap_iters);
+  } else {
+    rc = run_batch(ctx, n_pairs, references, currents, cfg, results, levels, cap_levels, iters, cap_iters);
+    if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
+  }
   if (!ctx->deferred.empty()) {                                // (a path without launches to hide it behind, or a batch that ended early)
     const int rc_deferred = flush_deferred(ctx);
     if (rc == DVO_HIP_OK) rc = rc_deferred;

@@ -9,6 +9,13 @@ import numpy as np
 from . import _lib
 from .tracker import FrameSet, device_pointer_array, _RESULT_DTYPE
 
+class _Lane(C.Structure):
+    """dvo_stream_lane (stream_pipeline.cpp)"""
+    _pp = C.POINTER(C.c_void_p)
+    _fields_ = [("ctx", C.c_void_p), ("n", C.c_int), ("refs", _pp * 2), ("curs", _pp * 2),
+                ("grey_ref", _pp), ("raw_ref", _pp), ("grey_cur", _pp), ("raw_cur", _pp)]
+
+
 _PIPE_PATH = os.path.join(os.path.dirname(os.path.abspath(_lib.LIB_PATH)), "libdvo_stream.so")
 _pipe = None
 
@@ -26,6 +33,12 @@ def _load():
         L.dvo_stream_step_host.argtypes = L.dvo_stream_step.argtypes
         L.dvo_stream_pack_records.argtypes = [C.c_int, C.POINTER(_lib.Result), C.POINTER(C.c_double)]
         L.dvo_stream_pack_records.restype = None
+        L.dvo_stream_lanes_create.argtypes = [C.c_int, C.POINTER(_Lane), C.c_float, C.POINTER(_lib.Config), C.c_int]
+        L.dvo_stream_lanes_create.restype = vp
+        L.dvo_stream_lanes_submit.argtypes = [vp]
+        L.dvo_stream_lanes_collect.argtypes = [vp, C.POINTER(_lib.Result)]
+        L.dvo_stream_lanes_destroy.argtypes = [vp]
+        L.dvo_stream_lanes_destroy.restype = None
         _pipe = L
     return _pipe
 
@@ -78,3 +91,65 @@ class StreamPipeline:
         self.ctx.check(self.L.dvo_stream_step(self.ctx.ptr, self.n, nr, nc, g_ref, z_ref, g_cur, z_cur, self.scale, ar, ac,
                                               C.byref(self.ccfg), self.cres))
         return self.results
+
+
+class StreamLanes:
+    """The streaming loop over G lanes on ONE GPU (dvo_stream_lanes_*, stream_pipeline.cpp): the n pairs of a step are dealt to the lanes
+    -- lane l takes the pairs l, l + G, ... -- each lane a context of its own on the device and a host thread that runs its shard's
+    steps without waiting for the others.  make_frames(ctx, indices) -> (ref frames, cur frames) creates one frame set of a lane in that
+    lane's context; grey_ref ... depth_cur: the n device pointers the raw planes of every step are read from."""
+
+    def __init__(self, contexts, config, n, make_frames, grey_ref, depth_ref, grey_cur, depth_cur, depth_scale=1.0 / 5000.0, depth=2):
+        self.L = _load()
+        self.contexts, self.n, self.G = list(contexts), n, len(contexts)
+        self.keep = []                                            # everything the C side holds pointers into
+        lanes = (_Lane * self.G)()
+        for l, ctx in enumerate(self.contexts):
+            idx = list(range(l, n, self.G))
+            lanes[l].ctx, lanes[l].n = ctx.ptr, len(idx)
+            for k in range(2):
+                r, c = make_frames(ctx, idx)
+                r, c = (r if isinstance(r, FrameSet) else FrameSet(r)), (c if isinstance(c, FrameSet) else FrameSet(c))
+                self.keep += [r, c]
+                lanes[l].refs[k], lanes[l].curs[k] = C.cast(r.handles, _Lane._pp), C.cast(c.handles, _Lane._pp)
+            for name, src in (("grey_ref", grey_ref), ("raw_ref", depth_ref), ("grey_cur", grey_cur), ("raw_cur", depth_cur)):
+                arr = device_pointer_array([src[i] for i in idx])
+                self.keep.append(arr)
+                setattr(lanes[l], name, C.cast(arr, _Lane._pp))
+        self.ccfg = config.to_c()
+        self.keep.append(lanes)
+        self.ptr = self.L.dvo_stream_lanes_create(self.G, lanes, depth_scale, C.byref(self.ccfg), depth)
+        if not self.ptr:
+            raise _lib.DvoHipError(_lib.ERR_HIP, "dvo_stream_lanes_create failed: " + "; ".join(c._lib.dvo_hip_last_error(c.ptr).decode() for c in self.contexts))
+        self.depth = depth
+        self.cres = (_lib.Result * n)()
+        self.results = np.frombuffer(self.cres, dtype=_RESULT_DTYPE)
+        self._records = np.zeros((n, 32), np.float64)
+        self.outstanding = 0
+
+    def submit(self):
+        """One more step on every lane (returns at once); at most `depth` steps may await their collect()."""
+        rc = self.L.dvo_stream_lanes_submit(self.ptr)
+        if rc != 0:
+            raise _lib.DvoHipError(rc, "dvo_stream_lanes_submit: %d steps are waiting to be collected" % self.outstanding)
+        self.outstanding += 1
+
+    def collect(self):
+        """Waits for the oldest submitted step; returns the result view (pair order as dealt: pair i from lane i % G)."""
+        rc = self.L.dvo_stream_lanes_collect(self.ptr, self.cres)
+        self.outstanding -= 1
+        if rc != 0:
+            raise _lib.DvoHipError(rc, "a lane's step failed: " + "; ".join(c._lib.dvo_hip_last_error(c.ptr).decode() for c in self.contexts))
+        return self.results
+
+    def records(self):
+        self.L.dvo_stream_pack_records(self.n, self.cres, self._records.ctypes.data_as(C.POINTER(C.c_double)))
+        return self._records
+
+    def close(self):
+        if self.ptr:
+            self.L.dvo_stream_lanes_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.close()

@@ -294,6 +294,8 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * step is costly; n >= 2: costly means n workgroups or more per step; 0 = 131072),
  * "solver_waves" (wavefronts of a solver-step workgroup, 2 or 4; 0 = two on the smallest levels of a batch of more than two
  * workgroups per compute unit, four otherwise -- the records do not depend on it),
+ * "solver_occupancy" (experiment: 3 = the four-wavefront solver step built for three workgroups per compute unit, 168 registers and part
+ * of the serial lane's state in scratch, instead of the compiler's 184 = two; 0 = default.  Level on the boxes of round 6),
  * "min_workgroups" (tile-height heuristic: smallest launch that counts as filling the chip; 0 = built-in table),
  * "defer_ingest" (default 0; 1: dvo_hip_frames_update_raw_device_as only RECORDS its request -- the pointer arrays are copied, the
  * raw planes must stay valid as for any asynchronous ingest -- and the next dvo_hip_match_batch carries it out right behind the first
@@ -331,13 +333,23 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * many frames leaves them -- the coarsest one (DVO_HIP_TRACE_PLAN in the environment prints the plan of every batch to stderr); 0: one to three launches per Gauss-Newton step always; 1: every level resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
  * pass; default 24), "resident_group" (workgroups per pair, a power of two <= 64; 0 = as many as fit the device),
  * "resident_cooperative" (1: groups are launched with hipLaunchCooperativeKernel), "resident_flags" (measurement / test hooks).
+ * "batch_groups" (default 0 = one group; 2 .. 4: a batch is aligned as that many sub-batches AT ONCE (of at least 64 pairs each) -- the
+ * caller's thread runs the first on this context, helper threads the others on twin contexts of the same device (own stream, own
+ * scratch; created when first needed), the way the reference spreads independent match() calls over the workers of a
+ * tbb::parallel_reduce (dvo_slam/src/keyframe_graph.cpp:576-593).  A pair's record is what its sub-batch gives it: bit-identical to the
+ * ungrouped batch's where both fall into the same batch-size class of the schedule, equal to the precision of the stopping rule
+ * otherwise.  Off by default: groups that start together stay in phase -- 1024 pairs 11.75 -> 11.1-11.9 ms per streaming step with two
+ * groups; what several contexts on one GPU gain, they gain by running OUT of phase, which a streaming caller gets from the lanes of
+ * dvo_slam_amd/apps/stream_pipeline.cpp (dvo_stream_lanes_*: 11.3 -> 10.8 ms).  Not under "deterministic" or "ref_compat"; counter
+ * "grouped_batches"),
  * "sweep_tail" (default 0; 1: on the levels whose log-likelihood pass runs inside the solver step -- up to 160 x 120 pixels, 320 x 240
  * in batches of 512 pairs and more -- under the default schedule, the workgroup of the sweep that completes the LAST tile of a pair
  * runs the pair's Gauss-Newton step right there: one launch per iteration instead of two (dvo_slam_amd/csrc/solver_step.h; the
  * reference's loop body follows its residual pass without leaving the thread either, dvo_core/src/dense_tracking.cpp:240-357).  The
- * records are the two-launch form's bit for bit.  Off by default: measured slower (128 pairs 1.82 -> 2.20 ms per step, 1024 pairs
- * 11.8 -> 14.4): the step's serial float64 lane wants ~180 registers and the sweep it rides in is built for 96 -- DESIGN.md section 10;
- * counter "tail_steps"),
+ * records are the two-launch form's bit for bit; 2: only the WIDE half of the step -- reduction and log-likelihood -- in the tail, the serial
+ * half in a one-wavefront launch behind it.  Off by default: both forms measured slower (128 pairs 1.8 -> 2.2 / 2.3 ms per step, 1024
+ * pairs 11.6 -> 14.4 / 13.6): every workgroup of the sweep waits ~5 us for its write-through stores before it can take the pair's
+ * ticket, as long as its tile takes -- profiles/r06_sweep_tail.txt; counter "tail_steps"),
  * "coarse" (default 0; 1: wherever the levels admit it -- the default schedule, no "ref_compat", levels of up to 160 x 120 pixels --
  * the leading pyramid levels run in ONE launch, a workgroup per pair from the level's begin to its termination, level after level,
  * like one thread runs one match() in the reference (dvo_core/src/dense_tracking.cpp:200-357, dvo_slam/src/keyframe_graph.cpp:576-593):
@@ -361,6 +373,7 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 
 /* Event counters of a context.  key: "resident_launches" (matches, or coarse-level runs, done by the resident kernel),
  * "resident_levels" (pyramid levels those launches ran, summed),
+ * "grouped_batches" (batches aligned as concurrent sub-batches, option "batch_groups"),
  * "tail_steps" (Gauss-Newton steps of a batch enqueued as ONE launch, the sweep with the solver step in its tail, option "sweep_tail"),
  * "coarse_launches" / "coarse_levels" (the same for the fused coarse-level kernel, option "coarse"),
  * "resident_timeouts" (batches repeated on the launch-per-step path because a workgroup group of the resident kernel waited

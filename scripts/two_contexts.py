@@ -8,7 +8,7 @@ import torch
 import dvo_slam_amd as d
 from dvo_slam_amd import datagen
 
-W, H, B = 640, 480, 128
+W, H, B = 640, 480, int(os.environ.get("DVO_PAIRS", "128"))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 b = datagen.synth_batch(0, B, W, H)
 dev = torch.device("cuda", 0)
@@ -65,5 +65,5 @@ for T in [int(x) for x in sys.argv[1].split(",")]:
             t.join()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-    print("threads %d: %.3f ms per 128-pair step, %.0f alignments/s" % (T, el / steps * 1e3, B * steps / el))
+    print("threads %d: %.3f ms per %d-pair step, %.0f alignments/s" % (T, el / steps * 1e3, B, B * steps / el))
     del workers
