@@ -37,8 +37,8 @@ ALGO_BYTES_PER_PIXEL = 40.0          # SURVEY.md section 8d's ALGORITHMIC bytes:
                                      # What the shipped sweep MOVES is less (reference {Zsel, I} 8 B + current {I, Z} 8 B x the staged
                                      # window's halo, read; 8 B residual pair written): reported beside it as roofline.moved_bytes_per_pixel
 PCIE_PEAK_GBPS = 63.0                # PCIe Gen5 x16, spec (MI355X_MICROARCH.md "Host link")
-BACKGROUND_BUILD_WORKGROUPS = 256    # cap on the workgroups of background build kernels (library option build_workgroups): one per compute unit --
-                                     # with the strip ingest the alignment's short kernels get through beside it (r03: 14.23 -> 13.77 ms per step)
+# (the cap on the workgroups of background build kernels -- library option build_workgroups -- is one per compute unit, the library's policy for
+# the device, counter "background_build_workgroups": with the strip ingest the alignment's short kernels get through beside it, r03: 14.23 -> 13.77 ms)
 HBM_PEAK_GBPS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -117,6 +117,7 @@ def main():
                     "with --rows-per-wave: records that do not depend on the batch size")
     ap.add_argument("--lanes", type=int, default=0, help="lanes of the streaming loop on one GPU (contexts + host threads that run their shards' steps out of "
                     "phase, dvo_stream_lanes_*): 0 = by the pairs per GPU (two from three and a half pairs per compute unit on), 1 = one")
+    ap.add_argument("--lane-depth", type=int, default=2, help="steps the lanes may be submitted ahead of their collection")
     ap.add_argument("--option", action="append", default=[], help="library option key=value (dvo_hip_set_option), for experiments")
     ap.add_argument("--resident-rows", type=int, default=0, help="library option resident_rows (0 = default 24)")
     ap.add_argument("--iters-per-sync", type=int, default=0)
@@ -212,7 +213,8 @@ def main():
         ctx.set_option("iters_per_sync", args.iters_per_sync)
     if not args.no_overlap:
         # the next batch is built in the background of the current match
-        ctx.set_option("build_workgroups", BACKGROUND_BUILD_WORKGROUPS if args.build_workgroups < 0 else args.build_workgroups)
+        # (one workgroup per compute unit: the library's policy for the device, counter "background_build_workgroups" -- 256 on MI355X)
+        ctx.set_option("build_workgroups", ctx.counter("background_build_workgroups") if args.build_workgroups < 0 else args.build_workgroups)
     cam = d.RgbdCameraPyramid(W, H, pairs_np["K"], ctx)
     cam.build(4)
     # two frame sets: while batch k is being aligned, batch k+1 is re-ingested and its pyramids / role planes are built on the
@@ -289,11 +291,13 @@ def main():
     # with four; 512 pairs 5.80 -> 5.72, 768 pairs level: two lanes from three and a half pairs per compute unit on)
     n_lanes = args.lanes if args.lanes > 0 else (1 if args.no_overlap else 2 if 2 * B >= 7 * cus else 1)
     n_lanes = max(1, min(n_lanes, B // 64 if B >= 128 else 1))
-    LANE_DEPTH = 2
+    LANE_DEPTH = max(1, args.lane_depth)
     lanes = None
     if n_lanes > 1:
         from dvo_slam_amd.stream import StreamLanes
-        lane_cap = {2: 192, 3: 96}.get(n_lanes, max(64, 384 // n_lanes)) if args.build_workgroups < 0 else args.build_workgroups
+        # (the lanes' background builds share the chip: 3/4 workgroup per compute unit each for two lanes -- 192 on MI355X -- 3/8 for three)
+        per_cu = ctx.counter("background_build_workgroups")
+        lane_cap = (per_cu * 3 // 4 if n_lanes == 2 else max(64, per_cu * 3 // 2 // n_lanes)) if args.build_workgroups < 0 else args.build_workgroups
         lane_ctx, lane_cam = [], {}
         for _ in range(n_lanes):
             c = d.Context(local_rank)

@@ -30,7 +30,11 @@ int dvo_stream_step(dvo_hip_context* ctx, int n, dvo_hip_frame* const* next_refs
   // (measured, scripts/r5_midsize.py, builds alternated on one box: 16 pairs 0.575 -> 0.553 ms per step, 128 pairs 1.863 -> 1.825; a
   // 1024-pair step is better off with the early ingest, 11.57 vs 11.74 ms -- it hides beside the latency-bound coarse levels, and half a
   // millisecond later there is less of them left)
-  static const int defer_max = std::getenv("DVO_STREAM_DEFER_MAX") ? std::atoi(std::getenv("DVO_STREAM_DEFER_MAX")) : 256;
+  // (up to one pair per compute unit: the library's batch-size policy for the context's device, dvo_slam_amd/csrc/batch_policy.h)
+  static const int defer_env = std::getenv("DVO_STREAM_DEFER_MAX") ? std::atoi(std::getenv("DVO_STREAM_DEFER_MAX")) : -1;
+  long long defer_policy = 256;
+  if (defer_env < 0) (void)dvo_hip_get_counter(ctx, "defer_ingest_max_pairs", &defer_policy);
+  const int defer_max = defer_env >= 0 ? defer_env : int(defer_policy);
   // (per-call flags, not the context's options: the caller's own settings stay what they were, and another thread on the context
   // never sees a toggled option -- round-5 advisor finding)
   const bool deferring = n <= defer_max && next_refs && now_refs;

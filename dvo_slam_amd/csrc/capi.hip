@@ -24,6 +24,7 @@
 
 #include "../../include/dvo_hip.h"
 #include "device_types.h"
+#include "batch_policy.h"
 #include "launch.h"
 
 using namespace dvo_hip;
@@ -589,7 +590,6 @@ constexpr int kResidentErrorWords = 8;
 
 const int kLlBlocksPerPair = 32;
 const size_t kCostlyEmptyStepWorkgroups = 131072;   // (see run_batch: from here on the step ahead of the poll is held back on a level's tail)
-const int kLlBlocksPerPairBatch = 8;   // (a batch of 256 pairs or more, packed residuals; see run_batch)
 const int kFusedLoglikMaxPixels = 160 * 120;      // any batch
 const int kFusedLoglikMaxPixelsBatch = 320 * 240;  // batches of 512 pairs and more (run_batch)
 
@@ -700,11 +700,11 @@ int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int le
   // A large batch fills the device whatever the tile: short tiles (2 rows per wavefront: the schedule with the pinned prologue) run the
   // coarse levels' sweeps 6-11 % faster than tall ones since the f16 Gram (scripts/ab_sweep.py: 1024 pairs, 160x120 0.200 -> 0.187 ms,
   // 80x60 0.056 -> 0.050 ms; bench step 14.22 -> 13.89 ms)
-  if (n_pairs >= 256 && ctx->opt_variant >= 7) return 2;
+  if (BatchPolicy(ctx->compute_units).short_gather_tiles(n_pairs) && ctx->opt_variant >= 7) return 2;
   const int candidates[4] = {8, 4, 2, 1};   // measured (profiles/r01_c_tile_sweep.txt): 8 rows is at or near the optimum on every level
   // The tallest tile that still yields this many workgroups.  Fewer, taller tiles also mean fewer partial rows for the
   // bookkeeping kernel, which matters most when there are few pairs (whole-match timings: profiles/r01_f_tile_heuristic.txt).
-  const size_t enough = ctx->opt_min_workgroups > 0 ? size_t(ctx->opt_min_workgroups) : (n_pairs <= 8 ? 512 : n_pairs < 64 ? 1024 : 2048);
+  const size_t enough = ctx->opt_min_workgroups > 0 ? size_t(ctx->opt_min_workgroups) : size_t(BatchPolicy(ctx->compute_units).min_workgroups(n_pairs));
   for (int r : candidates) {
     int tx, ty;
     level_tiles(cam->w[level], cam->h[level], r, level_is_linear(ctx, cam->w[level]), &tx, &ty);
@@ -805,7 +805,7 @@ int eager_current_flavor(const dvo_hip_context* ctx, const CameraGeom* cam, int 
   // (round 5: from an eighth as many frames as compute units on, plane C alone -- the taps cost three times the bytes to write, and a
   // streaming step of 32 / 48 / 64 pairs that re-ingests them every step is 0.885 / 0.98 / 1.24 -> 0.783 / 0.93 / 1.09 ms without them and
   // with the first level alone resident: plan_resident looks at what the frames hold)
-  return n_frames * 8 >= (ctx->compute_units > 0 ? ctx->compute_units : 256) ? kCurC : (kCurAB | kCurC);
+  return BatchPolicy(ctx->compute_units).ingest_skips_taps(n_frames) ? kCurC : (kCurAB | kCurC);
 }
 
 int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, const void* const* grey, const void* const* raw,
@@ -1315,7 +1315,6 @@ struct ResidentPlan {
   bool direct = false;                         // the whole match of a small batch: results and statistics land in pinned host memory
 };
 
-constexpr int kResidentDirectPairs = 16;
 constexpr size_t kResidentDirectStatsBytes = size_t(64) << 20;
 
 // `taps_missing`: current frames of the batch hold plane C but not the taps A + B on the level below the first one (they were ingested
@@ -1353,8 +1352,10 @@ ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg
   // (the same from an eighth of the compute units on when the batch came from a streaming ingest that left the taps out -- see
   // eager_current_flavor; frames that hold them, or nothing yet, get the coarse levels resident as before: a match of 64 prepared pairs
   // 0.96 ms against 1.02 with the first level alone)
-  const bool first_level_only = ctx->opt_resident < 0 && ctx->opt_resident_group == 0 && (bp.n * 4 > cus || (bp.n * 8 >= cus && taps_missing));
-  if (first_level_only && (bp.n * 2 * 8 > cus * 7 || level_uses_window(ctx, bp.cam->w[cfg->first_level], bp.cam->h[cfg->first_level]))) return rp;
+  const BatchPolicy policy(ctx->compute_units);
+  const bool first_level_only = ctx->opt_resident < 0 && ctx->opt_resident_group == 0 &&
+                                (!policy.resident_takes_coarse_levels(bp.n) || (policy.taps_missing_prefers_first_level_only(bp.n) && taps_missing));
+  if (first_level_only && (!policy.resident_first_level_fits(bp.n) || level_uses_window(ctx, bp.cam->w[cfg->first_level], bp.cam->h[cfg->first_level]))) return rp;
   // all workgroups of a launch with groups must be resident at once: one workgroup (8 wavefronts, up to 256 registers) per compute unit
   int group = 1;
   while (group * 2 <= kResidentMaxGroup && bp.n * group * 2 <= cus) group *= 2;
@@ -1377,7 +1378,7 @@ ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg
   if (trace_plan)
     std::fprintf(stderr, "plan_resident: %d pairs, taps missing %d -> %s, %d workgroup(s) per pair, %d level(s) resident\n", bp.n, int(taps_missing),
                  first_level_only ? "first level only" : "coarse levels", rp.group, rp.levels);
-  rp.direct = rp.levels == cfg->first_level - cfg->last_level + 1 && bp.n <= kResidentDirectPairs &&
+  rp.direct = rp.levels == cfg->first_level - cfg->last_level + 1 && bp.n <= policy.resident_direct_max_pairs() &&
               size_t(bp.n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats) <= kResidentDirectStatsBytes;   // (pinned, if asked for)
   return rp;
 }
@@ -1552,6 +1553,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   } variant_scope{ctx, ctx->opt_variant};
   BatchPlan bp;
   make_plan(ctx, refs[0]->cam, cfg, n, bp);
+  const BatchPolicy policy(ctx->compute_units);               // every batch-size threshold below: batch_policy.h
   // The coarse levels -- for a small batch every level -- run inside ONE launch (align_resident.hip): no launch per iteration, no
   // host poll, the pairs of a batch do not wait for each other.
   const ResidentPlan rp = plan_paths(ctx, cfg, bp, window_taps_missing(ctx, cfg, n, curs));
@@ -1660,7 +1662,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // it, and the results are written by the steps behind the last level (NextLevel) -- no launch between two levels, none at the end:
     // builds alternated on one box, 16 / 64 / 128 pairs 0.558 -> 0.553 / 1.196 -> 1.187 / 1.825 -> 1.807 ms per step; 256 and 1024
     // pairs level, 512 pairs 5.79 -> 5.88 (the launches k_level_begin / k_finish stay there)
-    const bool hand_over = n <= 256;
+    const bool hand_over = policy.level_hand_over(n);
     if (level == level_from || !hand_over) {
       Range range(kPrep[level]);
       launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);
@@ -1682,7 +1684,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     const int fuse_opt = ctx->opt_fused_ll_pixels;
     // (round 5, packed residual pairs, the streaming step beside its ingest, scripts/r5_midsize.py: level 1 in a launch of its own
     // 64 pairs 1.456 -> 1.378 ms, 128 pairs 1.939 -> 1.908, 256 pairs 3.308 -> 3.286, 512 pairs 5.859 -> 5.880: fused from 512 pairs)
-    const bool fused_ll = g.w * g.h <= (fuse_opt > 0 ? fuse_opt : (n >= 512 && !ctx->opt_deterministic ? kFusedLoglikMaxPixelsBatch : kFusedLoglikMaxPixels));
+    const bool fused_ll = g.w * g.h <= (fuse_opt > 0 ? fuse_opt : (policy.fused_loglik_on_large_levels(n) && !ctx->opt_deterministic ? kFusedLoglikMaxPixelsBatch : kFusedLoglikMaxPixels));
     // Chunks of `per_sync` iterations are enqueued ONE AHEAD of the poll: while the host waits for the status word of
     // chunk k, chunk k+1 is already queued, so the GPU never idles for a host round trip.  Iterations enqueued past the
     // end of the level are no-ops (workgroups exit on !active).
@@ -1691,14 +1693,13 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // (round 5, mid-size batches, scripts/r5_midsize.py: 16 instead of 32 workgroups per pair 64 / 128 / 200 pairs 1.179 -> 1.173 /
     // 1.775 -> 1.760 / 2.558 -> 2.538 ms per step; 8: 1.183 / 1.760 / 2.546)
     const int ll_blocks = ctx->opt_ll_blocks > 0 ? std::min(ctx->opt_ll_blocks, kLlBlocksPerPair)
-                          : (!g.compact || ctx->opt_deterministic ? kLlBlocksPerPair : n >= 256 ? kLlBlocksPerPairBatch : n >= 48 ? 16 : kLlBlocksPerPair);
+                          : (!g.compact || ctx->opt_deterministic ? kLlBlocksPerPair : policy.loglik_blocks(n));
     // the solver step of the smallest levels in two-wavefront workgroups (four per compute unit instead of two): a batch that otherwise
     // needs two goes of 512 resident workgroups (option solver_waves 2 / 4 to force; the records do not depend on it).  Measured at
     // 1024 pairs (scripts/r4_trace.sh): 80 x 60 46 -> 36 us per step; 160 x 120 with packed residuals 77 -> 90 (two wavefronts walk
     // its 96 slots in six rounds instead of three), 320 x 240 and the finest level level: those keep four.
     const bool solver_two_waves = ctx->opt_solver_waves == 2 ||
-                                  (ctx->opt_solver_waves == 0 && fused_ll && !g.compact && g.tiles_x * g.tiles_y <= 32 &&
-                                   n > 2 * (ctx->compute_units > 0 ? ctx->compute_units : 256));
+                                  (ctx->opt_solver_waves == 0 && fused_ll && !g.compact && g.tiles_x * g.tiles_y <= 32 && policy.solver_two_waves(n));
     // The step in the sweep's launch (round 6): where the log-likelihood pass runs inside the solver step anyway and the level's sweep
     // has the instantiation, the workgroup that completes a pair's last tile runs the pair's step -- ONE launch per iteration
     const bool tail = ctx->opt_sweep_tail != 0 && fused_ll && sweep_has_tail(ctx->opt_variant, bp.rpw[level], g);
@@ -1741,7 +1742,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       // alternated on one box: seven instead of three more 256 pairs 3.288 -> 3.216 ms per step, 128 pairs 1.837 -> 1.856, 64 pairs
       // 1.199 -> 1.210)
       if (size_t(g.tiles_x) * g.tiles_y * size_t(n) < 65536) {
-        const int lead = std::min((n >= 192 ? 7 : 3) * per_sync, per_level - enqueued);
+        const int lead = std::min(policy.deferred_ingest_lead(n) * per_sync, per_level - enqueued);
         if (lead > 0) {
           enqueue_chunk(lead);
           enqueued += lead;
@@ -1813,7 +1814,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       DVO_WS_TRY(w, sync_stream(s));                           // every group has to be gone before the batch is repeated
     }
   } else {
-    if (level_from >= cfg->last_level && n > 256) launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());
+    if (level_from >= cfg->last_level && policy.finish_launch(n)) launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());
     // (else the results are in place: written by the resident launch, or by the solver steps behind the pairs' last level)
     DVO_WS_TRY(w, hipMemcpyAsync(results, w.results.p, size_t(n) * sizeof(dvo_hip_result), hipMemcpyDeviceToHost, s));
     if (levels && cap_levels > 0) {
@@ -2100,6 +2101,10 @@ int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value)
   else if (std::strcmp(key, "resident_levels") == 0) *value = ctx->resident_levels;
   else if (std::strcmp(key, "resident_timeouts") == 0) *value = ctx->resident_timeouts;
   else if (std::strcmp(key, "grouped_batches") == 0) *value = ctx->grouped_batches;
+  // (what the batch-size policy says for this context's device, for callers that stream: batch_policy.h)
+  else if (std::strcmp(key, "compute_units") == 0) *value = BatchPolicy(ctx->compute_units).cus;
+  else if (std::strcmp(key, "defer_ingest_max_pairs") == 0) *value = BatchPolicy(ctx->compute_units).defer_ingest_max_pairs();
+  else if (std::strcmp(key, "background_build_workgroups") == 0) *value = BatchPolicy(ctx->compute_units).background_build_workgroups();
   else if (std::strcmp(key, "tail_steps") == 0) {
     *value = ctx->tail_steps;
     for (const GroupWorker* gw : ctx->group_workers) *value += gw->twin->tail_steps;

@@ -374,6 +374,10 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
 /* Event counters of a context.  key: "resident_launches" (matches, or coarse-level runs, done by the resident kernel),
  * "resident_levels" (pyramid levels those launches ran, summed),
  * "grouped_batches" (batches aligned as concurrent sub-batches, option "batch_groups"),
+ * "compute_units" (of the context's device), "defer_ingest_max_pairs" and "background_build_workgroups" (not events: what the library's
+ * batch-size policy, dvo_slam_amd/csrc/batch_policy.h, says for that device -- the largest batch whose re-ingest a streaming caller
+ * should defer behind the alignment's first launches, and the grid a background frame build should be capped at with option
+ * "build_workgroups": one pair / one workgroup per compute unit),
  * "tail_steps" (Gauss-Newton steps of a batch enqueued as ONE launch, the sweep with the solver step in its tail, option "sweep_tail"),
  * "coarse_launches" / "coarse_levels" (the same for the fused coarse-level kernel, option "coarse"),
  * "resident_timeouts" (batches repeated on the launch-per-step path because a workgroup group of the resident kernel waited

@@ -102,7 +102,9 @@ def test_stream_pipeline_object_builds_and_binds_only_the_c_abi():
     assert "dvo_stream_step" in defined
     ours = [u for u in undefined if u.startswith("dvo_hip_")]
     assert "dvo_stream_step_host" in defined
-    assert sorted(ours) == ["dvo_hip_flush_deferred", "dvo_hip_frames_update_raw_as_ex", "dvo_hip_frames_update_raw_device_as_ex", "dvo_hip_match_batch"]
+    assert sorted(ours) == ["dvo_hip_flush_deferred", "dvo_hip_frames_update_raw_as_ex", "dvo_hip_frames_update_raw_device_as_ex", "dvo_hip_get_counter",
+                            "dvo_hip_match_batch"]
+    assert all(name in defined for name in ("dvo_stream_lanes_create", "dvo_stream_lanes_submit", "dvo_stream_lanes_collect", "dvo_stream_lanes_destroy"))
     assert all(u.startswith("dvo_hip_") or "GLIBC" in u or u.startswith(("mem", "__")) for u in undefined), undefined
 
 
@@ -148,3 +150,52 @@ def test_every_option_and_counter_of_the_library_is_documented_in_the_header():
     assert len(options) >= 10 and len(counters) >= 10, (options, counters)
     missing = sorted(k for k in options | counters if not re.search(r"\b%s\b" % re.escape(k), header))
     assert not missing, "not mentioned in include/dvo_hip.h: %s" % missing
+
+
+def test_batch_policy_reproduces_the_measured_thresholds(tmp_path):
+    """dvo_slam_amd/csrc/batch_policy.h: every batch-size threshold of the host driver as a function of the device's compute units.  On 256
+    compute units (MI355X) each rule gives the constant rounds 2-5 measured and pinned; on another device they scale with what the chip
+    holds at once.  The rules (pairs per compute unit):
+      resident kernel, whole match with results in pinned memory ... 1/16      (16 pairs)
+      resident kernel, coarse levels ............................... 1/4       (64)
+      resident kernel, first level alone ........................... 7/16      (112); from 1/8 (32) for frames streamed in without taps
+      role-aware ingest leaves the taps out ........................ 1/8 frame (32 frames)
+      short gathering tiles, level hand-over in the solver steps, 8 log-likelihood workgroups per pair, deferred ingest ... 1 (256)
+      16 log-likelihood workgroups per pair ........................ 3/16      (48)
+      seven steps ahead of a deferred ingest ....................... 3/4       (192)
+      320 x 240 log-likelihood inside the solver step, two-wavefront solver steps ... 2 (512; the latter: beyond)
+      background build grid ........................................ one workgroup per compute unit (256)"""
+    import subprocess
+    src = tmp_path / "policy.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "batch_policy.h"
+int main(int argc, char** argv) {
+  const dvo_hip::BatchPolicy p(argc > 1 ? atoi(argv[1]) : 256);
+  int first_no_coarse = 0, first_no_first = 0, first_taps = 0, first_skip = 0, first_short = 0, last_hand = 0, first_fused = 0, first_two = 0, first_lead7 = 0;
+  int ll16 = 0, ll8 = 0;
+  for (int n = 1; n <= 4096; ++n) {
+    if (!first_no_coarse && !p.resident_takes_coarse_levels(n)) first_no_coarse = n;
+    if (!first_no_first && !p.resident_first_level_fits(n)) first_no_first = n;
+    if (!first_taps && p.taps_missing_prefers_first_level_only(n)) first_taps = n;
+    if (!first_skip && p.ingest_skips_taps(n)) first_skip = n;
+    if (!first_short && p.short_gather_tiles(n)) first_short = n;
+    if (p.level_hand_over(n)) last_hand = n;
+    if (!first_fused && p.fused_loglik_on_large_levels(n)) first_fused = n;
+    if (!first_two && p.solver_two_waves(n)) first_two = n;
+    if (!first_lead7 && p.deferred_ingest_lead(n) == 7) first_lead7 = n;
+    if (!ll16 && p.loglik_blocks(n) == 16) ll16 = n;
+    if (!ll8 && p.loglik_blocks(n) == 8) ll8 = n;
+  }
+  std::printf("%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", p.resident_direct_max_pairs(), first_no_coarse, first_no_first, first_taps, first_skip,
+              first_short, last_hand, first_fused, first_two, first_lead7, ll16, ll8, p.min_workgroups(8), p.min_workgroups(9), p.min_workgroups(63),
+              p.min_workgroups(64), p.defer_ingest_max_pairs(), p.background_build_workgroups());
+  return 0;
+}
+''')
+    exe = tmp_path / "policy"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-include", "cstdlib", "-I" + os.path.join(ROOT, "dvo_slam_amd", "csrc"), str(src), "-o", str(exe)])
+    at = lambda cus: [int(v) for v in subprocess.check_output([str(exe), str(cus)], text=True).split()]
+    #                     direct !coarse !first taps skip short hand fused two  lead7 ll16 ll8 min(8) min(9) min(63) min(64) defer build
+    assert at(256) == [16, 65, 113, 32, 32, 256, 256, 512, 513, 192, 48, 256, 512, 1024, 1024, 2048, 256, 256]
+    assert at(304) == [19, 77, 134, 38, 38, 304, 304, 608, 609, 228, 57, 304, 608, 608, 1216, 1216, 304, 304]   # (an MI300X: every rule scales with the chip)
