@@ -923,10 +923,11 @@ int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int 
   if (l1 > l0) {
     LevelSpan span;
     span.l0 = l0; span.l1 = l1;
-    bool uniform = true;
+    bool uniform = n <= 64;                                                             // (the check below is quadratic; large batches come through the ingest.
+    // Round 6: the size test used to FOLLOW the double loop -- 524 288 comparisons per role of a 1024-pair batch, 0.4 ms of the host
+    // thread in front of every streaming step's first launch)
     for (int i = 0; i < n && uniform; ++i)
       for (int j = 0; j < i && uniform; ++j) uniform = frames[i] != frames[j];        // (a frame listed twice: the general path skips its second visit)
-    if (n > 64) uniform = false;                                                        // (the check above is quadratic; large batches come through the ingest)
     int tiles = 0;
     for (int l = l0; l <= l1 && uniform; ++l) {
       const int want = role == 0 ? (cur_want ? cur_want[l] : kCurAB) & (frames[0]->lv[l].C ? (kCurAB | kCurC) : kCurAB) : 0;
