@@ -12,7 +12,7 @@
 #include "align_common.h"
 #include "solver_logic.h"
 
-// DVO_TAIL_CLOCKS (experiment build of one translation unit, scripts/r6_tailclk.sh): where the time of a sweep's tail goes -- 100 MHz wall
+// DVO_TAIL_CLOCKS (experiment build of one translation unit, scripts/r6_tailclk.py on a library built with -DDVO_TAIL_CLOCKS): where the time of a sweep's tail goes -- 100 MHz wall
 // clock, thread 0 of every workgroup (arrival) / of the pair's last workgroup (the rest); g_tail_clk[k] sums, g_tail_clk[8 + k] counts
 #ifdef DVO_TAIL_CLOCKS
 namespace dvo_hip { __device__ unsigned long long g_tail_clk[16]; }
