@@ -449,8 +449,8 @@ def main():
                     moved_bytes_per_pixel=None if traffic is None else round(traffic / (W * H * B), 2),
                     moved_GBps=None if traffic is None else round(traffic / (k_ms[0] * 1e-3) / 1e9, 1),
                     moved_frac=None if traffic is None else round(traffic / (k_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                    limited_by="vector-instruction issue (profiles/r05_pmc3_v8_summary.txt: 170 vector instructions per 64-pixel row, the vector ALU active ~79 % "
-                               "of the kernel's cycles, the LDS array ~68 %); `achieved` / `frac` price the launch at SURVEY.md 8(d)'s 40 ALGORITHMIC bytes per pixel -- a "
+                    limited_by="vector-instruction issue (profiles/r06_pmc_finest_sweep.txt: 183 vector instructions per 64-pixel row with every low part kept, the vector "
+                               "ALU active ~80 % of the kernel's cycles, the LDS array ~68 %); `achieved` / `frac` price the launch at SURVEY.md 8(d)'s 40 ALGORITHMIC bytes per pixel -- a "
                                "derived rate, the contract's definition -- while the bytes the kernel really moves (`traffic`, PMC) give `moved_GBps` / "
                                "`moved_frac`: the kernel is not near any memory limit",
                     timed_at="converged transform, t-distribution weights on (3 warm-up Gauss-Newton steps on the level)",
@@ -544,7 +544,7 @@ def main():
         ref_compat = {"value": round(n_total * args.steps / el_c, 2), "unit": "alignments/s", "ms_per_step": round(el_c / args.steps * 1e3, 3),
                       "max_twist_error_vs_truth": float(np.abs(parallel.twists_of(last["T"]) - pairs_np["xi_true"]).max()),
                       "note": "the same HBM-resident loop with option ref_compat on (the opt-in mode whose trajectories follow the reference's own, "
-                              "DESIGN.md section 2); the finest-level sweep is then dvo_hip::k_sweep_fast<2, false, true, 2, true>: the contracted window sweep with the "
+                              "DESIGN.md section 2); the finest-level sweep is then dvo_hip::k_sweep_fast<2, false, true, 2, false, 0>: the contracted window sweep with the "
                               "host CPU's _mm_rcp_ps table in projection and weights (round 5; rounds 3-4: k_sweep_window<true, true, 4>, "
                               "still the bit-exact anchor of the mode under option variant 7)"}
         ctx.set_option("ref_compat", 0)
@@ -706,8 +706,8 @@ def main():
 
 def _kernel_label(variant, pairs):
     """Name of the finest-level sweep kernel the schedule `variant` launches (launch_residual_reduce, align_common.h), as rocprofv3 prints it."""
-    names = {8: "dvo_hip::k_sweep_fast<2, false, true, 0, false> (template arguments: operand stores without lane swaps, no partial tile column, "
-                "packed residual pairs, not the ref_compat arithmetic, every operand an f16 high + low pair)", 9: "dvo_hip::k_sweep_fast<1, false, true, 0, false>", 7: "dvo_hip::k_sweep_window<true, false, 4>",
+    names = {8: "dvo_hip::k_sweep_fast<2, false, true, 0, false, 0> (template arguments: operand stores without lane swaps, no partial tile column, "
+                "packed residual pairs, not the ref_compat arithmetic, every operand an f16 high + low pair, no solver step in the tail)", 9: "dvo_hip::k_sweep_fast<1, false, true, 0, false, 0>", 7: "dvo_hip::k_sweep_window<true, false, 4>",
              6: "dvo_hip::k_sweep_window<false, false, 4>", 5: "dvo_hip::k_residual_reduce_mfma", 0: "dvo_hip::k_residual_reduce"}
     what = ("64 x 16 tiles, the current frame's {I, Z} window staged in LDS, contracted f32 pixel arithmetic, Gram accumulation on the f16 matrix "
             "pipe: every component as an exact hi + lo pair") if variant >= 8 else "option variant=%d, see include/dvo_hip.h" % variant
@@ -718,10 +718,10 @@ def _per_kernel_rooflines(k_ms, pairs):
     """Every kernel that takes 3 % of the step or more, with its roofline: `achieved` / `frac` price a full launch at its ALGORITHMIC bytes
     (the 40 B per level-pixel of SURVEY.md 8(d) for the sweeps) -- for the four sweep levels from the launch times
     measured live above (HIP events), for the others from the in-situ rocprofv3 trace; `moved_GBps` / `moved_frac` are the bytes the
-    kernel really moved (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes over the bench loop: scripts/r5_rooflines.sh ->
-    profiles/r05_kernel_rooflines.json, which bench.py cannot collect itself)."""
+    kernel really moved (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes over the bench loop: scripts/r6_rooflines.sh ->
+    profiles/r06_kernel_rooflines.json, which bench.py cannot collect itself)."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r05_kernel_rooflines.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r06_kernel_rooflines.json")))
     except (OSError, ValueError):
         return None
     if rec.get("pairs") != pairs:
@@ -743,7 +743,7 @@ def _per_kernel_rooflines(k_ms, pairs):
         out.append(e)
     worst = min((e for e in out if e["frac"] is not None), key=lambda e: e["frac"], default=None)
     return {"kernels": out, "worst_at_algorithmic_bytes": None if worst is None else "%s (%d workgroups): %.3f" % (worst["kernel"], worst["workgroups"], worst["frac"]),
-            "source": "profiles/r05_kernel_rooflines.json + profiles/r05_kernel_rooflines.md"}
+            "source": "profiles/r06_kernel_rooflines.json + profiles/r06_kernel_rooflines.md"}
 
 
 def _pmc_traffic(pairs):
