@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock, WG_PER_CU) void k_match_coarse(const Coarse
 // what the kernel is built for: the contracted window sweep with packed residual pairs (tile height 16), or the gathering sweep with the
 // contracted arithmetic at kCoarseRowsPerWave rows per wavefront; no reciprocal table (option "ref_compat" stays on the launch path)
 bool coarse_kernel_takes(const LevelGeom& g, bool window_level) {
-  if (g.rcp_table || g.gram_hi_j) return false;
+  if (g.rcp_table || g.gram_hi_j || g.small) return false;   // (a small level's sweep reads plane C out of LDS, align_small.hip: no tile function of this kernel)
   if (window_level) return g.compact != 0 && !g.linear && fast_sweep_supports(g);
   const int th = kWavesPerBlock * kCoarseRowsPerWave;
   const int want_y = g.linear ? ((g.w * g.h + kTileW - 1) / kTileW + th - 1) / th : (g.h + th - 1) / th;

@@ -157,6 +157,7 @@ static void launch_rr(hipStream_t s, bool finest, const LevelGeom& g, const Pair
 
 // the sweep of this level has an instantiation that ends with the pairs' solver steps (launch_residual_reduce's own dispatch)
 bool sweep_has_tail(int variant, int rows_per_wave, const LevelGeom& g) {
+  if (g.small) return false;
   if (variant >= 8 && rows_per_wave == 4 && fast_sweep_supports(g)) return sweep_fast_has_tail(variant, g);
   if (variant >= 6 && rows_per_wave == 4 && window_sweep_supports(g)) return false;
   return variant >= 5 && mfma_sweep_has_tail(variant, rows_per_wave, g);
@@ -165,6 +166,10 @@ bool sweep_has_tail(int variant, int rows_per_wave, const LevelGeom& g) {
 void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
                             const PairState* states, int n_pairs, float* partials, float2* scratch, unsigned long long* window_fallbacks, int* f16_range_flag,
                             const SolverStepArgs* tail) {
+  if (g.small) {                                              // (the default schedule on a level small enough for LDS: align_small.hip)
+    launch_sweep_small(s, rows_per_wave, g, pairs, states, n_pairs, partials, scratch, f16_range_flag);
+    return;
+  }
   if (variant >= 8 && rows_per_wave == 4 && fast_sweep_supports(g)) {
     launch_sweep_fast(s, variant, g, pairs, states, n_pairs, partials, scratch, window_fallbacks, f16_range_flag, tail);
     return;

@@ -49,6 +49,14 @@ struct BatchPolicy {
   // the solver step of the smallest levels in two-wavefront workgroups: a batch beyond two four-wavefront workgroups per compute unit (512)
   bool solver_two_waves(int n) const { return n > 2 * cus; }
 
+  // workgroups per pair of a small level's sweep (align_small.hip: three 53-KB workgroups per compute unit): as many as give the batch whole
+  // rounds of the chip's slots -- 3 from one pair per compute unit on (1024 pairs: four rounds), 6 at half a pair (128 pairs: one round) --
+  // at most 8 (every workgroup copies the whole level into LDS first)
+  int small_level_tiles(int n) const {
+    const int t = (3 * cus + n / 2) / (n > 0 ? n : 1);
+    return t < 3 ? 3 : t > 8 ? 8 : t;
+  }
+
   // ---- a streaming caller (dvo_slam_amd/apps/stream_pipeline.cpp, bench.py) ----
   // the ingest of the next batch deferred behind the alignment's first launches: up to one pair per compute unit (256)
   int defer_ingest_max_pairs() const { return cus; }

@@ -416,6 +416,11 @@ struct dvo_hip_context {
   std::vector<GroupWorker*> group_workers;
   hipEvent_t roles_ready = nullptr;   // recorded behind ensure_batch_roles: the twins' streams wait for it
   long long grouped_batches = 0;
+  // 1: levels small enough for LDS run align_small.hip under the default schedule; 0 (default): the gathering sweep.  Measured level: an
+  // 80 x 60 launch of 1024 pairs 45-50 us against 46-48, of 128 pairs 10.2-11.3 against 9.0-9.5 -- three 53-KB workgroups per compute unit
+  // hide a row's latencies no better than the gathering sweep's eight wavefronts per SIMD hide its taps' 
+  int opt_small_sweep = 0;
+  int opt_small_tiles = 0;         // its workgroups per pair (0 = BatchPolicy::small_level_tiles)
   int opt_coarse = 0;              // the fused coarse-level kernel (align_coarse.hip): 0 = off (default: measured and lost), 1 = whenever the levels admit it
   int opt_coarse_pixels = 0;       // levels of up to this many pixels run in it (0 = kCoarseMaxPixels)
   int opt_coarse_wgs = 0;          // its workgroups per compute unit: 0 / 4 (128 registers) or 3 (168)
@@ -665,11 +670,18 @@ bool level_uses_fast_window(const dvo_hip_context* ctx, int w, int h) {
   return ctx->opt_variant >= 8 && fast_sweep_takes_width(w) && w < 32768 && h < 32768;   // (option "ref_compat" included: the COMPAT instantiations)
 }
 
+// the sweep with the whole current level in LDS (align_small.hip): the default schedule's levels that the window sweeps do not take
+bool level_uses_small(const dvo_hip_context* ctx, int w, int h);
+
 bool level_is_linear(const dvo_hip_context* ctx, int w) { return ctx->opt_variant >= 5 && w % kTileW != 0 && !level_uses_fast_window(ctx, w, 4); }
 
 // the sweep that stages the current frame's window in LDS (align_window.hip, variants 6 / 7; align_fast.hip) handles this level; its tile is 64 x 16
 bool level_uses_window(const dvo_hip_context* ctx, int w, int h) {
   return (ctx->opt_variant >= 6 && w % kTileW == 0 && w < 32768 && h < 32768) || level_uses_fast_window(ctx, w, h);
+}
+
+bool level_uses_small(const dvo_hip_context* ctx, int w, int h) {
+  return ctx->opt_small_sweep && ctx->opt_variant >= 8 && !ctx->opt_ref_compat && !level_uses_window(ctx, w, h) && level_is_linear(ctx, w) && small_sweep_takes(w, h);
 }
 
 LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int rows_per_wave) {
@@ -687,6 +699,7 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   g.rcp_packed = ctx->opt_ref_compat == 1 ? ctx->rcp_packed : 0;   // (2: the table through memory, the path of a table that does not pack)
   // (not under "ref_compat": a run that is compared with the reference's own numbers keeps every low part -- round-5 advisor finding)
   g.gram_hi_j = !ctx->opt_gram_lo_parts && !ctx->opt_deterministic && !ctx->opt_ref_compat && ctx->opt_variant == 8 && size_t(g.w) * g.h >= 150000 ? 1 : 0;
+  g.small = level_uses_small(ctx, g.w, g.h) ? 1 : 0;
   g.compact = ctx->opt_compact_residuals && ctx->opt_variant >= 8 && rows_per_wave == 4 && fast_sweep_supports(g) ? 1 : 0;   // (launch_residual_reduce's test)
   return g;
 }
@@ -695,6 +708,13 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
 // keep all 256 CUs busy when the batch is small
 int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_pairs) {
   if (level_uses_window(ctx, cam->w[level], cam->h[level])) return 4;
+  if (level_uses_small(ctx, cam->w[level], cam->h[level]) && ctx->opt_rows_per_wave == 0) {
+    // segments per wavefront such that a pair gets BatchPolicy::small_level_tiles workgroups
+    const int tiles = ctx->opt_small_tiles > 0 ? ctx->opt_small_tiles : BatchPolicy(ctx->compute_units).small_level_tiles(n_pairs);
+    const int segments = (cam->w[level] * cam->h[level] + kTileW - 1) / kTileW;
+    const int rows = (segments + kWavesPerBlock * tiles - 1) / (kWavesPerBlock * tiles);
+    return rows < 1 ? 1 : rows;
+  }
   if (ctx->opt_deterministic) return ctx->opt_rows_per_wave > 0 ? ctx->opt_rows_per_wave : 4;   // one tile height whatever the batch
   if (ctx->opt_rows_per_wave > 0) return ctx->opt_rows_per_wave;
   // A large batch fills the device whatever the tile: short tiles (2 rows per wavefront: the schedule with the pinned prologue) run the
@@ -715,6 +735,8 @@ int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int le
 
 // (whatever the schedule variant of the moment: a frame outlives option changes)
 static bool width_may_use_window(int w) { return w % kTileW == 0 || fast_sweep_takes_width(w); }
+// (... or the small-level sweep: both read plane C)
+static bool level_may_read_plane_c(int w, int h) { return width_may_use_window(w) || small_sweep_takes(w, h); }
 
 // device layout of a frame: [raw staging][per level: I Z A B R][sel counts]
 int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, dvo_hip_frame** out, size_t* raw_off) {
@@ -734,7 +756,7 @@ int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels
   for (int l = 0; l < levels; ++l) {
     const size_t n = size_t(cam->w[l]) * cam->h[l];
     // (C = {I, Z} of a current frame, the plane the window sweep stages in LDS: levels that sweep can handle)
-    const size_t sz[6] = {n * 4, n * 4, n * 16, n * 8, n * 8, width_may_use_window(cam->w[l]) ? n * 8 : 0};
+    const size_t sz[6] = {n * 4, n * 4, n * 16, n * 8, n * 8, level_may_read_plane_c(cam->w[l], cam->h[l]) ? n * 8 : 0};
     for (int k = 0; k < 6; ++k) {
       offs[l][k] = total;
       total += align_up(sz[k], 256);
@@ -766,7 +788,7 @@ int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels
     L.A = reinterpret_cast<float4*>(base + offs[l][2]);
     L.B = reinterpret_cast<float2*>(base + offs[l][3]);
     L.R = reinterpret_cast<float2*>(base + offs[l][4]);
-    L.C = width_may_use_window(cam->w[l]) ? reinterpret_cast<float2*>(base + offs[l][5]) : nullptr;
+    L.C = level_may_read_plane_c(cam->w[l], cam->h[l]) ? reinterpret_cast<float2*>(base + offs[l][5]) : nullptr;
   }
   f->sel_count = reinterpret_cast<int*>(base + cnt_off);
   *out = f;
@@ -801,6 +823,10 @@ bool aligned_to(const void* p, size_t a) { return reinterpret_cast<uintptr_t>(p)
 // write); a small one may run the level resident (taps A + B) or on the launch path (C): both.  Whatever is missing at match time is
 // derived then (ensure_roles).
 int eager_current_flavor(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_frames) {
+  // a small level (align_small.hip reads plane C): a batch that may still run this level in the resident kernel (the gathered taps) gets
+  // both flavours -- 38 KB and 115 KB per frame at 80 x 60 -- a larger one plane C alone
+  if (level_uses_small(ctx, cam->w[level], cam->h[level]))
+    return BatchPolicy(ctx->compute_units).resident_first_level_fits(n_frames) ? (kCurAB | kCurC) : kCurC;
   if (!level_uses_window(ctx, cam->w[level], cam->h[level])) return kCurAB;
   // (round 5: from an eighth as many frames as compute units on, plane C alone -- the taps cost three times the bytes to write, and a
   // streaming step of 32 / 48 / 64 pairs that re-ingests them every step is 0.885 / 0.98 / 1.24 -> 0.783 / 0.93 / 1.09 ms without them and
@@ -1129,7 +1155,7 @@ int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, 
   const int resident = launch_path_only ? 0 : resident_levels_of(ctx, cfg, cam, n, window_taps_missing(ctx, cfg, n, curs));
   int want[kMaxLevels];
   for (int l = 0; l < kMaxLevels; ++l)
-    want[l] = l > cfg->first_level - resident || l >= cam->levels || !level_uses_window(ctx, cam->w[l], cam->h[l]) ? kCurAB : kCurC;
+    want[l] = l > cfg->first_level - resident || l >= cam->levels || !(level_uses_window(ctx, cam->w[l], cam->h[l]) || level_uses_small(ctx, cam->w[l], cam->h[l])) ? kCurAB : kCurC;
   rc = ensure_roles(ctx, n, curs, 0, cfg->last_level, cfg->first_level, 0.0f, 0.0f, /*eager=*/false, want);
   if (rc == DVO_HIP_OK)
     rc = ensure_roles(ctx, n, refs, 1, cfg->last_level, cfg->first_level, cfg->intensity_derivative_threshold, cfg->depth_derivative_threshold);
@@ -1961,7 +1987,7 @@ void mirror_options(const dvo_hip_context* from, dvo_hip_context* to) {
   DVO_MIRROR(opt_condition_number); DVO_MIRROR(opt_fused_ll_pixels); DVO_MIRROR(opt_variant); DVO_MIRROR(opt_resident);
   DVO_MIRROR(opt_resident_rows); DVO_MIRROR(opt_resident_group); DVO_MIRROR(opt_resident_flags); DVO_MIRROR(opt_resident_cooperative);
   DVO_MIRROR(opt_sweep_tail); DVO_MIRROR(opt_coarse); DVO_MIRROR(opt_coarse_pixels); DVO_MIRROR(opt_coarse_wgs);
-  DVO_MIRROR(opt_deterministic); DVO_MIRROR(compute_units);
+  DVO_MIRROR(opt_deterministic); DVO_MIRROR(opt_small_sweep); DVO_MIRROR(opt_small_tiles); DVO_MIRROR(compute_units);
 #undef DVO_MIRROR
 }
 
@@ -2346,6 +2372,16 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
   if (std::strcmp(key, "resident") == 0) {
     if (value < -1 || value > 1) return fail(ctx, DVO_HIP_ERR_INVALID, "resident must be -1 (automatic), 0 (off) or 1 (every level)");
     ctx->opt_resident = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "small_sweep") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "small_sweep must be 0 or 1");
+    ctx->opt_small_sweep = value;
+    return DVO_HIP_OK;
+  }
+  if (std::strcmp(key, "small_tiles") == 0) {
+    if (value < 0 || value > 32) return fail(ctx, DVO_HIP_ERR_INVALID, "small_tiles must be 0 (by batch size) .. 32");
+    ctx->opt_small_tiles = value;
     return DVO_HIP_OK;
   }
   if (std::strcmp(key, "batch_groups") == 0) {
@@ -3193,7 +3229,7 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs, dvo_hip_frame* co
   hipEvent_t e0, e1;
   DVO_HIP_TRY(ctx, hipEventCreate(&e0));
   DVO_HIP_TRY(ctx, hipEventCreate(&e1));
-  const bool window_planes = level_uses_window(ctx, g.w, g.h);   // the planes the level's sweep really reads
+  const bool window_planes = level_uses_window(ctx, g.w, g.h) || level_uses_small(ctx, g.w, g.h);   // the planes the level's sweep really reads
   launch_stream_mix(s, pp, bp.n, g.w * g.h, scratch, sink, window_planes);   // warm
   DVO_HIP_TRY(ctx, hipEventRecord(e0, s));
   for (int r = 0; r < reps; ++r) launch_stream_mix(s, pp, bp.n, g.w * g.h, scratch, sink, window_planes);

@@ -59,6 +59,8 @@ struct LevelGeom {                    // identical for every pair of a batch (on
   // then moves half the bytes.  Contracted window sweep only (align_fast.hip); 0 = one pair per pixel at its pixel's place, NaN
   // where there is no constraint (every other sweep, and whenever the caller wants the residuals by pixel).
   int compact;
+  // 1: a SMALL level of the default schedule (align_small.hip): the whole current level staged in LDS, walked linearly
+  int small;
   // 1: the contracted window sweep forms its Gram operands from the f16 HIGH parts of the twelve Jacobian components alone (the two
   // residual components keep high + low parts): levels of 150 000 pixels and more, where the rounding of a component (2^-12, at random)
   // averages out over the constraints -- align_fast.hip, fast_gram_row; option "gram_lo_parts" 1 keeps every low part

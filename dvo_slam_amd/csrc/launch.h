@@ -67,6 +67,11 @@ bool fast_sweep_supports(const LevelGeom& g);
 void launch_sweep_fast(hipStream_t s, int variant, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
                        float* partials, float2* scratch, unsigned long long* fallback_count, int* f16_range_flag = nullptr,
                        const SolverStepArgs* tail = nullptr);
+// align_small.hip: a level small enough for the whole current plane C to live in LDS ((w + 2) x (h + 2) cells of 8 B <= 43 KB, even width:
+// 80 x 60, 40 x 30 ...), walked linearly, rows_per_wave segments per wavefront and workgroup; contracted arithmetic, f16 Gram, residual pairs by pixel
+bool small_sweep_takes(int w, int h);
+void launch_sweep_small(hipStream_t s, int rows_per_wave, const LevelGeom& g, const PairPtrs* pairs, const PairState* states, int n_pairs,
+                        float* partials, float2* scratch, int* f16_range_flag = nullptr);
 // scratch == null: read-only (one float per workgroup goes to `sink`, which must hold a float per (8 * 256)-pixel block)
 // window_planes: the planes the window sweep reads (reference 8 B + current {I, Z} 8 B) instead of the gathering sweep's 8 + 16 + 8 B
 void launch_stream_mix(hipStream_t s, const PairPtrs* pairs, int n_pairs, int n_px, float2* scratch, float* sink, bool window_planes = false);

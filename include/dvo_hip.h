@@ -333,6 +333,11 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * many frames leaves them -- the coarsest one (DVO_HIP_TRACE_PLAN in the environment prints the plan of every batch to stderr); 0: one to three launches per Gauss-Newton step always; 1: every level resident), "resident_rows" (a level runs resident when a sweeping wavefront gets at most this many 64-pixel segments per
  * pass; default 24), "resident_group" (workgroups per pair, a power of two <= 64; 0 = as many as fit the device),
  * "resident_cooperative" (1: groups are launched with hipLaunchCooperativeKernel), "resident_flags" (measurement / test hooks).
+ * "small_sweep" (default 0; 1: under the default schedule a pyramid level small enough for its whole current plane {I, Z} to live in LDS --
+ * even width, (w + 2) x (h + 2) cells of 8 B within 43 KB: 80 x 60, 40 x 30 -- is swept by dvo_slam_amd/csrc/align_small.hip: a workgroup
+ * copies the level into LDS once and finds every tap there, one memory round trip per pixel row instead of the gathering sweep's two.  Same
+ * function, rounding differences of a few ulp in the blended gradients.  Off by default: measured level with the gathering sweep -- 45-50 us
+ * against 46-48 per 1024-pair launch -- DESIGN.md section 10), "small_tiles" (its workgroups per pair; 0 = by batch size, 3 .. 8),
  * "batch_groups" (default 0 = one group; 2 .. 4: a batch is aligned as that many sub-batches AT ONCE (of at least 64 pairs each) -- the
  * caller's thread runs the first on this context, helper threads the others on twin contexts of the same device (own stream, own
  * scratch; created when first needed), the way the reference spreads independent match() calls over the workers of a

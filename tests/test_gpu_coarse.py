@@ -70,6 +70,7 @@ def test_coarse_kernel_records_are_the_launch_path_s_bit_for_bit(ctx, w, h, firs
     cfg = d.Config(FirstLevel=first, LastLevel=last, Mu=mu, UseInitialEstimate=init, Precision=precision, MaxIterationsPerLevel=50 if init else 100)
     T0 = [po.se3_exp(0.5 * np.asarray(b["xi_true"][i])) for i in range(n)] if init else None
     ctx.set_option("resident", 0)
+    ctx.set_option("small_sweep", 0)                   # (the fused kernel has the gathering sweep for small levels, not align_small.hip's)
     ctx.set_option("rows_per_wave", 2)                 # the fused kernel's tile height on the levels that gather their taps
     ctx.set_option("coarse", 0)
     before, levels_before = ctx.counter("coarse_launches"), ctx.counter("coarse_levels")
@@ -105,6 +106,7 @@ def test_the_fused_kernel_is_opt_in_and_declines_what_it_has_no_instantiation_fo
     trk = d.DenseTracker(d.Config(FirstLevel=3, LastLevel=0), ctx)
     order = [i % n for i in range(160)]
     before = ctx.counter("coarse_launches")
+    ctx.set_option("small_sweep", 0)
     base = trk.match_batch_arrays([refs[i] for i in order], [curs[i] for i in order])
     assert ctx.counter("coarse_launches") == before
     ctx.set_option("coarse", 1)
@@ -137,6 +139,7 @@ def test_pairs_leave_the_fused_kernel_independently(ctx):
                 cam.create_raw(flat, b["depth_cur"][2]), cam.create_raw(b["grey_cur"][2], b["depth_cur"][2])]
     cfg = d.Config(FirstLevel=3, LastLevel=0)
     ctx.set_option("resident", 0)
+    ctx.set_option("small_sweep", 0)
     ctx.set_option("rows_per_wave", 2)
     ctx.set_option("coarse", 1)
     together = raw_match(ctx, cfg, frames_r, frames_c)

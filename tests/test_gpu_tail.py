@@ -40,6 +40,7 @@ def test_step_in_the_sweep_s_launch_gives_the_two_launch_records_bit_for_bit(ctx
     cfg = d.Config(FirstLevel=first, LastLevel=last, Mu=mu, UseInitialEstimate=init, Precision=precision, MaxIterationsPerLevel=50 if init else 100)
     T0 = [po.se3_exp(0.5 * np.asarray(b["xi_true"][i])) for i in order] if init else None
     ctx.set_option("resident", 0)
+    ctx.set_option("small_sweep", 0)                   # (the gathering sweep on the small levels: the one with a tail)
     ctx.set_option("sweep_tail", 0)
     before = ctx.counter("tail_steps")
     base = raw_match(ctx, cfg, refs, curs, T0)
