@@ -1978,130 +1978,7 @@ struct EffectiveVariantScope {
   ~EffectiveVariantScope() { c->opt_variant = keep; }
 };
 
-// ---- concurrent pair groups (dvo_hip_context::opt_batch_groups) -----------------------------------------------------------------------
-// the options a group's twin context aligns with: the owner's, as they are in effect for this batch
-void mirror_options(const dvo_hip_context* from, dvo_hip_context* to) {
-#define DVO_MIRROR(f) to->f = from->f
-  DVO_MIRROR(opt_rows_per_wave); DVO_MIRROR(opt_iters_per_sync); DVO_MIRROR(opt_tail_speculation); DVO_MIRROR(opt_solver_waves);
-  DVO_MIRROR(opt_ll_blocks); DVO_MIRROR(opt_compact_residuals); DVO_MIRROR(opt_gram_lo_parts); DVO_MIRROR(opt_min_workgroups);
-  DVO_MIRROR(opt_condition_number); DVO_MIRROR(opt_fused_ll_pixels); DVO_MIRROR(opt_variant); DVO_MIRROR(opt_resident);
-  DVO_MIRROR(opt_resident_rows); DVO_MIRROR(opt_resident_group); DVO_MIRROR(opt_resident_flags); DVO_MIRROR(opt_resident_cooperative);
-  DVO_MIRROR(opt_sweep_tail); DVO_MIRROR(opt_coarse); DVO_MIRROR(opt_coarse_pixels); DVO_MIRROR(opt_coarse_wgs);
-  DVO_MIRROR(opt_deterministic); DVO_MIRROR(opt_small_sweep); DVO_MIRROR(opt_small_tiles); DVO_MIRROR(compute_units);
-#undef DVO_MIRROR
-}
-
-void group_worker_main(GroupWorker* gw) {
-  (void)hipSetDevice(gw->twin->device);
-  for (;;) {
-    std::unique_lock<std::mutex> lock(gw->m);
-    gw->cv.wait(lock, [&] { return gw->has_job || gw->quit; });
-    if (gw->quit) return;
-    gw->has_job = false;
-    lock.unlock();
-    dvo_hip_context* t = gw->twin;
-    t->batch_entry = std::chrono::steady_clock::now();
-    int rc = DVO_HIP_OK;
-    if (hipStreamWaitEvent(t->stream, gw->after, 0) != hipSuccess) {
-      t->err = "match: a pair group could not wait for the batch's role planes";
-      rc = DVO_HIP_ERR_HIP;
-    }
-    if (rc == DVO_HIP_OK) {
-      rc = run_batch(t, gw->n, gw->refs, gw->curs, gw->cfg, gw->results, gw->levels, gw->cap_levels, gw->iters, gw->cap_iters);
-      if (rc != DVO_HIP_OK) t->err = t->ws[0].err;
-    }
-    lock.lock();
-    gw->rc = rc;
-    gw->done = true;
-    lock.unlock();
-    gw->cv.notify_all();
-  }
-}
-
-// how many groups a batch of n pairs is aligned in
-int batch_groups_of(const dvo_hip_context* ctx, int n) {
-  if (ctx->is_twin || ctx->opt_ref_compat || ctx->opt_deterministic) return 1;   // (the reciprocal table lives in the owner; one schedule per pair)
-  // Asked for by name only.  Measured (round 6, streaming loop, one box): 1024 pairs 11.75 -> 11.1-11.9 ms per step with two groups,
-  // 11.4-12.0 with three -- groups that start together stay in phase, and two sweeps of the same level side by side gain nothing; the
-  // gain of several contexts on one GPU comes from running OUT of phase, which a streaming caller gets from lanes
-  // (dvo_slam_amd/apps/stream_pipeline.cpp, dvo_stream_lanes_*: 11.3 -> 10.8).
-  return ctx->opt_batch_groups > 1 ? std::min(ctx->opt_batch_groups, std::max(1, n / 64)) : 1;
-}
-
-int ensure_group_workers(dvo_hip_context* ctx, int groups) {
-  while (int(ctx->group_workers.size()) < groups - 1) {
-    dvo_hip_context* twin = nullptr;
-    const int rc = dvo_hip_context_create(ctx->device, &twin);
-    if (rc != DVO_HIP_OK) return fail(ctx, rc, "match: could not create a pair group's context");
-    twin->is_twin = true;
-    GroupWorker* gw = new GroupWorker();
-    gw->twin = twin;
-    gw->thread = std::thread(group_worker_main, gw);
-    ctx->group_workers.push_back(gw);
-  }
-  if (!ctx->roles_ready) DVO_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->roles_ready, hipEventDisableTiming));
-  return DVO_HIP_OK;
-}
-
-void destroy_group_workers(dvo_hip_context* ctx) {
-  for (GroupWorker* gw : ctx->group_workers) {
-    {
-      std::lock_guard<std::mutex> lock(gw->m);
-      gw->quit = true;
-    }
-    gw->cv.notify_all();
-    if (gw->thread.joinable()) gw->thread.join();
-    dvo_hip_context_destroy(gw->twin);
-    delete gw;
-  }
-  ctx->group_workers.clear();
-  if (ctx->roles_ready) (void)hipEventDestroy(ctx->roles_ready);
-  ctx->roles_ready = nullptr;
-}
-
-// the batch as `groups` sub-batches at once: pairs [0, n_0) on the caller's thread and context, the other slices on the helpers
-int run_batch_grouped(dvo_hip_context* ctx, int groups, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
-                      dvo_hip_result* results, dvo_hip_level_stats* levels, int cap_levels, dvo_hip_iteration_stats* iters, int cap_iters) {
-  int rc = ensure_group_workers(ctx, groups);
-  if (rc != DVO_HIP_OK) return rc;
-  DVO_HIP_TRY(ctx, hipEventRecord(ctx->roles_ready, ctx->stream));
-  const int base = n / groups, extra = n % groups;             // slice g: base pairs, the first `extra` slices one more
-  const int n0 = base + (extra > 0 ? 1 : 0);
-  int at = n0;
-  for (int g = 1; g < groups; ++g) {
-    GroupWorker* gw = ctx->group_workers[g - 1];
-    const int m = base + (g < extra ? 1 : 0);
-    mirror_options(ctx, gw->twin);
-    {
-      std::lock_guard<std::mutex> lock(gw->m);
-      gw->n = m;
-      gw->refs = refs + at; gw->curs = curs + at; gw->cfg = cfg; gw->results = results + at;
-      gw->levels = levels && cap_levels > 0 ? levels + size_t(at) * cap_levels : nullptr;
-      gw->iters = iters && cap_iters > 0 ? iters + size_t(at) * cap_iters : nullptr;
-      gw->cap_levels = cap_levels; gw->cap_iters = cap_iters;
-      gw->after = ctx->roles_ready;
-      gw->done = false;
-      gw->has_job = true;
-    }
-    gw->cv.notify_all();
-    at += m;
-  }
-  ctx->grouped_batches += 1;
-  rc = run_batch(ctx, n0, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
-  if (rc != DVO_HIP_OK) ctx->err = ctx->ws[0].err;
-  for (int g = 1; g < groups; ++g) {                          // every helper is awaited whatever the outcome: its slice of the caller's arrays is in use
-    GroupWorker* gw = ctx->group_workers[g - 1];
-    std::unique_lock<std::mutex> lock(gw->m);
-    gw->cv.wait(lock, [&] { return gw->done; });
-    if (gw->rc != DVO_HIP_OK && (rc == DVO_HIP_OK || rc == DVO_HIP_ERR_CAPACITY)) {
-      rc = gw->rc;
-      ctx->err = gw->twin->err;
-    }
-    ctx->f16_range_repeats += gw->twin->f16_range_repeats;
-    gw->twin->f16_range_repeats = 0;
-  }
-  return rc;
-}
+#include "capi_groups.inc"   // concurrent pair groups (option "batch_groups"): run_batch_grouped, destroy_group_workers
 
 // preparation for the parity / measurement entry points
 int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg, BatchPlan& bp) {
@@ -2121,48 +1998,7 @@ int prepare_single(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_
 
 extern "C" {
 
-int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value) {
-  if (!ctx || !key || !value) return DVO_HIP_ERR_INVALID;
-  std::unique_lock<std::recursive_mutex> guard(ctx->mutex);
-  if (std::strcmp(key, "resident_launches") == 0) *value = ctx->resident_launches;
-  else if (std::strcmp(key, "resident_levels") == 0) *value = ctx->resident_levels;
-  else if (std::strcmp(key, "resident_timeouts") == 0) *value = ctx->resident_timeouts;
-  else if (std::strcmp(key, "grouped_batches") == 0) *value = ctx->grouped_batches;
-  // (what the batch-size policy says for this context's device, for callers that stream: batch_policy.h)
-  else if (std::strcmp(key, "compute_units") == 0) *value = BatchPolicy(ctx->compute_units).cus;
-  else if (std::strcmp(key, "defer_ingest_max_pairs") == 0) *value = BatchPolicy(ctx->compute_units).defer_ingest_max_pairs();
-  else if (std::strcmp(key, "background_build_workgroups") == 0) *value = BatchPolicy(ctx->compute_units).background_build_workgroups();
-  else if (std::strcmp(key, "tail_steps") == 0) {
-    *value = ctx->tail_steps;
-    for (const GroupWorker* gw : ctx->group_workers) *value += gw->twin->tail_steps;
-  }
-  else if (std::strcmp(key, "coarse_launches") == 0) *value = ctx->coarse_launches;
-  else if (std::strcmp(key, "coarse_levels") == 0) *value = ctx->coarse_levels;
-  else if (std::strcmp(key, "window_fallbacks") == 0) {
-    unsigned long long v = 0;
-    if (ctx->ws[0].win_fallbacks.p) {
-      DVO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      DVO_HIP_TRY(ctx, hipMemcpy(&v, ctx->ws[0].win_fallbacks.p, sizeof(v), hipMemcpyDeviceToHost));
-    }
-    *value = (long long)v;
-  }
-  else if (std::strcmp(key, "strip_ingests") == 0) *value = ctx->strip_ingests;
-  else if (std::strcmp(key, "warmup_wait_us") == 0) *value = ctx->warmup_wait_us;
-  else if (std::strcmp(key, "rendezvous_pairs") == 0) {
-    std::lock_guard<std::mutex> lock(ctx->rendezvous_mutex);
-    *value = ctx->rendezvous_pairs;
-  }
-  else if (std::strcmp(key, "f16_range_repeats") == 0) *value = ctx->f16_range_repeats;
-  else if (std::strcmp(key, "table_uploads_skipped") == 0) *value = ctx->tables.skipped;
-  else if (std::strcmp(key, "deferred_ingests") == 0) *value = ctx->deferred_ingests;
-  else if (std::strcmp(key, "host_batches") == 0) *value = ctx->host_batches;
-  else if (std::strcmp(key, "host_ns_prepare") == 0) *value = ctx->host_ns[0];
-  else if (std::strcmp(key, "host_ns_enqueue") == 0) *value = ctx->host_ns[1];
-  else if (std::strcmp(key, "host_ns_wait") == 0) *value = ctx->host_ns[2];
-  else if (std::strcmp(key, "host_ns_finish") == 0) *value = ctx->host_ns[3];
-  else return fail(ctx, DVO_HIP_ERR_INVALID, "unknown counter");
-  return DVO_HIP_OK;
-}
+int dvo_hip_get_counter(dvo_hip_context* ctx, const char* key, long long* value);   // (capi_options.inc, below)
 
 const char* dvo_hip_version(void) { return "dvo_hip 0.1 (gfx950)"; }
 
@@ -2328,201 +2164,8 @@ void* dvo_hip_context_stream(dvo_hip_context* ctx) { return ctx ? static_cast<vo
 
 int dvo_hip_context_device(const dvo_hip_context* ctx) { return ctx ? ctx->device : -1; }
 
-int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value) {
-  std::unique_lock<std::recursive_mutex> guard;
-  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
-  if (!ctx || !key) return DVO_HIP_ERR_INVALID;
-  if (std::strcmp(key, "rows_per_wave") == 0) {
-    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
-      return fail(ctx, DVO_HIP_ERR_INVALID, "rows_per_wave must be 0,1,2,4,8,16");
-    ctx->opt_rows_per_wave = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "iters_per_sync") == 0) {
-    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "iters_per_sync must be >= 0");
-    ctx->opt_iters_per_sync = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "variant") == 0) {
-    if (value != 0 && (value < 5 || value > 9))
-      return fail(ctx, DVO_HIP_ERR_INVALID, "variant must be 0 (all-VALU schedule), 5 (matrix-core schedule), 6 or 7 (current-frame window staged in LDS, residuals bit-identical to the oracle's), 8 or 9 (the same with contracted arithmetic)");
-    ctx->opt_variant = value;
-    ctx->f32_gram_hold = 0;                                    // (a schedule asked for by name starts without history)
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "rendezvous") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "rendezvous must be 0 or 1");
-    ctx->opt_rendezvous = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "deterministic") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "deterministic must be 0 or 1");
-    ctx->opt_deterministic = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "ref_compat") == 0) {
-    if (value < 0 || value > 2) return fail(ctx, DVO_HIP_ERR_INVALID, "ref_compat must be 0, 1 or 2 (2: as 1, the table read through memory by every sweep)");
-    if (value && !ctx->rcp_table.p) {
-      const int rc = build_rcp_table(ctx);
-      if (rc != DVO_HIP_OK) return rc;
-    }
-    ctx->opt_ref_compat = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "resident") == 0) {
-    if (value < -1 || value > 1) return fail(ctx, DVO_HIP_ERR_INVALID, "resident must be -1 (automatic), 0 (off) or 1 (every level)");
-    ctx->opt_resident = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "small_sweep") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "small_sweep must be 0 or 1");
-    ctx->opt_small_sweep = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "small_tiles") == 0) {
-    if (value < 0 || value > 32) return fail(ctx, DVO_HIP_ERR_INVALID, "small_tiles must be 0 (by batch size) .. 32");
-    ctx->opt_small_tiles = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "batch_groups") == 0) {
-    if (value < 0 || value > 4) return fail(ctx, DVO_HIP_ERR_INVALID, "batch_groups must be 0 or 1 (one group) .. 4");
-    ctx->opt_batch_groups = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "solver_occupancy") == 0) {
-    if (value != 0 && value != 3) return fail(ctx, DVO_HIP_ERR_INVALID, "solver_occupancy must be 0 or 3");
-    g_solver_occupancy = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "sweep_tail") == 0) {
-    if (value < 0 || value > 2) return fail(ctx, DVO_HIP_ERR_INVALID, "sweep_tail must be 0, 1 (the whole step in the sweep's tail) or 2 (its wide half; the serial half in a launch behind it)");
-    ctx->opt_sweep_tail = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "coarse") == 0) {
-    if (value < 0 || value > 1) return fail(ctx, DVO_HIP_ERR_INVALID, "coarse must be 0 (off) or 1 (whenever the levels admit it)");
-    ctx->opt_coarse = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "coarse_pixels") == 0) {
-    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "coarse_pixels must be >= 0");
-    ctx->opt_coarse_pixels = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "coarse_workgroups") == 0) {
-    if (value != 0 && value != 3 && value != 4) return fail(ctx, DVO_HIP_ERR_INVALID, "coarse_workgroups must be 0, 3 or 4");
-    ctx->opt_coarse_wgs = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "resident_flags") == 0) {
-    ctx->opt_resident_flags = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "resident_cooperative") == 0) {
-    ctx->opt_resident_cooperative = value != 0;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "resident_rows") == 0) {
-    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "resident_rows must be >= 0");
-    ctx->opt_resident_rows = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "resident_group") == 0) {
-    if (value < 0 || value > kResidentMaxGroup || (value & (value - 1))) return fail(ctx, DVO_HIP_ERR_INVALID, "resident_group must be 0 or a power of two <= 64");
-    ctx->opt_resident_group = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "build_workgroups") == 0) {
-    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "build_workgroups must be >= 0");
-    ctx->opt_build_workgroups = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "tail_speculation") == 0) {
-    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "tail_speculation must be >= 0");
-    ctx->opt_tail_speculation = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "solver_waves") == 0) {
-    if (value != 0 && value != 2 && value != 4) return fail(ctx, DVO_HIP_ERR_INVALID, "solver_waves must be 0, 2 or 4");
-    ctx->opt_solver_waves = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "ll_blocks") == 0) {
-    if (value < 0 || value > kLlBlocksPerPair) return fail(ctx, DVO_HIP_ERR_INVALID, "ll_blocks must be 0..32");
-    ctx->opt_ll_blocks = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "gram_lo_parts") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "gram_lo_parts must be 0 or 1");
-    ctx->opt_gram_lo_parts = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "compact_residuals") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "compact_residuals must be 0 or 1");
-    ctx->opt_compact_residuals = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "min_workgroups") == 0) {
-    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "min_workgroups must be >= 0");
-    ctx->opt_min_workgroups = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "condition_number") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "condition_number must be 0 or 1");
-    ctx->opt_condition_number = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "defer_ingest") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "defer_ingest must be 0 or 1");
-    ctx->opt_defer_ingest = value;
-    if (!value) DVO_FLUSH_DEFERRED(ctx);
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "keep_raw_copy") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "keep_raw_copy must be 0 or 1");
-    ctx->opt_keep_raw_copy = value;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "table_cache") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, DVO_HIP_ERR_INVALID, "table_cache must be 0 or 1");
-    ctx->tables.cache = value != 0;
-    for (PinnedRing::Sent& c : ctx->tables.sent) c.dst = nullptr;
-    return DVO_HIP_OK;
-  }
-  if (std::strcmp(key, "fused_ll_pixels") == 0) {
-    if (value < 0) return fail(ctx, DVO_HIP_ERR_INVALID, "fused_ll_pixels must be >= 0");
-    ctx->opt_fused_ll_pixels = value;
-    return DVO_HIP_OK;
-  }
-  return fail(ctx, DVO_HIP_ERR_INVALID, "unknown option");
-}
+#include "capi_options.inc"   // dvo_hip_get_counter, dvo_hip_set_option
 
-int dvo_hip_frame_create_f32(dvo_hip_context* ctx, int width, int height, const float K[4], const float* intensity,
-                             const float* depth, int levels, dvo_hip_frame** out) {
-  std::unique_lock<std::recursive_mutex> guard;
-  if (ctx) guard = std::unique_lock<std::recursive_mutex>(ctx->mutex);
-  DVO_FLUSH_DEFERRED(ctx);
-  if (!ctx || !out || !intensity || !depth || !K) return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create_f32: null argument");
-  size_t raw_off;
-  dvo_hip_frame* f = nullptr;
-  int rc = frame_alloc(ctx, width, height, K, levels, &f, &raw_off);
-  if (rc != DVO_HIP_OK) return rc;
-  const size_t n = size_t(width) * height;
-  hipError_t e = hipMemcpyAsync(f->lv[0].I, intensity, n * 4, hipMemcpyHostToDevice, ctx->build_stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(f->lv[0].Z, depth, n * 4, hipMemcpyHostToDevice, ctx->build_stream);
-  if (e == hipSuccess) e = hipMemsetAsync(f->sel_count, 0, sizeof(int) * kMaxLevels, ctx->build_stream);
-  if (e == hipSuccess) {
-    rc = frames_build(ctx, 1, &f, nullptr, nullptr, 0.0f);
-    if (rc == DVO_HIP_OK) e = sync_stream(ctx->build_stream);   // the caller's host buffers may go away
-  }
-  if (e != hipSuccess) ctx->err = std::string("frame_create_f32: ") + hipGetErrorString(e);
-  if (e != hipSuccess || rc != DVO_HIP_OK) {
-    dvo_hip_frame_destroy(ctx, f);
-    return rc != DVO_HIP_OK ? rc : DVO_HIP_ERR_HIP;
-  }
-  *out = f;
-  return DVO_HIP_OK;
-}
 
 int dvo_hip_frame_create_raw(dvo_hip_context* ctx, int width, int height, const float K[4], const uint8_t* grey,
                              const uint16_t* raw_depth, float depth_scale, int levels, dvo_hip_frame** out) {

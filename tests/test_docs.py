@@ -43,7 +43,7 @@ def test_reference_citations_stay_within_the_cited_files():
 
 def test_every_option_and_counter_key_is_documented_in_the_header():
     """include/dvo_hip.h names every key dvo_hip_set_option and dvo_hip_get_counter accept (the parser in capi.hip is the list)."""
-    src = open(os.path.join(ROOT, "dvo_slam_amd", "csrc", "capi.hip")).read()
+    src = open(os.path.join(ROOT, "dvo_slam_amd", "csrc", "capi_options.inc")).read()      # (textually included by capi.hip)
     header = open(os.path.join(ROOT, "include", "dvo_hip.h")).read()
     documented = set(re.findall(r'"([a-z_0-9]+)"', header))
     for entry in ("int dvo_hip_set_option(", "int dvo_hip_get_counter("):
