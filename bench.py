@@ -265,11 +265,34 @@ def main():
     gatherer = None
     if gathering and gather_kind == "native":
         # the communicator's 128-byte id travels once through the launcher's process group; every gather after that is the library's own
-        uid = torch.zeros(128, dtype=torch.uint8, device=comm_dev)
+        # A rank on which the library cannot set the communicator up (no librccl beside the library, an id that did not arrive) must not
+        # leave the others waiting inside a collective: every step below is followed by an agreement of all ranks, and without it all of
+        # them take torch.distributed's all-gather instead (reported in the line: config.parallelism).
+        def agreed(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=comm_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+        uid, why = torch.zeros(128, dtype=torch.uint8, device=comm_dev), ""
         if rank == 0:
-            uid = torch.frombuffer(bytearray(parallel.NativeRecordGatherer.unique_id(ctx)), dtype=torch.uint8).to(comm_dev)
+            try:
+                uid = torch.frombuffer(bytearray(parallel.NativeRecordGatherer.unique_id(ctx)), dtype=torch.uint8).to(comm_dev)
+            except Exception as e:                                      # noqa: BLE001 -- whatever it is, the ranks must agree on it
+                why = str(e)
         dist.broadcast(uid, src=0)
-        gatherer = parallel.NativeRecordGatherer(ctx, bytes(uid.cpu().numpy().tobytes()), n_total, rank, world)
+        if agreed(bool(uid.any().item())):
+            try:
+                gatherer = parallel.NativeRecordGatherer(ctx, bytes(uid.cpu().numpy().tobytes()), n_total, rank, world)
+            except Exception as e:                                      # noqa: BLE001
+                why = str(e)
+            if not agreed(gatherer is not None):
+                if gatherer is not None:
+                    gatherer.close()
+                gatherer = None
+        if gatherer is None:
+            if why:
+                print("bench.py: rank %d: native record gather unavailable (%s); all ranks use torch.distributed" % (rank, why), file=sys.stderr)
+            gather_kind = "torch"
+            gatherer = parallel.RecordGatherer(n_total, rank, world, device=comm_dev)
     elif gathering:
         gatherer = parallel.RecordGatherer(n_total, rank, world, device=comm_dev)
 
