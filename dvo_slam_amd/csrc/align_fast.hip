@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256, COMPAT == 2 ? 4 : 5) void k_sweep_fast(
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int item = xcd * blocks_per_xcd + slot;
   if (item >= total) return;
-  const int pair = item / tiles, tile = item - pair * tiles;
+  const int entry = item / tiles, tile = item - entry * tiles;
+  const int pair = pair_of_launch_index(g, entry);           // (a level's overlapped tail: the launch covers a list of pairs)
+  if (pair < 0) return;
   const PairState& st = states[pair];
   __shared__ __attribute__((aligned(16))) float slab[4][kSlabFloatsF16];
   __shared__ __attribute__((aligned(16))) float2 win[kFastCells];

@@ -163,6 +163,14 @@ bool sweep_has_tail(int variant, int rows_per_wave, const LevelGeom& g) {
   return variant >= 5 && mfma_sweep_has_tail(variant, rows_per_wave, g);
 }
 
+// (the kernels that read LevelGeom::pair_list: k_sweep_fast and k_residual_reduce_mfma -- what launch_residual_reduce picks below for
+// the default schedule, variants 8 / 9, on every level but those of the opt-in small-level sweep and widths of 64 the exact window sweep takes)
+bool sweep_takes_pair_list(int variant, int rows_per_wave, const LevelGeom& g) {
+  if (variant < 8 || g.small) return false;
+  if (rows_per_wave == 4 && fast_sweep_supports(g)) return true;
+  return !(rows_per_wave == 4 && window_sweep_supports(g));
+}
+
 void launch_residual_reduce(hipStream_t s, int variant, int rows_per_wave, bool finest, const LevelGeom& g, const PairPtrs* pairs,
                             const PairState* states, int n_pairs, float* partials, float2* scratch, unsigned long long* window_fallbacks, int* f16_range_flag,
                             const SolverStepArgs* tail) {

@@ -37,7 +37,9 @@ __global__ __launch_bounds__(kBlock, TAIL ? 5 : 1) void k_residual_reduce_mfma(
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int item = xcd * blocks_per_xcd + slot;
   if (item >= total) return;
-  const int pair = item / tiles, tile = item - pair * tiles;
+  const int entry = item / tiles, tile = item - entry * tiles;
+  const int pair = pair_of_launch_index(g, entry);           // (a level's overlapped tail: the launch covers a list of pairs)
+  if (pair < 0) return;
   const PairState& st = states[pair];
   constexpr int kSlabBytes = kWavesPerBlock * mfma_slab_floats<MODE>() * 4;
   constexpr int kLdsFloats = TAIL && int(sizeof(SweepTailLds)) + 16 > kSlabBytes ? (int(sizeof(SweepTailLds)) + 16 + 3) / 4 : kSlabBytes / 4;   // (the step's LDS lies over the slabs)

@@ -306,6 +306,11 @@ struct Workspace {
   bool device_may_lag = true;      // the last batch returned without waiting for the stream (the resident kernel's direct path)
   int resident_error_word = 0;     // index of the current resident launch's error word in host_status (a ring, see kResidentErrorWords)
   unsigned resident_launch_counter = 0;
+  // the overlapped tail of a level (run_batch, option "overlap_tails"): the stragglers' steps run on a stream of their own beside the
+  // next level's, with partial rows and residual pairs of their own (two levels index those by different tile counts)
+  hipStream_t tail_stream = nullptr;
+  hipEvent_t tail_split = nullptr, tail_end = nullptr;
+  DevBuf tail_partials, tail_scratch, tail_flags, tail_list;
 };
 
 // a helper thread of the concurrent pair groups (dvo_hip_context::opt_batch_groups) and the slice of the caller's batch it aligns
@@ -407,6 +412,15 @@ struct dvo_hip_context {
   // in is built for 96 (five workgroups per compute unit), and the spilled step takes 40-50 us instead of 15
   int opt_sweep_tail = 0;
   long long tail_steps = 0;        // Gauss-Newton steps enqueued as ONE launch (sweep with a tail)
+  // The overlapped tail of a level (round 6, run_batch): once at most opt_overlap_fraction-th of a large batch's pairs is still on a level, the
+  // others begin the next level and the stragglers finish theirs beside it, on a stream of their own -- each pair leaves its level
+  // independently, like the reference's match() calls do (dense_tracking.cpp:357).  0: off; 1: on (levels whose log-likelihood pass
+  // runs inside the solver step, batches beyond the solver steps' hand-over).
+  int opt_overlap_tails = 0;
+  int opt_overlap_fraction = 8;
+  long long overlapped_tails = 0;  // levels whose tail ran beside the next level (counter "overlapped_tails")
+  long long overlapped_steps = 0;  // Gauss-Newton steps enqueued on the tail stream (counter "overlapped_steps")
+  long long tail_drains = 0;       // times the main chain had to wait for a tail (counter "tail_drains")
   // Concurrent pair groups (round 6): a large batch is aligned as two or three sub-batches at once -- the caller's thread runs the first
   // on this context, helper threads the others on TWIN contexts (same device, own stream, own scratch), like the reference spreads
   // independent match() calls over the workers of a tbb::parallel_reduce (dvo_slam/src/keyframe_graph.cpp:576-593).  Option
@@ -540,8 +554,15 @@ void workspace_destroy(Workspace& w) {
   (void)hipStreamSynchronize(w.stream);
   for (DevBuf& b : w.pair_ptrs) b.release();
   for (DevBuf* b : {&w.states, &w.partials, &w.scratch, &w.ll_partials, &w.lvl_stats, &w.it_stats, &w.results,
-                    &w.t_init, &w.counters, &w.exchange, &w.win_fallbacks, &w.pair_sums})
+                    &w.t_init, &w.counters, &w.exchange, &w.win_fallbacks, &w.pair_sums, &w.tail_partials, &w.tail_scratch, &w.tail_flags, &w.tail_list})
     b->release();
+  if (w.tail_stream) {
+    (void)hipStreamSynchronize(w.tail_stream);
+    (void)hipStreamDestroy(w.tail_stream);
+    (void)hipEventDestroy(w.tail_split);
+    (void)hipEventDestroy(w.tail_end);
+    w.tail_stream = nullptr;
+  }
   if (w.host_status) (void)hipHostFree(w.host_status);
   w.host_status = nullptr;
   w.host_status_words = 0;
@@ -692,6 +713,7 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   g.half_wi_x = 0.5f * g.wi_x; g.half_wi_y = 0.5f * g.wi_y; g.half_fx = 0.5f * g.fx; g.half_fy = 0.5f * g.fy;
   g.tx = cam->tx[level]; g.ty = cam->ty[level];
   g.level = level;
+  g.pair_list = nullptr;
   g.linear = level_is_linear(ctx, g.w) ? 1 : 0;
   level_tiles(g.w, g.h, rows_per_wave, g.linear != 0, &g.tiles_x, &g.tiles_y);
   g.rcp_table = ctx->opt_ref_compat ? ctx->rcp_table.as<float>() : nullptr;
@@ -1225,6 +1247,20 @@ int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* cons
 
 // Spin on the pinned status word the device writes when the last workgroup of a step is through (publish_step in
 // solver_kernels.hip).  A host-memory poll sees the word ~2 us after the store; an event synchronisation took ~10 us.
+int step_wait_check(Workspace& w, std::chrono::steady_clock::time_point t0) {
+  const hipError_t q = hipStreamQuery(w.stream);
+  if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();   // "still running" is not an error to keep
+  if (q != hipSuccess && q != hipErrorNotReady) {
+    w.err = std::string("match: stream failed while waiting for a Gauss-Newton step: ") + hipGetErrorString(q);
+    return DVO_HIP_ERR_HIP;
+  }
+  if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+    w.err = "match: timed out waiting for a Gauss-Newton step";
+    return DVO_HIP_ERR_HIP;
+  }
+  return DVO_HIP_OK;
+}
+
 int wait_for_step(Workspace& w, int step, int* active) {
   volatile int* word = w.host_status + step;
   const auto t0 = std::chrono::steady_clock::now();
@@ -1235,16 +1271,8 @@ int wait_for_step(Workspace& w, int step, int* active) {
       return DVO_HIP_OK;
     }
     if ((spins & 0xfffff) == 0) {                            // every ~1M polls: has the stream died, or are we stuck?
-      const hipError_t q = hipStreamQuery(w.stream);
-      if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();   // "still running" is not an error to keep
-      if (q != hipSuccess && q != hipErrorNotReady) {
-        w.err = std::string("match: stream failed while waiting for a Gauss-Newton step: ") + hipGetErrorString(q);
-        return DVO_HIP_ERR_HIP;
-      }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
-        w.err = "match: timed out waiting for a Gauss-Newton step";
-        return DVO_HIP_ERR_HIP;
-      }
+      const int rc = step_wait_check(w, t0);
+      if (rc != DVO_HIP_OK) return rc;
     }
   }
 }
@@ -1594,10 +1622,36 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   for (int i = 0; i < n; ++i) std::memcpy(&tinit[size_t(i) * 16], results[i].transformation, 16 * sizeof(double));
   if (!tables_inline) DVO_WS_TRY(w, w.tables->upload(s, w.t_init.p, tinit.data(), tinit.size() * sizeof(double)));
   // per-step tallies (device) and status words (pinned host memory the device writes, see publish_step)
-  const size_t n_steps = size_t(bp.cap_iters) + 8 + kResidentErrorWords;
+  const size_t main_steps = size_t(bp.cap_iters) + 8 + kResidentErrorWords;
+  // The overlapped tail of a level (option "overlap_tails"): see the level loop below.  Batches whose levels are begun by launches (beyond the
+  // solver steps' hand-over), the plain launch chain (no step in the sweep's tail), more than one level on this path.
+  const bool overlap_batch = ctx->opt_overlap_tails != 0 && !policy.level_hand_over(n) && ctx->opt_sweep_tail == 0 && rp.levels == 0 && bp.coarse_levels == 0 &&
+                             cfg->first_level > cfg->last_level;
+  const size_t tail_steps_cap = overlap_batch ? size_t(bp.cap_iters) + 4 * size_t(bp.nlev) + 8 : 0;
+  const size_t n_steps = main_steps + tail_steps_cap;         // (the tail's status words and tallies lie behind the main chain's)
+  if (overlap_batch) {
+    size_t t_tiles = 1, t_entries = 0;
+    for (int l = cfg->last_level + 1; l <= cfg->first_level; ++l) {
+      t_tiles = std::max(t_tiles, size_t(bp.geom[l].tiles_x) * bp.geom[l].tiles_y);
+      t_entries = std::max(t_entries, residual_entries(bp.geom[l]));
+    }
+    DVO_WS_TRY(w, w.tail_partials.reserve(size_t(n) * t_tiles * kAccStride * sizeof(float)));
+    DVO_WS_TRY(w, w.tail_scratch.reserve(size_t(n) * t_entries * sizeof(float2)));
+    DVO_WS_TRY(w, w.tail_flags.reserve(align_up(size_t(n), 256)));
+    DVO_WS_TRY(w, w.tail_list.reserve(align_up(size_t(n) * sizeof(int), 256)));
+    DVO_WS_TRY(w, w.counters.reserve(n_steps * sizeof(unsigned long long) + align_up(size_t(n) * sizeof(int), 8)));
+    if (!w.tail_stream) {
+      int prio_least = 0, prio_greatest = 0;
+      DVO_WS_TRY(w, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+      DVO_WS_TRY(w, hipStreamCreateWithPriority(&w.tail_stream, hipStreamNonBlocking, prio_greatest));
+      DVO_WS_TRY(w, hipEventCreateWithFlags(&w.tail_split, hipEventDisableTiming));
+      DVO_WS_TRY(w, hipEventCreateWithFlags(&w.tail_end, hipEventDisableTiming));
+    }
+  }
   // a batch that ended early (time-out, HIP error) may have left steps queued: nothing of it may still be running when the
   // status words and tallies are reset
   if (w.needs_drain) {
+    if (w.tail_stream) DVO_WS_TRY(w, hipStreamSynchronize(w.tail_stream));
     DVO_WS_TRY(w, sync_stream(s));
     // ... and the f16 range words it may have raised are nobody's business any more (they are cleared where they are read, at a batch's
     // regular end: left standing, the next batch would repeat unrelated pairs at the same indices -- round-5 advisor finding)
@@ -1679,6 +1733,92 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     }
     level_from = cfg->first_level - bp.coarse_levels;
   }
+  // ---- the overlapped tail of a level (round 6, option "overlap_tails") ------------------------------------------------------------------
+  // The pairs of a batch need different numbers of passes on a level, and the launch chain runs a level until its LAST pair has left it: on
+  // the bench's 1024-pair batches 11 of a step's 32 iterations are such tail launches, a few dozen pairs each, while the chip waits (1.1 ms
+  // of 11).  In the reference every match() leaves its level on its own (dense_tracking.cpp:357).  Here, once at most 1/8 of the pairs is
+  // still on a level, their indices go into a list (k_mark_stragglers), the other pairs begin the next level on the batch's stream, and
+  // the stragglers' remaining steps -- sweep and solver step launched over the LIST (LevelGeom::pair_list), with partial rows and
+  // residual pairs of their own, status words of their own -- run on a second stream beside it.  When the host sees the tail's last
+  // pair leave the level, the stragglers begin the next level behind whatever step of it is enqueued (an event, a k_level_begin over the
+  // flagged pairs) and are part of the batch again; if the next level runs out of pairs first, the host waits for the tail.  One tail at a
+  // time; the last level's tail is not overlapped (nothing follows).  A pair's arithmetic does not know in which launch it runs: the
+  // records are the synchronous chain's bit for bit (tests/test_gpu_overlap.py).
+  struct TailChain {
+    bool live = false, finished = false;
+    int level = -1, cap = 0, rpw = 0, ll_blocks = 0;
+    LevelGeom g;
+    const PairPtrs* pp = nullptr;
+    int first = 0, enqueued = 0, seen = 0, last_active = -1;
+  } tc;
+  int tail_next = 0;                                           // tail steps enqueued in this batch so far (index of the next status word)
+  auto tail_enqueue = [&](int count) {
+    for (int c = 0; c < count && size_t(tail_next) < tail_steps_cap; ++c, ++tail_next) {
+      const size_t idx = main_steps + size_t(tail_next);
+      launch_residual_reduce(w.tail_stream, ctx->opt_variant, tc.rpw, false, tc.g, tc.pp, states, tc.cap, w.tail_partials.as<float>(), w.tail_scratch.as<float2>(),
+                             w.win_fallbacks.as<unsigned long long>(), w.f16_range_flag);
+      launch_solver_step(w.tail_stream, states, tc.cap, bp.prm, tc.g, w.tail_partials.as<float>(), ll_partials, tc.ll_blocks, w.tail_scratch.as<float2>(), d_levels, d_iters,
+                         tallies + idx, w.host_status + idx, false, cfg->first_level - tc.level, nullptr);
+      tc.enqueued += 1;
+      ctx->overlapped_steps += 1;
+    }
+    (void)hipEventRecord(w.tail_end, w.tail_stream);           // (the join waits for the latest record: everything enqueued so far)
+  };
+  // what the tail's status words say by now (never waits); two steps are kept enqueued ahead of what has been seen
+  auto tail_service = [&]() {
+    if (!tc.live || tc.finished) return;
+    while (tc.seen < tc.enqueued) {
+      const int v = static_cast<volatile int*>(w.host_status)[main_steps + size_t(tc.first + tc.seen)];
+      if (!(v & kStepDoneFlag)) break;
+      tc.last_active = v & ~kStepDoneFlag;
+      tc.seen += 1;
+    }
+    if (tc.seen > 0 && tc.last_active == 0) tc.finished = true;
+    else if (tc.enqueued - tc.seen < 2) tail_enqueue(2);
+  };
+  auto tail_drain = [&]() -> int {                             // the main chain has nothing left to do before the stragglers join
+    ctx->tail_drains += 1;
+    while (!tc.finished) {
+      int unused = 0;
+      const int rc_wait = wait_for_step(w, int(main_steps) + tc.first + tc.enqueued - 1, &unused);
+      if (rc_wait != DVO_HIP_OK) return rc_wait;
+      const int before = tc.enqueued;
+      tail_service();
+      if (!tc.finished && tc.enqueued == before) {             // (no status word left for another step: cannot happen within the iteration cap)
+        w.err = "match: a level's overlapped tail ran out of steps";
+        return DVO_HIP_ERR_HIP;
+      }
+    }
+    return DVO_HIP_OK;
+  };
+  // the stragglers of level tc.level begin level tc.level - 1 on the batch's stream, behind everything enqueued there so far
+  auto tail_join = [&]() -> int {
+    const int lv = tc.level - 1;
+    DVO_WS_TRY(w, hipStreamWaitEvent(s, w.tail_end, 0));
+    launch_level_begin(s, states, n, bp.prm, bp.geom[lv], lv, bp.pair_ptrs + size_t(lv) * n, d_levels, nullptr, w.tail_flags.as<unsigned char>(), 1);
+    tc.live = false;
+    return DVO_HIP_OK;
+  };
+  // the main chain's wait for a step, looking after the tail meanwhile
+  auto wait_main = [&](int idx, int* active) -> int {
+    if (!tc.live) return wait_for_step(w, idx, active);
+    volatile int* word = w.host_status + idx;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+      const int v = *word;
+      if (v & kStepDoneFlag) {
+        *active = v & ~kStepDoneFlag;
+        tail_service();
+        return DVO_HIP_OK;
+      }
+      if ((spins & 0x3f) == 0) tail_service();
+      if ((spins & 0xfffff) == 0) {
+        const int rc_check = step_wait_check(w, t0);
+        if (rc_check != DVO_HIP_OK) return rc_check;
+      }
+    }
+  };
+
   for (int level = level_from; level >= cfg->last_level; --level) {
     const LevelGeom& g = bp.geom[level];
     const PairPtrs* pp = bp.pair_ptrs + size_t(level) * n;
@@ -1692,7 +1832,9 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     const bool hand_over = policy.level_hand_over(n);
     if (level == level_from || !hand_over) {
       Range range(kPrep[level]);
-      launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr);
+      // (the stragglers of the level before -- its overlapped tail, below -- are still on it: they begin this level when they join)
+      launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr,
+                         tc.live ? w.tail_flags.as<unsigned char>() : nullptr, 0);
     }
     NextLevel next;
     std::memset(&next, 0, sizeof(next));
@@ -1782,32 +1924,72 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       }
     }
     int watched = step - 1;                                  // last step of the chunk whose outcome is awaited
+    int valid_from = 0;                                      // what a step enqueued before this one reports says nothing about pairs that joined since
+    const bool may_split = overlap_batch && level > cfg->last_level && fused_ll && !tail && sweep_takes_pair_list(ctx->opt_variant, bp.rpw[level], g);
     // Where an EMPTY step is expensive -- the dispatcher needs 95 us for the 307 200 workgroups of a 1024-pair finest-level sweep
     // that all exit at once, 114 us with its log-likelihood and solver launches -- the step ahead of the poll is not enqueued once
     // only a few pairs are left on the level: the host then waits for the outcome first (a bubble of ~15 us if another step is
     // needed).  Elsewhere the speculative step is cheaper than the bubble.
     const bool empty_step_is_costly = size_t(g.tiles_x) * g.tiles_y * size_t(n) >= (ctx->opt_tail_speculation >= 2 ? size_t(ctx->opt_tail_speculation) : kCostlyEmptyStepWorkgroups) && ctx->opt_tail_speculation != 1;
     int last_active = n;
-    for (;;) {
-      const bool hold = empty_step_is_costly && last_active * 8 <= n;
-      int more = hold ? 0 : std::min(per_sync, per_level - enqueued);
-      if (more > 0) {
-        enqueue_chunk(more);
-        enqueued += more;
-      }
-      int active = 0;
-      rc = wait_for_step(w, watched, &active);
-      if (rc != DVO_HIP_OK) return rc;
-      last_active = active;
-      if (hold && active > 0) {                              // (the held-back step is needed after all)
-        more = std::min(per_sync, per_level - enqueued);
+    for (;;) {                                               // (once more when the stragglers of the level before join after this level's own pairs are through)
+      for (;;) {
+        const bool hold = empty_step_is_costly && last_active * 8 <= n;
+        int more = hold ? 0 : std::min(per_sync, per_level - enqueued);
         if (more > 0) {
           enqueue_chunk(more);
           enqueued += more;
         }
+        int active = 0;
+        rc = wait_main(watched, &active);
+        if (rc != DVO_HIP_OK) return rc;
+        if (tc.live && tc.finished) {                        // the tail of the level before is through: its pairs are on this level from the next step on
+          rc = tail_join();
+          if (rc != DVO_HIP_OK) return rc;
+          valid_from = step;
+          enqueued = 0;                                      // (their passes are counted from here; the cap per pair is the device's)
+        }
+        const bool known = watched >= valid_from;
+        if (!known) active = n;
+        last_active = active;
+        if (hold && active > 0) {                            // (the held-back step is needed after all)
+          more = std::min(per_sync, per_level - enqueued);
+          if (more > 0) {
+            enqueue_chunk(more);
+            enqueued += more;
+          }
+        }
+        if (known && may_split && !tc.live && active > 0 && size_t(active) * size_t(ctx->opt_overlap_fraction) <= size_t(n)) {
+          // the level's tail: the pairs still on it (at most `active`) finish it on the tail stream, the others go on
+          Range range("split");
+          tc = TailChain();
+          tc.live = true;
+          tc.level = level; tc.cap = active; tc.rpw = bp.rpw[level]; tc.ll_blocks = ll_blocks;
+          tc.g = g; tc.g.pair_list = w.tail_list.as<int>();
+          tc.pp = pp;
+          tc.first = tail_next;
+          launch_mark_stragglers(s, states, n, level, w.tail_flags.as<unsigned char>(), w.tail_list.as<int>(), active);
+          DVO_WS_TRY(w, hipEventRecord(w.tail_split, s));
+          DVO_WS_TRY(w, hipStreamWaitEvent(w.tail_stream, w.tail_split, 0));
+          tail_enqueue(3);
+          ctx->overlapped_tails += 1;
+          break;
+        }
+        if (active == 0 || more <= 0) break;                 // every pair left this level (or the iteration cap is reached)
+        watched = step - 1;
       }
-      if (active == 0 || more <= 0) break;                   // every pair left this level (or the iteration cap is reached)
+      if (!(tc.live && tc.level == level + 1)) break;
+      // this level's own pairs are through (or handed to a tail... no: one tail at a time) and the stragglers of the level before have not
+      // joined yet: wait for them, let them begin, and iterate on
+      rc = tail_drain();
+      if (rc != DVO_HIP_OK) return rc;
+      rc = tail_join();
+      if (rc != DVO_HIP_OK) return rc;
+      valid_from = step;
+      enqueued = std::min(per_sync, per_level);
+      enqueue_chunk(enqueued);
       watched = step - 1;
+      last_active = n;
     }
     // The pairs that ended the level in the step just awaited are handed over (NextLevel) by the step that was enqueued ahead of the poll.
     // If there is none -- the step was held back, or the iteration cap is reached -- one solver launch does nothing else.

@@ -26,10 +26,14 @@ __global__ void k_init_pairs(PairState* states, int n_pairs, SolverParams prm, c
 }
 
 // T_init != null: the first level of a match -- the pair is initialised here as well (one launch less per match)
+// flags != null (a level whose predecessor's tail is overlapped, capi.hip::run_batch): which == 0 -- every pair but the flagged ones, the
+// stragglers still on the level before; which == 1 -- the flagged ones, when they have left it
 __global__ void k_level_begin(PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
-                              const PairPtrs* __restrict__ pairs, dvo_hip_level_stats* levels, const double* __restrict__ T_init) {
+                              const PairPtrs* __restrict__ pairs, dvo_hip_level_stats* levels, const double* __restrict__ T_init,
+                              const unsigned char* __restrict__ flags, int which) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
+  if (flags && int(flags[p] != 0) != which) return;
   if (T_init) gn_init_pair(states[p], prm, T_init + size_t(p) * 16);
   gn_level_begin(states[p], prm, g, level, *pairs[p].n_selected, levels + size_t(p) * prm.cap_levels);
 }
@@ -49,7 +53,49 @@ extern "C" int dvo_hip_debug_gn_clocks(unsigned long long* out16, int reset) {
 template <int WAVES, int MIN_WG = 1>
 __global__ __launch_bounds__(WAVES * 64, MIN_WG) void k_solver_step(LevelGeom g, SolverStepArgs a) {
   __shared__ SolverLds L;
-  solver_step_body<WAVES>(L, g, a, blockIdx.x);
+  const int pair = pair_of_launch_index(g, blockIdx.x);
+  if (pair < 0) {                                             // (an empty entry of a straggler list: counted, nothing else)
+    if (threadIdx.x == 0) publish_step(a.step_tally, a.host_status, a.n_pairs, false);
+    return;
+  }
+  solver_step_body<WAVES>(L, g, a, pair);
+}
+
+// The stragglers of a level (round 6, the overlapped tail -- capi.hip::run_batch): the pairs still active on `level`, in ascending order,
+// into list[0 .. cap) (-1 behind the last; the host's `cap` is the count its last poll saw, which only shrinks), and a flag byte per pair.
+// One workgroup: a batch has a few thousand pairs at most, and the order must not depend on who arrives first.
+__global__ __launch_bounds__(1024) void k_mark_stragglers(const PairState* __restrict__ states, int n_pairs, int level, unsigned char* __restrict__ flags,
+                                                          int* __restrict__ list, int cap) {
+  __shared__ int wave_count[16];
+  __shared__ int running;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  for (int base = 0; base < n_pairs; base += 1024) {
+    const int p = base + int(threadIdx.x);
+    const bool is = p < n_pairs && states[p].active != 0 && states[p].level == level;
+    if (p < n_pairs) flags[p] = is ? 1 : 0;
+    const unsigned long long ballot = __ballot(is);
+    if (lane == 0) wave_count[wave] = __popcll(ballot);
+    __syncthreads();
+    int before = running;
+    for (int w2 = 0; w2 < wave; ++w2) before += wave_count[w2];
+    const int pos = before + __popcll(ballot & ((1ull << lane) - 1ull));
+    if (is && pos < cap) list[pos] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int total = 0;
+      for (int w2 = 0; w2 < 16; ++w2) total += wave_count[w2];
+      running += total;
+    }
+    __syncthreads();
+  }
+  for (int k = running + int(threadIdx.x); k < cap; k += 1024) list[k] = -1;
+}
+
+__global__ void k_clear_flags(unsigned char* flags, int n_pairs) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_pairs) flags[p] = 0;
 }
 
 // the serial half of the step, one wavefront per pair: the sums and log-likelihood terms of the pass come from the sweep's tail
@@ -115,8 +161,16 @@ void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverPara
 }
 
 void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
-                        const PairPtrs* pairs, dvo_hip_level_stats* levels, const double* T_init_or_null) {
-  k_level_begin<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, g, level, pairs, levels, T_init_or_null);
+                        const PairPtrs* pairs, dvo_hip_level_stats* levels, const double* T_init_or_null, const unsigned char* flags, int which) {
+  k_level_begin<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, g, level, pairs, levels, T_init_or_null, flags, which);
+}
+
+void launch_mark_stragglers(hipStream_t s, const PairState* states, int n_pairs, int level, unsigned char* flags, int* list, int cap) {
+  k_mark_stragglers<<<dim3(1), dim3(1024), 0, s>>>(states, n_pairs, level, flags, list, cap);
+}
+
+void launch_clear_flags(hipStream_t s, unsigned char* flags, int n_pairs) {
+  k_clear_flags<<<dim3((n_pairs + 255) / 256), dim3(256), 0, s>>>(flags, n_pairs);
 }
 
 void launch_solver_serial(hipStream_t s, int n_pairs, LevelGeom g, const SolverStepArgs& a) {
