@@ -420,7 +420,7 @@ def main():
                               "value": round(n_total * args.steps / elapsed, 2), "unit": "alignments/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "loop_only": True,
                               "config": {"pairs": n_total, "pairs_per_gpu": B, "lanes": n_lanes},
-                              "counters": {k: ctx.counter(k) for k in ("overlapped_tails", "overlapped_steps", "tail_drains")},
+                              "counters": {k: ctx.counter(k) for k in ("overlapped_tails", "overlapped_steps", "tail_drains", "tail_wait_us")},
                               "ms_per_step_one_lane": None if elapsed_lanes is None else round(elapsed_one_lane / args.steps * 1e3, 3)}))
         return
     twist_err = float(np.abs(parallel.twists_of(last["T"]) - pairs_np["xi_true"]).max())

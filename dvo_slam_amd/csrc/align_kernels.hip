@@ -119,7 +119,8 @@ template <int LOADS>
 __global__ __launch_bounds__(kBlock) void k_loglik(const LevelGeom g, const PairState* __restrict__ states, int n_pairs,
                                                    const float* __restrict__ partials, const float2* __restrict__ scratch,
                                                    double* __restrict__ ll_partials, int blocks_per_pair) {
-  const int pair = blockIdx.y;
+  const int pair = pair_of_launch_index(g, blockIdx.y);       // (the slow lane of a batch: a list of pairs; the batch's own launches skip its pairs)
+  if (pair < 0) return;
   if (!states[pair].active || states[pair].level != g.level) return;
   __shared__ double sh[16];
   __shared__ double sums[4];
@@ -249,7 +250,7 @@ void launch_loglik(hipStream_t s, const LevelGeom& g, const PairState* states, i
   // few pairs: the sweep is a handful of dependent round trips per lane, more loads in flight shorten it (one pair 0.52 -> 0.50 ms);
   // a full batch is bandwidth-bound and runs 6 % slower with the larger chunks
   // (one_schedule: the grouping of the partial sums must not follow the batch size -- option "deterministic")
-  if (n_pairs <= 16 && !one_schedule) k_loglik<8><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, blocks_per_pair);
+  if (n_pairs <= 16 && !one_schedule && !g.pair_list) k_loglik<8><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, blocks_per_pair);
   else k_loglik<4><<<dim3(blocks_per_pair, n_pairs), dim3(kBlock), 0, s>>>(g, states, n_pairs, partials, scratch, ll_partials, blocks_per_pair);
 }
 

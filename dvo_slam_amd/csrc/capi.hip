@@ -306,11 +306,11 @@ struct Workspace {
   bool device_may_lag = true;      // the last batch returned without waiting for the stream (the resident kernel's direct path)
   int resident_error_word = 0;     // index of the current resident launch's error word in host_status (a ring, see kResidentErrorWords)
   unsigned resident_launch_counter = 0;
-  // the overlapped tail of a level (run_batch, option "overlap_tails"): the stragglers' steps run on a stream of their own beside the
-  // next level's, with partial rows and residual pairs of their own (two levels index those by different tile counts)
+  // the slow lane of a batch (run_batch, option "overlap_tails"): the stragglers of the levels run on a stream of their own beside the
+  // batch's chain, with partial rows, residual pairs and log-likelihood sums of their own (two levels index those by different tile counts)
   hipStream_t tail_stream = nullptr;
   hipEvent_t tail_split = nullptr, tail_end = nullptr;
-  DevBuf tail_partials, tail_scratch, tail_flags, tail_list;
+  DevBuf tail_partials, tail_scratch, tail_ll, tail_flags, tail_list;
 };
 
 // a helper thread of the concurrent pair groups (dvo_hip_context::opt_batch_groups) and the slice of the caller's batch it aligns
@@ -418,9 +418,15 @@ struct dvo_hip_context {
   // runs inside the solver step, batches beyond the solver steps' hand-over).
   int opt_overlap_tails = 0;
   int opt_overlap_fraction = 8;
+  // Active-pair lists (round 6): where an empty step is expensive (kCostlyEmptyStepWorkgroups) and at most 1/8 of the pairs is left on the
+  // level, the steps that follow are launched over a LIST of those pairs -- tiles x active workgroups instead of tiles x pairs that
+  // all but a few leave at once.  1: on.
+  int opt_tail_lists = 0;
+  long long listed_steps = 0;      // steps launched over an active-pair list (counter "listed_steps")
   long long overlapped_tails = 0;  // levels whose tail ran beside the next level (counter "overlapped_tails")
   long long overlapped_steps = 0;  // Gauss-Newton steps enqueued on the tail stream (counter "overlapped_steps")
-  long long tail_drains = 0;       // times the main chain had to wait for a tail (counter "tail_drains")
+  long long tail_drains = 0;       // batches that ended with a slow lane (counter "tail_drains") ...
+  long long tail_wait_ns = 0;      // ... and how long the host waited for it behind the chain's last step (counter "tail_wait_us")
   // Concurrent pair groups (round 6): a large batch is aligned as two or three sub-batches at once -- the caller's thread runs the first
   // on this context, helper threads the others on TWIN contexts (same device, own stream, own scratch), like the reference spreads
   // independent match() calls over the workers of a tbb::parallel_reduce (dvo_slam/src/keyframe_graph.cpp:576-593).  Option
@@ -554,7 +560,7 @@ void workspace_destroy(Workspace& w) {
   (void)hipStreamSynchronize(w.stream);
   for (DevBuf& b : w.pair_ptrs) b.release();
   for (DevBuf* b : {&w.states, &w.partials, &w.scratch, &w.ll_partials, &w.lvl_stats, &w.it_stats, &w.results,
-                    &w.t_init, &w.counters, &w.exchange, &w.win_fallbacks, &w.pair_sums, &w.tail_partials, &w.tail_scratch, &w.tail_flags, &w.tail_list})
+                    &w.t_init, &w.counters, &w.exchange, &w.win_fallbacks, &w.pair_sums, &w.tail_partials, &w.tail_scratch, &w.tail_ll, &w.tail_flags, &w.tail_list})
     b->release();
   if (w.tail_stream) {
     (void)hipStreamSynchronize(w.tail_stream);
@@ -714,6 +720,7 @@ LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level
   g.tx = cam->tx[level]; g.ty = cam->ty[level];
   g.level = level;
   g.pair_list = nullptr;
+  g.skip_flags = nullptr;
   g.linear = level_is_linear(ctx, g.w) ? 1 : 0;
   level_tiles(g.w, g.h, rows_per_wave, g.linear != 0, &g.tiles_x, &g.tiles_y);
   g.rcp_table = ctx->opt_ref_compat ? ctx->rcp_table.as<float>() : nullptr;
@@ -1623,22 +1630,25 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   if (!tables_inline) DVO_WS_TRY(w, w.tables->upload(s, w.t_init.p, tinit.data(), tinit.size() * sizeof(double)));
   // per-step tallies (device) and status words (pinned host memory the device writes, see publish_step)
   const size_t main_steps = size_t(bp.cap_iters) + 8 + kResidentErrorWords;
-  // The overlapped tail of a level (option "overlap_tails"): see the level loop below.  Batches whose levels are begun by launches (beyond the
-  // solver steps' hand-over), the plain launch chain (no step in the sweep's tail), more than one level on this path.
-  const bool overlap_batch = ctx->opt_overlap_tails != 0 && !policy.level_hand_over(n) && ctx->opt_sweep_tail == 0 && rp.levels == 0 && bp.coarse_levels == 0 &&
-                             cfg->first_level > cfg->last_level;
+  // The slow lane of a batch (option "overlap_tails"): see in front of the level loop below.  Batches whose levels are begun by launches
+  // (beyond the solver steps' hand-over), the plain launch chain (no step in the sweep's tail), more than one level on this path.
+  bool overlap_batch = ctx->opt_overlap_tails != 0 && !policy.level_hand_over(n) && ctx->opt_sweep_tail == 0 && rp.levels == 0 && bp.coarse_levels == 0 &&
+                       cfg->first_level > cfg->last_level;
+  for (int l = cfg->last_level; l <= cfg->first_level; ++l)   // (the lane passes through every level: each one's sweep must take a list of pairs)
+    overlap_batch = overlap_batch && sweep_takes_pair_list(ctx->opt_variant, bp.rpw[l], bp.geom[l]);
   const size_t tail_steps_cap = overlap_batch ? size_t(bp.cap_iters) + 4 * size_t(bp.nlev) + 8 : 0;
   const size_t n_steps = main_steps + tail_steps_cap;         // (the tail's status words and tallies lie behind the main chain's)
   if (overlap_batch) {
     size_t t_tiles = 1, t_entries = 0;
-    for (int l = cfg->last_level + 1; l <= cfg->first_level; ++l) {
+    for (int l = cfg->last_level; l <= cfg->first_level; ++l) {
       t_tiles = std::max(t_tiles, size_t(bp.geom[l].tiles_x) * bp.geom[l].tiles_y);
       t_entries = std::max(t_entries, residual_entries(bp.geom[l]));
     }
     DVO_WS_TRY(w, w.tail_partials.reserve(size_t(n) * t_tiles * kAccStride * sizeof(float)));
     DVO_WS_TRY(w, w.tail_scratch.reserve(size_t(n) * t_entries * sizeof(float2)));
     DVO_WS_TRY(w, w.tail_flags.reserve(align_up(size_t(n), 256)));
-    DVO_WS_TRY(w, w.tail_list.reserve(align_up(size_t(n) * sizeof(int), 256)));
+    DVO_WS_TRY(w, w.tail_ll.reserve(size_t(n) * kLlBlocksPerPair * sizeof(double)));
+
     DVO_WS_TRY(w, w.counters.reserve(n_steps * sizeof(unsigned long long) + align_up(size_t(n) * sizeof(int), 8)));
     if (!w.tail_stream) {
       int prio_least = 0, prio_greatest = 0;
@@ -1648,6 +1658,8 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       DVO_WS_TRY(w, hipEventCreateWithFlags(&w.tail_end, hipEventDisableTiming));
     }
   }
+  // (the lane's two lists -- the one in use and the one being made -- and the chain's own active-pair list)
+  if (overlap_batch || ctx->opt_tail_lists) DVO_WS_TRY(w, w.tail_list.reserve(3 * align_up(size_t(n), 64) * sizeof(int)));
   // a batch that ended early (time-out, HIP error) may have left steps queued: nothing of it may still be running when the
   // status words and tallies are reset
   if (w.needs_drain) {
@@ -1733,75 +1745,114 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     }
     level_from = cfg->first_level - bp.coarse_levels;
   }
-  // ---- the overlapped tail of a level (round 6, option "overlap_tails") ------------------------------------------------------------------
+  // ---- the slow lane of a batch (round 6, option "overlap_tails") ------------------------------------------------------------------------
   // The pairs of a batch need different numbers of passes on a level, and the launch chain runs a level until its LAST pair has left it: on
   // the bench's 1024-pair batches 11 of a step's 32 iterations are such tail launches, a few dozen pairs each, while the chip waits (1.1 ms
-  // of 11).  In the reference every match() leaves its level on its own (dense_tracking.cpp:357).  Here, once at most 1/8 of the pairs is
-  // still on a level, their indices go into a list (k_mark_stragglers), the other pairs begin the next level on the batch's stream, and
-  // the stragglers' remaining steps -- sweep and solver step launched over the LIST (LevelGeom::pair_list), with partial rows and
-  // residual pairs of their own, status words of their own -- run on a second stream beside it.  When the host sees the tail's last
-  // pair leave the level, the stragglers begin the next level behind whatever step of it is enqueued (an event, a k_level_begin over the
-  // flagged pairs) and are part of the batch again; if the next level runs out of pairs first, the host waits for the tail.  One tail at a
-  // time; the last level's tail is not overlapped (nothing follows).  A pair's arithmetic does not know in which launch it runs: the
-  // records are the synchronous chain's bit for bit (tests/test_gpu_overlap.py).
-  struct TailChain {
-    bool live = false, finished = false;
-    int level = -1, cap = 0, rpw = 0, ll_blocks = 0;
-    LevelGeom g;
-    const PairPtrs* pp = nullptr;
-    int first = 0, enqueued = 0, seen = 0, last_active = -1;
-  } tc;
-  int tail_next = 0;                                           // tail steps enqueued in this batch so far (index of the next status word)
+  // of 11).  In the reference every match() runs on its own from start to end (dense_tracking.cpp:200-357).  Here, once at most 1/8 of
+  // the pairs is still on a level, those pairs leave the batch's chain for good: they get a flag byte and a place in a list
+  // (k_mark_stragglers), the chain goes on to the next level without them (LevelGeom::skip_flags), and a SLOW LANE -- a second stream, its
+  // own partial rows and residual pairs, its own status words -- runs them to the end of the match with launches over the list
+  // (LevelGeom::pair_list): the rest of that level, then level after level behind the main chain, taking up the stragglers the chain
+  // sheds on the way.  The lane works on one level at a time and never gets ahead of the chain: it leaves a level when none of its members is
+  // active on it AND the chain has left it (so nobody can still arrive there).  The batch ends when both have.  A pair's arithmetic does
+  // not know in which launch it runs: the records are the synchronous chain's bit for bit (tests/test_gpu_overlap.py).
+  struct LevelSchedule {
+    bool fused_ll = false, two_waves = false;
+    int ll_blocks = 0;
+  };
+  auto schedule_of = [&](int level) {
+    const LevelGeom& g = bp.geom[level];
+    LevelSchedule ls;
+    const int fuse_opt = ctx->opt_fused_ll_pixels;
+    ls.fused_ll = g.w * g.h <= (fuse_opt > 0 ? fuse_opt : (policy.fused_loglik_on_large_levels(n) && !ctx->opt_deterministic ? kFusedLoglikMaxPixelsBatch : kFusedLoglikMaxPixels));
+    ls.ll_blocks = ctx->opt_ll_blocks > 0 ? std::min(ctx->opt_ll_blocks, kLlBlocksPerPair)
+                   : (!g.compact || ctx->opt_deterministic ? kLlBlocksPerPair : policy.loglik_blocks(n));
+    ls.two_waves = ctx->opt_solver_waves == 2 ||
+                   (ctx->opt_solver_waves == 0 && ls.fused_ll && !g.compact && g.tiles_x * g.tiles_y <= 32 && policy.solver_two_waves(n));
+    return ls;
+  };
+  struct SlowLane {
+    bool live = false, done = false;
+    int level = -1;                  // the level its launches work on
+    int cap = 0;                     // entries of the current list: an upper bound of the flagged pairs
+    int list_sel = 0;                // which of the two list buffers is the current one (the other may still be read by launches in flight)
+    int seen = 0;                    // status words of the lane read so far (they complete in order: one stream)
+    int valid_from = 0;              // steps before this one say nothing about the lane's level as it is now (another level, or members have arrived since)
+    int last_active = -1;
+  } sl;
+  int tail_next = 0;                 // steps of the lane enqueued in this batch (index of its next status word, behind the chain's)
+  int main_level = level_from;       // the level the batch's own chain works on (below last_level: through)
+  unsigned char* const lane_flags = w.tail_flags.as<unsigned char>();
+  auto lane_list = [&](int sel) { return w.tail_list.as<int>() + size_t(sel) * align_up(size_t(n), 64); };
+  if (overlap_batch) launch_clear_flags(s, lane_flags, n);
   auto tail_enqueue = [&](int count) {
+    const LevelSchedule ls = schedule_of(sl.level);
+    LevelGeom g = bp.geom[sl.level];
+    g.pair_list = lane_list(sl.list_sel);
+    const PairPtrs* pp = bp.pair_ptrs + size_t(sl.level) * n;
+    float* lp = w.tail_partials.as<float>();
+    float2* lscr = w.tail_scratch.as<float2>();
+    double* lll = w.tail_ll.as<double>();
     for (int c = 0; c < count && size_t(tail_next) < tail_steps_cap; ++c, ++tail_next) {
       const size_t idx = main_steps + size_t(tail_next);
-      launch_residual_reduce(w.tail_stream, ctx->opt_variant, tc.rpw, false, tc.g, tc.pp, states, tc.cap, w.tail_partials.as<float>(), w.tail_scratch.as<float2>(),
-                             w.win_fallbacks.as<unsigned long long>(), w.f16_range_flag);
-      launch_solver_step(w.tail_stream, states, tc.cap, bp.prm, tc.g, w.tail_partials.as<float>(), ll_partials, tc.ll_blocks, w.tail_scratch.as<float2>(), d_levels, d_iters,
-                         tallies + idx, w.host_status + idx, false, cfg->first_level - tc.level, nullptr);
-      tc.enqueued += 1;
+      launch_residual_reduce(w.tail_stream, ctx->opt_variant, bp.rpw[sl.level], sl.level == 0, g, pp, states, sl.cap, lp, lscr, w.win_fallbacks.as<unsigned long long>(),
+                             w.f16_range_flag);
+      if (!ls.fused_ll) launch_loglik(w.tail_stream, g, states, sl.cap, lp, lscr, lll, ls.ll_blocks, ctx->opt_deterministic != 0);
+      launch_solver_step(w.tail_stream, states, sl.cap, bp.prm, g, lp, lll, ls.ll_blocks, ls.fused_ll ? lscr : nullptr, d_levels, d_iters,
+                         tallies + idx, w.host_status + idx, false, cfg->first_level - sl.level, nullptr);
       ctx->overlapped_steps += 1;
     }
-    (void)hipEventRecord(w.tail_end, w.tail_stream);           // (the join waits for the latest record: everything enqueued so far)
+    (void)hipEventRecord(w.tail_end, w.tail_stream);           // (the batch's end waits for the latest record: everything enqueued so far)
   };
-  // what the tail's status words say by now (never waits); two steps are kept enqueued ahead of what has been seen
+  // what the lane's status words say by now, and what follows from it (never waits)
   auto tail_service = [&]() {
-    if (!tc.live || tc.finished) return;
-    while (tc.seen < tc.enqueued) {
-      const int v = static_cast<volatile int*>(w.host_status)[main_steps + size_t(tc.first + tc.seen)];
+    if (!sl.live || sl.done) return;
+    while (sl.seen < tail_next) {
+      const int v = static_cast<volatile int*>(w.host_status)[main_steps + size_t(sl.seen)];
       if (!(v & kStepDoneFlag)) break;
-      tc.last_active = v & ~kStepDoneFlag;
-      tc.seen += 1;
+      if (sl.seen >= sl.valid_from) sl.last_active = v & ~kStepDoneFlag;
+      sl.seen += 1;
     }
-    if (tc.seen > 0 && tc.last_active == 0) tc.finished = true;
-    else if (tc.enqueued - tc.seen < 2) tail_enqueue(2);
-  };
-  auto tail_drain = [&]() -> int {                             // the main chain has nothing left to do before the stragglers join
-    ctx->tail_drains += 1;
-    while (!tc.finished) {
-      int unused = 0;
-      const int rc_wait = wait_for_step(w, int(main_steps) + tc.first + tc.enqueued - 1, &unused);
-      if (rc_wait != DVO_HIP_OK) return rc_wait;
-      const int before = tc.enqueued;
-      tail_service();
-      if (!tc.finished && tc.enqueued == before) {             // (no status word left for another step: cannot happen within the iteration cap)
-        w.err = "match: a level's overlapped tail ran out of steps";
-        return DVO_HIP_ERR_HIP;
+    if (sl.seen > sl.valid_from && sl.last_active == 0) {      // nobody of the lane is active on its level
+      if (sl.level <= main_level) return;                      // (the chain is still on it: its stragglers may yet arrive)
+      if (sl.level == cfg->last_level) {
+        sl.done = true;
+        return;
       }
+      // on to the next level: the members that have left this one begin it (those that arrived further down are on theirs already)
+      const int lv = sl.level - 1;
+      launch_level_begin(w.tail_stream, states, n, bp.prm, bp.geom[lv], lv, bp.pair_ptrs + size_t(lv) * n, d_levels, nullptr, lane_flags, 1, sl.level);
+      sl.level = lv;
+      sl.valid_from = tail_next;
+      sl.last_active = -1;
+      tail_enqueue(3);
+      return;
     }
+    if (tail_next - sl.seen < 2) tail_enqueue(2);
+  };
+  // the chain sheds the pairs still active on `level` (at most `active` of them) to the lane
+  auto tail_shed = [&](int level, int active) -> int {
+    Range range("shed");
+    const int next_sel = sl.live ? sl.list_sel ^ 1 : 0;
+    const int cap = std::min(n, sl.cap + active);
+    launch_mark_stragglers(s, states, n, level, lane_flags, lane_list(next_sel), cap);
+    DVO_WS_TRY(w, hipEventRecord(w.tail_split, s));
+    DVO_WS_TRY(w, hipStreamWaitEvent(w.tail_stream, w.tail_split, 0));
+    sl.cap = cap;
+    sl.list_sel = next_sel;
+    if (!sl.live) {
+      sl.live = true;
+      sl.level = level;
+    }
+    sl.valid_from = tail_next;                                 // (whatever level the lane is on: its launches read the new list from here on)
+    sl.last_active = -1;
+    tail_enqueue(3);
+    ctx->overlapped_tails += 1;
     return DVO_HIP_OK;
   };
-  // the stragglers of level tc.level begin level tc.level - 1 on the batch's stream, behind everything enqueued there so far
-  auto tail_join = [&]() -> int {
-    const int lv = tc.level - 1;
-    DVO_WS_TRY(w, hipStreamWaitEvent(s, w.tail_end, 0));
-    launch_level_begin(s, states, n, bp.prm, bp.geom[lv], lv, bp.pair_ptrs + size_t(lv) * n, d_levels, nullptr, w.tail_flags.as<unsigned char>(), 1);
-    tc.live = false;
-    return DVO_HIP_OK;
-  };
-  // the main chain's wait for a step, looking after the tail meanwhile
+  // the chain's wait for a step, looking after the lane meanwhile
   auto wait_main = [&](int idx, int* active) -> int {
-    if (!tc.live) return wait_for_step(w, idx, active);
+    if (!sl.live || sl.done) return wait_for_step(w, idx, active);
     volatile int* word = w.host_status + idx;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
@@ -1820,7 +1871,9 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
   };
 
   for (int level = level_from; level >= cfg->last_level; --level) {
-    const LevelGeom& g = bp.geom[level];
+    main_level = level;
+    LevelGeom g = bp.geom[level];
+    if (sl.live) g.skip_flags = lane_flags;                    // (the lane's pairs are not this chain's any more)
     const PairPtrs* pp = bp.pair_ptrs + size_t(level) * n;
     static const char* const kPrep[kMaxLevels] = {"prep L0", "prep L1", "prep L2", "prep L3", "prep L4", "prep L5", "prep L6", "prep L7"};
     static const char* const kErr[kMaxLevels] = {"err L0", "err L1", "err L2", "err L3", "err L4", "err L5", "err L6", "err L7"};
@@ -1832,9 +1885,9 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     const bool hand_over = policy.level_hand_over(n);
     if (level == level_from || !hand_over) {
       Range range(kPrep[level]);
-      // (the stragglers of the level before -- its overlapped tail, below -- are still on it: they begin this level when they join)
+      // (the slow lane's pairs begin their levels there)
       launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr,
-                         tc.live ? w.tail_flags.as<unsigned char>() : nullptr, 0);
+                         sl.live ? lane_flags : nullptr, 0);
     }
     NextLevel next;
     std::memset(&next, 0, sizeof(next));
@@ -1850,10 +1903,10 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
     // (measured, scripts/ab_match.py fused_ll_pixels: 128 pairs 2.152 -> 2.117 ms with level 1 fused; 16 pairs 0.756 -> 0.799, one
     // pair 0.524 -> 0.547: a lone workgroup per pair is slower than 32 blocks when the chip is empty)
-    const int fuse_opt = ctx->opt_fused_ll_pixels;
     // (round 5, packed residual pairs, the streaming step beside its ingest, scripts/r5_midsize.py: level 1 in a launch of its own
     // 64 pairs 1.456 -> 1.378 ms, 128 pairs 1.939 -> 1.908, 256 pairs 3.308 -> 3.286, 512 pairs 5.859 -> 5.880: fused from 512 pairs)
-    const bool fused_ll = g.w * g.h <= (fuse_opt > 0 ? fuse_opt : (policy.fused_loglik_on_large_levels(n) && !ctx->opt_deterministic ? kFusedLoglikMaxPixelsBatch : kFusedLoglikMaxPixels));
+    const LevelSchedule schedule = schedule_of(level);         // (the rule: schedule_of, above -- the slow lane runs its pairs by the same one)
+    const bool fused_ll = schedule.fused_ll;
     // Chunks of `per_sync` iterations are enqueued ONE AHEAD of the poll: while the host waits for the status word of
     // chunk k, chunk k+1 is already queued, so the GPU never idles for a host round trip.  Iterations enqueued past the
     // end of the level are no-ops (workgroups exit on !active).
@@ -1861,20 +1914,21 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     // a batch that fills the device anyway pays once per workgroup for nothing -- fewer, longer ones then (option ll_blocks to override)
     // (round 5, mid-size batches, scripts/r5_midsize.py: 16 instead of 32 workgroups per pair 64 / 128 / 200 pairs 1.179 -> 1.173 /
     // 1.775 -> 1.760 / 2.558 -> 2.538 ms per step; 8: 1.183 / 1.760 / 2.546)
-    const int ll_blocks = ctx->opt_ll_blocks > 0 ? std::min(ctx->opt_ll_blocks, kLlBlocksPerPair)
-                          : (!g.compact || ctx->opt_deterministic ? kLlBlocksPerPair : policy.loglik_blocks(n));
+    const int ll_blocks = schedule.ll_blocks;
     // the solver step of the smallest levels in two-wavefront workgroups (four per compute unit instead of two): a batch that otherwise
     // needs two goes of 512 resident workgroups (option solver_waves 2 / 4 to force; the records do not depend on it).  Measured at
     // 1024 pairs (scripts/r4_trace.sh): 80 x 60 46 -> 36 us per step; 160 x 120 with packed residuals 77 -> 90 (two wavefronts walk
     // its 96 slots in six rounds instead of three), 320 x 240 and the finest level level: those keep four.
-    const bool solver_two_waves = ctx->opt_solver_waves == 2 ||
-                                  (ctx->opt_solver_waves == 0 && fused_ll && !g.compact && g.tiles_x * g.tiles_y <= 32 && policy.solver_two_waves(n));
+    const bool solver_two_waves = schedule.two_waves;
     // The step in the sweep's launch (round 6): where the log-likelihood pass runs inside the solver step anyway and the level's sweep
     // has the instantiation, the workgroup that completes a pair's last tile runs the pair's step -- ONE launch per iteration
     const bool tail = ctx->opt_sweep_tail != 0 && fused_ll && sweep_has_tail(ctx->opt_variant, bp.rpw[level], g);
     // (option 2: the WIDE half of the step -- reduction and log-likelihood, its memory round trips -- in the sweep's tail, the serial half
     // in a one-wavefront launch behind it)
     double* pair_sums = tail && ctx->opt_sweep_tail == 2 ? w.pair_sums.as<double>() : nullptr;
+    // (what the chain's launches of this level cover: every pair, or -- its last steps, see "hold" below -- the list of those still active)
+    LevelGeom g_run = g;
+    int n_run = n;
     auto enqueue_chunk = [&](int count) {
       for (int c = 0; c < count; ++c, ++step) {
         if (tail) {
@@ -1892,12 +1946,13 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
         }
         {
           Range range(kErr[level]);
-          launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch, w.win_fallbacks.as<unsigned long long>(),
+          launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g_run, pp, states, n_run, partials, scratch, w.win_fallbacks.as<unsigned long long>(),
                                  w.f16_range_flag);
-          if (!fused_ll) launch_loglik(s, g, states, n, partials, scratch, ll_partials, ll_blocks, ctx->opt_deterministic != 0);
+          if (!fused_ll) launch_loglik(s, g_run, states, n_run, partials, scratch, ll_partials, ll_blocks, ctx->opt_deterministic != 0);
         }
+        if (g_run.pair_list) ctx->listed_steps += 1;
         Range range(kLinsys[level]);
-        launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, ll_blocks, fused_ll ? scratch : nullptr, d_levels, d_iters,
+        launch_solver_step(s, states, n_run, bp.prm, g_run, partials, ll_partials, ll_blocks, fused_ll ? scratch : nullptr, d_levels, d_iters,
                            tallies + step, w.host_status + step, solver_two_waves, cfg->first_level - level, &next);   // (the level record every pair on this level is at: fetched with the state)
       }
     };
@@ -1924,72 +1979,48 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
       }
     }
     int watched = step - 1;                                  // last step of the chunk whose outcome is awaited
-    int valid_from = 0;                                      // what a step enqueued before this one reports says nothing about pairs that joined since
-    const bool may_split = overlap_batch && level > cfg->last_level && fused_ll && !tail && sweep_takes_pair_list(ctx->opt_variant, bp.rpw[level], g);
+    // (the slow lane: every level but the last may shed its stragglers to it -- on the last one nothing follows that they could run beside)
+    const bool list_tails = ctx->opt_tail_lists != 0 && !tail && !hand_over && sweep_takes_pair_list(ctx->opt_variant, bp.rpw[level], g);
+    const bool may_shed = overlap_batch && level > cfg->last_level && !tail && sweep_takes_pair_list(ctx->opt_variant, bp.rpw[level], g);
     // Where an EMPTY step is expensive -- the dispatcher needs 95 us for the 307 200 workgroups of a 1024-pair finest-level sweep
     // that all exit at once, 114 us with its log-likelihood and solver launches -- the step ahead of the poll is not enqueued once
     // only a few pairs are left on the level: the host then waits for the outcome first (a bubble of ~15 us if another step is
     // needed).  Elsewhere the speculative step is cheaper than the bubble.
     const bool empty_step_is_costly = size_t(g.tiles_x) * g.tiles_y * size_t(n) >= (ctx->opt_tail_speculation >= 2 ? size_t(ctx->opt_tail_speculation) : kCostlyEmptyStepWorkgroups) && ctx->opt_tail_speculation != 1;
     int last_active = n;
-    for (;;) {                                               // (once more when the stragglers of the level before join after this level's own pairs are through)
-      for (;;) {
-        const bool hold = empty_step_is_costly && last_active * 8 <= n;
-        int more = hold ? 0 : std::min(per_sync, per_level - enqueued);
+    for (;;) {
+      const bool hold = empty_step_is_costly && last_active * 8 <= n;
+      int more = hold ? 0 : std::min(per_sync, per_level - enqueued);
+      if (more > 0) {
+        enqueue_chunk(more);
+        enqueued += more;
+      }
+      int active = 0;
+      rc = wait_main(watched, &active);
+      if (rc != DVO_HIP_OK) return rc;
+      last_active = active;
+      if (may_shed && active > 0 && size_t(active) * size_t(ctx->opt_overlap_fraction) <= size_t(n)) {
+        // the pairs still on the level (at most `active`: the steps enqueued ahead of this poll only take some away) go to the slow lane
+        rc = tail_shed(level, active);
+        if (rc != DVO_HIP_OK) return rc;
+        break;
+      }
+      if (hold && active > 0) {                              // (the held-back step is needed after all)
+        // ... by `active` pairs, none of whose steps is in flight: from here on the launches cover the list of them
+        if (list_tails && !g_run.pair_list) {
+          int* const own_list = w.tail_list.as<int>() + 2 * align_up(size_t(n), 64);
+          launch_mark_stragglers(s, states, n, level, sl.live ? lane_flags : nullptr, own_list, active, true);
+          g_run.pair_list = own_list;
+          n_run = active;
+        }
+        more = std::min(per_sync, per_level - enqueued);
         if (more > 0) {
           enqueue_chunk(more);
           enqueued += more;
         }
-        int active = 0;
-        rc = wait_main(watched, &active);
-        if (rc != DVO_HIP_OK) return rc;
-        if (tc.live && tc.finished) {                        // the tail of the level before is through: its pairs are on this level from the next step on
-          rc = tail_join();
-          if (rc != DVO_HIP_OK) return rc;
-          valid_from = step;
-          enqueued = 0;                                      // (their passes are counted from here; the cap per pair is the device's)
-        }
-        const bool known = watched >= valid_from;
-        if (!known) active = n;
-        last_active = active;
-        if (hold && active > 0) {                            // (the held-back step is needed after all)
-          more = std::min(per_sync, per_level - enqueued);
-          if (more > 0) {
-            enqueue_chunk(more);
-            enqueued += more;
-          }
-        }
-        if (known && may_split && !tc.live && active > 0 && size_t(active) * size_t(ctx->opt_overlap_fraction) <= size_t(n)) {
-          // the level's tail: the pairs still on it (at most `active`) finish it on the tail stream, the others go on
-          Range range("split");
-          tc = TailChain();
-          tc.live = true;
-          tc.level = level; tc.cap = active; tc.rpw = bp.rpw[level]; tc.ll_blocks = ll_blocks;
-          tc.g = g; tc.g.pair_list = w.tail_list.as<int>();
-          tc.pp = pp;
-          tc.first = tail_next;
-          launch_mark_stragglers(s, states, n, level, w.tail_flags.as<unsigned char>(), w.tail_list.as<int>(), active);
-          DVO_WS_TRY(w, hipEventRecord(w.tail_split, s));
-          DVO_WS_TRY(w, hipStreamWaitEvent(w.tail_stream, w.tail_split, 0));
-          tail_enqueue(3);
-          ctx->overlapped_tails += 1;
-          break;
-        }
-        if (active == 0 || more <= 0) break;                 // every pair left this level (or the iteration cap is reached)
-        watched = step - 1;
       }
-      if (!(tc.live && tc.level == level + 1)) break;
-      // this level's own pairs are through (or handed to a tail... no: one tail at a time) and the stragglers of the level before have not
-      // joined yet: wait for them, let them begin, and iterate on
-      rc = tail_drain();
-      if (rc != DVO_HIP_OK) return rc;
-      rc = tail_join();
-      if (rc != DVO_HIP_OK) return rc;
-      valid_from = step;
-      enqueued = std::min(per_sync, per_level);
-      enqueue_chunk(enqueued);
+      if (active == 0 || more <= 0) break;                   // every pair left this level (or the iteration cap is reached)
       watched = step - 1;
-      last_active = n;
     }
     // The pairs that ended the level in the step just awaited are handed over (NextLevel) by the step that was enqueued ahead of the poll.
     // If there is none -- the step was held back, or the iteration cap is reached -- one solver launch does nothing else.
@@ -2001,6 +2032,25 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     }
   }
 
+  if (sl.live) {
+    // the chain is through; the slow lane runs its pairs to the end of the match (from here on it may leave any level)
+    main_level = cfg->last_level - 1;
+    const auto t_wait = std::chrono::steady_clock::now();
+    tail_service();
+    while (!sl.done) {
+      if (tail_next == 0 || size_t(tail_next) >= tail_steps_cap) {
+        w.err = "match: the slow lane of the batch ran out of steps";
+        return DVO_HIP_ERR_HIP;
+      }
+      int unused = 0;
+      rc = wait_for_step(w, int(main_steps) + tail_next - 1, &unused);
+      if (rc != DVO_HIP_OK) return rc;
+      tail_service();
+    }
+    ctx->tail_drains += 1;
+    ctx->tail_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait).count();
+    DVO_WS_TRY(w, hipStreamWaitEvent(s, w.tail_end, 0));       // (k_finish and the copies below follow the lane's last step)
+  }
   const bool resident_used = rp.levels > 0;
   std::vector<dvo_hip_level_stats> hl;
   std::vector<dvo_hip_iteration_stats> hi;

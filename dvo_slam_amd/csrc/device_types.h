@@ -69,14 +69,20 @@ struct LevelGeom {                    // identical for every pair of a batch (on
   // (PairState::active && PairState::level == level) -- a pair that has left the level may already have begun the next one
   // (k_solver_step, NextLevel) and waits there for the rest of the batch
   int level;
-  // non-null (round 6, the overlapped tail of a level -- capi.hip::run_batch, "straggler list"): the launch covers the n_pairs ENTRIES of
+  // non-null (round 6, the slow lane of a batch -- capi.hip::run_batch): the launch covers the n_pairs ENTRIES of
   // this list instead of pairs 0 .. n_pairs - 1 -- entry k names the pair its workgroups work on, -1 = none (they leave at once).  Partial
   // rows, residual pairs, states and records stay where the pair's index puts them: a pair's arithmetic does not know about the list.
   const int* pair_list;
+  // non-null: a flag byte per pair -- the launch leaves the flagged pairs alone (they are the slow lane's: its launches name them in
+  // pair_list, the batch's own launches skip them)
+  const unsigned char* skip_flags;
 };
 
-// the pair a launch's index `k` stands for (LevelGeom::pair_list); negative: none
-DVO_HD int pair_of_launch_index(const LevelGeom& g, int k) { return g.pair_list ? g.pair_list[k] : k; }
+// the pair a launch's index `k` stands for (LevelGeom::pair_list, ::skip_flags); negative: none
+DVO_HD int pair_of_launch_index(const LevelGeom& g, int k) {
+  const int pair = g.pair_list ? g.pair_list[k] : k;
+  return pair >= 0 && g.skip_flags && g.skip_flags[pair] ? -1 : pair;
+}
 
 // What a solver step needs to hand the pairs that have LEFT its level over to the next one without a launch between the levels
 // (round 5): a pair that is no longer active when the step begins -- it ended the level in an earlier step -- begins the next level

@@ -90,13 +90,16 @@ hipError_t launch_match_coarse(hipStream_t s, const CoarseArgs& args, int workgr
 // solver_kernels.hip
 extern int g_solver_occupancy;   // experiment (option "solver_occupancy"): 3 / 4 = the four-wavefront solver step built for that many workgroups per compute unit
 void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, const double* T_init);
-// flags (may be null: every pair): which == 0 -- every pair whose flag byte is zero, which == 1 -- the flagged ones
+// flags (may be null: every pair): which == 0 -- every pair whose flag byte is zero, which == 1 -- the flagged ones; from_level >= 0:
+// of those, the pairs that have left that level
 void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
                         const PairPtrs* pairs, dvo_hip_level_stats* levels, const double* T_init_or_null = nullptr,
-                        const unsigned char* flags = nullptr, int which = 0);
-// the overlapped tail of a level (capi.hip::run_batch): the pairs still active on `level` -- a flag byte per pair, and their indices in
-// ascending order in list[0 .. cap), -1 behind the last; LevelGeom::pair_list then makes a launch cover the list
-void launch_mark_stragglers(hipStream_t s, const PairState* states, int n_pairs, int level, unsigned char* flags, int* list, int cap);
+                        const unsigned char* flags = nullptr, int which = 0, int from_level = -1);
+// the slow lane of a batch (capi.hip::run_batch): the pairs still active on `level` get their flag byte set, and the indices of all flagged
+// pairs go into list[0 .. cap) in ascending order, -1 behind the last; LevelGeom::pair_list then makes a launch cover the list, ::skip_flags
+// makes one leave the flagged pairs alone.  The flags of a batch start at zero (launch_clear_flags).
+// list_only: nothing is flagged; the list gets the unflagged pairs active on the level (flags may be null) -- the active-pair list of a level's last steps
+void launch_mark_stragglers(hipStream_t s, const PairState* states, int n_pairs, int level, unsigned char* flags, int* list, int cap, bool list_only = false);
 void launch_clear_flags(hipStream_t s, unsigned char* flags, int n_pairs);
 // ... which the sweep of the level must understand (the contracted window sweep and the gathering sweep of the default schedule do)
 bool sweep_takes_pair_list(int variant, int rows_per_wave, const LevelGeom& g);

@@ -26,14 +26,15 @@ __global__ void k_init_pairs(PairState* states, int n_pairs, SolverParams prm, c
 }
 
 // T_init != null: the first level of a match -- the pair is initialised here as well (one launch less per match)
-// flags != null (a level whose predecessor's tail is overlapped, capi.hip::run_batch): which == 0 -- every pair but the flagged ones, the
-// stragglers still on the level before; which == 1 -- the flagged ones, when they have left it
+// flags != null (a batch with a slow lane, capi.hip::run_batch): which == 0 -- every pair but the flagged ones (the batch's own chain);
+// which == 1 -- the flagged ones that have left level `from_level` (the slow lane's: its members arrive on different levels)
 __global__ void k_level_begin(PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
                               const PairPtrs* __restrict__ pairs, dvo_hip_level_stats* levels, const double* __restrict__ T_init,
-                              const unsigned char* __restrict__ flags, int which) {
+                              const unsigned char* __restrict__ flags, int which, int from_level) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
   if (flags && int(flags[p] != 0) != which) return;
+  if (from_level >= 0 && (states[p].level != from_level || states[p].active)) return;
   if (T_init) gn_init_pair(states[p], prm, T_init + size_t(p) * 16);
   gn_level_begin(states[p], prm, g, level, *pairs[p].n_selected, levels + size_t(p) * prm.cap_levels);
 }
@@ -61,11 +62,14 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WG) void k_solver_step(LevelGeom g,
   solver_step_body<WAVES>(L, g, a, pair);
 }
 
-// The stragglers of a level (round 6, the overlapped tail -- capi.hip::run_batch): the pairs still active on `level`, in ascending order,
-// into list[0 .. cap) (-1 behind the last; the host's `cap` is the count its last poll saw, which only shrinks), and a flag byte per pair.
-// One workgroup: a batch has a few thousand pairs at most, and the order must not depend on who arrives first.
+// The stragglers of a level (round 6, the slow lane -- capi.hip::run_batch): the pairs still active on `level` get a flag byte, and EVERY
+// flagged pair of the batch -- these and the ones of earlier levels -- goes into list[0 .. cap) in ascending order (-1 behind the last;
+// the host's `cap` adds up the counts its polls saw, which only shrink).  One workgroup: a batch has a few thousand pairs at most, and
+// the order must not depend on who arrives first.  (The state of a pair flagged earlier is not looked at: the slow lane is changing it.)
+// list_only (the active-pair list of a level's last steps on the batch's own chain): nothing is flagged -- the pairs active on the level
+// that are NOT flagged (not the lane's) go into the list.
 __global__ __launch_bounds__(1024) void k_mark_stragglers(const PairState* __restrict__ states, int n_pairs, int level, unsigned char* __restrict__ flags,
-                                                          int* __restrict__ list, int cap) {
+                                                          int* __restrict__ list, int cap, int list_only) {
   __shared__ int wave_count[16];
   __shared__ int running;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -73,8 +77,10 @@ __global__ __launch_bounds__(1024) void k_mark_stragglers(const PairState* __res
   __syncthreads();
   for (int base = 0; base < n_pairs; base += 1024) {
     const int p = base + int(threadIdx.x);
-    const bool is = p < n_pairs && states[p].active != 0 && states[p].level == level;
-    if (p < n_pairs) flags[p] = is ? 1 : 0;
+    const bool was = p < n_pairs && flags && flags[p] != 0;
+    const bool on_level = p < n_pairs && !was && states[p].active != 0 && states[p].level == level;
+    const bool is = list_only ? on_level : (was || on_level);
+    if (!list_only && on_level) flags[p] = 1;
     const unsigned long long ballot = __ballot(is);
     if (lane == 0) wave_count[wave] = __popcll(ballot);
     __syncthreads();
@@ -161,12 +167,13 @@ void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverPara
 }
 
 void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
-                        const PairPtrs* pairs, dvo_hip_level_stats* levels, const double* T_init_or_null, const unsigned char* flags, int which) {
-  k_level_begin<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, g, level, pairs, levels, T_init_or_null, flags, which);
+                        const PairPtrs* pairs, dvo_hip_level_stats* levels, const double* T_init_or_null, const unsigned char* flags, int which,
+                        int from_level) {
+  k_level_begin<<<dim3((n_pairs + 63) / 64), dim3(64), 0, s>>>(states, n_pairs, prm, g, level, pairs, levels, T_init_or_null, flags, which, from_level);
 }
 
-void launch_mark_stragglers(hipStream_t s, const PairState* states, int n_pairs, int level, unsigned char* flags, int* list, int cap) {
-  k_mark_stragglers<<<dim3(1), dim3(1024), 0, s>>>(states, n_pairs, level, flags, list, cap);
+void launch_mark_stragglers(hipStream_t s, const PairState* states, int n_pairs, int level, unsigned char* flags, int* list, int cap, bool list_only) {
+  k_mark_stragglers<<<dim3(1), dim3(1024), 0, s>>>(states, n_pairs, level, flags, list, cap, list_only ? 1 : 0);
 }
 
 void launch_clear_flags(hipStream_t s, unsigned char* flags, int n_pairs) {

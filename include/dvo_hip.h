@@ -355,13 +355,17 @@ int dvo_hip_time_stream_mix(dvo_hip_context* ctx, int n_pairs,
  * half in a one-wavefront launch behind it.  Off by default: both forms measured slower (128 pairs 1.8 -> 2.2 / 2.3 ms per step, 1024
  * pairs 11.6 -> 14.4 / 13.6): every workgroup of the sweep waits ~5 us for its write-through stores before it can take the pair's
  * ticket, as long as its tile takes -- profiles/r06_sweep_tail.txt; counter "tail_steps"),
- * "overlap_tails" (1: once at most 1 / "overlap_fraction" -- default 8 -- of a batch's pairs is still on a pyramid level, the
- * others begin the next level and the stragglers finish theirs beside it: their sweeps and solver steps are launched over a LIST of pairs on a
- * stream of their own, and they join the batch again when the last of them has left the level -- every pair leaves its level on its own, as in
- * the reference (dvo_core/src/dense_tracking.cpp:357), instead of the whole batch waiting for its slowest pair on every level.  Batches
- * beyond the solver steps' hand-over (more than one pair per compute unit), levels whose log-likelihood pass runs inside the solver step,
- * the default schedule; never the last level.  The records are the synchronous chain's bit for bit; counters "overlapped_tails",
- * "overlapped_steps", "tail_drains"),
+ * "overlap_tails" (1: once at most 1 / "overlap_fraction" -- default 8 -- of a batch's pairs is still on a pyramid level, those pairs
+ * leave the batch's launch chain: the chain goes on to the next level without them, and a SLOW LANE -- a second stream with buffers of
+ * its own -- runs them to the end of the match with launches over a list of pairs, level after level behind the chain, taking up the
+ * stragglers of the later levels on the way; the batch ends when both are through.  Every pair runs its levels on its own, as in the
+ * reference (dvo_core/src/dense_tracking.cpp:200-357), instead of the whole batch waiting for its slowest pair on every level.
+ * Batches beyond the solver steps' hand-over (more than one pair per compute unit), the default schedule; the last level sheds
+ * nothing.  The records are the synchronous chain's bit for bit; counters "overlapped_tails", "overlapped_steps", "tail_drains",
+ * "tail_wait_us"),
+ * "tail_lists" (1: where a step that finds no pair is expensive -- 131 072 workgroups and more per sweep, "tail_speculation" -- and at
+ * most an eighth of the pairs is left on a level, the steps that follow are launched over the LIST of those pairs: tiles x active
+ * workgroups instead of tiles x pairs of which all but a few leave at once; the same records; counter "listed_steps"),
  * "coarse" (default 0; 1: wherever the levels admit it -- the default schedule, no "ref_compat", levels of up to 160 x 120 pixels --
  * the leading pyramid levels run in ONE launch, a workgroup per pair from the level's begin to its termination, level after level,
  * like one thread runs one match() in the reference (dvo_core/src/dense_tracking.cpp:200-357, dvo_slam/src/keyframe_graph.cpp:576-593):
@@ -392,8 +396,10 @@ int dvo_hip_set_option(dvo_hip_context* ctx, const char* key, int value);
  * "build_workgroups": one pair / one workgroup per compute unit),
  * "tail_steps" (Gauss-Newton steps of a batch enqueued as ONE launch, the sweep with the solver step in its tail, option "sweep_tail"),
  * "coarse_launches" / "coarse_levels" (the same for the fused coarse-level kernel, option "coarse"),
- * "overlapped_tails" (levels whose last pairs finished beside the next level, option "overlap_tails"), "overlapped_steps" (the
- * Gauss-Newton steps enqueued for them on the tail stream), "tail_drains" (times the batch had to wait for such stragglers),
+ * "listed_steps" (Gauss-Newton steps launched over an active-pair list, option "tail_lists"),
+ * "overlapped_tails" (levels that shed their last pairs to the slow lane, option "overlap_tails"), "overlapped_steps" (the
+ * Gauss-Newton steps enqueued on the lane), "tail_drains" (batches that ended with a lane) and "tail_wait_us" (how long the host
+ * waited for the lane behind the chain's last step, summed),
  * "resident_timeouts" (batches repeated on the launch-per-step path because a workgroup group of the resident kernel waited
  * in vain for its peers -- the device was shared with another such kernel; the results are those of the repeat),
  * "window_fallbacks" (lanes of the window sweep whose bilinear taps fell outside the staged window and were fetched from memory),

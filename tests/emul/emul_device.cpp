@@ -49,6 +49,7 @@ void make_level(const emul_level& e, LevelCtx& c) {
   c.g.wi_x = 0.5f * e.fx / 255.0f; c.g.wi_y = 0.5f * e.fy / 255.0f;
   c.g.tx = c.tx.data(); c.g.ty = c.ty.data();
   c.g.pair_list = nullptr;
+  c.g.skip_flags = nullptr;
   c.g.rcp_table = nullptr; c.g.rcp_shift = 0;               // (the emulation runs the default arithmetic)
   c.g.tiles_x = (e.w + kTileW - 1) / kTileW;
   c.g.tiles_y = e.h;

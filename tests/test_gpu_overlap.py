@@ -1,6 +1,7 @@
-"""The overlapped tail of a level (capi.hip::run_batch, option "overlap_tails"): once a few pairs of a large batch are left on a level, the
-others begin the next one and the stragglers finish theirs beside it, on a stream of their own, launched over a list of pairs
-(LevelGeom::pair_list) -- every pair leaves its level on its own, as the reference's match() calls do (dvo_core/src/dense_tracking.cpp:357).
+"""The slow lane of a batch (capi.hip::run_batch, option "overlap_tails"): once a few pairs of a large batch are left on a level, they leave the
+batch's launch chain for good -- the chain goes on to the next level without them, and a second stream runs them to the end of the match with
+launches over a list of pairs (LevelGeom::pair_list), level after level behind the chain, taking up the stragglers of the later levels on the
+way.  Every pair runs its levels on its own, as the reference's match() calls do (dvo_core/src/dense_tracking.cpp:200-357).
 
 A pair's arithmetic does not know in which launch it runs, so the bar is BIT identity with the synchronous chain: every byte of every
 result, level record and iteration record."""
@@ -34,11 +35,12 @@ def spread_batch(seed, n_distinct, n, w, h):
 
 
 @pytest.mark.parametrize("w,h,first,last,n,fraction", [
-    (320, 240, 3, 0, 300, 8),     # beyond the solver steps' hand-over (256 pairs): levels 3, 2, 1 may split
-    (320, 240, 3, 1, 272, 4),     # the front end's levels: the last one (1) is never split
-    (640, 480, 3, 0, 264, 2),     # BASELINE config 4's shape, an early split (half of the pairs still on the level)
+    (320, 240, 3, 0, 300, 8),     # beyond the solver steps' hand-over (256 pairs): levels 3, 2, 1 may shed their stragglers
+    (320, 240, 3, 1, 272, 4),     # the front end's levels: the last one (1) sheds nothing
+    (640, 480, 3, 0, 264, 2),     # BASELINE config 4's shape, shed early (half of the pairs still on the level); the lane's level 0 has
+                                  # its log-likelihood pass in a launch of its own
 ])
-def test_overlapped_tails_leave_the_synchronous_chain_s_records(ctx, w, h, first, last, n, fraction):
+def test_the_slow_lane_leaves_the_synchronous_chain_s_records(ctx, w, h, first, last, n, fraction):
     b, order = spread_batch(40 + w, 24, n, w, h)
     refs0, curs0 = frames_of(ctx, b, w, h, first + 1, 24)
     refs, curs = [refs0[i] for i in order], [curs0[i] for i in order]
@@ -49,7 +51,7 @@ def test_overlapped_tails_leave_the_synchronous_chain_s_records(ctx, w, h, first
     ctx.set_option("overlap_tails", 1)
     ctx.set_option("overlap_fraction", fraction)
     over = raw_match(ctx, cfg, refs, curs)
-    assert ctx.counter("overlapped_tails") > before, "no level was split: the test does not test"
+    assert ctx.counter("overlapped_tails") > before, "no level shed a pair: the test does not test"
     assert ctx.counter("overlapped_steps") > 0
     assert over[0] == base[0], "results differ"
     assert over[1] == base[1], "level records differ"
@@ -94,3 +96,26 @@ def test_batches_the_overlap_does_not_take(ctx):
     assert ctx.counter("overlapped_tails") > before
     for k in range(300):
         assert np.array_equal(on["T"][k], base["T"][k]) and on["n_iterations"][k] == base["n_iterations"][k]
+
+
+def test_active_pair_lists_leave_the_records_alone(ctx):
+    """Option "tail_lists": the last steps of a level launched over the list of the pairs still on it.  "tail_speculation" 2 makes every
+    level one on which the host waits for a step's outcome once few pairs are left (by default only sweeps of 131 072 workgroups and more:
+    the finest level of 437 and more 640 x 480 pairs), so that a batch of a test's size gets its lists."""
+    w, h, n = 320, 240, 300
+    b, order = spread_batch(5, 75, n, w, h)                             # (many distinct pairs: the levels thin out pair by pair)
+    refs0, curs0 = frames_of(ctx, b, w, h, 4, 75)
+    refs, curs = [refs0[i] for i in order], [curs0[i] for i in order]
+    cfg = d.Config(FirstLevel=3, LastLevel=0)
+    ctx.set_option("tail_speculation", 2)
+    base = raw_match(ctx, cfg, refs, curs)
+    before = ctx.counter("listed_steps")
+    ctx.set_option("tail_lists", 1)
+    listed = raw_match(ctx, cfg, refs, curs)
+    assert ctx.counter("listed_steps") > before
+    assert listed[:3] == base[:3]
+    # with the slow lane beside it: the chain's list leaves the lane's pairs out
+    ctx.set_option("overlap_tails", 1)
+    ctx.set_option("overlap_fraction", 4)
+    both = raw_match(ctx, cfg, refs, curs)
+    assert both[:3] == base[:3]
