@@ -1636,7 +1636,7 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
                        cfg->first_level > cfg->last_level;
   for (int l = cfg->last_level; l <= cfg->first_level; ++l)   // (the lane passes through every level: each one's sweep must take a list of pairs)
     overlap_batch = overlap_batch && sweep_takes_pair_list(ctx->opt_variant, bp.rpw[l], bp.geom[l]);
-  const size_t tail_steps_cap = overlap_batch ? size_t(bp.cap_iters) + 4 * size_t(bp.nlev) + 8 : 0;
+  const size_t tail_steps_cap = overlap_batch ? size_t(bp.cap_iters) + 12 * size_t(bp.nlev) + 8 : 0;   // (per level: the passes of its slowest pair, and up to eight steps enqueued ahead of what is known)
   const size_t n_steps = main_steps + tail_steps_cap;         // (the tail's status words and tallies lie behind the main chain's)
   if (overlap_batch) {
     size_t t_tiles = 1, t_entries = 0;
