@@ -34,33 +34,37 @@ def spread_batch(seed, n_distinct, n, w, h):
     return b, order
 
 
-@pytest.mark.parametrize("w,h,first,last,n,fraction", [
-    (320, 240, 3, 0, 300, 8),     # beyond the solver steps' hand-over (256 pairs): levels 3, 2, 1 may shed their stragglers
-    (320, 240, 3, 1, 272, 4),     # the front end's levels: the last one (1) sheds nothing
-    (640, 480, 3, 0, 264, 2),     # BASELINE config 4's shape, shed early (half of the pairs still on the level); the lane's level 0 has
-                                  # its log-likelihood pass in a launch of its own
+@pytest.mark.parametrize("w,h,first,last,n,fraction,extra", [
+    (320, 240, 3, 0, 300, 8, {}),     # beyond the solver steps' hand-over (256 pairs): levels 3, 2, 1 may shed their stragglers
+    (320, 240, 3, 1, 272, 4, {}),     # the front end's levels: the last one (1) sheds nothing
+    (640, 480, 3, 0, 264, 2, {}),     # BASELINE config 4's shape, shed early (half of the pairs still on the level); the lane's level 0 has
+                                      # its log-likelihood pass in a launch of its own
+    (320, 240, 3, 0, 300, 2, dict(MaxIterationsPerLevel=8)),                      # levels that end on the iteration cap, in the chain and in the lane
+    (320, 240, 3, 1, 288, 2, dict(Mu=0.05, Precision=1e-4, MaxIterationsPerLevel=50, UseInitialEstimate=True)),   # benchmark.yaml: motion prior, initial estimate
 ])
-def test_the_slow_lane_leaves_the_synchronous_chain_s_records(ctx, w, h, first, last, n, fraction):
+def test_the_slow_lane_leaves_the_synchronous_chain_s_records(ctx, w, h, first, last, n, fraction, extra):
     b, order = spread_batch(40 + w, 24, n, w, h)
     refs0, curs0 = frames_of(ctx, b, w, h, first + 1, 24)
     refs, curs = [refs0[i] for i in order], [curs0[i] for i in order]
-    cfg = d.Config(FirstLevel=first, LastLevel=last)
+    cfg = d.Config(FirstLevel=first, LastLevel=last, **extra)
+    # (initial estimates of very different quality, so that the pairs need different numbers of passes under the loose stopping rule too)
+    T0 = [po.se3_exp((0.95 if k % 3 == 0 else 0.0) * np.asarray(b["xi_true"][i])) for k, i in enumerate(order)] if extra.get("UseInitialEstimate") else None
     ctx.set_option("overlap_tails", 0)
-    base = raw_match(ctx, cfg, refs, curs)
+    base = raw_match(ctx, cfg, refs, curs, T0)
     before = ctx.counter("overlapped_tails")
     ctx.set_option("overlap_tails", 1)
     ctx.set_option("overlap_fraction", fraction)
-    over = raw_match(ctx, cfg, refs, curs)
+    over = raw_match(ctx, cfg, refs, curs, T0)
     assert ctx.counter("overlapped_tails") > before, "no level shed a pair: the test does not test"
     assert ctx.counter("overlapped_steps") > 0
     assert over[0] == base[0], "results differ"
     assert over[1] == base[1], "level records differ"
     assert over[2] == base[2], "iteration records differ"
     # again: the buffers and status words of a tail are reused from batch to batch
-    again = raw_match(ctx, cfg, refs, curs)
+    again = raw_match(ctx, cfg, refs, curs, T0)
     assert again[:3] == base[:3]
     # ... and they are real alignments
-    if last == 0:
+    if last == 0 and not extra:
         pair = {k: b[k][order[0]] for k in ("grey_ref", "depth_ref", "grey_cur", "depth_cur")}
         pair["K"] = b["K"]
         oref, ocur = po.pyramids_from_pair(pair, first + 1)
