@@ -377,6 +377,7 @@ struct dvo_hip_context {
   };
   std::vector<DeferredIngest> deferred;
   int opt_defer_ingest = 0;
+  int opt_defer_ingest_pixels = 0; // a recorded ingest waits until the launch chain is on a level of at least this many pixels (0: the chain's first launches)
   int opt_keep_raw_copy = 1;       // 0: a frame ingested straight into the reference role keeps no copy of its raw planes (option "keep_raw_copy")
   long long deferred_ingests = 0;  // ingests carried out behind the first launches of a match (counter "deferred_ingests")
   int opt_build_workgroups = 0;    // cap on the workgroups of a build-stream kernel (0 = one per tile): background builds
@@ -1958,7 +1959,11 @@ int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_f
     };
     int enqueued = std::min(per_sync, per_level);
     enqueue_chunk(enqueued);
-    if (!ctx->deferred.empty()) {
+    // (option "defer_ingest_pixels": not before the chain has reached a level of that many pixels -- the frame build is bound by memory, and
+    // beside it the latency-bound sweeps and steps of the SMALL levels run 30-50 % longer (80 x 60: 52 -> 77 us, 160 x 120: 159 -> 212 us per
+    // 1024-pair launch), the issue-bound sweeps of the large ones 2 %: a large batch's ingest belongs beside levels 1 and 0)
+    const bool flush_here = ctx->opt_defer_ingest_pixels <= 0 || g.w * g.h >= ctx->opt_defer_ingest_pixels || level == cfg->last_level;
+    if (!ctx->deferred.empty() && flush_here) {
       // A recorded ingest of the caller's next batch (option "defer_ingest") is carried out now, behind the first launches of this
       // batch.  It is ~0.1-0.5 ms of host time during which nothing more would be enqueued here: where the level's steps are short,
       // a few more of them go out first (a pair needs more than four passes on its first level; a step too many exits at once).
