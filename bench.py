@@ -313,7 +313,7 @@ def main():
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     # (measured on 256 compute units, alternated on one box: 1024 pairs 11.3 -> 10.8 ms per step with two lanes, 10.9-11.2 with three, 11.1 with
     # four -- while the host thread still spent 0.8 ms per step in front of the first launch, which a second lane hid; with that fixed
-    # (capi.hip::ensure_roles) two lanes are within +-2 % of one, box by box: 10.9-11.0 against 11.05-11.3 on one, 11.2 against 11.07 on
+    # (capi_frames.inc::ensure_roles) two lanes are within +-2 % of one, box by box: 10.9-11.0 against 11.05-11.3 on one, 11.2 against 11.07 on
     # another.  The timed loop therefore runs on ONE lane unless --lanes asks for more; from three and a half pairs per compute unit on the
     # two-lane loop is timed as a leg of its own and reported under "lanes")
     lanes_leg = args.lanes == 0 and not args.no_overlap and not args.no_lanes_leg and not args.loop_only and 2 * B >= 7 * cus and world == 1

@@ -1,7 +1,7 @@
 // align_coarse.hip -- the coarse pyramid levels of a batch in ONE launch: a workgroup owns a pair from gn_level_begin to the
 // termination of the level, level after level, with the solver step inline.
 //
-// The launch path (capi.hip::run_batch) spends two launches per Gauss-Newton iteration of a level -- the sweep and the solver step --
+// The launch path (capi_schedule.inc::run_batch) spends two launches per Gauss-Newton iteration of a level -- the sweep and the solver step --
 // for the WHOLE batch, iteration after iteration, until the last pair has left the level.  On the fine levels that is the right shape:
 // a sweep is hundreds of microseconds of issue-bound work per launch.  On the coarse levels (160 x 120 and below) it is not: at 1024
 // pairs a level-3 iteration is 50 us of sweep at 0.31 of the kernel's roofline and a 36-us solver launch, fifteen times, the later ones

@@ -1,6 +1,6 @@
 // align_resident.hip -- a whole coarse-to-fine alignment (or its coarse levels) in ONE launch: the latency path.
 //
-// The launch path (capi.hip::run_batch) spends one to three launches per Gauss-Newton iteration; for a lone pair, or the two pairs
+// The launch path (capi_schedule.inc::run_batch) spends one to three launches per Gauss-Newton iteration; for a lone pair, or the two pairs
 // LocalTracker aligns per frame (dvo_slam/src/local_tracker.cpp:180-184), nearly all of a match is launch floor (5 us per
 // dependent launch on this queue) and memory round trips of few-microsecond kernels (profiles/r02_d_single_pair_timeline.txt:
 // 66 launches, 0.5 ms).  Here a pair is owned by a GROUP of G resident workgroups of 8 wavefronts for the whole match
@@ -21,7 +21,7 @@
 //              takes the reference's revert path.  tests/test_emul_device.py runs this control flow on the host against the plain
 //              loop: the same bits;
 //   levels     follow each other inside the kernel (gn_level_begin); the host is not involved until the launch ends, and for small
-//              batches not even then: results and statistics go to pinned host memory and a done word (capi.hip, direct path).
+//              batches not even then: results and statistics go to pinned host memory and a done word (capi_schedule.inc, direct path).
 //
 // The exchange is the "LL" protocol of collective libraries: a row is 8-byte slots {value, sequence number}, written with relaxed
 // agent-scope stores and polled with relaxed agent-scope loads (sc1: through the non-coherent per-XCD L2s).  An aligned 8-byte

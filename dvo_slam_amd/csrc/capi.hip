@@ -586,1616 +586,8 @@ int fail(dvo_hip_context* ctx, int code, const char* msg) {
   return code;
 }
 
-// ticket + event for work just enqueued on the build stream; stamps the frames it wrote
-int stamp_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames) {
-  const unsigned long long seq = ++ctx->build_seq;
-  DVO_HIP_TRY(ctx, hipEventRecord(ctx->build_events[seq % dvo_hip_context::kBuildRing], ctx->build_stream));
-  for (int i = 0; i < n; ++i) frames[i]->built_seq = seq;
-  return DVO_HIP_OK;
-}
-
-// make `stream` (the main stream, or the upload stream about to overwrite a transfer buffer) wait for build ticket `need`
-int wait_for_ticket(dvo_hip_context* ctx, unsigned long long need, bool upload) {
-  unsigned long long& waited = upload ? ctx->upload_waited_seq : ctx->main_waited_seq;
-  hipStream_t stream = upload ? ctx->upload_stream : ctx->stream;
-  if (need <= waited) return DVO_HIP_OK;
-  // tickets older than the ring have had their event re-recorded for a newer ticket of the same stream: waiting for the
-  // oldest live one still orders us after `need`
-  const unsigned long long oldest_live = ctx->build_seq >= dvo_hip_context::kBuildRing ? ctx->build_seq - dvo_hip_context::kBuildRing + 1 : 1;
-  const unsigned long long use = need < oldest_live ? oldest_live : need;
-  DVO_HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->build_events[use % dvo_hip_context::kBuildRing], 0));
-  waited = use;
-  return DVO_HIP_OK;
-}
-
-// the main stream must not touch these frames before the build-stream work that produced them is done
-int wait_for_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames) {
-  unsigned long long need = 0;
-  for (int i = 0; i < n; ++i)
-    if (frames[i] && frames[i]->built_seq > need) need = frames[i]->built_seq;
-  return wait_for_ticket(ctx, need, /*upload=*/false);
-}
-
-// The error word of a resident launch: one of a ring of words of Workspace::host_status indexed by the launch counter (the per-step
-// words start behind the ring).  A workgroup of an EARLIER launch that gives up late -- the host returns from the direct path as soon
-// as every pair is done, not when every workgroup has left -- raises its own launch's word, not the one the next batch has just reset.
-constexpr int kResidentErrorWords = 8;
-
-const int kLlBlocksPerPair = 32;
-const size_t kCostlyEmptyStepWorkgroups = 131072;   // (see run_batch: from here on the step ahead of the poll is held back on a level's tail)
-const int kFusedLoglikMaxPixels = 160 * 120;      // any batch
-const int kFusedLoglikMaxPixelsBatch = 320 * 240;  // batches of 512 pairs and more (run_batch)
-
-// RgbdCameraPyramid::build (rgbd_image.cpp:283-296) + RgbdCamera ctor template (:186-204)
-int get_camera(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, const CameraGeom** out) {
-  // one geometry per (size, intrinsics), with the tables of every level the size admits: frames of one camera share it
-  // whatever level count each was created with (a batch only needs FirstLevel + 1 levels on each pyramid)
-  for (CameraGeom* c : ctx->cameras)
-    if (c->w0 == w && c->h0 == h && std::memcmp(c->K0, K, 16) == 0) {
-      *out = c;
-      return DVO_HIP_OK;
-    }
-  int all = 1;
-  while (all < kMaxLevels && (w >> all) >= 2 && (h >> all) >= 2) ++all;
-  levels = all > levels ? all : levels;
-  CameraGeom* c = new CameraGeom();
-  c->w0 = w; c->h0 = h; c->levels = levels;
-  std::memcpy(c->K0, K, 16);
-  size_t total = 0;
-  for (int l = 0; l < levels; ++l) {
-    c->w[l] = l == 0 ? w : c->w[l - 1] / 2;
-    c->h[l] = l == 0 ? h : c->h[l - 1] / 2;
-    for (int k = 0; k < 4; ++k) c->K[l][k] = l == 0 ? K[k] : c->K[l - 1][k] * 0.5f;   // IntrinsicMatrix::scale(0.5f), Q17
-    total += align_up(size_t(c->w[l]) * 4, 256) + align_up(size_t(c->h[l]) * 4, 256);
-  }
-  hipError_t e = c->tables.reserve(total);
-  if (e != hipSuccess) {
-    delete c;
-    ctx->err = std::string("hipMalloc(camera tables): ") + hipGetErrorString(e);
-    return DVO_HIP_ERR_HIP;
-  }
-  std::vector<float> host;
-  char* base = c->tables.as<char>();
-  size_t off = 0;
-  for (int l = 0; l < levels; ++l) {
-    const float fx = c->K[l][0], fy = c->K[l][1], ox = c->K[l][2], oy = c->K[l][3];
-    host.resize(size_t(c->w[l]) + c->h[l]);
-    for (int x = 0; x < c->w[l]; ++x) host[x] = (float(x) - ox) / fx;            // rgbd_image.cpp:198
-    for (int y = 0; y < c->h[l]; ++y) host[c->w[l] + y] = (float(y) - oy) / fy;  // rgbd_image.cpp:199
-    c->tx[l] = reinterpret_cast<float*>(base + off);
-    off += align_up(size_t(c->w[l]) * 4, 256);
-    c->ty[l] = reinterpret_cast<float*>(base + off);
-    off += align_up(size_t(c->h[l]) * 4, 256);
-    e = hipMemcpy(c->tx[l], host.data(), size_t(c->w[l]) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(c->ty[l], host.data() + c->w[l], size_t(c->h[l]) * 4, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-      c->tables.release();
-      delete c;
-      ctx->err = std::string("hipMemcpy(camera tables): ") + hipGetErrorString(e);
-      return DVO_HIP_ERR_HIP;
-    }
-  }
-  ctx->cameras.push_back(c);
-  *out = c;
-  return DVO_HIP_OK;
-}
-
-// tiles of the sweep kernel for one pair (see LevelGeom::linear)
-void level_tiles(int w, int h, int rows_per_wave, bool linear, int* tiles_x, int* tiles_y) {
-  const int th = kWavesPerBlock * rows_per_wave;
-  if (linear) {
-    const int segments = (w * h + kTileW - 1) / kTileW;
-    *tiles_x = 1;
-    *tiles_y = (segments + th - 1) / th;
-  } else {
-    *tiles_x = (w + kTileW - 1) / kTileW;
-    *tiles_y = (h + th - 1) / th;
-  }
-}
-
-// the contracted window sweep (align_fast.hip, variants 8 / 9) also takes widths that are no multiple of its 64 columns (160 x 120)
-bool level_uses_fast_window(const dvo_hip_context* ctx, int w, int h) {
-  return ctx->opt_variant >= 8 && fast_sweep_takes_width(w) && w < 32768 && h < 32768;   // (option "ref_compat" included: the COMPAT instantiations)
-}
-
-// the sweep with the whole current level in LDS (align_small.hip): the default schedule's levels that the window sweeps do not take
-bool level_uses_small(const dvo_hip_context* ctx, int w, int h);
-
-bool level_is_linear(const dvo_hip_context* ctx, int w) { return ctx->opt_variant >= 5 && w % kTileW != 0 && !level_uses_fast_window(ctx, w, 4); }
-
-// the sweep that stages the current frame's window in LDS (align_window.hip, variants 6 / 7; align_fast.hip) handles this level; its tile is 64 x 16
-bool level_uses_window(const dvo_hip_context* ctx, int w, int h) {
-  return (ctx->opt_variant >= 6 && w % kTileW == 0 && w < 32768 && h < 32768) || level_uses_fast_window(ctx, w, h);
-}
-
-bool level_uses_small(const dvo_hip_context* ctx, int w, int h) {
-  return ctx->opt_small_sweep && ctx->opt_variant >= 8 && !ctx->opt_ref_compat && !level_uses_window(ctx, w, h) && level_is_linear(ctx, w) && small_sweep_takes(w, h);
-}
-
-LevelGeom make_geom(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int rows_per_wave) {
-  LevelGeom g;
-  g.w = cam->w[level]; g.h = cam->h[level];
-  g.fx = cam->K[level][0]; g.fy = cam->K[level][1]; g.ox = cam->K[level][2]; g.oy = cam->K[level][3];
-  g.wi_x = 0.5f * g.fx / 255.0f; g.wi_y = 0.5f * g.fy / 255.0f;
-  g.half_wi_x = 0.5f * g.wi_x; g.half_wi_y = 0.5f * g.wi_y; g.half_fx = 0.5f * g.fx; g.half_fy = 0.5f * g.fy;
-  g.tx = cam->tx[level]; g.ty = cam->ty[level];
-  g.level = level;
-  g.pair_list = nullptr;
-  g.skip_flags = nullptr;
-  g.linear = level_is_linear(ctx, g.w) ? 1 : 0;
-  level_tiles(g.w, g.h, rows_per_wave, g.linear != 0, &g.tiles_x, &g.tiles_y);
-  g.rcp_table = ctx->opt_ref_compat ? ctx->rcp_table.as<float>() : nullptr;
-  g.rcp_shift = ctx->rcp_shift;
-  g.rcp_packed = ctx->opt_ref_compat == 1 ? ctx->rcp_packed : 0;   // (2: the table through memory, the path of a table that does not pack)
-  // (not under "ref_compat": a run that is compared with the reference's own numbers keeps every low part -- round-5 advisor finding)
-  g.gram_hi_j = !ctx->opt_gram_lo_parts && !ctx->opt_deterministic && !ctx->opt_ref_compat && ctx->opt_variant == 8 && size_t(g.w) * g.h >= 150000 ? 1 : 0;
-  g.small = level_uses_small(ctx, g.w, g.h) ? 1 : 0;
-  g.compact = ctx->opt_compact_residuals && ctx->opt_variant >= 8 && rows_per_wave == 4 && fast_sweep_supports(g) ? 1 : 0;   // (launch_residual_reduce's test)
-  return g;
-}
-
-// rows of 64 pixels each wavefront sweeps: large tiles amortise the 85-value wave reduction, small tiles
-// keep all 256 CUs busy when the batch is small
-int pick_rows_per_wave(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_pairs) {
-  if (level_uses_window(ctx, cam->w[level], cam->h[level])) return 4;
-  if (level_uses_small(ctx, cam->w[level], cam->h[level]) && ctx->opt_rows_per_wave == 0) {
-    // segments per wavefront such that a pair gets BatchPolicy::small_level_tiles workgroups
-    const int tiles = ctx->opt_small_tiles > 0 ? ctx->opt_small_tiles : BatchPolicy(ctx->compute_units).small_level_tiles(n_pairs);
-    const int segments = (cam->w[level] * cam->h[level] + kTileW - 1) / kTileW;
-    const int rows = (segments + kWavesPerBlock * tiles - 1) / (kWavesPerBlock * tiles);
-    return rows < 1 ? 1 : rows;
-  }
-  if (ctx->opt_deterministic) return ctx->opt_rows_per_wave > 0 ? ctx->opt_rows_per_wave : 4;   // one tile height whatever the batch
-  if (ctx->opt_rows_per_wave > 0) return ctx->opt_rows_per_wave;
-  // A large batch fills the device whatever the tile: short tiles (2 rows per wavefront: the schedule with the pinned prologue) run the
-  // coarse levels' sweeps 6-11 % faster than tall ones since the f16 Gram (scripts/ab_sweep.py: 1024 pairs, 160x120 0.200 -> 0.187 ms,
-  // 80x60 0.056 -> 0.050 ms; bench step 14.22 -> 13.89 ms)
-  if (BatchPolicy(ctx->compute_units).short_gather_tiles(n_pairs) && ctx->opt_variant >= 7) return 2;
-  const int candidates[4] = {8, 4, 2, 1};   // measured (profiles/r01_c_tile_sweep.txt): 8 rows is at or near the optimum on every level
-  // The tallest tile that still yields this many workgroups.  Fewer, taller tiles also mean fewer partial rows for the
-  // bookkeeping kernel, which matters most when there are few pairs (whole-match timings: profiles/r01_f_tile_heuristic.txt).
-  const size_t enough = ctx->opt_min_workgroups > 0 ? size_t(ctx->opt_min_workgroups) : size_t(BatchPolicy(ctx->compute_units).min_workgroups(n_pairs));
-  for (int r : candidates) {
-    int tx, ty;
-    level_tiles(cam->w[level], cam->h[level], r, level_is_linear(ctx, cam->w[level]), &tx, &ty);
-    if (size_t(tx) * ty * n_pairs >= enough) return r;
-  }
-  return 1;
-}
-
-// (whatever the schedule variant of the moment: a frame outlives option changes)
-static bool width_may_use_window(int w) { return w % kTileW == 0 || fast_sweep_takes_width(w); }
-// (... or the small-level sweep: both read plane C)
-static bool level_may_read_plane_c(int w, int h) { return width_may_use_window(w) || small_sweep_takes(w, h); }
-
-// device layout of a frame: [raw staging][per level: I Z A B R][sel counts]
-int frame_alloc(dvo_hip_context* ctx, int w, int h, const float K[4], int levels, dvo_hip_frame** out, size_t* raw_off) {
-  if (!ctx) return DVO_HIP_ERR_INVALID;
-  if (w < 4 || h < 4 || levels < 1 || levels > kMaxLevels || (w >> (levels - 1)) < 2 || (h >> (levels - 1)) < 2)
-    return fail(ctx, DVO_HIP_ERR_INVALID, "frame_create: bad width/height/levels");
-  DVO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const CameraGeom* cam = nullptr;
-  int rc = get_camera(ctx, w, h, K, levels, &cam);
-  if (rc != DVO_HIP_OK) return rc;
-  dvo_hip_frame* f = new dvo_hip_frame();
-  f->levels = levels;
-  f->cam = cam;
-  size_t total = align_up(size_t(w) * h * 3, 256);   // u8 grey + u16 depth staging
-  *raw_off = 0;
-  size_t offs[kMaxLevels][6];
-  for (int l = 0; l < levels; ++l) {
-    const size_t n = size_t(cam->w[l]) * cam->h[l];
-    // (C = {I, Z} of a current frame, the plane the window sweep stages in LDS: levels that sweep can handle)
-    const size_t sz[6] = {n * 4, n * 4, n * 16, n * 8, n * 8, level_may_read_plane_c(cam->w[l], cam->h[l]) ? n * 8 : 0};
-    for (int k = 0; k < 6; ++k) {
-      offs[l][k] = total;
-      total += align_up(sz[k], 256);
-    }
-  }
-  const size_t cnt_off = total;
-  total += 256;
-  hipError_t e = hipSuccess;
-  for (size_t k = 0; k < ctx->frame_pool.size(); ++k)
-    if (ctx->frame_pool[k].bytes == total) {                 // a block of a destroyed frame of this very layout
-      f->pool.p = ctx->frame_pool[k].p;
-      f->pool.bytes = total;
-      ctx->frame_pool_bytes -= total;
-      ctx->frame_pool.erase(ctx->frame_pool.begin() + long(k));
-      break;
-    }
-  if (!f->pool.p) e = f->pool.reserve(total);
-  if (e != hipSuccess) {
-    delete f;
-    ctx->err = std::string("hipMalloc(frame): ") + hipGetErrorString(e);
-    return DVO_HIP_ERR_HIP;
-  }
-  char* base = f->pool.as<char>();
-  for (int l = 0; l < levels; ++l) {
-    FrameLevel& L = f->lv[l];
-    L.w = cam->w[l]; L.h = cam->h[l];
-    L.I = reinterpret_cast<float*>(base + offs[l][0]);
-    L.Z = reinterpret_cast<float*>(base + offs[l][1]);
-    L.A = reinterpret_cast<float4*>(base + offs[l][2]);
-    L.B = reinterpret_cast<float2*>(base + offs[l][3]);
-    L.R = reinterpret_cast<float2*>(base + offs[l][4]);
-    L.C = level_may_read_plane_c(cam->w[l], cam->h[l]) ? reinterpret_cast<float2*>(base + offs[l][5]) : nullptr;
-  }
-  f->sel_count = reinterpret_cast<int*>(base + cnt_off);
-  *out = f;
-  return DVO_HIP_OK;
-}
-
-void fill_build_ptrs(dvo_hip_frame* f, FrameBuildPtrs& p) {
-  p.grey = nullptr;
-  p.raw = nullptr;
-  p.keep_grey = nullptr;
-  p.keep_raw = nullptr;
-  for (int l = 0; l < f->levels; ++l) {
-    p.I[l] = f->lv[l].I; p.Z[l] = f->lv[l].Z; p.A[l] = f->lv[l].A; p.B[l] = f->lv[l].B; p.R[l] = f->lv[l].R; p.C[l] = f->lv[l].C;
-  }
-  for (int l = f->levels; l < kMaxLevels; ++l) p.C[l] = nullptr;
-  p.sel_count = f->sel_count;
-}
-
-// the frame's own staging area: [u16 depth][u8 grey], see frame_alloc
-uint16_t* staging_depth(dvo_hip_frame* f) { return f->pool.as<uint16_t>(); }
-uint8_t* staging_grey(dvo_hip_frame* f) { return f->pool.as<uint8_t>() + size_t(f->lv[0].w) * f->lv[0].h * 2; }
-
-bool aligned_to(const void* p, size_t a) { return reinterpret_cast<uintptr_t>(p) % a == 0; }
-
-// RgbdImagePyramid::build (rgbd_image.cpp:156-172) for n frames of one camera.  From float planes (grey == null: level 0 is
-// already in place): the pyr-down chain, one launch per level for the whole batch; derived planes are built lazily per role
-// (ensure_roles), like the reference's buildAccelerationStructure / PointSelection caches.  From raw planes: one fused pass
-// (k_build_from_raw) that also writes level 0 in role `role` (-1: not known yet, 0: current, 1: reference with the given
-// thresholds) and leaves a copy of the raw planes in the frame unless the current-role planes make it redundant.
-// flavours of the current role a consumer of `n_frames` freshly built frames will most likely ask for at `level`: where the window
-// sweep handles the level, a batch too large for the resident kernel only ever reads the 8-byte plane C (a third of the bytes to
-// write); a small one may run the level resident (taps A + B) or on the launch path (C): both.  Whatever is missing at match time is
-// derived then (ensure_roles).
-int eager_current_flavor(const dvo_hip_context* ctx, const CameraGeom* cam, int level, int n_frames) {
-  // a small level (align_small.hip reads plane C): a batch that may still run this level in the resident kernel (the gathered taps) gets
-  // both flavours -- 38 KB and 115 KB per frame at 80 x 60 -- a larger one plane C alone
-  if (level_uses_small(ctx, cam->w[level], cam->h[level]))
-    return BatchPolicy(ctx->compute_units).resident_first_level_fits(n_frames) ? (kCurAB | kCurC) : kCurC;
-  if (!level_uses_window(ctx, cam->w[level], cam->h[level])) return kCurAB;
-  // (round 5: from an eighth as many frames as compute units on, plane C alone -- the taps cost three times the bytes to write, and a
-  // streaming step of 32 / 48 / 64 pairs that re-ingests them every step is 0.885 / 0.98 / 1.24 -> 0.783 / 0.93 / 1.09 ms without them and
-  // with the first level alone resident: plan_resident looks at what the frames hold)
-  return BatchPolicy(ctx->compute_units).ingest_skips_taps(n_frames) ? kCurC : (kCurAB | kCurC);
-}
-
-int frames_build(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, const void* const* grey, const void* const* raw,
-                 float depth_scale, int role = -1, float ithr = 0.0f, float dthr = 0.0f, bool keep_raw_copy = true) {
-  Range range("build");
-  const CameraGeom* cam = frames[0]->cam;
-  const int levels = frames[0]->levels;
-  std::vector<FrameBuildPtrs> host(n);
-  bool wide = cam->w[0] % 4 == 0;
-  const int flavor0 = eager_current_flavor(ctx, cam, 0, n);
-  for (int i = 0; i < n; ++i) {
-    dvo_hip_frame* f = frames[i];
-    if (f->cam != cam || f->levels != levels) return fail(ctx, DVO_HIP_ERR_INVALID, "frames of one build batch must share camera and levels");
-    fill_build_ptrs(f, host[i]);
-    for (int l = 0; l < levels; ++l) {   // new pixels: every cached role plane is stale (PointSelection::setRgbdImagePyramid)
-      f->lv[l].cur_have = 0;
-      f->lv[l].selected = false;
-    }
-    f->raw0 = grey != nullptr;
-    f->raw_copy = false;
-    f->depth_scale = depth_scale;
-    if (!grey) continue;
-    host[i].grey = static_cast<const uint8_t*>(grey[i]);
-    host[i].raw = static_cast<const uint16_t*>(raw[i]);
-    const bool in_place = host[i].raw == staging_depth(f) && host[i].grey == staging_grey(f);
-    if (in_place) {
-      f->raw_copy = true;
-    } else if (role < 0 || (role == 1 && keep_raw_copy)) {
-      host[i].keep_grey = staging_grey(f);
-      host[i].keep_raw = staging_depth(f);
-      f->raw_copy = true;
-    }
-    wide = wide && aligned_to(host[i].grey, 4) && aligned_to(host[i].raw, 8) && aligned_to(staging_grey(f), 4);
-    if (role == 0) f->lv[0].cur_have = flavor0;
-    if (role == 1) { f->lv[0].selected = true; f->lv[0].ithr = ithr; f->lv[0].dthr = dthr; }
-  }
-  hipStream_t bs = ctx->build_stream;
-  // (one of a few buffers: the one that already holds this very table -- a streaming caller re-ingests the same frame sets from the same
-  // planes step after step -- else the next in turn)
-  int slot = ctx->tables.holder(ctx->build_tbl, dvo_hip_context::kTableSlots, bs, host.data(), size_t(n) * sizeof(FrameBuildPtrs));
-  if (slot < 0) slot = int(ctx->build_tbl_next++ % dvo_hip_context::kTableSlots);
-  DevBuf& build_tbl = ctx->build_tbl[slot];
-  DVO_HIP_TRY(ctx, build_tbl.reserve(size_t(n) * sizeof(FrameBuildPtrs)));
-  DVO_HIP_TRY(ctx, ctx->tables.upload(bs, build_tbl.p, host.data(), size_t(n) * sizeof(FrameBuildPtrs)));
-  const FrameBuildPtrs* tbl = build_tbl.as<FrameBuildPtrs>();
-  ctx->build_tbl_frames.assign(frames, frames + n);
-  ctx->build_tbl_cur = &build_tbl;
-  int built = 1;                                       // float ingest: level 0 is already in place
-  if (grey) {
-    // current frames: the {I, Z} plane of the pyramid levels the window sweep will read comes out of the same pass (no neighbours
-    // needed), where the strip ingest runs (ingest_strips.hip)
-    built = levels < 4 ? levels : 4;
-    int c_levels = 0;
-    if (role == 0 && ingest_strips_supports(cam->w[0], wide)) {
-      for (int l = 1; l < built; ++l)
-        if (eager_current_flavor(ctx, cam, l, n) & kCurC) c_levels |= 1 << l;
-      for (int i = 0; i < n; ++i)
-        for (int l = 1; l < built; ++l)
-          if ((c_levels >> l & 1) && frames[i]->lv[l].C) frames[i]->lv[l].cur_have |= kCurC;
-    }
-    launch_build_from_raw(bs, tbl, n, depth_scale, cam->w[0], cam->h[0], levels, role, wide, ithr, dthr, ctx->opt_build_workgroups, flavor0, c_levels);
-    if (ingest_strips_supports(cam->w[0], wide)) ctx->strip_ingests += n;
-  }
-  for (int l = built; l < levels; ++l) launch_pyr_down(bs, tbl, n, l, cam->w[l - 1], cam->h[l - 1]);
-  DVO_HIP_TRY(ctx, hipGetLastError());
-  return stamp_build(ctx, n, frames);
-}
-
-// Build the missing role planes of a set of frames for levels [l0, l1]: role 0 = current (flavours `cur_want[level]`, kCurAB | kCurC;
-// null: the taps A + B), role 1 = reference (R + selection count for the given thresholds).  One launch per level (and source) for
-// all frames that need it.
-// `eager`: on the build stream (dvo_hip_frames_prepare), otherwise on the main stream right before the planes are used.
-int ensure_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* frames, int role, int l0, int l1, float ithr, float dthr, bool eager = false,
-                 const int* cur_want = nullptr) {
-  const CameraGeom* cam = frames[0]->cam;
-  const size_t slice = size_t(n) * sizeof(FrameBuildPtrs);
-  DevBuf& table = eager ? (role == 0 ? ctx->prep_tbl_cur : ctx->prep_tbl_ref) : (role == 0 ? ctx->role_tbl_cur : ctx->role_tbl_ref);
-  hipStream_t stream = eager ? ctx->build_stream : ctx->stream;
-  const int cap = eager ? ctx->opt_build_workgroups : 0;   // planes needed right now are built at full width
-  // Every frame is checked before the state of any is touched: a frame ingested straight into a role without a copy of its raw planes
-  // (option "keep_raw_copy" 0) has nothing its level 0 could be derived from in another role, and the marks below -- planes "built" --
-  // are set while the launches are still being gathered (round-5 advisor finding: the error used to leave earlier frames of the list
-  // marked as built without their launches, and a retry aligned against stale planes).
-  if (l0 == 0)
-    for (int i = 0; i < n; ++i) {
-      const dvo_hip_frame* f = frames[i];
-      const FrameLevel& L = f->lv[0];
-      if (!f->raw0 || L.cur_have != 0 || f->raw_copy) continue;
-      const int want0 = role == 0 ? (cur_want ? cur_want[0] : kCurAB) & (L.C ? (kCurAB | kCurC) : kCurAB) : 0;
-      const bool need = role == 0 ? want0 != 0 : !(L.selected && L.ithr == ithr && L.dthr == dthr);
-      if (need) return fail(ctx, DVO_HIP_ERR_INVALID, "frame has neither sampling planes nor a raw copy at level 0");
-    }
-  bool launched = false;
-  int uploads = 0;                                           // table slices used so far (each launch reads its own)
-  auto upload = [&](const std::vector<FrameBuildPtrs>& host, const FrameBuildPtrs** tbl, bool plane_pointers_only = true) -> int {
-    if (plane_pointers_only && eager && ctx->build_tbl_cur && int(host.size()) == n && ctx->build_tbl_frames.size() == size_t(n) &&
-        std::equal(frames, frames + n, ctx->build_tbl_frames.begin())) {
-      *tbl = ctx->build_tbl_cur->as<FrameBuildPtrs>();      // the ingest of these very frames left their table on this stream
-      return DVO_HIP_OK;
-    }
-    constexpr int kSlices = 4 * kMaxLevels;
-    if (uploads == kSlices) {                                // (never in practice: a slice per level and source)
-      DVO_HIP_TRY(ctx, hipStreamSynchronize(stream));
-      uploads = 0;
-    }
-    DVO_HIP_TRY(ctx, table.reserve(slice * kSlices));
-    FrameBuildPtrs* up = reinterpret_cast<FrameBuildPtrs*>(table.as<char>() + slice * uploads++);
-    DVO_HIP_TRY(ctx, ctx->tables.upload(stream, up, host.data(), host.size() * sizeof(FrameBuildPtrs)));
-    *tbl = up;
-    return DVO_HIP_OK;
-  };
-  // Several levels, every frame missing the same planes on each of them, all to be derived from the float planes I / Z (a camera
-  // frame that has just been built): ONE launch for all levels (k_derive_levels) instead of a table upload, a counter reset and a
-  // launch per level.
-  if (l1 > l0) {
-    LevelSpan span;
-    span.l0 = l0; span.l1 = l1;
-    bool uniform = n <= 64;                                                             // (the check below is quadratic; large batches come through the ingest.
-    // Round 6: the size test used to FOLLOW the double loop -- 524 288 comparisons per role of a 1024-pair batch, 0.4 ms of the host
-    // thread in front of every streaming step's first launch)
-    for (int i = 0; i < n && uniform; ++i)
-      for (int j = 0; j < i && uniform; ++j) uniform = frames[i] != frames[j];        // (a frame listed twice: the general path skips its second visit)
-    int tiles = 0;
-    for (int l = l0; l <= l1 && uniform; ++l) {
-      const int want = role == 0 ? (cur_want ? cur_want[l] : kCurAB) & (frames[0]->lv[l].C ? (kCurAB | kCurC) : kCurAB) : 0;
-      int miss_all = -1;
-      for (int i = 0; i < n && uniform; ++i) {
-        dvo_hip_frame* f = frames[i];
-        const FrameLevel& L = f->lv[l];
-        const int miss = role == 0 ? want & ~L.cur_have : 0;
-        const bool need = role == 0 ? miss != 0 : !(L.selected && L.ithr == ithr && L.dthr == dthr);
-        uniform = need && !(l == 0 && f->raw0) && (role == 1 || L.cur_have == 0) && (miss_all < 0 || miss == miss_all);
-        miss_all = miss;
-      }
-      span.w[l] = cam->w[l]; span.h[l] = cam->h[l]; span.flavor[l] = miss_all;
-      span.tile0[l] = tiles;
-      tiles += ((cam->w[l] + 63) / 64) * ((cam->h[l] + 15) / 16);
-    }
-    span.tile0[l1 + 1] = tiles;
-    if (uniform) {
-      std::vector<FrameBuildPtrs> host(n);
-      for (int i = 0; i < n; ++i) fill_build_ptrs(frames[i], host[i]);
-      const FrameBuildPtrs* tbl = nullptr;
-      const int rc = upload(host, &tbl);
-      if (rc != DVO_HIP_OK) return rc;
-      launch_derive_levels(stream, tbl, n, span, role, ithr, dthr, cap);
-      for (int i = 0; i < n; ++i)
-        for (int l = l0; l <= l1; ++l) {
-          FrameLevel& L = frames[i]->lv[l];
-          if (role == 0) L.cur_have |= span.flavor[l];
-          else { L.selected = true; L.ithr = ithr; L.dthr = dthr; }
-        }
-      if (eager) {
-        const int rc2 = stamp_build(ctx, n, frames);
-        if (rc2 != DVO_HIP_OK) return rc2;
-      }
-      DVO_HIP_TRY(ctx, hipGetLastError());
-      return DVO_HIP_OK;
-    }
-  }
-  for (int l = l0; l <= l1; ++l) {
-    const int want = role == 0 ? (cur_want ? cur_want[l] : kCurAB) & (frames[0]->lv[l].C ? (kCurAB | kCurC) : kCurAB) : 0;
-    // sources, per frame: float planes I / Z (levels >= 1, and level 0 of frames created from float planes); at level 0 of a frame
-    // ingested from raw planes: the other flavour of the current role, else the frame's copy of its raw planes
-    std::vector<FrameBuildPtrs> from_planes[4], from_raw[4], ab_from_c, c_from_a, ref_from_c;
-    std::vector<dvo_hip_frame*> ref_from_ab;
-    float raw_scale = 0.0f;
-    bool deferred = false;                                   // frames of another depth scale than the launch gathered so far
-    for (int i = 0; i < n; ++i) {
-      dvo_hip_frame* f = frames[i];
-      FrameLevel& L = f->lv[l];
-      const int miss = role == 0 ? want & ~L.cur_have : 0;
-      const bool need = role == 0 ? miss != 0 : !(L.selected && L.ithr == ithr && L.dthr == dthr);
-      if (!need) continue;   // also skips the second visit of a frame that is listed twice
-      FrameBuildPtrs p;
-      fill_build_ptrs(f, p);
-      if (l == 0 && f->raw0) {
-        if (role == 0 && (L.cur_have & kCurC)) {
-          ab_from_c.push_back(p);
-        } else if (role == 0 && (L.cur_have & kCurAB)) {
-          c_from_a.push_back(p);
-        } else if (role == 1 && (L.cur_have & kCurAB)) {
-          ref_from_ab.push_back(f);
-        } else if (role == 1 && (L.cur_have & kCurC)) {
-          ref_from_c.push_back(p);
-        } else if (f->raw_copy && (raw_scale == 0.0f || f->depth_scale == raw_scale)) {
-          raw_scale = f->depth_scale;
-          p.grey = staging_grey(f);
-          p.raw = staging_depth(f);
-          from_raw[miss].push_back(p);
-        } else if (f->raw_copy) {
-          deferred = true;     // another depth scale than the frames gathered so far: picked up by the pass below
-          continue;
-        } else {
-          return fail(ctx, DVO_HIP_ERR_INVALID, "frame has neither sampling planes nor a raw copy at level 0");
-        }
-      } else {
-        from_planes[miss].push_back(p);
-      }
-      if (role == 0) L.cur_have |= miss;
-      else { L.selected = true; L.ithr = ithr; L.dthr = dthr; }
-    }
-    const FrameBuildPtrs* tbl = nullptr;
-    for (int miss = 0; miss < 4; ++miss) {
-      if (!from_planes[miss].empty()) {
-        int rc = upload(from_planes[miss], &tbl);
-        if (rc != DVO_HIP_OK) return rc;
-        if (role == 0) launch_derive_current(stream, tbl, int(from_planes[miss].size()), l, cam->w[l], cam->h[l], cap, miss);
-        else launch_derive_reference(stream, tbl, int(from_planes[miss].size()), l, cam->w[l], cam->h[l], ithr, dthr, cap);
-        launched = true;
-      }
-      if (!from_raw[miss].empty()) {
-        int rc = upload(from_raw[miss], &tbl, /*plane_pointers_only=*/false);
-        if (rc != DVO_HIP_OK) return rc;
-        launch_build_from_raw(stream, tbl, int(from_raw[miss].size()), raw_scale, cam->w[0], cam->h[0], /*levels=*/1, role, cam->w[0] % 4 == 0, ithr, dthr, cap, miss);
-        launched = true;
-      }
-    }
-    const struct { std::vector<FrameBuildPtrs>* list; int mode; } conversions[3] = {{&ab_from_c, 0}, {&c_from_a, 1}, {&ref_from_c, 2}};
-    for (const auto& c : conversions) {
-      if (c.list->empty()) continue;
-      int rc = upload(*c.list, &tbl);
-      if (rc != DVO_HIP_OK) return rc;
-      launch_from_current_plane(stream, tbl, int(c.list->size()), l, cam->w[l], cam->h[l], c.mode, ithr, dthr, cap);
-      launched = true;
-    }
-    for (dvo_hip_frame* f : ref_from_ab) {   // PointSelection over a frame that has been a current frame so far
-      FrameLevel& L = f->lv[0];
-      DVO_HIP_TRY(ctx, hipMemsetAsync(f->sel_count, 0, sizeof(int), stream));
-      launch_select_pack(stream, L.A, L.B, L.w * L.h, ithr, dthr, L.R, f->sel_count, nullptr);
-      launched = true;
-    }
-    if (deferred) {   // frames of a second depth scale (one kernel launch takes one scale): rare, one more pass each
-      if (eager && launched) {
-        const int rc = stamp_build(ctx, n, frames);
-        if (rc != DVO_HIP_OK) return rc;
-      }
-      DVO_HIP_TRY(ctx, hipStreamSynchronize(stream));   // the table slices are reused
-      return ensure_roles(ctx, n, frames, role, l0, l1, ithr, dthr, eager, cur_want);
-    }
-  }
-  if (eager && launched) {
-    const int rc = stamp_build(ctx, n, frames);
-    if (rc != DVO_HIP_OK) return rc;
-  }
-  DVO_HIP_TRY(ctx, hipGetLastError());
-  return DVO_HIP_OK;
-}
-
-struct BatchPlan {
-  int n = 0, nlev = 0, cap_levels = 0, cap_iters = 0;
-  SolverParams prm;
-  const CameraGeom* cam = nullptr;
-  std::vector<int> rpw;          // per absolute level
-  std::vector<LevelGeom> geom;   // per absolute level
-  PairPtrs* pair_ptrs = nullptr; // device [levels][n] (null when the table only travels in kernel arguments)
-  std::vector<PairPtrs> host_ptrs;   // the same table on the host
-  int coarse_levels = 0;         // leading levels (first_level, first_level - 1, ...) the fused coarse-level kernel runs (plan_coarse)
-};
-
-int validate_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg) {
-  if (!ctx || n < 1 || !refs || !curs || !cfg) return fail(ctx, DVO_HIP_ERR_INVALID, "match: null argument");
-  if (cfg->first_level < cfg->last_level || cfg->last_level < 0 || cfg->first_level >= kMaxLevels)   // Config::IsSane, DT.cpp:74
-    return fail(ctx, DVO_HIP_ERR_INVALID, "match: need 0 <= last_level <= first_level < DVO_HIP_MAX_LEVELS");
-  if (cfg->max_iterations_per_level < 1) return fail(ctx, DVO_HIP_ERR_INVALID, "match: max_iterations_per_level < 1");
-  const int need_levels = cfg->first_level + 1;   // Config::getNumLevels
-  const CameraGeom* cam = refs[0] ? refs[0]->cam : nullptr;
-  for (int i = 0; i < n; ++i) {
-    if (!refs[i] || !curs[i]) return fail(ctx, DVO_HIP_ERR_INVALID, "match: null frame");
-    if (refs[i]->levels < need_levels || curs[i]->levels < need_levels)
-      return fail(ctx, DVO_HIP_ERR_INVALID, "match: frame pyramid has fewer levels than first_level + 1");
-    if (refs[i]->cam != cam || curs[i]->cam != cam)
-      return fail(ctx, DVO_HIP_ERR_INVALID, "match: all frames of a batch must share size and intrinsics");
-  }
-  return DVO_HIP_OK;
-}
-
-void make_plan(const dvo_hip_context* ctx, const CameraGeom* cam, const dvo_hip_config* cfg, int n, BatchPlan& bp) {
-  const int need_levels = cfg->first_level + 1;
-  bp.n = n;
-  bp.cam = cam;
-  bp.nlev = cfg->first_level - cfg->last_level + 1;
-  bp.cap_levels = bp.nlev;
-  bp.cap_iters = bp.nlev * cfg->max_iterations_per_level;
-  bp.prm.max_iterations = cfg->max_iterations_per_level;
-  bp.prm.first_level = cfg->first_level;
-  bp.prm.last_level = cfg->last_level;
-  bp.prm.use_initial_estimate = cfg->use_initial_estimate;
-  bp.prm.precision = cfg->precision;
-  bp.prm.mu = cfg->mu;
-  bp.prm.cap_iters = bp.cap_iters;
-  bp.prm.cap_levels = bp.cap_levels;
-  bp.prm.max_points_level0 = cam->w0 * cam->h0;
-  bp.prm.want_condition_number = ctx->opt_condition_number;
-  bp.prm.record_prefilled = 0;
-  bp.rpw.assign(need_levels, 1);
-  bp.geom.resize(need_levels);
-  for (int l = cfg->last_level; l <= cfg->first_level; ++l) {
-    bp.rpw[l] = pick_rows_per_wave(ctx, cam, l, n);
-    bp.geom[l] = make_geom(ctx, cam, l, bp.rpw[l]);
-  }
-}
-
-// buildAccelerationStructure for the current frames, PointSelection::select for the reference frames (both cached per
-// frame and level); enqueued on the context's main stream
-// `launch_path_only`: the caller runs every level on the launch-per-step path (the parity / measurement entry points)
-int resident_levels_of(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const CameraGeom* cam, int n, bool taps_missing);
-bool window_taps_missing(const dvo_hip_context* ctx, const dvo_hip_config* cfg, int n, dvo_hip_frame* const* curs);
-
-int ensure_batch_roles(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
-                       bool launch_path_only = false) {
-  Range range("build");
-  ctx->last_sel_ithr = cfg->intensity_derivative_threshold;   // (what a speculative reference preparation will assume, prepare_roles)
-  ctx->last_sel_dthr = cfg->depth_derivative_threshold;
-  int rc = wait_for_build(ctx, n, refs);
-  if (rc == DVO_HIP_OK) rc = wait_for_build(ctx, n, curs);
-  if (rc != DVO_HIP_OK) return rc;
-  // the flavour of the current role each level is read in: the resident kernel and the gathering sweep read the taps A + B, the
-  // window sweep the 8-byte plane C
-  const CameraGeom* cam = curs[0]->cam;
-  const int resident = launch_path_only ? 0 : resident_levels_of(ctx, cfg, cam, n, window_taps_missing(ctx, cfg, n, curs));
-  int want[kMaxLevels];
-  for (int l = 0; l < kMaxLevels; ++l)
-    want[l] = l > cfg->first_level - resident || l >= cam->levels || !(level_uses_window(ctx, cam->w[l], cam->h[l]) || level_uses_small(ctx, cam->w[l], cam->h[l])) ? kCurAB : kCurC;
-  rc = ensure_roles(ctx, n, curs, 0, cfg->last_level, cfg->first_level, 0.0f, 0.0f, /*eager=*/false, want);
-  if (rc == DVO_HIP_OK)
-    rc = ensure_roles(ctx, n, refs, 1, cfg->last_level, cfg->first_level, cfg->intensity_derivative_threshold, cfg->depth_derivative_threshold);
-  return rc;
-}
-
-// Device scratch for n pairs + the per-level pointer tables
-int prepare_buffers(Workspace& w, const dvo_hip_config* cfg, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, BatchPlan& bp,
-                    bool upload_table = true) {
-  const int n = bp.n, need_levels = cfg->first_level + 1;
-  size_t max_tiles = 1;
-  for (int l = cfg->last_level; l <= cfg->first_level; ++l) max_tiles = std::max(max_tiles, size_t(bp.geom[l].tiles_x) * bp.geom[l].tiles_y);
-  size_t npx = 0;                                             // residual entries per pair: the largest level's (packed ones own whole tiles)
-  for (int l = cfg->last_level; l <= cfg->first_level; ++l) npx = std::max(npx, residual_entries(bp.geom[l]));
-  DVO_WS_TRY(w, w.states.reserve(size_t(n) * sizeof(PairState)));
-
-  DVO_WS_TRY(w, w.partials.reserve(size_t(n) * max_tiles * kAccStride * sizeof(float)));
-  DVO_WS_TRY(w, w.scratch.reserve(size_t(n) * npx * sizeof(float2)));
-  DVO_WS_TRY(w, w.ll_partials.reserve(size_t(n) * kLlBlocksPerPair * sizeof(double)));
-  DVO_WS_TRY(w, w.lvl_stats.reserve(size_t(n) * bp.cap_levels * sizeof(dvo_hip_level_stats)));
-  DVO_WS_TRY(w, w.it_stats.reserve(size_t(n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats)));
-  DVO_WS_TRY(w, w.results.reserve(size_t(n) * sizeof(dvo_hip_result)));
-  DVO_WS_TRY(w, w.pair_sums.reserve(size_t(n) * kPairSumsStride * sizeof(double)));
-  DVO_WS_TRY(w, w.t_init.reserve(size_t(n) * 16 * sizeof(double)));
-  // per-step tallies, and behind them one arrival word per pair (the sweeps' tail, solver_step.h): cleared together at the start of a batch
-  DVO_WS_TRY(w, w.counters.reserve(size_t(bp.cap_iters + 8 + kResidentErrorWords) * sizeof(unsigned long long) + align_up(size_t(n) * sizeof(int), 8)));
-  if (!w.win_fallbacks.p) {
-    DVO_WS_TRY(w, w.win_fallbacks.reserve(64));
-    DVO_WS_TRY(w, hipMemsetAsync(w.win_fallbacks.p, 0, 64, w.stream));
-  }
-  if (w.f16_range_words < size_t(n)) {
-    // (the words are only ever written by sweeps of a batch that is over by the time the next one is prepared: a larger array can
-    // replace the old one here once the stream has drained)
-    if (w.f16_range_flag) {
-      DVO_WS_TRY(w, hipStreamSynchronize(w.stream));
-      (void)hipHostFree(w.f16_range_flag);
-      w.f16_range_flag = nullptr;
-      w.f16_range_words = 0;
-    }
-    const size_t words = std::max<size_t>(64, size_t(n));
-    DVO_WS_TRY(w, hipHostMalloc(reinterpret_cast<void**>(&w.f16_range_flag), words * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
-    std::memset(w.f16_range_flag, 0, words * sizeof(int));
-    w.f16_range_words = words;
-  }
-  std::vector<PairPtrs>& host = bp.host_ptrs;
-  host.assign(size_t(n) * need_levels, PairPtrs());
-  for (int l = cfg->last_level; l <= cfg->first_level; ++l)
-    for (int i = 0; i < n; ++i) {
-      PairPtrs& p = host[size_t(l) * n + i];
-      p.refR = refs[i]->lv[l].R;
-      p.curA = curs[i]->lv[l].A;
-      p.curB = curs[i]->lv[l].B;
-      p.n_selected = refs[i]->sel_count + l;
-      p.curC = curs[i]->lv[l].C;
-    }
-  bp.pair_ptrs = nullptr;
-  if (upload_table) {
-    int slot = w.tables->holder(w.pair_ptrs, Workspace::kTableSlots, w.stream, host.data(), host.size() * sizeof(PairPtrs));
-    if (slot < 0) slot = int(w.pair_ptrs_next++ % Workspace::kTableSlots);
-    DevBuf& pair_ptrs = w.pair_ptrs[slot];
-    DVO_WS_TRY(w, pair_ptrs.reserve(size_t(n) * need_levels * sizeof(PairPtrs)));
-    DVO_WS_TRY(w, w.tables->upload(w.stream, pair_ptrs.p, host.data(), host.size() * sizeof(PairPtrs)));
-    bp.pair_ptrs = pair_ptrs.as<PairPtrs>();
-  }
-  return DVO_HIP_OK;
-}
-
-// Spin on the pinned status word the device writes when the last workgroup of a step is through (publish_step in
-// solver_kernels.hip).  A host-memory poll sees the word ~2 us after the store; an event synchronisation took ~10 us.
-int step_wait_check(Workspace& w, std::chrono::steady_clock::time_point t0) {
-  const hipError_t q = hipStreamQuery(w.stream);
-  if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();   // "still running" is not an error to keep
-  if (q != hipSuccess && q != hipErrorNotReady) {
-    w.err = std::string("match: stream failed while waiting for a Gauss-Newton step: ") + hipGetErrorString(q);
-    return DVO_HIP_ERR_HIP;
-  }
-  if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
-    w.err = "match: timed out waiting for a Gauss-Newton step";
-    return DVO_HIP_ERR_HIP;
-  }
-  return DVO_HIP_OK;
-}
-
-int wait_for_step(Workspace& w, int step, int* active) {
-  volatile int* word = w.host_status + step;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned spins = 1;; ++spins) {
-    const int v = *word;
-    if (v & kStepDoneFlag) {
-      *active = v & ~kStepDoneFlag;
-      return DVO_HIP_OK;
-    }
-    if ((spins & 0xfffff) == 0) {                            // every ~1M polls: has the stream died, or are we stuck?
-      const int rc = step_wait_check(w, t0);
-      if (rc != DVO_HIP_OK) return rc;
-    }
-  }
-}
-
-// The direct path of the resident kernel: spin on the pinned word in which the kernel counts the pairs whose results (and statistics)
-// are complete in pinned host memory; a group that timed out raises the error word instead (the caller repeats the batch).
-int wait_for_direct(Workspace& w, int n_pairs) {
-  volatile int* done = w.direct_done.as<int>();
-  volatile int* error_word = w.host_status + w.resident_error_word;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned spins = 1;; ++spins) {
-    if (*error_word != 0) return DVO_HIP_OK;                 // (looked at first: an error raised in this launch is reported by this launch)
-    if (*done >= n_pairs) {
-      std::atomic_thread_fence(std::memory_order_acquire);
-      return DVO_HIP_OK;
-    }
-    if ((spins & 0xfffff) == 0) {
-      const hipError_t q = hipStreamQuery(w.stream);
-      if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();
-      if (q == hipSuccess && *done < n_pairs && *error_word == 0) {   // the kernel is gone and has not reported: it never ran
-        w.err = "match: the resident kernel ended without reporting its pairs";
-        return DVO_HIP_ERR_HIP;
-      }
-      if (q != hipSuccess && q != hipErrorNotReady) {
-        w.err = std::string("match: stream failed while the resident kernel ran: ") + hipGetErrorString(q);
-        return DVO_HIP_ERR_HIP;
-      }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
-        w.err = "match: timed out waiting for the resident kernel";
-        return DVO_HIP_ERR_HIP;
-      }
-    }
-  }
-}
-
-// pinned status words the device writes (publish_step): coherent + mapped, so that a system-scope store is visible to the
-// polling host thread whatever HIP_HOST_COHERENT says
-int ensure_host_status(Workspace& w, size_t n_steps) {
-  if (w.host_status_words < n_steps) {
-    if (w.host_status) (void)hipHostFree(w.host_status);
-    w.host_status = nullptr;
-    w.host_status_words = 0;
-    DVO_WS_TRY(w, hipHostMalloc(reinterpret_cast<void**>(&w.host_status), n_steps * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
-    w.host_status_words = n_steps;
-  }
-  return DVO_HIP_OK;
-}
-
-// ---- the resident kernel: which levels, how many workgroups per pair ------------------------------------------------------------
-// Workgroups of a group wait for each other, so all groups in flight on a device must be on it together.  Contexts of one process
-// (one per host thread, like the reference's one DenseTracker per TBB worker, keyframe_graph.cpp:576-593) share a per-device budget
-// of compute units: launches with groups run SIDE BY SIDE as long as their workgroups fit the device together (one 512-thread
-// workgroup per compute unit), and wait for each other beyond that.  (Round 2 let only one such launch run at a time: side by side,
-// one launch in seven had timed out.  The cause was the exchange's missing flow control towards idle workgroups -- fixed in
-// align_resident.hip, "Flow control" -- which a second launch on the device, delaying some workgroups' start, merely exposed.)
-// Another PROCESS on the same device is not seen here; there a group can time out, and the batch is repeated on the launch path.
-struct ResidentBudget {
-  std::mutex m;
-  std::condition_variable cv;
-  int in_flight = 0;
-  static ResidentBudget& of(int device) {
-    static ResidentBudget budgets[64];
-    return budgets[device >= 0 && device < 64 ? device : 63];
-  }
-  struct Hold {
-    ResidentBudget* b = nullptr;
-    int n = 0;
-    Hold() = default;
-    Hold(const Hold&) = delete;
-    Hold& operator=(const Hold&) = delete;
-    void take(ResidentBudget& budget, int workgroups, int capacity) {
-      std::unique_lock<std::mutex> lock(budget.m);
-      budget.cv.wait(lock, [&] { return budget.in_flight == 0 || budget.in_flight + workgroups <= capacity; });
-      budget.in_flight += workgroups;
-      b = &budget;
-      n = workgroups;
-    }
-    ~Hold() {
-      if (!b) return;
-      {
-        std::lock_guard<std::mutex> lock(b->m);
-        b->in_flight -= n;
-      }
-      b->cv.notify_all();
-    }
-  };
-};
-
-constexpr int kResidentRowsDefault = 24;      // segments per wavefront and iteration up to which a level runs resident
-
-
-struct ResidentPlan {
-  int group = 1;                               // workgroups per pair
-  int levels = 0;                              // leading levels (first_level, first_level - 1, ...) that run resident
-  bool direct = false;                         // the whole match of a small batch: results and statistics land in pinned host memory
-};
-
-constexpr size_t kResidentDirectStatsBytes = size_t(64) << 20;
-
-// `taps_missing`: current frames of the batch hold plane C but not the taps A + B on the level below the first one (they were ingested
-// straight into their role in a batch of an eighth as many frames as compute units or more, eager_current_flavor): the resident kernel
-// would have to have the taps derived for it first
-bool window_taps_missing(const dvo_hip_context* ctx, const dvo_hip_config* cfg, int n, dvo_hip_frame* const* curs) {
-  const int level = cfg->first_level - 1;
-  if (level < cfg->last_level || level >= curs[0]->levels || !level_uses_window(ctx, curs[0]->cam->w[level], curs[0]->cam->h[level])) return false;
-  for (int i = 0; i < n; ++i) {
-    const int have = curs[i]->lv[level].cur_have;
-    if ((have & kCurC) && !(have & kCurAB)) return true;
-  }
-  return false;
-}
-
-ResidentPlan plan_resident(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const BatchPlan& bp, bool taps_missing) {
-  ResidentPlan rp;
-  if (ctx->opt_resident == 0 || ctx->opt_deterministic) return rp;   // (deterministic: one path whatever the batch size, and that is the launch path)
-  const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
-  // more pairs than compute units: the workgroups would run in shifts, and the launch path, which gives every phase the whole chip,
-  // is as fast (measured: 256 pairs -3 %, 512 pairs +1.6 % against it).  (Not with a pinned group size: the caller asks for
-  // records that do not depend on the batch size, so the choice of path must not either.)
-  // (round 3: with the f16 Gram and the short tiles the launch path is level with or ahead of ONE workgroup per pair as well -- 192 / 256
-  // pairs: screening stage 0.278 / 0.306 vs 0.293 / 0.341 ms, levels 3 -> 1 0.82 / 0.95 vs 0.87 / 1.01, full match equal; the resident
-  // kernel is kept for batches that get at least two workgroups per pair -- with launches limited to half the chip that is
-  // pairs <= compute units / 4.  Measured at the end of round 3, 96 / 128 pairs with ONE workgroup each: full match 1.63 / 1.93 ms
-  // resident against 1.61 / 1.90 on the launch path, levels 3 -> 1 0.60 / 0.67 against 0.57 / 0.65, and a streaming step of 128 pairs
-  // beside its background ingest 2.50 against 2.41 ms; at 64 pairs (two workgroups each) resident still wins, 1.19 against 1.26.)
-  // (round 5: up to 7/16 as many pairs as compute units the FIRST level alone -- 18 of a streaming step's 34 iterations in BASELINE
-  // config 4, each a sweep and a solver launch of 11 + 12 us -- is still quicker resident with two workgroups per pair, which leave
-  // an eighth of the chip to the background ingest: streaming step of 72 / 80 / 96 / 112 pairs 1.215 / 1.283 / 1.440 / 1.634 ->
-  // 1.172 / 1.232 / 1.378 / 1.587 ms.  128 pairs: two workgroups each 1.808 against 1.776, one 1.748 on one box and level on two
-  // others -- left on the launch path; with the second level resident as well 1.59 at 96 pairs.  Only a level the launch path
-  // reads through the taps too: its planes exist.)
-  // (the same from an eighth of the compute units on when the batch came from a streaming ingest that left the taps out -- see
-  // eager_current_flavor; frames that hold them, or nothing yet, get the coarse levels resident as before: a match of 64 prepared pairs
-  // 0.96 ms against 1.02 with the first level alone)
-  const BatchPolicy policy(ctx->compute_units);
-  const bool first_level_only = ctx->opt_resident < 0 && ctx->opt_resident_group == 0 &&
-                                (!policy.resident_takes_coarse_levels(bp.n) || (policy.taps_missing_prefers_first_level_only(bp.n) && taps_missing));
-  if (first_level_only && (!policy.resident_first_level_fits(bp.n) || level_uses_window(ctx, bp.cam->w[cfg->first_level], bp.cam->h[cfg->first_level]))) return rp;
-  // all workgroups of a launch with groups must be resident at once: one workgroup (8 wavefronts, up to 256 registers) per compute unit
-  int group = 1;
-  while (group * 2 <= kResidentMaxGroup && bp.n * group * 2 <= cus) group *= 2;
-  if (ctx->opt_resident_group > 0) group = std::min(group, ctx->opt_resident_group);
-  if (first_level_only) {                                       // the groups leave an eighth of the chip free
-    group = 1;
-    while (group * 2 <= kResidentMaxGroup && bp.n * group * 2 * 8 <= cus * 7) group *= 2;
-  }
-  rp.group = group;
-  const int rows_max = ctx->opt_resident_rows > 0 ? ctx->opt_resident_rows : kResidentRowsDefault;
-  for (int level = cfg->first_level; level >= cfg->last_level; --level) {
-    const int segments = (bp.cam->w[level] * bp.cam->h[level] + kTileW - 1) / kTileW;
-    const int rows = (segments + group * kResidentSweepers - 1) / (group * kResidentSweepers);
-    if (ctx->opt_resident != 1 && rows > rows_max) break;
-    if (first_level_only && rp.levels == 1) break;
-    if (size_t(bp.cam->w[level]) * bp.cam->h[level] >= (size_t(1) << 24)) break;   // the kernel locates a pixel with one float multiply
-    rp.levels += 1;
-  }
-  static const bool trace_plan = std::getenv("DVO_HIP_TRACE_PLAN") != nullptr;     // (stderr: which plan a batch got)
-  if (trace_plan)
-    std::fprintf(stderr, "plan_resident: %d pairs, taps missing %d -> %s, %d workgroup(s) per pair, %d level(s) resident\n", bp.n, int(taps_missing),
-                 first_level_only ? "first level only" : "coarse levels", rp.group, rp.levels);
-  rp.direct = rp.levels == cfg->first_level - cfg->last_level + 1 && bp.n <= policy.resident_direct_max_pairs() &&
-              size_t(bp.n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats) <= kResidentDirectStatsBytes;   // (pinned, if asked for)
-  return rp;
-}
-
-// ---- the fused coarse-level kernel (align_coarse.hip): which levels -----------------------------------------------------------------
-// One workgroup per pair runs the leading levels of the match to their termination in ONE launch (sweep over all tiles, reduction,
-// log-likelihood, loop body), with the launch path's device functions on the launch path's data layout: the records are the launch
-// path's bit for bit.  The levels: from the first one down, as long as the level is small (kCoarseMaxPixels) and the kernel has an
-// instantiation for it (coarse_kernel_takes).  OPT-IN (option "coarse" 1): measured in round 6 against the launch path at 128 / 256 /
-// 512 / 1024 pairs per step and slower at every size (1.80 -> 3.08, 3.16 -> 4.43, 6.0 -> 7.2, 11.5 -> 12.5 ms per streaming step): a
-// workgroup walks the 10 + 34 tiles of levels 3 and 2 one after the other -- 60 / 200 us per iteration where the launch path, which
-// spreads the tiles of an iteration over the chip, needs 25 / 40 -- and with as many pairs as workgroup slots (1024 = 256 compute units x
-// 4) the launch lasts as long as its slowest pair (15 + 9 iterations against a mean of 8 + 5).  It pays where pairs outnumber the slots
-// several times over; kept for that case and as the bit-exact cross-check of the launch path's hand-over logic.
-constexpr int kCoarseMaxPixels = 160 * 120;
-
-void plan_coarse(const dvo_hip_context* ctx, const dvo_hip_config* cfg, BatchPlan& bp, const ResidentPlan& rp) {
-  bp.coarse_levels = 0;
-  if (ctx->opt_coarse == 0 || rp.levels > 0 || ctx->opt_variant != 8) return;
-  const int max_pixels = ctx->opt_coarse_pixels > 0 ? ctx->opt_coarse_pixels : kCoarseMaxPixels;
-  for (int level = cfg->first_level; level >= cfg->last_level; --level) {
-    if (bp.cam->w[level] * bp.cam->h[level] > max_pixels) break;
-    const bool window_level = level_uses_window(ctx, bp.cam->w[level], bp.cam->h[level]);
-    const int rpw = window_level ? 4 : kCoarseRowsPerWave;
-    if (!window_level && ctx->opt_rows_per_wave > 0 && ctx->opt_rows_per_wave != rpw) break;   // (a tile height asked for by name stays)
-    const LevelGeom g = make_geom(ctx, bp.cam, level, rpw);
-    if (!coarse_kernel_takes(g, window_level)) break;
-    bp.rpw[level] = rpw;
-    bp.geom[level] = g;
-    bp.coarse_levels += 1;
-  }
-}
-
-// which of the two one-launch kernels takes the leading levels of a batch, if any
-ResidentPlan plan_paths(const dvo_hip_context* ctx, const dvo_hip_config* cfg, BatchPlan& bp, bool taps_missing) {
-  ResidentPlan rp = plan_resident(ctx, cfg, bp, taps_missing);
-  if (ctx->opt_coarse == 1) {                                  // (option "coarse" 1: the fused coarse-level kernel wherever the levels admit it)
-    const ResidentPlan none;
-    plan_coarse(ctx, cfg, bp, none);
-    if (bp.coarse_levels > 0) rp = none;
-  } else {
-    plan_coarse(ctx, cfg, bp, rp);
-  }
-  return rp;
-}
-
-int resident_levels_of(const dvo_hip_context* ctx, const dvo_hip_config* cfg, const CameraGeom* cam, int n, bool taps_missing) {
-  BatchPlan bp;
-  make_plan(ctx, cam, cfg, n, bp);
-  return plan_paths(ctx, cfg, bp, taps_missing).levels;
-}
-
-int run_resident(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, const BatchPlan& bp, const ResidentPlan& rp,
-                 const double* tinit, bool want_stats) {
-  hipStream_t s = w.stream;
-  ResidentArgs args;
-  std::memset(&args, 0, sizeof(args));
-  for (int l = cfg->last_level; l <= cfg->first_level; ++l) args.geom[l] = bp.geom[l];
-  args.pair_ptrs = bp.pair_ptrs;
-  args.states = w.states.as<PairState>();
-  args.levels = w.lvl_stats.as<dvo_hip_level_stats>();
-  args.iters = w.it_stats.as<dvo_hip_iteration_stats>();
-  args.T_init = w.t_init.as<double>();
-  args.scratch = w.scratch.as<float2>();
-  args.error_word = w.host_status + w.resident_error_word;
-  args.prm = bp.prm;
-  args.n_pairs = bp.n;
-  args.group = rp.group;
-  args.first_level = cfg->first_level;
-  args.last_level = cfg->first_level - rp.levels + 1;
-  args.flags = ctx->opt_resident_flags;
-  args.results = args.last_level == cfg->last_level ? w.results.as<dvo_hip_result>() : nullptr;
-  if (bp.n <= kResidentInline) {                               // no table in device memory, no copy commands in front of the launch
-    args.use_inline = 1;
-    for (int l = cfg->last_level; l <= cfg->first_level; ++l)
-      for (int i = 0; i < bp.n; ++i) args.inline_ptrs[l * bp.n + i] = bp.host_ptrs[size_t(l) * bp.n + i];
-    std::memcpy(args.inline_T, tinit, size_t(bp.n) * 16 * sizeof(double));
-  }
-  if (rp.direct) {
-    DVO_WS_TRY(w, w.direct_results.reserve(size_t(bp.n) * sizeof(dvo_hip_result)));
-    DVO_WS_TRY(w, w.direct_done.reserve(64));
-    args.results = w.direct_results.as<dvo_hip_result>();
-    args.done_word = w.direct_done.as<int>();
-    *static_cast<volatile int*>(args.done_word) = 0;
-    if (want_stats) {
-      DVO_WS_TRY(w, w.direct_levels.reserve(size_t(bp.n) * bp.cap_levels * sizeof(dvo_hip_level_stats)));
-      DVO_WS_TRY(w, w.direct_iters.reserve(size_t(bp.n) * bp.cap_iters * sizeof(dvo_hip_iteration_stats)));
-      args.host_levels = w.direct_levels.as<dvo_hip_level_stats>();
-      args.host_iters = w.direct_iters.as<dvo_hip_iteration_stats>();
-    }
-  }
-  ctx->resident_launches += 1;
-  ctx->resident_levels += rp.levels;
-  if (rp.group > 1) {
-    // the rows of every group, and behind them one heartbeat word per workgroup (align_resident.hip, "Flow control")
-    const size_t bytes = size_t(bp.n) * rp.group * kResidentRing * kResidentSlots * sizeof(unsigned long long) + align_up(size_t(bp.n) * rp.group * sizeof(unsigned), 256);
-    const bool grown = bytes > w.exchange.bytes;
-    DVO_WS_TRY(w, w.exchange.reserve(bytes));
-    // sequence numbers never repeat between launches; when they would wrap (or the rows are new / in doubt) the rows are cleared
-    const unsigned long long need64 = 2ull * unsigned(rp.levels) * unsigned(cfg->max_iterations_per_level) + 4ull;
-    const unsigned need = need64 < 0x40000000ull ? unsigned(need64) : 0x40000000u;   // (more exchanges than that do not happen)
-    // (... or the batch has another shape than the last one: the heartbeat words live BEHIND the rows, at an offset that follows pairs x
-    // group, and a word that was a row slot of the previous launch -- the float half of a slot, 0x3f800000, reads as a beat far ahead --
-    // would let a workgroup skip the wait the heartbeat exists for)
-    const long long shape = (long long)bp.n * rp.group;
-    if (grown || shape != w.exchange_shape || need64 >= 0x40000000ull || w.resident_sequence > 0xffffffffu - need - 1u) {
-      DVO_WS_TRY(w, hipMemsetAsync(w.exchange.p, 0, w.exchange.bytes, s));
-      w.resident_sequence = 0;
-      w.exchange_shape = shape;
-    }
-    args.exchange = w.exchange.as<unsigned long long>();
-    args.sequence_base = w.resident_sequence;
-    w.resident_sequence += need;
-  }
-  DVO_WS_TRY(w, launch_match_resident(s, args, ctx->opt_resident_cooperative != 0));
-  return DVO_HIP_OK;
-}
-
-int run_coarse(dvo_hip_context* ctx, Workspace& w, const dvo_hip_config* cfg, const BatchPlan& bp) {
-  CoarseArgs args;
-  std::memset(&args, 0, sizeof(args));
-  for (int l = cfg->last_level; l <= cfg->first_level; ++l) args.geom[l] = bp.geom[l];
-  args.pair_ptrs = bp.pair_ptrs;
-  args.states = w.states.as<PairState>();
-  args.levels = w.lvl_stats.as<dvo_hip_level_stats>();
-  args.iters = w.it_stats.as<dvo_hip_iteration_stats>();
-  args.T_init = w.t_init.as<double>();
-  args.partials = w.partials.as<float>();
-  args.scratch = w.scratch.as<float2>();
-  args.fallback_count = w.win_fallbacks.as<unsigned long long>();
-  args.f16_range_flag = w.f16_range_flag;
-  args.prm = bp.prm;
-  args.n_pairs = bp.n;
-  args.first_level = cfg->first_level;
-  args.last_level = cfg->first_level - bp.coarse_levels + 1;
-  for (int l = args.last_level; l <= args.first_level; ++l) {   // (prepare_buffers sized both buffers for the largest level of the match)
-    args.max_tiles = std::max(args.max_tiles, bp.geom[l].tiles_x * bp.geom[l].tiles_y);
-    args.max_entries = std::max(args.max_entries, residual_entries(bp.geom[l]));
-  }
-  args.results = args.last_level == cfg->last_level ? w.results.as<dvo_hip_result>() : nullptr;
-  ctx->coarse_launches += 1;
-  ctx->coarse_levels += bp.coarse_levels;
-  DVO_WS_TRY(w, launch_match_coarse(w.stream, args, ctx->opt_coarse_wgs == 3 ? 3 : 4));
-  return DVO_HIP_OK;
-}
-
-std::mutex g_rare_path_mutex;   // (see run_batch: the repeat of pairs that left the f16 range)
-
-constexpr int kF32GramHoldBatches = 32;   // after a batch left the f16 range of the Gram operands: this many batches go straight to the f32 Gram
-
-hipEvent_t g_trace_ev[2] = {nullptr, nullptr};   // DVO_HIP_TRACE_SLOW: device time stamps around a batch's preparation
-
-// The coarse-to-fine Gauss-Newton driver of a batch (dense_tracking.cpp:131-376 for every pair at once).
-int run_batch(dvo_hip_context* ctx, int n, dvo_hip_frame* const* refs, dvo_hip_frame* const* curs, const dvo_hip_config* cfg,
-              dvo_hip_result* results, dvo_hip_level_stats* levels, int cap_levels, dvo_hip_iteration_stats* iters, int cap_iters) {
-  Workspace& w = ctx->ws[0];
-  hipStream_t s = w.stream;
-  // DVO_HIP_TRACE_SLOW=<ms>: where the host thread spent the time before the first launch of a batch whose preparation took longer
-  static const double trace_slow_ms = std::getenv("DVO_HIP_TRACE_SLOW") ? std::atof(std::getenv("DVO_HIP_TRACE_SLOW")) : 0.0;
-  double mark_ms[5] = {0, 0, 0, 0, 0};
-  auto mark = [&](int k) { if (trace_slow_ms > 0.0) mark_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ctx->batch_entry).count(); };
-  mark(0);                                                     // roles ensured (dvo_hip_match_batch)
-  if (trace_slow_ms > 0.0) {
-    if (!g_trace_ev[0]) { (void)hipEventCreate(&g_trace_ev[0]); (void)hipEventCreate(&g_trace_ev[1]); }
-    (void)hipEventRecord(g_trace_ev[0], s);
-  }
-  // (the Gram schedule of the batch -- f16 high + low operand pairs or f32 -- was decided by the caller, effective_variant_scope; what
-  // this function changes for a repeat is undone when it returns)
-  struct VariantScope {
-    dvo_hip_context* c; int keep;
-    ~VariantScope() { c->opt_variant = keep; }
-  } variant_scope{ctx, ctx->opt_variant};
-  BatchPlan bp;
-  make_plan(ctx, refs[0]->cam, cfg, n, bp);
-  const BatchPolicy policy(ctx->compute_units);               // every batch-size threshold below: batch_policy.h
-  // The coarse levels -- for a small batch every level -- run inside ONE launch (align_resident.hip): no launch per iteration, no
-  // host poll, the pairs of a batch do not wait for each other.
-  const ResidentPlan rp = plan_paths(ctx, cfg, bp, window_taps_missing(ctx, cfg, n, curs));
-  const bool tables_inline = rp.direct && n <= kResidentInline;   // plane pointers and initial guesses travel as kernel arguments
-  int rc = prepare_buffers(w, cfg, refs, curs, bp, !tables_inline);
-  if (rc != DVO_HIP_OK) return rc;
-  mark(1);
-
-  // initial guesses (Result.Transformation is in/out, dense_tracking.cpp:137-147)
-  std::vector<double> tinit(size_t(n) * 16);
-  for (int i = 0; i < n; ++i) std::memcpy(&tinit[size_t(i) * 16], results[i].transformation, 16 * sizeof(double));
-  if (!tables_inline) DVO_WS_TRY(w, w.tables->upload(s, w.t_init.p, tinit.data(), tinit.size() * sizeof(double)));
-  // per-step tallies (device) and status words (pinned host memory the device writes, see publish_step)
-  const size_t main_steps = size_t(bp.cap_iters) + 8 + kResidentErrorWords;
-  // The slow lane of a batch (option "overlap_tails"): see in front of the level loop below.  Batches whose levels are begun by launches
-  // (beyond the solver steps' hand-over), the plain launch chain (no step in the sweep's tail), more than one level on this path.
-  bool overlap_batch = ctx->opt_overlap_tails != 0 && !policy.level_hand_over(n) && ctx->opt_sweep_tail == 0 && rp.levels == 0 && bp.coarse_levels == 0 &&
-                       cfg->first_level > cfg->last_level;
-  for (int l = cfg->last_level; l <= cfg->first_level; ++l)   // (the lane passes through every level: each one's sweep must take a list of pairs)
-    overlap_batch = overlap_batch && sweep_takes_pair_list(ctx->opt_variant, bp.rpw[l], bp.geom[l]);
-  const size_t tail_steps_cap = overlap_batch ? size_t(bp.cap_iters) + 12 * size_t(bp.nlev) + 8 : 0;   // (per level: the passes of its slowest pair, and up to eight steps enqueued ahead of what is known)
-  const size_t n_steps = main_steps + tail_steps_cap;         // (the tail's status words and tallies lie behind the main chain's)
-  if (overlap_batch) {
-    size_t t_tiles = 1, t_entries = 0;
-    for (int l = cfg->last_level; l <= cfg->first_level; ++l) {
-      t_tiles = std::max(t_tiles, size_t(bp.geom[l].tiles_x) * bp.geom[l].tiles_y);
-      t_entries = std::max(t_entries, residual_entries(bp.geom[l]));
-    }
-    DVO_WS_TRY(w, w.tail_partials.reserve(size_t(n) * t_tiles * kAccStride * sizeof(float)));
-    DVO_WS_TRY(w, w.tail_scratch.reserve(size_t(n) * t_entries * sizeof(float2)));
-    DVO_WS_TRY(w, w.tail_flags.reserve(align_up(size_t(n), 256)));
-    DVO_WS_TRY(w, w.tail_ll.reserve(size_t(n) * kLlBlocksPerPair * sizeof(double)));
-
-    DVO_WS_TRY(w, w.counters.reserve(n_steps * sizeof(unsigned long long) + align_up(size_t(n) * sizeof(int), 8)));
-    if (!w.tail_stream) {
-      int prio_least = 0, prio_greatest = 0;
-      DVO_WS_TRY(w, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-      DVO_WS_TRY(w, hipStreamCreateWithPriority(&w.tail_stream, hipStreamNonBlocking, prio_greatest));
-      DVO_WS_TRY(w, hipEventCreateWithFlags(&w.tail_split, hipEventDisableTiming));
-      DVO_WS_TRY(w, hipEventCreateWithFlags(&w.tail_end, hipEventDisableTiming));
-    }
-  }
-  // (the lane's two lists -- the one in use and the one being made -- and the chain's own active-pair list)
-  if (overlap_batch || ctx->opt_tail_lists) DVO_WS_TRY(w, w.tail_list.reserve(3 * align_up(size_t(n), 64) * sizeof(int)));
-  // a batch that ended early (time-out, HIP error) may have left steps queued: nothing of it may still be running when the
-  // status words and tallies are reset
-  if (w.needs_drain) {
-    if (w.tail_stream) DVO_WS_TRY(w, hipStreamSynchronize(w.tail_stream));
-    DVO_WS_TRY(w, sync_stream(s));
-    // ... and the f16 range words it may have raised are nobody's business any more (they are cleared where they are read, at a batch's
-    // regular end: left standing, the next batch would repeat unrelated pairs at the same indices -- round-5 advisor finding)
-    if (w.f16_range_flag) std::memset(w.f16_range_flag, 0, w.f16_range_words * sizeof(int));
-  }
-  w.needs_drain = true;                                        // until this batch has come to its regular end
-  mark(2);
-  rc = ensure_host_status(w, n_steps);
-  if (rc != DVO_HIP_OK) return rc;
-  mark(3);
-  w.resident_error_word = int(w.resident_launch_counter++ % kResidentErrorWords);
-  if (rp.direct) {
-    w.host_status[w.resident_error_word] = 0;
-  } else {
-    // (the previous batch may have ended on the host's side before the device was through with the step words: the direct path)
-    // (only then: a batch that ended with a stream wait left nothing behind, and a wait for the table uploads just enqueued has been
-    // seen to return 14-24 ms after the device was done with them -- 19 microseconds by its own time stamps: r03, the validator's
-    // 128-pair batches in the first process on a box, never under the profiler)
-    if (trace_slow_ms > 0.0) (void)hipEventRecord(g_trace_ev[1], s);
-    if (w.device_may_lag) DVO_WS_TRY(w, sync_stream(s));
-    w.device_may_lag = false;
-    if (trace_slow_ms > 0.0) {
-      mark(4);
-      float gpu_ms = -1.0f;
-      if (mark_ms[4] - mark_ms[3] > trace_slow_ms && hipEventElapsedTime(&gpu_ms, g_trace_ev[0], g_trace_ev[1]) == hipSuccess)
-        std::fprintf(stderr, "dvo_hip: the stream wait took %.3f ms on the host; on the device %.3f ms passed between the batch's first and last command so far\n",
-                     mark_ms[4] - mark_ms[3], gpu_ms);
-    }
-    std::memset(w.host_status, 0, n_steps * sizeof(int));
-    DVO_WS_TRY(w, hipMemsetAsync(w.counters.p, 0, n_steps * sizeof(unsigned long long) + align_up(size_t(n) * sizeof(int), 8), s));
-  }
-
-  PairState* states = w.states.as<PairState>();
-  dvo_hip_level_stats* d_levels = w.lvl_stats.as<dvo_hip_level_stats>();
-  dvo_hip_iteration_stats* d_iters = w.it_stats.as<dvo_hip_iteration_stats>();
-  float* partials = w.partials.as<float>();
-  float2* scratch = w.scratch.as<float2>();
-  double* ll_partials = w.ll_partials.as<double>();
-  unsigned long long* tallies = w.counters.as<unsigned long long>();
-  int* arrivals = reinterpret_cast<int*>(tallies + n_steps);
-  const int per_level = cfg->max_iterations_per_level;
-  const int per_sync = ctx->opt_iters_per_sync > 0 ? ctx->opt_iters_per_sync : 1;
-  int step = kResidentErrorWords;                           // the first status words belong to the resident kernel's launches
-  mark(4);
-  if (trace_slow_ms > 0.0 && mark_ms[4] > trace_slow_ms)
-    std::fprintf(stderr, "dvo_hip: slow preparation of a %d-pair batch: roles %.3f, plan + buffers + tables %.3f, initial guesses + drain %.3f, status words %.3f, "
-                 "stream wait + reset %.3f ms\n", n, mark_ms[0], mark_ms[1] - mark_ms[0], mark_ms[2] - mark_ms[1], mark_ms[3] - mark_ms[2], mark_ms[4] - mark_ms[3]);
-  const auto t_launch = std::chrono::steady_clock::now();
-  int level_from = cfg->first_level;
-  const bool want_stats = (levels && cap_levels > 0) || (iters && cap_iters > 0);
-  ResidentBudget::Hold compute_units;                          // released when this batch is through with the device
-  if (rp.levels > 0 && rp.group > 1)
-    compute_units.take(ResidentBudget::of(ctx->device), n * rp.group, ctx->compute_units > 0 ? ctx->compute_units : 256);
-  if (rp.levels > 0) {
-    Range range("resident");
-    rc = run_resident(ctx, w, cfg, bp, rp, tinit.data(), want_stats);
-    if (rc != DVO_HIP_OK) return rc;
-    if (!ctx->deferred.empty()) {                              // (see the launch path below)
-      const int rc_deferred = flush_deferred(ctx);
-      if (rc_deferred != DVO_HIP_OK) {
-        w.err = ctx->err;
-        return rc_deferred;
-      }
-    }
-    level_from = cfg->first_level - rp.levels;
-  }
-  if (bp.coarse_levels > 0) {
-    // the coarse levels of every pair in ONE launch, a workgroup per pair (align_coarse.hip): nothing to poll -- the host goes on to
-    // enqueue the first steps of the level behind them
-    Range range("coarse");
-    rc = run_coarse(ctx, w, cfg, bp);
-    if (rc != DVO_HIP_OK) return rc;
-    if (!ctx->deferred.empty()) {
-      const int rc_deferred = flush_deferred(ctx);
-      if (rc_deferred != DVO_HIP_OK) {
-        w.err = ctx->err;
-        return rc_deferred;
-      }
-    }
-    level_from = cfg->first_level - bp.coarse_levels;
-  }
-  // ---- the slow lane of a batch (round 6, option "overlap_tails") ------------------------------------------------------------------------
-  // The pairs of a batch need different numbers of passes on a level, and the launch chain runs a level until its LAST pair has left it: on
-  // the bench's 1024-pair batches 11 of a step's 32 iterations are such tail launches, a few dozen pairs each, while the chip waits (1.1 ms
-  // of 11).  In the reference every match() runs on its own from start to end (dense_tracking.cpp:200-357).  Here, once at most 1/8 of
-  // the pairs is still on a level, those pairs leave the batch's chain for good: they get a flag byte and a place in a list
-  // (k_mark_stragglers), the chain goes on to the next level without them (LevelGeom::skip_flags), and a SLOW LANE -- a second stream, its
-  // own partial rows and residual pairs, its own status words -- runs them to the end of the match with launches over the list
-  // (LevelGeom::pair_list): the rest of that level, then level after level behind the main chain, taking up the stragglers the chain
-  // sheds on the way.  The lane works on one level at a time and never gets ahead of the chain: it leaves a level when none of its members is
-  // active on it AND the chain has left it (so nobody can still arrive there).  The batch ends when both have.  A pair's arithmetic does
-  // not know in which launch it runs: the records are the synchronous chain's bit for bit (tests/test_gpu_overlap.py).
-  struct LevelSchedule {
-    bool fused_ll = false, two_waves = false;
-    int ll_blocks = 0;
-  };
-  auto schedule_of = [&](int level) {
-    const LevelGeom& g = bp.geom[level];
-    LevelSchedule ls;
-    const int fuse_opt = ctx->opt_fused_ll_pixels;
-    ls.fused_ll = g.w * g.h <= (fuse_opt > 0 ? fuse_opt : (policy.fused_loglik_on_large_levels(n) && !ctx->opt_deterministic ? kFusedLoglikMaxPixelsBatch : kFusedLoglikMaxPixels));
-    ls.ll_blocks = ctx->opt_ll_blocks > 0 ? std::min(ctx->opt_ll_blocks, kLlBlocksPerPair)
-                   : (!g.compact || ctx->opt_deterministic ? kLlBlocksPerPair : policy.loglik_blocks(n));
-    ls.two_waves = ctx->opt_solver_waves == 2 ||
-                   (ctx->opt_solver_waves == 0 && ls.fused_ll && !g.compact && g.tiles_x * g.tiles_y <= 32 && policy.solver_two_waves(n));
-    return ls;
-  };
-  struct SlowLane {
-    bool live = false, done = false;
-    int level = -1;                  // the level its launches work on
-    int cap = 0;                     // entries of the current list: an upper bound of the flagged pairs
-    int list_sel = 0;                // which of the two list buffers is the current one (the other may still be read by launches in flight)
-    int seen = 0;                    // status words of the lane read so far (they complete in order: one stream)
-    int valid_from = 0;              // steps before this one say nothing about the lane's level as it is now (another level, or members have arrived since)
-    int last_active = -1;
-  } sl;
-  int tail_next = 0;                 // steps of the lane enqueued in this batch (index of its next status word, behind the chain's)
-  int main_level = level_from;       // the level the batch's own chain works on (below last_level: through)
-  unsigned char* const lane_flags = w.tail_flags.as<unsigned char>();
-  auto lane_list = [&](int sel) { return w.tail_list.as<int>() + size_t(sel) * align_up(size_t(n), 64); };
-  if (overlap_batch) launch_clear_flags(s, lane_flags, n);
-  auto tail_enqueue = [&](int count) {
-    const LevelSchedule ls = schedule_of(sl.level);
-    LevelGeom g = bp.geom[sl.level];
-    g.pair_list = lane_list(sl.list_sel);
-    const PairPtrs* pp = bp.pair_ptrs + size_t(sl.level) * n;
-    float* lp = w.tail_partials.as<float>();
-    float2* lscr = w.tail_scratch.as<float2>();
-    double* lll = w.tail_ll.as<double>();
-    for (int c = 0; c < count && size_t(tail_next) < tail_steps_cap; ++c, ++tail_next) {
-      const size_t idx = main_steps + size_t(tail_next);
-      launch_residual_reduce(w.tail_stream, ctx->opt_variant, bp.rpw[sl.level], sl.level == 0, g, pp, states, sl.cap, lp, lscr, w.win_fallbacks.as<unsigned long long>(),
-                             w.f16_range_flag);
-      if (!ls.fused_ll) launch_loglik(w.tail_stream, g, states, sl.cap, lp, lscr, lll, ls.ll_blocks, ctx->opt_deterministic != 0);
-      launch_solver_step(w.tail_stream, states, sl.cap, bp.prm, g, lp, lll, ls.ll_blocks, ls.fused_ll ? lscr : nullptr, d_levels, d_iters,
-                         tallies + idx, w.host_status + idx, false, cfg->first_level - sl.level, nullptr);
-      ctx->overlapped_steps += 1;
-    }
-    (void)hipEventRecord(w.tail_end, w.tail_stream);           // (the batch's end waits for the latest record: everything enqueued so far)
-  };
-  // what the lane's status words say by now, and what follows from it (never waits)
-  auto tail_service = [&]() {
-    if (!sl.live || sl.done) return;
-    while (sl.seen < tail_next) {
-      const int v = static_cast<volatile int*>(w.host_status)[main_steps + size_t(sl.seen)];
-      if (!(v & kStepDoneFlag)) break;
-      if (sl.seen >= sl.valid_from) sl.last_active = v & ~kStepDoneFlag;
-      sl.seen += 1;
-    }
-    if (sl.seen > sl.valid_from && sl.last_active == 0) {      // nobody of the lane is active on its level
-      if (sl.level <= main_level) return;                      // (the chain is still on it: its stragglers may yet arrive)
-      if (sl.level == cfg->last_level) {
-        sl.done = true;
-        return;
-      }
-      // on to the next level: the members that have left this one begin it (those that arrived further down are on theirs already)
-      const int lv = sl.level - 1;
-      launch_level_begin(w.tail_stream, states, n, bp.prm, bp.geom[lv], lv, bp.pair_ptrs + size_t(lv) * n, d_levels, nullptr, lane_flags, 1, sl.level);
-      sl.level = lv;
-      sl.valid_from = tail_next;
-      sl.last_active = -1;
-      tail_enqueue(3);
-      return;
-    }
-    if (tail_next - sl.seen < 2) tail_enqueue(2);
-  };
-  // the chain sheds the pairs still active on `level` (at most `active` of them) to the lane
-  auto tail_shed = [&](int level, int active) -> int {
-    Range range("shed");
-    const int next_sel = sl.live ? sl.list_sel ^ 1 : 0;
-    const int cap = std::min(n, sl.cap + active);
-    launch_mark_stragglers(s, states, n, level, lane_flags, lane_list(next_sel), cap);
-    DVO_WS_TRY(w, hipEventRecord(w.tail_split, s));
-    DVO_WS_TRY(w, hipStreamWaitEvent(w.tail_stream, w.tail_split, 0));
-    sl.cap = cap;
-    sl.list_sel = next_sel;
-    if (!sl.live) {
-      sl.live = true;
-      sl.level = level;
-    }
-    sl.valid_from = tail_next;                                 // (whatever level the lane is on: its launches read the new list from here on)
-    sl.last_active = -1;
-    tail_enqueue(3);
-    ctx->overlapped_tails += 1;
-    return DVO_HIP_OK;
-  };
-  // the chain's wait for a step, looking after the lane meanwhile
-  auto wait_main = [&](int idx, int* active) -> int {
-    if (!sl.live || sl.done) return wait_for_step(w, idx, active);
-    volatile int* word = w.host_status + idx;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 1;; ++spins) {
-      const int v = *word;
-      if (v & kStepDoneFlag) {
-        *active = v & ~kStepDoneFlag;
-        tail_service();
-        return DVO_HIP_OK;
-      }
-      if ((spins & 0x3f) == 0) tail_service();
-      if ((spins & 0xfffff) == 0) {
-        const int rc_check = step_wait_check(w, t0);
-        if (rc_check != DVO_HIP_OK) return rc_check;
-      }
-    }
-  };
-
-  for (int level = level_from; level >= cfg->last_level; --level) {
-    main_level = level;
-    LevelGeom g = bp.geom[level];
-    if (sl.live) g.skip_flags = lane_flags;                    // (the lane's pairs are not this chain's any more)
-    const PairPtrs* pp = bp.pair_ptrs + size_t(level) * n;
-    static const char* const kPrep[kMaxLevels] = {"prep L0", "prep L1", "prep L2", "prep L3", "prep L4", "prep L5", "prep L6", "prep L7"};
-    static const char* const kErr[kMaxLevels] = {"err L0", "err L1", "err L2", "err L3", "err L4", "err L5", "err L6", "err L7"};
-    static const char* const kLinsys[kMaxLevels] = {"linsys L0", "linsys L1", "linsys L2", "linsys L3", "linsys L4", "linsys L5", "linsys L6", "linsys L7"};
-    // Batches of up to 256 pairs: every level but the launch path's first is begun pair by pair by the solver steps of the level before
-    // it, and the results are written by the steps behind the last level (NextLevel) -- no launch between two levels, none at the end:
-    // builds alternated on one box, 16 / 64 / 128 pairs 0.558 -> 0.553 / 1.196 -> 1.187 / 1.825 -> 1.807 ms per step; 256 and 1024
-    // pairs level, 512 pairs 5.79 -> 5.88 (the launches k_level_begin / k_finish stay there)
-    const bool hand_over = policy.level_hand_over(n);
-    if (level == level_from || !hand_over) {
-      Range range(kPrep[level]);
-      // (the slow lane's pairs begin their levels there)
-      launch_level_begin(s, states, n, bp.prm, g, level, pp, d_levels, level == cfg->first_level ? w.t_init.as<double>() : nullptr,
-                         sl.live ? lane_flags : nullptr, 0);
-    }
-    NextLevel next;
-    std::memset(&next, 0, sizeof(next));
-    if (hand_over && level > cfg->last_level) {
-      const LevelGeom& gn = bp.geom[level - 1];
-      next.valid = 1;
-      next.level = level - 1;
-      next.fx = gn.fx; next.fy = gn.fy; next.ox = gn.ox; next.oy = gn.oy;
-      next.pairs = bp.pair_ptrs + size_t(level - 1) * n;
-    } else if (hand_over) {
-      next.results = w.results.as<dvo_hip_result>();           // the last level: a pair that has left it gets its result written
-    }
-    // levels this small run the log-likelihood sweep inside the solver workgroup (one launch less per iteration)
-    // (measured, scripts/ab_match.py fused_ll_pixels: 128 pairs 2.152 -> 2.117 ms with level 1 fused; 16 pairs 0.756 -> 0.799, one
-    // pair 0.524 -> 0.547: a lone workgroup per pair is slower than 32 blocks when the chip is empty)
-    // (round 5, packed residual pairs, the streaming step beside its ingest, scripts/r5_midsize.py: level 1 in a launch of its own
-    // 64 pairs 1.456 -> 1.378 ms, 128 pairs 1.939 -> 1.908, 256 pairs 3.308 -> 3.286, 512 pairs 5.859 -> 5.880: fused from 512 pairs)
-    const LevelSchedule schedule = schedule_of(level);         // (the rule: schedule_of, above -- the slow lane runs its pairs by the same one)
-    const bool fused_ll = schedule.fused_ll;
-    // Chunks of `per_sync` iterations are enqueued ONE AHEAD of the poll: while the host waits for the status word of
-    // chunk k, chunk k+1 is already queued, so the GPU never idles for a host round trip.  Iterations enqueued past the
-    // end of the level are no-ops (workgroups exit on !active).
-    // workgroups per pair of the log-likelihood pass: each begins by reducing the pair's scale sums (a latency chain of ~10 us), which
-    // a batch that fills the device anyway pays once per workgroup for nothing -- fewer, longer ones then (option ll_blocks to override)
-    // (round 5, mid-size batches, scripts/r5_midsize.py: 16 instead of 32 workgroups per pair 64 / 128 / 200 pairs 1.179 -> 1.173 /
-    // 1.775 -> 1.760 / 2.558 -> 2.538 ms per step; 8: 1.183 / 1.760 / 2.546)
-    const int ll_blocks = schedule.ll_blocks;
-    // the solver step of the smallest levels in two-wavefront workgroups (four per compute unit instead of two): a batch that otherwise
-    // needs two goes of 512 resident workgroups (option solver_waves 2 / 4 to force; the records do not depend on it).  Measured at
-    // 1024 pairs (scripts/r4_trace.sh): 80 x 60 46 -> 36 us per step; 160 x 120 with packed residuals 77 -> 90 (two wavefronts walk
-    // its 96 slots in six rounds instead of three), 320 x 240 and the finest level level: those keep four.
-    const bool solver_two_waves = schedule.two_waves;
-    // The step in the sweep's launch (round 6): where the log-likelihood pass runs inside the solver step anyway and the level's sweep
-    // has the instantiation, the workgroup that completes a pair's last tile runs the pair's step -- ONE launch per iteration
-    const bool tail = ctx->opt_sweep_tail != 0 && fused_ll && sweep_has_tail(ctx->opt_variant, bp.rpw[level], g);
-    // (option 2: the WIDE half of the step -- reduction and log-likelihood, its memory round trips -- in the sweep's tail, the serial half
-    // in a one-wavefront launch behind it)
-    double* pair_sums = tail && ctx->opt_sweep_tail == 2 ? w.pair_sums.as<double>() : nullptr;
-    // (what the chain's launches of this level cover: every pair, or -- its last steps, see "hold" below -- the list of those still active)
-    LevelGeom g_run = g;
-    int n_run = n;
-    auto enqueue_chunk = [&](int count) {
-      for (int c = 0; c < count; ++c, ++step) {
-        if (tail) {
-          Range range(kErr[level]);
-          const SolverStepArgs a = make_solver_step_args(states, n, bp.prm, partials, ll_partials, ll_blocks, scratch, d_levels, d_iters, tallies + step, w.host_status + step,
-                                                         cfg->first_level - level, &next, arrivals, pair_sums);
-          launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g, pp, states, n, partials, scratch, w.win_fallbacks.as<unsigned long long>(),
-                                 w.f16_range_flag, &a);
-          if (pair_sums) {
-            Range range2(kLinsys[level]);
-            launch_solver_serial(s, n, g, a);
-          }
-          ctx->tail_steps += 1;
-          continue;
-        }
-        {
-          Range range(kErr[level]);
-          launch_residual_reduce(s, ctx->opt_variant, bp.rpw[level], level == 0, g_run, pp, states, n_run, partials, scratch, w.win_fallbacks.as<unsigned long long>(),
-                                 w.f16_range_flag);
-          if (!fused_ll) launch_loglik(s, g_run, states, n_run, partials, scratch, ll_partials, ll_blocks, ctx->opt_deterministic != 0);
-        }
-        if (g_run.pair_list) ctx->listed_steps += 1;
-        Range range(kLinsys[level]);
-        launch_solver_step(s, states, n_run, bp.prm, g_run, partials, ll_partials, ll_blocks, fused_ll ? scratch : nullptr, d_levels, d_iters,
-                           tallies + step, w.host_status + step, solver_two_waves, cfg->first_level - level, &next);   // (the level record every pair on this level is at: fetched with the state)
-      }
-    };
-    int enqueued = std::min(per_sync, per_level);
-    enqueue_chunk(enqueued);
-    // (option "defer_ingest_pixels": not before the chain has reached a level of that many pixels -- the frame build is bound by memory, and
-    // beside it the latency-bound sweeps and steps of the SMALL levels run 30-50 % longer (80 x 60: 52 -> 77 us, 160 x 120: 159 -> 212 us per
-    // 1024-pair launch), the issue-bound sweeps of the large ones 2 %: a large batch's ingest belongs beside levels 1 and 0)
-    const bool flush_here = ctx->opt_defer_ingest_pixels <= 0 || g.w * g.h >= ctx->opt_defer_ingest_pixels || level == cfg->last_level;
-    if (!ctx->deferred.empty() && flush_here) {
-      // A recorded ingest of the caller's next batch (option "defer_ingest") is carried out now, behind the first launches of this
-      // batch.  It is ~0.1-0.5 ms of host time during which nothing more would be enqueued here: where the level's steps are short,
-      // a few more of them go out first (a pair needs more than four passes on its first level; a step too many exits at once).
-      // (how many: the ingest of 2 n frames is ~0.3 us of host time per frame, a step of a small level ~20 us -- measured, builds
-      // alternated on one box: seven instead of three more 256 pairs 3.288 -> 3.216 ms per step, 128 pairs 1.837 -> 1.856, 64 pairs
-      // 1.199 -> 1.210)
-      if (size_t(g.tiles_x) * g.tiles_y * size_t(n) < 65536) {
-        const int lead = std::min(policy.deferred_ingest_lead(n) * per_sync, per_level - enqueued);
-        if (lead > 0) {
-          enqueue_chunk(lead);
-          enqueued += lead;
-        }
-      }
-      const int rc_deferred = flush_deferred(ctx);
-      if (rc_deferred != DVO_HIP_OK) {
-        w.err = ctx->err;
-        return rc_deferred;
-      }
-    }
-    int watched = step - 1;                                  // last step of the chunk whose outcome is awaited
-    // (the slow lane: every level but the last may shed its stragglers to it -- on the last one nothing follows that they could run beside)
-    const bool list_tails = ctx->opt_tail_lists != 0 && !tail && !hand_over && sweep_takes_pair_list(ctx->opt_variant, bp.rpw[level], g);
-    const bool may_shed = overlap_batch && level > cfg->last_level && !tail && sweep_takes_pair_list(ctx->opt_variant, bp.rpw[level], g);
-    // Where an EMPTY step is expensive -- the dispatcher needs 95 us for the 307 200 workgroups of a 1024-pair finest-level sweep
-    // that all exit at once, 114 us with its log-likelihood and solver launches -- the step ahead of the poll is not enqueued once
-    // only a few pairs are left on the level: the host then waits for the outcome first (a bubble of ~15 us if another step is
-    // needed).  Elsewhere the speculative step is cheaper than the bubble.
-    const bool empty_step_is_costly = size_t(g.tiles_x) * g.tiles_y * size_t(n) >= (ctx->opt_tail_speculation >= 2 ? size_t(ctx->opt_tail_speculation) : kCostlyEmptyStepWorkgroups) && ctx->opt_tail_speculation != 1;
-    int last_active = n;
-    for (;;) {
-      const bool hold = empty_step_is_costly && last_active * 8 <= n;
-      int more = hold ? 0 : std::min(per_sync, per_level - enqueued);
-      if (more > 0) {
-        enqueue_chunk(more);
-        enqueued += more;
-      }
-      int active = 0;
-      rc = wait_main(watched, &active);
-      if (rc != DVO_HIP_OK) return rc;
-      last_active = active;
-      if (may_shed && active > 0 && size_t(active) * size_t(ctx->opt_overlap_fraction) <= size_t(n)) {
-        // the pairs still on the level (at most `active`: the steps enqueued ahead of this poll only take some away) go to the slow lane
-        rc = tail_shed(level, active);
-        if (rc != DVO_HIP_OK) return rc;
-        break;
-      }
-      if (hold && active > 0) {                              // (the held-back step is needed after all)
-        // ... by `active` pairs, none of whose steps is in flight: from here on the launches cover the list of them
-        if (list_tails && !g_run.pair_list) {
-          int* const own_list = w.tail_list.as<int>() + 2 * align_up(size_t(n), 64);
-          launch_mark_stragglers(s, states, n, level, sl.live ? lane_flags : nullptr, own_list, active, true);
-          g_run.pair_list = own_list;
-          n_run = active;
-        }
-        more = std::min(per_sync, per_level - enqueued);
-        if (more > 0) {
-          enqueue_chunk(more);
-          enqueued += more;
-        }
-      }
-      if (active == 0 || more <= 0) break;                   // every pair left this level (or the iteration cap is reached)
-      watched = step - 1;
-    }
-    // The pairs that ended the level in the step just awaited are handed over (NextLevel) by the step that was enqueued ahead of the poll.
-    // If there is none -- the step was held back, or the iteration cap is reached -- one solver launch does nothing else.
-    if (hand_over && step - 1 <= watched) {
-      Range range(kLinsys[level]);
-      launch_solver_step(s, states, n, bp.prm, g, partials, ll_partials, ll_blocks, nullptr, d_levels, d_iters, tallies + step, w.host_status + step,
-                         solver_two_waves, cfg->first_level - level, &next);
-      ++step;
-    }
-  }
-
-  if (sl.live) {
-    // the chain is through; the slow lane runs its pairs to the end of the match (from here on it may leave any level)
-    main_level = cfg->last_level - 1;
-    const auto t_wait = std::chrono::steady_clock::now();
-    tail_service();
-    while (!sl.done) {
-      if (tail_next == 0 || size_t(tail_next) >= tail_steps_cap) {
-        w.err = "match: the slow lane of the batch ran out of steps";
-        return DVO_HIP_ERR_HIP;
-      }
-      int unused = 0;
-      rc = wait_for_step(w, int(main_steps) + tail_next - 1, &unused);
-      if (rc != DVO_HIP_OK) return rc;
-      tail_service();
-    }
-    ctx->tail_drains += 1;
-    ctx->tail_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait).count();
-    DVO_WS_TRY(w, hipStreamWaitEvent(s, w.tail_end, 0));       // (k_finish and the copies below follow the lane's last step)
-  }
-  const bool resident_used = rp.levels > 0;
-  std::vector<dvo_hip_level_stats> hl;
-  std::vector<dvo_hip_iteration_stats> hi;
-  const dvo_hip_level_stats* hl_src = nullptr;
-  const dvo_hip_iteration_stats* hi_src = nullptr;
-  std::chrono::steady_clock::time_point t_enqueued, t_done;
-  if (rp.direct) {
-    // the kernel writes results (and statistics) into pinned host memory and counts the pairs done: the host thread watches that
-    // word -- no copy command, no stream synchronisation on the way out
-    t_enqueued = std::chrono::steady_clock::now();
-    rc = wait_for_direct(w, n);
-    w.device_may_lag = true;
-    if (rc != DVO_HIP_OK) return rc;
-    t_done = std::chrono::steady_clock::now();
-    if (w.host_status[w.resident_error_word] == 0) {
-      std::memcpy(results, w.direct_results.p, size_t(n) * sizeof(dvo_hip_result));
-      if (levels && cap_levels > 0) hl_src = w.direct_levels.as<dvo_hip_level_stats>();
-      if (iters && cap_iters > 0) hi_src = w.direct_iters.as<dvo_hip_iteration_stats>();
-    } else {
-      DVO_WS_TRY(w, sync_stream(s));                           // every group has to be gone before the batch is repeated
-    }
-  } else {
-    if (level_from >= cfg->last_level && policy.finish_launch(n)) launch_finish(s, states, n, bp.prm, d_levels, d_iters, w.results.as<dvo_hip_result>());
-    // (else the results are in place: written by the resident launch, or by the solver steps behind the pairs' last level)
-    DVO_WS_TRY(w, hipMemcpyAsync(results, w.results.p, size_t(n) * sizeof(dvo_hip_result), hipMemcpyDeviceToHost, s));
-    if (levels && cap_levels > 0) {
-      hl.resize(size_t(n) * bp.cap_levels);
-      DVO_WS_TRY(w, hipMemcpyAsync(hl.data(), d_levels, hl.size() * sizeof(dvo_hip_level_stats), hipMemcpyDeviceToHost, s));
-      hl_src = hl.data();
-    }
-    if (iters && cap_iters > 0) {
-      hi.resize(size_t(n) * bp.cap_iters);
-      DVO_WS_TRY(w, hipMemcpyAsync(hi.data(), d_iters, hi.size() * sizeof(dvo_hip_iteration_stats), hipMemcpyDeviceToHost, s));
-      hi_src = hi.data();
-    }
-    t_enqueued = std::chrono::steady_clock::now();
-    DVO_WS_TRY(w, sync_stream(s));
-    DVO_WS_TRY(w, hipGetLastError());
-    t_done = std::chrono::steady_clock::now();
-  }
-  if (resident_used && w.host_status[w.resident_error_word] != 0) {
-    // A group of the resident kernel gave up waiting for its peers: its workgroups were not all on the device at once (the
-    // device is shared with another process that does the same, or a compute-unit mask shrank it).  Nothing is wrong with the
-    // batch: it runs again, one launch per step, and the context stops using groups.
-    w.resident_sequence = 0xffffffffu;                       // the exchange rows are in an unknown state: cleared before the next use
-    ctx->resident_timeouts += 1;
-    // (not after a single incident: a launch that started late once -- the device busy with another process for a moment -- is no
-    // reason to give up the latency path for the rest of the context's life)
-    if (ctx->resident_timeouts >= 3) ctx->opt_resident_group = 1;
-    for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, &tinit[size_t(i) * 16], 16 * sizeof(double));
-    const int keep = ctx->opt_resident;
-    ctx->opt_resident = 0;
-    w.needs_drain = true;
-    rc = ensure_batch_roles(ctx, n, refs, curs, cfg);          // (the launch path may read another flavour of the current planes)
-    if (rc == DVO_HIP_OK) rc = run_batch(ctx, n, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
-    ctx->opt_resident = keep;
-    return rc;
-  }
-  // Pairs in which a Jacobian component of some pixel was beyond +-65504: the f16 high / low split of the Gram operands (variants 7-9)
-  // does not represent it, the sweep's epilogue has raised the pair's word.  Those pairs run again with the f32 Gram of the same sweep
-  // family (variant 6): the whole batch when most of it is concerned (one chain of launches either way; the batches that follow then
-  // start on the f32 Gram, kF32GramHoldBatches), otherwise ONLY the flagged pairs, as a batch of their own, behind the copy-out below
-  // (round 5: a single close depth step used to repeat all 1024 pairs of a batch).
-  std::vector<int> out_of_range;
-  if (ctx->opt_variant >= 7)
-    for (int i = 0; i < n; ++i)
-      if (static_cast<volatile int*>(w.f16_range_flag)[i] != 0) {
-        static_cast<volatile int*>(w.f16_range_flag)[i] = 0;
-        out_of_range.push_back(i);
-      }
-  // (the repeats below prepare role planes and run another batch: two groups of one batch -- dvo_hip_match_batch -- do not do that at once)
-  std::unique_lock<std::mutex> rare_path;
-  if (!out_of_range.empty()) rare_path = std::unique_lock<std::mutex>(g_rare_path_mutex);
-  if (!out_of_range.empty() && out_of_range.size() * 2 >= size_t(n)) {
-    ctx->f16_range_repeats += (long long)out_of_range.size();
-    ctx->f32_gram_hold = kF32GramHoldBatches;
-    for (int i = 0; i < n; ++i) std::memcpy(results[i].transformation, &tinit[size_t(i) * 16], 16 * sizeof(double));
-    ctx->opt_variant = 6;                                      // (restored by variant_scope)
-    rc = ensure_batch_roles(ctx, n, refs, curs, cfg);          // (another sweep, maybe another flavour of the current planes)
-    if (rc != DVO_HIP_OK) return rc;
-    return run_batch(ctx, n, refs, curs, cfg, results, levels, cap_levels, iters, cap_iters);
-  }
-  bool truncated = false;
-  for (int i = 0; i < n; ++i) {
-    if (hl_src) {
-      const int nl = std::min(results[i].n_levels, std::min(cap_levels, bp.cap_levels));
-      std::memcpy(levels + size_t(i) * cap_levels, hl_src + size_t(i) * bp.cap_levels, size_t(nl) * sizeof(dvo_hip_level_stats));
-      truncated |= results[i].n_levels > cap_levels;
-    }
-    if (hi_src) {
-      const int ni = std::min(results[i].n_iterations_total, std::min(cap_iters, bp.cap_iters));
-      std::memcpy(iters + size_t(i) * cap_iters, hi_src + size_t(i) * bp.cap_iters, size_t(ni) * sizeof(dvo_hip_iteration_stats));
-      truncated |= results[i].n_iterations_total > cap_iters;
-    }
-  }
-  {
-    using std::chrono::duration_cast;
-    using std::chrono::nanoseconds;
-    ctx->host_ns[0] += duration_cast<nanoseconds>(t_launch - ctx->batch_entry).count();
-    ctx->host_ns[1] += duration_cast<nanoseconds>(t_enqueued - t_launch).count();
-    ctx->host_ns[2] += duration_cast<nanoseconds>(t_done - t_enqueued).count();
-    ctx->host_ns[3] += duration_cast<nanoseconds>(std::chrono::steady_clock::now() - t_done).count();
-    ctx->host_batches += 1;
-  }
-  w.needs_drain = false;
-  if (!out_of_range.empty()) {
-    // the flagged pairs again, f32 Gram, as a batch of their own; their records replace the ones just copied out
-    const int m = int(out_of_range.size());
-    ctx->f16_range_repeats += m;
-    std::vector<dvo_hip_frame*> r2(m), c2(m);
-    std::vector<dvo_hip_result> res2(m);
-    for (int k = 0; k < m; ++k) {
-      const int i = out_of_range[k];
-      r2[k] = refs[i];
-      c2[k] = curs[i];
-      res2[k] = results[i];
-      std::memcpy(res2[k].transformation, &tinit[size_t(i) * 16], 16 * sizeof(double));
-    }
-    const bool want_l = levels && cap_levels > 0, want_i = iters && cap_iters > 0;
-    std::vector<dvo_hip_level_stats> l2(want_l ? size_t(m) * cap_levels : 0);
-    std::vector<dvo_hip_iteration_stats> i2(want_i ? size_t(m) * cap_iters : 0);
-    ctx->opt_variant = 6;                                      // (restored by variant_scope)
-    rc = ensure_batch_roles(ctx, m, r2.data(), c2.data(), cfg);
-    if (rc == DVO_HIP_OK)
-      rc = run_batch(ctx, m, r2.data(), c2.data(), cfg, res2.data(), want_l ? l2.data() : nullptr, cap_levels, want_i ? i2.data() : nullptr, cap_iters);
-    if (rc != DVO_HIP_OK && rc != DVO_HIP_ERR_CAPACITY) return rc;
-    truncated |= rc == DVO_HIP_ERR_CAPACITY;
-    for (int k = 0; k < m; ++k) {
-      const int i = out_of_range[k];
-      results[i] = res2[k];
-      if (want_l) std::memcpy(levels + size_t(i) * cap_levels, l2.data() + size_t(k) * cap_levels, size_t(cap_levels) * sizeof(dvo_hip_level_stats));
-      if (want_i) std::memcpy(iters + size_t(i) * cap_iters, i2.data() + size_t(k) * cap_iters, size_t(cap_iters) * sizeof(dvo_hip_iteration_stats));
-    }
-  }
-  if (truncated) {
-    w.err = "match: statistics arrays too small (results are valid)";
-    return DVO_HIP_ERR_CAPACITY;
-  }
-  return DVO_HIP_OK;
-}
+#include "capi_frames.inc"     // cameras, frame allocation and build, role planes (ensure_roles)
+#include "capi_schedule.inc"   // batch plan, buffers, waits, resident / coarse plans, run_batch
 
 // The Gram schedule of a batch, decided ONCE, before the planes of the roles are prepared for it (round-4 advisor finding: deciding it
 // inside run_batch prepared two flavours of the current role for every new frame).  The default accumulates on the f16 matrix pipe

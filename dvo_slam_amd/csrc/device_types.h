@@ -69,7 +69,7 @@ struct LevelGeom {                    // identical for every pair of a batch (on
   // (PairState::active && PairState::level == level) -- a pair that has left the level may already have begun the next one
   // (k_solver_step, NextLevel) and waits there for the rest of the batch
   int level;
-  // non-null (round 6, the slow lane of a batch -- capi.hip::run_batch): the launch covers the n_pairs ENTRIES of
+  // non-null (round 6, the slow lane of a batch -- capi_schedule.inc::run_batch): the launch covers the n_pairs ENTRIES of
   // this list instead of pairs 0 .. n_pairs - 1 -- entry k names the pair its workgroups work on, -1 = none (they leave at once).  Partial
   // rows, residual pairs, states and records stay where the pair's index puts them: a pair's arithmetic does not know about the list.
   const int* pair_list;

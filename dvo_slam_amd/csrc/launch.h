@@ -95,7 +95,7 @@ void launch_init_pairs(hipStream_t s, PairState* states, int n_pairs, SolverPara
 void launch_level_begin(hipStream_t s, PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
                         const PairPtrs* pairs, dvo_hip_level_stats* levels, const double* T_init_or_null = nullptr,
                         const unsigned char* flags = nullptr, int which = 0, int from_level = -1);
-// the slow lane of a batch (capi.hip::run_batch): the pairs still active on `level` get their flag byte set, and the indices of all flagged
+// the slow lane of a batch (capi_schedule.inc::run_batch): the pairs still active on `level` get their flag byte set, and the indices of all flagged
 // pairs go into list[0 .. cap) in ascending order, -1 behind the last; LevelGeom::pair_list then makes a launch cover the list, ::skip_flags
 // makes one leave the flagged pairs alone.  The flags of a batch start at zero (launch_clear_flags).
 // list_only: nothing is flagged; the list gets the unflagged pairs active on the level (flags may be null) -- the active-pair list of a level's last steps

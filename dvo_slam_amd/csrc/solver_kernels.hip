@@ -26,7 +26,7 @@ __global__ void k_init_pairs(PairState* states, int n_pairs, SolverParams prm, c
 }
 
 // T_init != null: the first level of a match -- the pair is initialised here as well (one launch less per match)
-// flags != null (a batch with a slow lane, capi.hip::run_batch): which == 0 -- every pair but the flagged ones (the batch's own chain);
+// flags != null (a batch with a slow lane, capi_schedule.inc::run_batch): which == 0 -- every pair but the flagged ones (the batch's own chain);
 // which == 1 -- the flagged ones that have left level `from_level` (the slow lane's: its members arrive on different levels)
 __global__ void k_level_begin(PairState* states, int n_pairs, SolverParams prm, LevelGeom g, int level,
                               const PairPtrs* __restrict__ pairs, dvo_hip_level_stats* levels, const double* __restrict__ T_init,
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WG) void k_solver_step(LevelGeom g,
   solver_step_body<WAVES>(L, g, a, pair);
 }
 
-// The stragglers of a level (round 6, the slow lane -- capi.hip::run_batch): the pairs still active on `level` get a flag byte, and EVERY
+// The stragglers of a level (round 6, the slow lane -- capi_schedule.inc::run_batch): the pairs still active on `level` get a flag byte, and EVERY
 // flagged pair of the batch -- these and the ones of earlier levels -- goes into list[0 .. cap) in ascending order (-1 behind the last;
 // the host's `cap` adds up the counts its polls saw, which only shrink).  One workgroup: a batch has a few thousand pairs at most, and
 // the order must not depend on who arrives first.  (The state of a pair flagged earlier is not looked at: the slow lane is changing it.)

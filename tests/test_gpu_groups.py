@@ -1,4 +1,4 @@
-"""Concurrent pair groups (option "batch_groups", dvo_slam_amd/csrc/capi.hip::run_batch_grouped): a large batch is aligned as two or three
+"""Concurrent pair groups (option "batch_groups", dvo_slam_amd/csrc/capi_groups.inc::run_batch_grouped): a large batch is aligned as two or three
 sub-batches at once, the caller's thread on its context, helper threads on twin contexts of the same device -- the way the reference
 spreads independent match() calls over the workers of a tbb::parallel_reduce (dvo_slam/src/keyframe_graph.cpp:576-593).  A pair's record
 is what its sub-batch gives it: bit-identical to the ungrouped batch wherever both fall into the same schedule class."""

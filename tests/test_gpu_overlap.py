@@ -1,4 +1,4 @@
-"""The slow lane of a batch (capi.hip::run_batch, option "overlap_tails"): once a few pairs of a large batch are left on a level, they leave the
+"""The slow lane of a batch (capi_schedule.inc::run_batch, option "overlap_tails"): once a few pairs of a large batch are left on a level, they leave the
 batch's launch chain for good -- the chain goes on to the next level without them, and a second stream runs them to the end of the match with
 launches over a list of pairs (LevelGeom::pair_list), level after level behind the chain, taking up the stragglers of the later levels on the
 way.  Every pair runs its levels on its own, as the reference's match() calls do (dvo_core/src/dense_tracking.cpp:200-357).
