@@ -12,6 +12,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import dvo_slam_amd as d
 from dvo_slam_amd import datagen
 
+only = None                                                             # --only sync | lane: one mode, for a profiler run
+if "--only" in sys.argv:
+    k = sys.argv.index("--only")
+    only = sys.argv[k + 1]
+    del sys.argv[k:k + 2]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 fractions = [int(a) for a in sys.argv[2:]] or [8, 4]
 W, H, F = 640, 480, 48
@@ -39,6 +44,11 @@ def timed(reps=6):
 ms, base = timed(2)
 its = np.asarray(base["n_iterations"])
 print("pairs %d; passes per pair: min %d, median %d, 90th percentile %d, max %d" % (n, its.min(), np.median(its), np.percentile(its, 90), its.max()))
+if only:
+    ctx.set_option("overlap_tails", 1 if only == "lane" else 0)
+    ctx.set_option("overlap_fraction", fractions[0])
+    print(only, "%.3f ms" % timed(4)[0])
+    sys.exit(0)
 for rep in range(3):
     ctx.set_option("overlap_tails", 0)
     ms0, _ = timed()
